@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s of Level-0 isosurface extraction (marching tetrahedra) on MI355X.
+
+One "step" = one pass of the hot path over one volume resident in HBM: (N>1: one-plane halo
+exchange over RCCL) -> classify/interpolate kernel -> triangle emit kernel, leaving the indexed
+mesh (vertex records + index triples) in HBM.  Workload (BASELINE.json configs[2] shape at N=1):
+512^3 fp32 smooth-noise field, single isovalue 0; with N GPUs every rank owns one such 512^3
+slab of a (N*512) x 512 x 512 volume partitioned along array axis 0 ("z-slab"), weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = samples of all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512, help="samples per axis of one rank's slab")
+    ap.add_argument("--passes", type=int, default=1400, help="[1,2,1]/4 smoothing passes of the noise field")
+    ap.add_argument("--value", type=float, default=0.0)
+    ap.add_argument("--rotate", type=int, default=0, help="number of distinct grids cycled (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the shape-agnostic classify kernel")
+    return ap.parse_args()
+
+
+def cpu_baseline(field_host, value, budget_s=20.0):
+    """time the C oracle (1 thread) on a bounded sub-volume of the same field"""
+    import numpy as np
+    from oracle import level0
+    n0 = field_host.shape[0]
+    # calibrate on 16 planes, then size the sample for ~budget_s
+    t0 = time.time()
+    level0.march3d(np.ascontiguousarray(field_host[:16]), value, diag_mode=1)
+    per_plane = (time.time() - t0) / 15.0
+    planes = int(max(16, min(n0, budget_s / max(per_plane, 1e-9))))
+    sub = np.ascontiguousarray(field_host[:planes])
+    t0 = time.time()
+    O = level0.march3d(sub, value, diag_mode=1)
+    dt = time.time() - t0
+    return {"value": sub.size / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": "planes 0:%d of the %s field (%d samples, %d triangles) in %.1f s, oracle/march_oracle.c single thread"
+                      % (planes, "x".join(str(n) for n in field_host.shape), sub.size, len(O["tris"]), dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from contourist_amd import _ffi, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+    n = args.size
+    nrot = args.rotate or (1 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
+
+    # every rank owns `n` planes (+1 halo plane from its upper neighbour, except the last rank)
+    has_upper = distributed and rank + 1 < world
+    slabs = []
+    for r in range(nrot):
+        own = synthetic.smooth_noise_torch((n, n, n), 1235 + 97 * rank + r, args.passes, dev)
+        buf = torch.empty((n + (1 if has_upper else 0), n, n), dtype=torch.float32, device=dev)
+        buf[:n] = own
+        del own
+        slabs.append(buf)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    ctx = _ffi.Context(local_rank, stream=stream.cuda_stream)
+    flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
+
+    def halo_exchange(buf):
+        """lower plane of rank r+1 -> halo plane of rank r (RCCL send/recv over xGMI)"""
+        ops = []
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, buf[0], rank - 1))
+        if has_upper:
+            ops.append(dist.P2POp(dist.irecv, buf[n], rank + 1))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def step(i):
+        buf = slabs[i % nrot]
+        if distributed:
+            halo_exchange(buf)
+        ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
+        ctx.extract3d_async(args.value, flags)
+
+    # size the output buffers once (synchronous extract grows them as needed)
+    counts = None
+    for r in range(nrot):
+        if distributed:
+            halo_exchange(slabs[r])
+        ctx.adopt_device_grid(slabs[r].data_ptr(), tuple(slabs[r].shape), keepalive=slabs[r])
+        c = ctx.extract3d(args.value, flags)
+        counts = c if counts is None else {k: max(counts[k], c[k]) for k in c}
+    ctx.reserve(int(counts["n_cells"] * 1.05) + 1024, int(counts["n_vertices"] * 1.05) + 1024,
+                int(counts["n_triangles"] * 1.05) + 1024)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.timing_enable(True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.timing_read()
+    final = ctx.counts()           # also verifies that the last extract fitted its buffers
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_rank = n ** 3
+    if rank == 0:
+        nt = max(timing["n"], 1)
+        k1_ms = timing["classify_ms"] / nt
+        k2_ms = timing["emit_ms"] / nt
+        alg_bytes = 4.0 * slabs[0].numel()             # 4 B per input sample, read once
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("classify_%d" % n)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mvoxels/s isosurface extraction on 512^3 fp32 grid" if n == 512 else "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % n,
+            "value": world * samples_per_rank * args.steps / elapsed / 1e6,
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%dx%d fp32 smooth-noise slab per GPU ([1,2,1]/4 x %d passes, closed interior), isovalue %g, marching tetrahedra Level-0 (classify+interpolate+emit indexed mesh)"
+                            % (n, n, n, args.passes, args.value),
+                "partition": "axis-0 slabs, 1-plane halo over RCCL" if distributed else "single GPU",
+                "active_voxel_fraction": final["n_border_voxels"] / float((n - 1) ** 3),
+                "vertices": final["n_vertices"], "triangles": final["n_triangles"],
+                "grids_rotated": nrot,
+                "classify_kernel": "generic" if args.generic else "auto",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "classify+interpolate (dominant)", "kernel_ms": k1_ms,
+                "emit_kernel_ms": k2_ms,
+                "level0_frac": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms + k2_ms > 0 else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            host = slabs[0].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(host, args.value)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""ctypes binding of libcontourist_hip.so (C ABI: include/contourist_hip.h).
+
+The HIP library is the product path: if it is missing or cannot be loaded this module raises --
+there is no CPU fallback anywhere in `contourist_amd`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcontourist_hip.so")
+
+CX_OK = 0
+CX_ERR_CAPACITY = -5
+CX_DIAG_CANONICAL = 0
+CX_DIAG_CPYTHON310 = 1
+CX_KERNEL_GENERIC = 0x100
+
+# every symbol include/contourist_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
+    "cx_grid_upload", "cx_grid_adopt_device", "cx_reserve",
+    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
+    "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
+    "cx_timing_enable", "cx_timing_read", "cx_version",
+]
+
+
+class CxCounts(ctypes.Structure):
+    _fields_ = [("n_cells", ctypes.c_int64), ("n_vertices", ctypes.c_int64),
+                ("n_triangles", ctypes.c_int64), ("n_border_voxels", ctypes.c_int64)]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """load (once) and type the shared library; raises HipLibraryMissing loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found: build it with `python -m contourist_amd.build` (hipcc --offload-arch=gfx950). "
+            "contourist_amd has no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, u32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_double
+    L.cx_version.restype = ctypes.c_char_p
+    L.cx_version.argtypes = []
+    L.cx_last_error.restype = ctypes.c_char_p
+    L.cx_last_error.argtypes = [vp]
+    sigs = {
+        "cx_ctx_create": [ctypes.c_int, ctypes.POINTER(vp)],
+        "cx_ctx_destroy": [vp],
+        "cx_set_stream": [vp, vp],
+        "cx_synchronize": [vp],
+        "cx_grid_upload": [vp, vp, i64, i64, i64],
+        "cx_grid_adopt_device": [vp, vp, i64, i64, i64],
+        "cx_reserve": [vp, i64, i64, i64],
+        "cx_extract3d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
+        "cx_extract3d_async": [vp, dbl, u32],
+        "cx_counts_get": [vp, ctypes.POINTER(CxCounts)],
+        "cx_level0_download": [vp, vp, vp],
+        "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
+        "cx_postprocess3d": [vp, u32, vp],
+        "cx_level1_download": [vp, vp, vp],
+        "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
+        "cx_timing_enable": [vp, ctypes.c_int],
+        "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class CxError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "contourist_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class Context(object):
+    """One device + one HIP stream (cx_ctx).  Not thread safe."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = ctypes.c_void_p()
+        rc = self.lib.cx_ctx_create(int(device), ctypes.byref(h))
+        if rc != CX_OK:
+            raise CxError(rc, "cx_ctx_create(device=%d) failed (no HIP device?)" % device)
+        self.handle = h
+        self.device = int(device)
+        self._keep = None      # keeps an adopted tensor / uploaded array alive
+        self.shape = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != CX_OK:
+            raise CxError(rc, self.lib.cx_last_error(self.handle).decode("utf-8", "replace"))
+
+    def set_stream(self, stream):
+        self._check(self.lib.cx_set_stream(self.handle, ctypes.c_void_p(int(stream) if stream else 0)))
+
+    def synchronize(self):
+        self._check(self.lib.cx_synchronize(self.handle))
+
+    def upload_grid(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        assert a.ndim == 3, "3-D sample array expected"
+        self._check(self.lib.cx_grid_upload(self.handle, a.ctypes.data, *a.shape))
+        self.shape = tuple(int(n) for n in a.shape)
+        self._keep = None
+
+    def adopt_device_grid(self, device_ptr, shape, keepalive=None):
+        assert len(shape) == 3
+        self._check(self.lib.cx_grid_adopt_device(self.handle, ctypes.c_void_p(int(device_ptr)), *[int(n) for n in shape]))
+        self.shape = tuple(int(n) for n in shape)
+        self._keep = keepalive
+
+    def reserve(self, max_cells=0, max_vertices=0, max_triangles=0):
+        self._check(self.lib.cx_reserve(self.handle, int(max_cells), int(max_vertices), int(max_triangles)))
+
+    def extract3d(self, value, flags=CX_DIAG_CPYTHON310):
+        c = CxCounts()
+        self._check(self.lib.cx_extract3d(self.handle, float(value), int(flags), ctypes.byref(c)))
+        return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_triangles=c.n_triangles,
+                    n_border_voxels=c.n_border_voxels)
+
+    def extract3d_async(self, value, flags=CX_DIAG_CPYTHON310):
+        self._check(self.lib.cx_extract3d_async(self.handle, float(value), int(flags)))
+
+    def counts(self):
+        c = CxCounts()
+        self._check(self.lib.cx_counts_get(self.handle, ctypes.byref(c)))
+        return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_triangles=c.n_triangles,
+                    n_border_voxels=c.n_border_voxels)
+
+    def download_level0(self, counts):
+        """-> (xyz (V,3) float32 grid coordinates, edge ids (V,) uint32, triangles (T,3) int32)"""
+        nv, nt = int(counts["n_vertices"]), int(counts["n_triangles"])
+        verts = np.empty((nv, 4), dtype=np.float32)
+        tris = np.empty((nt, 3), dtype=np.int32)
+        self._check(self.lib.cx_level0_download(self.handle, verts.ctypes.data, tris.ctypes.data))
+        keys = verts[:, 3].copy().view(np.uint32)
+        return verts[:, :3].copy(), keys, tris
+
+    def postprocess3d(self, flags=0):
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cx_postprocess3d(self.handle, int(flags), out.ctypes.data))
+        return dict(n_vertices=int(out[0]), n_triangles=int(out[1]), n_after_weld=int(out[2]),
+                    n_after_tiny=int(out[3]), n_components=int(out[4]))
+
+    def download_level1(self, counts):
+        pts = np.empty((int(counts["n_vertices"]), 3), dtype=np.float64)
+        tris = np.empty((int(counts["n_triangles"]), 3), dtype=np.int32)
+        self._check(self.lib.cx_level1_download(self.handle, pts.ctypes.data, tris.ctypes.data))
+        return pts, tris
+
+    def surface_geometry(self, points, triangles, do_clean):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()
+        tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3).copy()
+        nv = ctypes.c_int64(len(pts))
+        nt = ctypes.c_int64(len(tris))
+        self._check(self.lib.cx_surface_geometry(self.handle, pts.ctypes.data, ctypes.byref(nv),
+                                                 tris.ctypes.data, ctypes.byref(nt), int(bool(do_clean))))
+        return pts[:nv.value].copy(), tris[:nt.value].copy()
+
+    def timing_enable(self, on=True):
+        self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))
+
+    def timing_read(self):
+        ms = (ctypes.c_double * 3)()
+        n = ctypes.c_int()
+        self._check(self.lib.cx_timing_read(self.handle, ms, ctypes.byref(n)))
+        return dict(classify_ms=ms[0], emit_ms=ms[1], total_ms=ms[2], n=n.value)

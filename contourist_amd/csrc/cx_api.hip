@@ -1,0 +1,304 @@
+// cx_api.hip -- C ABI (include/contourist_hip.h) of the gfx950 isosurface extractor: context,
+// device memory, kernel sequencing.  No torch types, no global state.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "cx_ctx.h"
+
+#define CX_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return (e__ == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;                      \
+        }                                                                                        \
+    } while (0)
+
+static int fail(cx_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" const char* cx_version(void) { return "contourist_hip gfx950 " __DATE__; }
+
+extern "C" int cx_ctx_create(int device_id, cx_ctx** out) {
+    if (!out) return CX_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return CX_ERR_HIP;
+    cx_ctx* ctx = new (std::nothrow) cx_ctx();
+    if (!ctx) return CX_ERR_NOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return CX_ERR_HIP;
+    }
+    ctx->own_stream = ctx->stream;
+    if (hipMalloc(&ctx->counters, CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&ctx->counters_host, CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        cx_ctx_destroy(ctx);
+        return CX_ERR_NOMEM;
+    }
+    *out = ctx;
+    return CX_OK;
+}
+
+static void free_outputs(cx_ctx* ctx) {
+    if (ctx->verts) (void)hipFree(ctx->verts);
+    if (ctx->cells) (void)hipFree(ctx->cells);
+    if (ctx->tris) (void)hipFree(ctx->tris);
+    ctx->verts = nullptr; ctx->cells = nullptr; ctx->tris = nullptr;
+    ctx->vcap = ctx->ccap = ctx->tcap = 0;
+}
+
+extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
+    if (!ctx) return CX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    cx_post_free(ctx);
+    free_outputs(ctx);
+    if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
+    if (ctx->emask8) (void)hipFree(ctx->emask8);
+    if (ctx->rowbase) (void)hipFree(ctx->rowbase);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
+    for (auto& ev : ctx->events)
+        for (int n = 0; n < 3; n++)
+            if (ev.e[n]) (void)hipEventDestroy(ev.e[n]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return CX_OK;
+}
+
+extern "C" const char* cx_last_error(cx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int cx_set_stream(cx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return CX_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CX_OK;
+}
+
+extern "C" int cx_synchronize(cx_ctx* ctx) {
+    if (!ctx) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+static int set_grid_dims(cx_ctx* ctx, int64_t n0, int64_t n1, int64_t n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return fail(ctx, CX_ERR_INVALID, "grid must have at least 2 samples per axis");
+    const int64_t N = n0 * n1 * n2;
+    if (N > (1LL << 29)) return fail(ctx, CX_ERR_UNSUPPORTED, "more than 2^29 samples in one grid: partition into slabs");
+    // side tables sized for this grid
+    if (ctx->tables_for < (size_t)N) {
+        if (ctx->emask8) (void)hipFree(ctx->emask8);
+        if (ctx->rowbase) (void)hipFree(ctx->rowbase);
+        ctx->emask8 = nullptr; ctx->rowbase = nullptr; ctx->tables_for = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->emask8, ((size_t)N + 64 + 7) & ~(size_t)7));
+        CX_HIP(ctx, hipMalloc(&ctx->rowbase, ((size_t)N / 8 + 16) * sizeof(uint32_t)));
+        ctx->tables_for = (size_t)N;
+    }
+    ctx->n0 = n0; ctx->n1 = n1; ctx->n2 = n2;
+    ctx->extracted = false;
+    ctx->post_valid = false;
+    return CX_OK;
+}
+
+extern "C" int cx_grid_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2) {
+    if (!ctx || !host) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = set_grid_dims(ctx, n0, n1, n2);
+    if (rc) return rc;
+    const size_t bytes = (size_t)(n0 * n1 * n2) * sizeof(float);
+    if (ctx->grid_owned_bytes < bytes) {
+        if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
+        ctx->grid_owned = nullptr; ctx->grid_owned_bytes = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->grid_owned, bytes));
+        ctx->grid_owned_bytes = bytes;
+    }
+    CX_HIP(ctx, hipMemcpyAsync(ctx->grid_owned, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->grid = ctx->grid_owned;
+    return CX_OK;
+}
+
+extern "C" int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2) {
+    if (!ctx || !device_ptr) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = set_grid_dims(ctx, n0, n1, n2);
+    if (rc) return rc;
+    ctx->grid = (const float*)device_ptr;
+    return CX_OK;
+}
+
+extern "C" int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max_triangles) {
+    if (!ctx || max_cells < 0 || max_vertices < 0 || max_triangles < 0) return CX_ERR_INVALID;
+    if (max_cells > 0xFFFFFFF0LL || max_vertices > 0xFFFFFFF0LL || max_triangles > 0x7FFFFFF0LL)
+        return fail(ctx, CX_ERR_UNSUPPORTED, "capacity beyond 32-bit indices");
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (max_cells > (int64_t)ctx->ccap) {
+        if (ctx->cells) (void)hipFree(ctx->cells);
+        ctx->cells = nullptr; ctx->ccap = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->cells, (size_t)max_cells * sizeof(uint4)));
+        ctx->ccap = (uint32_t)max_cells;
+    }
+    if (max_vertices > (int64_t)ctx->vcap) {
+        if (ctx->verts) (void)hipFree(ctx->verts);
+        ctx->verts = nullptr; ctx->vcap = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->verts, (size_t)max_vertices * sizeof(float4)));
+        ctx->vcap = (uint32_t)max_vertices;
+    }
+    if (max_triangles > (int64_t)ctx->tcap) {
+        if (ctx->tris) (void)hipFree(ctx->tris);
+        ctx->tris = nullptr; ctx->tcap = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->tris, (size_t)max_triangles * 3 * sizeof(int32_t)));
+        ctx->tcap = (uint32_t)max_triangles;
+    }
+    ctx->extracted = false;
+    ctx->post_valid = false;
+    return CX_OK;
+}
+
+static float fp32_threshold(double value) {
+    // smallest fp32 t with t >= value, so that for every fp32 sample f:  (double)f < value  <=>  f < t
+    float t = (float)value;
+    if ((double)t < value) t = std::nextafterf(t, INFINITY);
+    return t;
+}
+
+static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
+    if (!ctx->grid) return fail(ctx, CX_ERR_STATE, "no grid: call cx_grid_upload or cx_grid_adopt_device first");
+    if (!(value == value)) return fail(ctx, CX_ERR_INVALID, "isovalue is NaN");
+    const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
+    if (!ctx->cells || !ctx->verts || !ctx->tris) {
+        int rc = cx_reserve(ctx, N / 16 + 4096, N / 8 + 4096, N / 4 + 4096);
+        if (rc) return rc;
+    }
+    cx_params P;
+    memset(&P, 0, sizeof(P));
+    P.grid = ctx->grid;
+    P.n0 = (uint32_t)ctx->n0; P.n1 = (uint32_t)ctx->n1; P.n2 = (uint32_t)ctx->n2;
+    P.nsamples = (uint32_t)N;
+    P.div_plane = cx_fdiv_make(P.n1 * P.n2);
+    P.div_row = cx_fdiv_make(P.n2);
+    P.vcmp = fp32_threshold(value);
+    P.value = value;
+    P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
+    P.flags = flags;
+    P.emask8 = ctx->emask8; P.rowbase = ctx->rowbase;
+    P.verts = ctx->verts; P.cells = ctx->cells; P.tris = ctx->tris;
+    P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
+    P.counters = ctx->counters;
+    ctx->last = P;
+    cx_ctx::evset* ev = nullptr;
+    if (ctx->timing) {
+        if (ctx->nevents < (int)(sizeof(ctx->events) / sizeof(ctx->events[0]))) {
+            ev = &ctx->events[ctx->nevents++];
+            for (int n = 0; n < 3; n++)
+                if (!ev->e[n]) CX_HIP(ctx, hipEventCreate(&ev->e[n]));
+        }
+    }
+    CX_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
+    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[0], ctx->stream));
+    if (!(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported(P)) cx_launch_classify_fast(P, ctx->stream);
+    else cx_launch_classify_generic(P, ctx->stream);
+    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
+    cx_launch_emit_triangles(P, ctx->stream);
+    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    CX_HIP(ctx, hipGetLastError());
+    ctx->extracted = true;
+    ctx->post_valid = false;
+    return CX_OK;
+}
+
+extern "C" int cx_extract3d_async(cx_ctx* ctx, double value, uint32_t flags) {
+    if (!ctx) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    return enqueue_extract(ctx, value, flags);
+}
+
+extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
+    if (!ctx || !out) return CX_ERR_INVALID;
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no extraction enqueued");
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    CX_HIP(ctx, hipMemcpyAsync(ctx->counters_host, ctx->counters, CX_CNT_WORDS * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_cells = ctx->counters_host[CX_CNT_CELLS];
+    out->n_vertices = ctx->counters_host[CX_CNT_VERTS];
+    out->n_triangles = ctx->counters_host[CX_CNT_TRIS];
+    out->n_border_voxels = ctx->counters_host[CX_CNT_BORDER];
+    ctx->counts = *out;
+    if (out->n_cells > ctx->ccap || out->n_vertices > ctx->vcap || out->n_triangles > ctx->tcap) {
+        ctx->extracted = false;
+        return fail(ctx, CX_ERR_CAPACITY, "output buffers too small for this isosurface");
+    }
+    return CX_OK;
+}
+
+extern "C" int cx_extract3d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out) {
+    if (!ctx) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    cx_counts c;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        int rc = enqueue_extract(ctx, value, flags);
+        if (rc) return rc;
+        rc = cx_counts_get(ctx, &c);
+        if (out) *out = c;
+        if (rc != CX_ERR_CAPACITY) return rc;
+        // grow to what this surface needs (+5 %) and run again
+        rc = cx_reserve(ctx, c.n_cells + c.n_cells / 20 + 1024, c.n_vertices + c.n_vertices / 20 + 1024,
+                        c.n_triangles + c.n_triangles / 20 + 1024);
+        if (rc) return rc;
+    }
+    return fail(ctx, CX_ERR_CAPACITY, "output buffers still too small after growing");
+}
+
+extern "C" int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    if (verts_xyzk && ctx->counts.n_vertices)
+        CX_HIP(ctx, hipMemcpyAsync(verts_xyzk, ctx->verts, (size_t)ctx->counts.n_vertices * sizeof(float4),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (tris && ctx->counts.n_triangles)
+        CX_HIP(ctx, hipMemcpyAsync(tris, ctx->tris, (size_t)ctx->counts.n_triangles * 3 * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+extern "C" int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
+    if (verts_xyzk) *verts_xyzk = ctx->verts;
+    if (tris) *tris = ctx->tris;
+    return CX_OK;
+}
+
+extern "C" int cx_timing_enable(cx_ctx* ctx, int on) {
+    if (!ctx) return CX_ERR_INVALID;
+    ctx->timing = on != 0;
+    ctx->nevents = 0;
+    return CX_OK;
+}
+
+extern "C" int cx_timing_read(cx_ctx* ctx, double ms[3], int* n) {
+    if (!ctx || !ms) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ms[0] = ms[1] = ms[2] = 0.0;
+    for (int i = 0; i < ctx->nevents; i++) {
+        float a = 0, b = 0;
+        CX_HIP(ctx, hipEventElapsedTime(&a, ctx->events[i].e[0], ctx->events[i].e[1]));
+        CX_HIP(ctx, hipEventElapsedTime(&b, ctx->events[i].e[1], ctx->events[i].e[2]));
+        ms[0] += a; ms[1] += b; ms[2] += a + b;
+    }
+    if (n) *n = ctx->nevents;
+    ctx->nevents = 0;
+    return CX_OK;
+}

@@ -1,0 +1,47 @@
+// cx_ctx.h -- the context object behind the C ABI (host side only).
+#pragma once
+#include <string>
+
+#include "cx_common.h"
+
+struct cx_post_state;  // Level-1 buffers (cx_post.hip)
+
+struct cx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // stream created by the context
+    std::string err;
+    // sampled field
+    const float* grid = nullptr;
+    float* grid_owned = nullptr;
+    size_t grid_owned_bytes = 0;
+    int64_t n0 = 0, n1 = 0, n2 = 0;
+    // side tables of the march
+    uint8_t* emask8 = nullptr;
+    uint32_t* rowbase = nullptr;
+    size_t tables_for = 0;
+    // Level-0 outputs
+    float4* verts = nullptr;
+    uint4* cells = nullptr;
+    int32_t* tris = nullptr;
+    uint32_t vcap = 0, ccap = 0, tcap = 0;
+    uint32_t* counters = nullptr;
+    uint32_t* counters_host = nullptr;
+    bool extracted = false;
+    cx_counts counts = {0, 0, 0, 0};
+    cx_params last;
+    // Level-1
+    cx_post_state* post = nullptr;
+    bool post_valid = false;
+    // timing
+    struct evset { hipEvent_t e[3] = {nullptr, nullptr, nullptr}; };
+    bool timing = false;
+    int nevents = 0;
+    evset events[256];
+};
+
+// cx_march3d_fast.hip
+bool cx_fast_classify_supported(const cx_params& P);
+void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
+// cx_post.hip
+void cx_post_free(cx_ctx* ctx);

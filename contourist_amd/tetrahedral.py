@@ -1,0 +1,286 @@
+"""3-D isosurfaces by marching tetrahedra on MI355X -- host-side mirror of the reference's
+`contourist/tetrahedral.py` (Delta3DContour :50-87, TriangulatedIsosurfaces :89-101,
+Grid3DContour :104-107, GridContour3d :514-621).
+
+Same class names, constructor arguments, methods and return conventions as the reference; the
+work happens in hand-written HIP kernels behind the C ABI (include/contourist_hip.h):
+
+    search_for_endpoints()        -> Level-0 march on the device (crossing search, active voxels,
+                                     tetrahedra classification, edge interpolation, triangle emit)
+    get_points_and_triangles()    -> device post-passes (weld, tiny collapse, clean, orient) and
+                                     one download; returns (points, triangles)
+
+Differences a caller can observe (see DESIGN.md "Boundary"):
+  * points is a (V,3) float64 ndarray and triangles a (T,3) int32 ndarray (rows sorted); both
+    index / iterate like the reference's list of arrays / sorted list of tuples.
+  * the march is a dense scan: EVERY component of the isosurface inside the grid is returned,
+    not only those reachable from the seed segments.
+  * linear_interpolate=False (re-evaluating f off-grid) and flatten=True (serial LP decimation)
+    are not offered on the device path and raise NotImplementedError.
+"""
+import itertools
+
+import numpy as np
+
+from . import _ffi
+from . import grid_field
+from . import surface_geometry
+
+# cube corners, Kuhn tetrahedra and the 26-neighbourhood, in the reference's order
+# (tetrahedral.py:20-47): corner c = 4*di + 2*dj + dk, tetrahedra = monotone paths A..H.
+CUBE = np.array(list(itertools.product((0, 1), repeat=3)), dtype=int)
+_A, _B, _C, _D, _E, _F, _G, _H = (tuple(c) for c in CUBE)
+TETRAHEDRA = np.array([[_A, _H, _B, _D], [_A, _H, _D, _C], [_A, _H, _C, _G],
+                       [_A, _H, _G, _E], [_A, _H, _E, _F], [_A, _H, _F, _B]], dtype=int)
+OFFSETS = np.array([o for o in itertools.product((-1, 0, 1), repeat=3) if any(o)], dtype=int)
+
+_DEFAULT_DEVICE = [0]
+
+
+def set_default_device(device):
+    _DEFAULT_DEVICE[0] = int(device)
+
+
+class GridContour3d(object):
+    """Device-backed counterpart of GridContour3d (tetrahedral.py:514-621) working in GRID coordinates.
+
+    corner   = voxels per axis (the reference's `corner`); the sample array has corner+1 per axis.
+    samples  = dense fp32 array (numpy) or torch tensor on the GPU, shape corner+1.
+    """
+
+    def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True,
+                 callback=None, device=None, diagonal="cpython310", context=None):
+        self.corner = np.array(corner, dtype=int)
+        assert self.corner.shape == (3,), "dimension must be 3"
+        if segment_endpoints is not None:
+            for (p1, p2) in segment_endpoints:
+                assert len(p1) == 3
+                assert len(p2) == 3
+        if not linear_interpolate:
+            raise NotImplementedError("linear_interpolate=False needs f off the grid; the device march "
+                                      "interpolates linearly between dense samples")
+        self.dimension = 3
+        self.linear_interpolate = True
+        self.end_points = segment_endpoints
+        self.value = float(value)
+        self.callback = callback
+        self.flatten = False
+        self.smooth = None
+        self.samples = samples
+        shape = tuple(int(n) for n in samples.shape)
+        assert shape == tuple(int(c) + 1 for c in self.corner), (shape, self.corner)
+        self.shape = shape
+        self.device = _DEFAULT_DEVICE[0] if device is None else int(device)
+        self.flags = {"cpython310": _ffi.CX_DIAG_CPYTHON310, "canonical": _ffi.CX_DIAG_CANONICAL}[diagonal]
+        self._ctx = context
+        self._counts = None
+        self._post = None
+
+    # -- device plumbing ----------------------------------------------------------------------------
+    def context(self):
+        if self._ctx is None:
+            self._ctx = _ffi.Context(self.device)
+        return self._ctx
+
+    def _bind_grid(self):
+        ctx = self.context()
+        s = self.samples
+        if grid_field._is_torch(s):
+            assert s.is_cuda and s.is_contiguous() and str(s.dtype) == "torch.float32", \
+                "device samples must be a contiguous float32 tensor on the GPU"
+            ctx.adopt_device_grid(s.data_ptr(), self.shape, keepalive=s)
+        else:
+            ctx.upload_grid(s)
+
+    def march(self, force=False):
+        "Level 0 on the device (idempotent). returns the counts dict."
+        if self._counts is None or force:
+            self._bind_grid()
+            self._counts = self.context().extract3d(self.value, self.flags)
+            self._post = None
+        return self._counts
+
+    def level0(self):
+        """Level-0 mesh as host arrays: dict(xyz (V,3) f32 grid coords, keys (V,) u32 edge ids,
+        triangles (T,3) i32 wound low->high, counts)."""
+        counts = self.march()
+        xyz, keys, tris = self.context().download_level0(counts)
+        return dict(xyz=xyz, keys=keys, triangles=tris, counts=counts)
+
+    # -- reference API -------------------------------------------------------------------------------
+    def extract_surface_geometry(self, clean=True):
+        "SurfaceGeometry of the welded, cleaned and oriented mesh in grid coordinates (tetrahedral.py:604-621)"
+        self.march()
+        if self.flatten:
+            raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
+        if self.smooth:
+            raise NotImplementedError("smooth is not on the device path yet")
+        ctx = self.context()
+        if self._post is None:
+            self._post = ctx.postprocess3d(0 if clean else 1)
+        pts, tris = ctx.download_level1(self._post)
+        return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
+
+    def get_points_and_triangles(self, clean=True):
+        "(grid_points (V,3) float64, triangles (T,3) int32 sorted rows)  (tetrahedral.py:528-552)"
+        geometry = self.extract_surface_geometry(clean)
+        if self.callback:
+            self.callback(self)
+        return (geometry.vertices, geometry.oriented_triangles)
+
+    extract_points_and_triangles = get_points_and_triangles
+
+    # lazily derived views of the reference's bookkeeping (tetrahedral.py:158-169)
+    @property
+    def interpolated_contour_pairs(self):
+        "{((i,j,k) low, (i,j,k) high): grid xyz} as the reference keeps it -- host side, for inspection only"
+        L = self.level0()
+        lo, hi = unpack_edge_ids(L["keys"], self.shape)
+        S = np.asarray(self.samples if not grid_field._is_torch(self.samples) else self.samples.cpu().numpy())
+        swap = S[tuple(lo.T)] > S[tuple(hi.T)]
+        a = np.where(swap[:, None], hi, lo)
+        b = np.where(swap[:, None], lo, hi)
+        return {(tuple(int(x) for x in p), tuple(int(x) for x in q)): np.array(c, dtype=float)
+                for p, q, c in zip(a, b, L["xyz"])}
+
+
+def unpack_edge_ids(keys, shape):
+    "edge id (lin << 3 | d) -> (lower lattice point (V,3), upper lattice point (V,3))"
+    keys = np.asarray(keys).astype(np.int64)
+    lin, d = keys >> 3, keys & 7
+    i, r = np.divmod(lin, shape[1] * shape[2])
+    j, k = np.divmod(r, shape[2])
+    lo = np.stack([i, j, k], axis=1)
+    hi = lo + np.stack([(d >> 2) & 1, (d >> 1) & 1, d & 1], axis=1)
+    return lo, hi
+
+
+def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_endpoints,
+                  linear_interpolate=True, callback=None, device=None):
+    """Grid3DContour(n, m, l, function, value, segment_endpoints, ...)  (tetrahedral.py:104-107).
+    `function(i, j, k)` over grid coordinates is sampled once into a dense (n+1, m+1, l+1) array;
+    pass a numpy array / GPU tensor of that shape instead of a callable to skip the sampling."""
+    corner = (int(horizontal_n), int(vertical_m), int(forward_l))
+    if callable(function):
+        g = grid_field.FunctionGrid([0, 0, 0], [c - 0.5 for c in corner], [1, 1, 1], function)
+        assert tuple(g.grid_dimensions) == corner
+        samples = g.dense_samples()
+    else:
+        samples = function
+    return GridContour3d(corner, samples, value, segment_endpoints, linear_interpolate, callback, device)
+
+
+class Delta3DContour(object):
+    """World-coordinate facade (tetrahedral.py:50-87 on top of triangulated.ContourGrid :79-118)."""
+
+    linear_interpolate = True
+    flatten = False
+    minimum_ratio = None
+    minimum_extent = None
+    smooth = None
+    device = None
+
+    def __init__(self, function_grid, value, segment_endpoints=None, linear_interpolate=True):
+        self.linear_interpolate = linear_interpolate
+        self.grid = function_grid
+        self.value = value
+        self.segment_endpoints = segment_endpoints
+        grid_endpoints = None
+        if segment_endpoints is not None:
+            grid_endpoints = []
+            for (start_xy, end_xy) in segment_endpoints:
+                # the reference asserts len == 2 here (a 2-D leftover, triangulated.py:96) which makes
+                # non-empty 3-D endpoints unusable at HEAD; both 2- and 3-vectors are accepted here.
+                assert len(start_xy) == len(end_xy) == self.grid.dimension
+                grid_endpoint = self.to_grid_endpoint(start_xy, end_xy)
+                if grid_endpoint is not None:
+                    grid_endpoints.append(grid_endpoint)
+            if len(grid_endpoints) < 1:
+                grid_endpoints = None
+        self.contour_maker = self.get_contour_maker(grid_endpoints)
+        self.grid_values = None
+
+    def to_grid_endpoint(self, start_xy, end_xy):
+        "first pair of surrounding lattice points whose values straddle the isovalue (triangulated.py:109-118)"
+        grid = self.grid
+        value = self.value
+        for start_grid in grid.surrounding_vertices(np.array(start_xy, dtype=float)):
+            for end_grid in grid.surrounding_vertices(np.array(end_xy, dtype=float)):
+                if not np.all(start_grid == end_grid):
+                    if (grid.grid_function(*start_grid) - value) * (grid.grid_function(*end_grid) - value) <= 0:
+                        return (start_grid, end_grid)
+        return None
+
+    def get_contour_maker(self, grid_endpoints):
+        grid = self.grid
+        self.grid_endpoints = grid_endpoints
+        if self.flatten:
+            raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
+        result = GridContour3d(tuple(int(n) for n in grid.grid_dimensions), grid.dense_samples(), self.value,
+                               grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device)
+        result.flatten = self.flatten
+        result.smooth = self.smooth
+        return result
+
+    def search_for_endpoints(self, skip=1):
+        """Reference: exhaustive crossing search + new contour maker (tetrahedral.py:74-81).
+        Here: run the device march (which contains the crossing search); `grid_endpoints` is then
+        derived from the crossing edges the march found.  `skip` only thins that list."""
+        self.contour_maker = self.get_contour_maker(None)
+        self.contour_maker.march()
+        self._skip = skip
+        self.grid_endpoints = _LazyEndpoints(self.contour_maker, skip)
+
+    def get_points_and_triangles(self):
+        (grid_points, triangles) = self.contour_maker.get_points_and_triangles()
+        points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
+        return (points, triangles)
+
+
+class _LazyEndpoints(object):
+    "sequence of (vertex0, vertex1) crossing lattice segments, materialised on first use"
+
+    def __init__(self, maker, skip):
+        self._maker, self._skip, self._list = maker, skip, None
+
+    def _get(self):
+        if self._list is None:
+            L = self._maker.level0()
+            lo, hi = unpack_edge_ids(L["keys"], self._maker.shape)
+            if self._skip > 1:
+                keep = np.all(lo % self._skip == 0, axis=1)
+                lo, hi = lo[keep], hi[keep]
+            self._list = list(zip(lo, hi))
+        return self._list
+
+    def __len__(self):
+        return len(self._get())
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, n):
+        return self._get()[n]
+
+
+class TriangulatedIsosurfaces(Delta3DContour):
+    """TriangulatedIsosurfaces(mins, maxes, delta, function, value, segment_endpoints, ...)
+    (tetrahedral.py:89-101).  `function` may be a callable f(x, y, z) in world coordinates (sampled
+    once, vectorised when it broadcasts) or a dense sample array / GPU tensor of shape
+    grid_dimensions+1."""
+
+    def __init__(self, mins, maxes, delta, function, value, segment_endpoints,
+                 linear_interpolate=True, flatten=False, minimum_ratio=None, minimum_extent=None,
+                 smooth=None, device=None):
+        self.flatten = flatten
+        self.smooth = smooth
+        self.device = device
+        if minimum_ratio is not None:
+            self.minimum_ratio = minimum_ratio
+        if minimum_extent is not None:
+            self.minimum_extent = minimum_extent
+        if callable(function):
+            grid = grid_field.FunctionGrid(mins, maxes, delta, function)
+        else:
+            grid = grid_field.FunctionGrid.from_array(function, mins, delta)
+        Delta3DContour.__init__(self, grid, value, segment_endpoints, linear_interpolate=linear_interpolate)

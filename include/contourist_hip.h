@@ -1,0 +1,120 @@
+/*
+ * contourist_hip.h -- C ABI of the MI355X (gfx950) isosurface extractor.
+ *
+ * The reference (AaronWatters/contourist) is pure Python and has no FFI; its boundary for this
+ * path is a Python class API.  Each entry point below names the reference interface whose work
+ * it replaces (paths relative to the reference checkout, contourist/...).  The Python host side
+ * (contourist_amd/) mirrors the reference's classes 1:1 and calls these through ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions: every function returns 0 (CX_OK) or a negative cx_status, never throws, keeps no
+ * global state.  One cx_ctx == one device + one HIP stream; contexts are independent and a
+ * context must not be used from two threads at once.  The caller owns every host buffer; the
+ * library owns every device buffer it allocates until cx_ctx_destroy (an adopted grid pointer
+ * stays the caller's).  Sample arrays are C-ordered fp32, A[n0][n1][n2], last axis fastest;
+ * array axes (0,1,2) are the reference's (x,y,z).
+ */
+#ifndef CONTOURIST_HIP_H
+#define CONTOURIST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cx_ctx cx_ctx;
+
+typedef enum {
+    CX_OK = 0,
+    CX_ERR_INVALID = -1,     /* bad argument */
+    CX_ERR_HIP = -2,         /* a HIP runtime call failed; see cx_last_error */
+    CX_ERR_NOMEM = -3,       /* device or host allocation failed */
+    CX_ERR_STATE = -4,       /* call out of order (no grid, no extraction yet, ...) */
+    CX_ERR_CAPACITY = -5,    /* output buffers too small; counts say what is needed */
+    CX_ERR_UNSUPPORTED = -6  /* e.g. more than 2^29 samples in one grid (32-bit vertex ids) */
+} cx_status;
+
+/* flags of cx_extract3d */
+#define CX_DIAG_CANONICAL 0u   /* 2-2 tetrahedron: quad split follows the tetrahedron's vertex order */
+#define CX_DIAG_CPYTHON310 1u  /* quad split reproduces CPython 3.10 set iteration order, i.e. the
+                                  reference as it runs today (tetrahedral.py:592-595) */
+#define CX_KERNEL_GENERIC 0x100u /* force the shape-agnostic classify kernel (default: auto) */
+
+typedef struct {
+    int64_t n_cells;         /* lattice cells with a sign change among their corners */
+    int64_t n_vertices;      /* interpolated edge crossings == len(interpolated_contour_pairs) */
+    int64_t n_triangles;     /* == len(simplex_sets) before quantize_interpolations */
+    int64_t n_border_voxels; /* voxels for which GridContour.border_voxel() is true */
+} cx_counts;
+
+/* ---- context --------------------------------------------------------------------------------- */
+int cx_ctx_create(int device_id, cx_ctx** out);
+int cx_ctx_destroy(cx_ctx* ctx);
+const char* cx_last_error(cx_ctx* ctx);
+/* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int cx_set_stream(cx_ctx* ctx, void* hip_stream);
+int cx_synchronize(cx_ctx* ctx);
+
+/* ---- the sampled field ------------------------------------------------------------------------
+ * Replaces grid_field.FunctionGrid.materialize_array / grid_function (grid_field.py:34-44, 95-118):
+ * the dense fp32 array the march reads instead of calling f(x,y,z) per corner per use. */
+int cx_grid_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2);
+int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2);
+
+/* optional: pre-size the output buffers (cells / vertices / triangles); 0 keeps the default. */
+int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max_triangles);
+
+/* ---- Level 0: the voxel march -------------------------------------------------------------------
+ * Replaces, for a dense grid, in one pass over the samples:
+ *   FunctionGrid.find_contour_crossing_grid_segments   grid_field.py:64-84     (crossing edges)
+ *   GridContour.find_initial_voxels/expand_voxels/border_voxel  tetrahedral.py:383-469 (active voxels)
+ *   GridContour3d.enumerate_voxel_triangles / enumerate_tetrahedron_triangles  tetrahedral.py:554-595
+ *   GridContour.add_simplex / interpolate_pair / contour_pair_interpolation    tetrahedral.py:176-188, 471-512
+ * Result (device resident): vertex records float4 {x, y, z, bits(edge id)} in grid coordinates,
+ * edge id = (linear index of the edge's lower lattice point << 3) | direction(1..7, = 4di+2dj+dk),
+ * and triangles as int32 index triples wound so the normal points from f<value to f>=value.
+ * cx_extract3d enqueues the kernels and returns the counts (one device->host copy);
+ * the _async form only enqueues.  Returns CX_ERR_CAPACITY (with valid counts) if a buffer was too
+ * small: call cx_reserve with the counts and extract again. */
+int cx_extract3d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
+int cx_extract3d_async(cx_ctx* ctx, double value, uint32_t flags);
+int cx_counts_get(cx_ctx* ctx, cx_counts* out);
+/* copy the Level-0 mesh to host: verts = n_vertices*4 floats, tris = n_triangles*3 int32 */
+int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris);
+/* device pointers of the Level-0 buffers (valid until the next extract / reserve / destroy) */
+int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris);
+
+/* ---- Level 1: mesh post-passes -------------------------------------------------------------------
+ * Replaces GridContour.quantize_interpolations (tetrahedral.py:190-215), remove_tiny_simplices
+ * (:353-375), GridContour3d.extract_surface_geometry (:604-621), SurfaceGeometry.clean_triangles
+ * (surface_geometry.py:14-50) and SurfaceGeometry.orient_triangles (:52-140) on the device.
+ * corner = grid_dimensions of the reference (= n-1 per axis).  out_counts: [0] vertices, [1] triangles,
+ * [2] triangles after weld, [3] triangles after tiny collapse, [4] connected components. */
+int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts);
+/* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
+int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
+
+/* ---- standalone SurfaceGeometry operator ---------------------------------------------------------
+ * SurfaceGeometry(vertices, triangles).clean_triangles() / .orient_triangles()
+ * (surface_geometry.py:6-12, 14-50, 52-140) on caller-supplied host arrays.
+ * do_clean != 0 runs clean_triangles first.  Outputs are written in place: *nv / *nt are updated,
+ * points (nv*3 doubles) and tris (nt*3 int32) are overwritten with the cleaned / oriented mesh. */
+int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv, int32_t* tris, int64_t* nt,
+                        int do_clean);
+
+/* ---- measurement ----------------------------------------------------------------------------------
+ * When enabled, every extract records HIP events around its kernels on the context's stream.
+ * cx_timing_read synchronises and returns the summed milliseconds since the last reset:
+ * ms[0] classify+vertex kernel, ms[1] triangle emit kernel, ms[2] whole extract (incl. memset),
+ * *n = number of extracts accumulated. */
+int cx_timing_enable(cx_ctx* ctx, int on);
+int cx_timing_read(cx_ctx* ctx, double ms[3], int* n);
+
+/* library build info: "gfx950;<git describe or date>" */
+const char* cx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

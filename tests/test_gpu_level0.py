@@ -1,0 +1,118 @@
+"""GPU: Level-0 parity of the HIP march (through the C ABI) with the oracle and with the goldens
+produced by the real reference.  Bit-exact for edge sets, orientation and triangle index sets;
+vertex coordinates within 1e-6 relative (fp32 device arithmetic vs the reference's float64)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_names
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6      # BASELINE.json north_star: vertex coords within 1e-6 relative fp32
+ABS_FLOOR = 1e-6    # + absolute floor for coordinates near 0 (in voxel units)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from contourist_amd import _ffi
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def hip_level0(ctx, A, v, flags):
+    ctx.upload_grid(A)
+    counts = ctx.extract3d(v, flags)
+    xyz, keys, tris = ctx.download_level0(counts)
+    return counts, xyz, keys.astype(np.int64), tris.astype(np.int64)
+
+
+def check_against_oracle(ctx, A, v, flags, diag_mode):
+    from oracle import level0
+    shape = A.shape
+    counts, xyz, keys, tris = hip_level0(ctx, A, v, flags)
+    O = level0.march3d(A, v, diag_mode=diag_mode)
+    ko = level0.edge_keys_from_pairs(O["pairs"], shape)
+    co = level0.canonical_level0(ko, O["xyz"], O["tris"])
+    ch = level0.canonical_level0(keys, xyz, tris)
+    assert counts["n_vertices"] == len(ko) and counts["n_triangles"] == len(O["tris"])
+    assert counts["n_border_voxels"] == O["nborder"]
+    assert len(np.unique(keys)) == len(keys)
+    assert np.array_equal(co[0], ch[0])                                  # crossing-edge set, exact
+    err = np.abs(ch[1].astype(np.float64) - co[1])
+    assert np.all(err <= REL_TOL * np.abs(co[1]) + ABS_FLOOR), err.max()
+    assert np.array_equal(co[2], ch[2])                                  # triangle key triples, exact
+    # winding: normal must point from low to high, checked geometrically where the triangle has area
+    order = np.argsort(ko)
+    pos = {int(k): n for n, k in enumerate(ko[order])}
+    P = O["xyz"][order]
+    pairs = O["pairs"][order].astype(np.float64)
+    grad = pairs[:, 3:] - pairs[:, :3]
+    idx = np.vectorize(pos.get)(keys[tris]) if len(tris) else np.zeros((0, 3), int)
+    p0, p1, p2 = P[idx[:, 0]], P[idx[:, 1]], P[idx[:, 2]]
+    n = np.cross(p1 - p0, p2 - p0)
+    g = grad[idx[:, 0]] + grad[idx[:, 1]] + grad[idx[:, 2]]
+    s = np.einsum("ij,ij->i", n, g)
+    area = np.linalg.norm(n, axis=1)
+    assert np.all(s[area > 1e-9] > 0)
+    return counts
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fields_match_oracle_and_reference(ctx, name):
+    from contourist_amd import _ffi
+    from oracle import level0
+    G = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310, 1)
+    check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CANONICAL, 0)
+    # and directly against the reference's own Level-0 snapshot
+    counts, xyz, keys, tris = hip_level0(ctx, A, v, _ffi.CX_DIAG_CPYTHON310)
+    kr = level0.edge_keys_from_pairs(G["l0_pairs"], A.shape)
+    cr = level0.canonical_level0(kr, G["l0_xyz"], G["l0_tris"])
+    ch = level0.canonical_level0(keys, xyz, tris)
+    assert np.array_equal(cr[0], ch[0]) and np.array_equal(cr[2], ch[2])
+    assert np.all(np.abs(ch[1] - cr[1]) <= REL_TOL * np.abs(cr[1]) + ABS_FLOOR)
+    assert counts["n_border_voxels"] == len(G["surface_voxels"])
+
+
+@pytest.mark.parametrize("shape,seed", [((5, 7, 9), 1), ((2, 2, 2), 2), ((2, 9, 3), 3), ((17, 16, 65), 4),
+                                        ((33, 31, 64), 5), ((64, 64, 64), 6), ((40, 24, 136), 7)])
+def test_random_fields_ragged_shapes(ctx, shape, seed):
+    """open-boundary white noise (surface cuts every array face), odd and minimum sizes"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal(shape).astype(np.float32)
+    for v in (0.0, 0.3):
+        check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310, 1)
+
+
+def test_empty_and_full(ctx):
+    from contourist_amd import _ffi
+    A = np.ones((8, 8, 8), dtype=np.float32)
+    ctx.upload_grid(A)
+    for v in (0.5, 2.0, 1.0):     # all high, all low, all exactly equal (f == v is HIGH)
+        c = ctx.extract3d(v, _ffi.CX_DIAG_CPYTHON310)
+        assert c["n_vertices"] == 0 and c["n_triangles"] == 0 and c["n_cells"] == 0
+
+
+def test_values_equal_to_isovalue_and_tolerances(ctx):
+    """samples exactly at the isovalue, and fields within the reference's np.allclose tolerances"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(9)
+    A = np.round(rng.standard_normal((12, 13, 14)) * 2) / 2
+    check_against_oracle(ctx, A.astype(np.float32), 0.5, _ffi.CX_DIAG_CPYTHON310, 1)
+    B = (rng.standard_normal((12, 12, 12)) * 3e-9).astype(np.float32)          # |f - v| ~ 1e-8 absolute tolerance
+    check_against_oracle(ctx, B, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+    C = (100.0 + rng.standard_normal((12, 12, 12)) * 1.5e-3).astype(np.float32)  # ~ 1e-5 relative tolerance
+    check_against_oracle(ctx, C, 100.0, _ffi.CX_DIAG_CPYTHON310, 1)
+    check_against_oracle(ctx, C, 100.0007, _ffi.CX_DIAG_CPYTHON310, 1)           # isovalue not representable in fp32
+
+
+def test_capacity_growth(ctx):
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(3)
+    A = rng.standard_normal((48, 48, 48)).astype(np.float32)    # ~all voxels active: exceeds default buffers
+    check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
