@@ -61,8 +61,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_post_free(ctx);
     free_outputs(ctx);
     if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
-    if (ctx->emask8) (void)hipFree(ctx->emask8);
-    if (ctx->rowbase) (void)hipFree(ctx->rowbase);
+    if (ctx->celltab) (void)hipFree(ctx->celltab);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -94,11 +93,9 @@ static int set_grid_dims(cx_ctx* ctx, int64_t n0, int64_t n1, int64_t n2) {
     if (N > (1LL << 29)) return fail(ctx, CX_ERR_UNSUPPORTED, "more than 2^29 samples in one grid: partition into slabs");
     // side tables sized for this grid
     if (ctx->tables_for < (size_t)N) {
-        if (ctx->emask8) (void)hipFree(ctx->emask8);
-        if (ctx->rowbase) (void)hipFree(ctx->rowbase);
-        ctx->emask8 = nullptr; ctx->rowbase = nullptr; ctx->tables_for = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->emask8, ((size_t)N + 64 + 7) & ~(size_t)7));
-        CX_HIP(ctx, hipMalloc(&ctx->rowbase, ((size_t)N / 8 + 16) * sizeof(uint32_t)));
+        if (ctx->celltab) (void)hipFree(ctx->celltab);
+        ctx->celltab = nullptr; ctx->tables_for = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
         ctx->tables_for = (size_t)N;
     }
     ctx->n0 = n0; ctx->n1 = n1; ctx->n2 = n2;
@@ -186,10 +183,12 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.div_plane = cx_fdiv_make(P.n1 * P.n2);
     P.div_row = cx_fdiv_make(P.n2);
     P.vcmp = fp32_threshold(value);
+    P.vabs = std::nextafterf((float)std::fabs(value), INFINITY);
+    P.near_screen = 1.1e-5f;
     P.value = value;
     P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
     P.flags = flags;
-    P.emask8 = ctx->emask8; P.rowbase = ctx->rowbase;
+    P.celltab = ctx->celltab;
     P.verts = ctx->verts; P.cells = ctx->cells; P.tris = ctx->tris;
     P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
     P.counters = ctx->counters;

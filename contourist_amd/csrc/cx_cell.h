@@ -1,0 +1,194 @@
+// cx_cell.h -- per-cell device logic of the marching-tetrahedra march, shared by the classify kernels.
+//
+// Reference semantics restated (paths relative to the reference checkout, contourist/...):
+//   border_voxel                      tetrahedral.py:383-394
+//   enumerate_tetrahedron_triangles   tetrahedral.py:561-595
+//   contour_pair_interpolation        tetrahedral.py:471-487
+#pragma once
+#include "cx_common.h"
+
+// corner masks of the 6 tetrahedra: bit c set <=> cube corner c is a vertex of tet t
+#define CX_TETMASK(t) (uint32_t)((1u << cx_d_tet_corners[t][0]) | (1u << cx_d_tet_corners[t][1]) | \
+                                  (1u << cx_d_tet_corners[t][2]) | (1u << cx_d_tet_corners[t][3]))
+
+__device__ __forceinline__ uint32_t cx_lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t cx_mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// exclusive prefix sum over the wave of a small per-lane count (< 2^NBITS), plus the wave total,
+// from NBITS ballots (no LDS, no cross-lane data movement).
+template <int NBITS>
+__device__ __forceinline__ uint32_t cx_wave_prefix_small(uint32_t x, uint32_t& total) {
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int b = 0; b < NBITS; b++) {
+        const uint64_t m = __ballot((x >> b) & 1u);
+        pre += cx_mbcnt(m) << b;
+        tot += (uint32_t)__popcll(m) << b;
+    }
+    total = tot;
+    return pre;
+}
+
+// pattern of tet t inside a voxel sign mask: bit m set <=> tet vertex m is low
+__device__ __forceinline__ uint32_t cx_tet_pattern(uint32_t sm, int t) {
+    return ((sm >> cx_d_tet_corners[t][0]) & 1u) | (((sm >> cx_d_tet_corners[t][1]) & 1u) << 1) |
+           (((sm >> cx_d_tet_corners[t][2]) & 1u) << 2) | (((sm >> cx_d_tet_corners[t][3]) & 1u) << 3);
+}
+
+__device__ __forceinline__ uint32_t cx_tet_ntri(uint32_t pattern) {
+    const uint32_t n = __popc(pattern);
+    return (n == 2) ? 2u : ((n == 1 || n == 3) ? 1u : 0u);
+}
+
+// np.allclose(value, f) for one sample (border_voxel, tetrahedral.py:391): |v-f| <= 1e-8 + 1e-5|f|
+__device__ __forceinline__ bool cx_near_b(double f, double v) { return fabs(v - f) <= 1e-8 + 1e-5 * fabs(f); }
+
+// Is the crossing lattice edge (q, q+d) used by at least one emitted triangle?  Only reached when
+// both end points are within the reference's np.allclose tolerances of the isovalue, where the
+// reference may skip whole voxels (border_voxel) or single tetrahedra (tetrahedral.py:576).
+static __device__ __forceinline__ bool cx_edge_used_slow(const float* A, uint32_t n0, uint32_t n1, uint32_t n2,
+                                                      double value, double tol_value, uint32_t i, uint32_t j,
+                                                      uint32_t k, uint32_t d) {
+    for (uint32_t o = 0; o < 8; o++) {
+        if (o & d) continue;  // q is corner o of voxel p = q - o, q+d is corner o|d
+        const uint32_t oi = (o >> 2) & 1u, oj = (o >> 1) & 1u, ok = o & 1u;
+        if (i < oi || j < oj || k < ok) continue;
+        const uint32_t pi = i - oi, pj = j - oj, pk = k - ok;
+        if (pi + 1 >= n0 || pj + 1 >= n1 || pk + 1 >= n2) continue;
+        uint32_t near_a = 0, all_b = 1;
+        for (uint32_t c = 0; c < 8; c++) {
+            const double f = (double)A[((size_t)(pi + ((c >> 2) & 1u)) * n1 + (pj + ((c >> 1) & 1u))) * n2 + (pk + (c & 1u))];
+            if (fabs(f - value) <= tol_value) near_a |= 1u << c;
+            if (!cx_near_b(f, value)) all_b = 0;
+        }
+        if (all_b) continue;  // not a border voxel: never enumerated
+        const uint32_t c1 = o, c2 = o | d;
+        for (int t = 0; t < 6; t++) {
+            const uint32_t tm = CX_TETMASK(t);
+            if (((tm >> c1) & 1u) && ((tm >> c2) & 1u) && (near_a & tm) != tm) return true;
+        }
+    }
+    return false;
+}
+
+struct cx_cell_info {
+    uint32_t sm;       // bit c: f(corner c) < value   (clamped corners repeat their source)
+    uint32_t emask;    // bit d (1..7): owned edge q->q+d crosses and is used by an emitted triangle
+    uint32_t ntri;     // triangles this voxel emits
+    uint32_t tetskip;  // bit t: tetrahedron t emits nothing because of the reference's tolerances
+    uint32_t border;   // 1 if this is a voxel with a sign change that border_voxel() accepts
+};
+
+// load the 8 corners of cell (i,j,k), out-of-array corners clamped onto the array; vm = validity mask
+__device__ __forceinline__ uint32_t cx_load_corners(const cx_params& P, uint32_t lin, uint32_t i, uint32_t j,
+                                                    uint32_t k, float f[8]) {
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+    const bool vi = (i + 1 < P.n0), vj = (j + 1 < P.n1), vk = (k + 1 < P.n2);
+    const uint32_t oi = vi ? plane : 0u, oj = vj ? P.n2 : 0u, ok = vk ? 1u : 0u;
+    f[0] = A[lin];
+    f[1] = A[lin + ok];
+    f[2] = A[lin + oj];
+    f[3] = A[lin + oj + ok];
+    f[4] = A[lin + oi];
+    f[5] = A[lin + oi + ok];
+    f[6] = A[lin + oi + oj];
+    f[7] = A[lin + oi + oj + ok];
+    uint32_t vm = 1u | (vk ? 2u : 0u) | (vj ? 4u : 0u) | ((vj && vk) ? 8u : 0u);
+    vm |= vi ? (vm << 4) : 0u;
+    return vm;
+}
+
+__device__ __forceinline__ uint32_t cx_sign_mask(const cx_params& P, const float f[8]) {
+    uint32_t sm = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
+    return sm;
+}
+
+// classification of one ACTIVE cell (sign change among its valid corners)
+__device__ __forceinline__ cx_cell_info cx_classify_cell(const cx_params& P, const float f[8], uint32_t vm,
+                                                         uint32_t sm, uint32_t i, uint32_t j, uint32_t k) {
+    cx_cell_info R;
+    R.sm = sm;
+    R.ntri = 0;
+    R.tetskip = 0;
+    R.border = 0;
+    // crossing mask of the 7 owned edges: corner d valid and on the other side than corner 0
+    const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+    R.emask = ((sm ^ s0) & vm) & 0xFEu;
+    // cheap fp32 screen for the reference's np.allclose tolerances (a superset of both float64 tests)
+    bool any_near = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) any_near |= fabsf(f[c] - P.vcmp) <= P.near_screen * fmaxf(fabsf(f[c]), P.vabs) + 4e-8f;
+    const bool real_voxel = (vm == 0xFFu);
+    if (!any_near) {
+        if (real_voxel) {
+            R.border = 1;
+            R.ntri = cx_d_voxel_ntri[sm];
+        } else {
+            R.tetskip = 0x3Fu;  // no voxel here (upper array boundary): the cell only owns edges
+        }
+        return R;
+    }
+    // tolerance masks in float64, exactly as the reference evaluates them
+    uint32_t near_a = 0, nb = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const double fc = (double)f[c];
+        near_a |= (fabs(fc - P.value) <= P.tol_value) ? (1u << c) : 0u;
+        nb |= cx_near_b(fc, P.value) ? (1u << c) : 0u;
+    }
+    if (real_voxel) {
+        if (nb == 0xFFu) {
+            R.tetskip = 0x3Fu;  // border_voxel() false: np.allclose(value, function_values)
+        } else {
+            R.border = 1;
+            for (int t = 0; t < 6; t++) {
+                const uint32_t tm = CX_TETMASK(t);
+                if ((near_a & tm) == tm) R.tetskip |= 1u << t;
+                else R.ntri += cx_tet_ntri(cx_tet_pattern(sm, t));
+            }
+        }
+    } else {
+        R.tetskip = 0x3Fu;
+    }
+    // drop owned crossings that no emitted triangle uses (tolerance skips around them)
+    if (R.emask && ((near_a & 1u) || (nb & 1u))) {
+        for (uint32_t d = 1; d < 8; d++) {
+            if (!((R.emask >> d) & 1u)) continue;
+            const bool suspicious = (((near_a >> d) & near_a & 1u) | ((nb >> d) & nb & 1u)) != 0u;
+            if (suspicious && !cx_edge_used_slow(P.grid, P.n0, P.n1, P.n2, P.value, P.tol_value, i, j, k, d))
+                R.emask &= ~(1u << d);
+        }
+    }
+    return R;
+}
+
+// write the vertex records of one cell starting at slot `slot`
+__device__ __forceinline__ void cx_emit_vertices(const cx_params& P, const float f[8], uint32_t emask, uint32_t lin,
+                                                 uint32_t i, uint32_t j, uint32_t k, uint32_t slot) {
+    const float fi = (float)i, fj = (float)j, fk = (float)k;
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d++) {
+        if ((emask >> d) & 1u) {
+            // fraction from the owning lattice point: (v - f(q)) / (f(q+d) - f(q)); the reference
+            // interpolates from the low end with ratio=(v-flow)/(fhigh-flow), or 0.5 when
+            // |fhigh-flow| <= 1e-8 (tetrahedral.py:483-487) -- identical in exact arithmetic.
+            const double den = (double)f[d] - (double)f[0];
+            float t = 0.5f;
+            if (fabs(den) > 1e-8) t = (float)(P.value - (double)f[0]) / (float)den;
+            float4 rec4;
+            rec4.x = (d & 4u) ? fi + t : fi;
+            rec4.y = (d & 2u) ? fj + t : fj;
+            rec4.z = (d & 1u) ? fk + t : fk;
+            rec4.w = __uint_as_float((lin << 3) | d);
+            P.verts[slot++] = rec4;
+        }
+    }
+}

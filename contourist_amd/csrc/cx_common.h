@@ -35,12 +35,13 @@ struct cx_params {
     cx_fdiv div_plane;     // / (n1*n2)
     cx_fdiv div_row;       // / n2
     float vcmp;            // smallest fp32 >= value :  (double)f < value  <=>  f < vcmp
+    float vabs;            // >= |value| (fp32, rounded up)
+    float near_screen;     // fp32 screen factor (superset of the float64 np.allclose tests)
     double value;          // isovalue (float64, as the reference computes)
     double tol_value;      // 1e-8 + 1e-5*|value|   (np.allclose(values, value), tetrahedral.py:576)
     uint32_t flags;
     // outputs
-    uint8_t* emask8;       // [nsamples + pad] 7-bit crossing mask of the edges each lattice point owns
-    uint32_t* rowbase;     // [nsamples/8 + 1] vertex index of the first vertex owned by an 8-cell row
+    uint64_t* celltab;     // [nsamples] per lattice cell that owns a vertex: (crossing mask << 32) | first vertex index
     float4* verts;         // [vcap]  {x,y,z,bits(edge id)}
     uint4* cells;          // [ccap]  {lin, sign|tetskip<<8|ntri<<16|emask<<24, tri base, first own vertex}
     int32_t* tris;         // [tcap*3]
@@ -57,4 +58,6 @@ extern __device__ __constant__ uint8_t cx_d_voxel_ntri[256];
 
 // kernel launchers (cx_march3d.hip)
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s);
+bool cx_fast_classify_supported(const cx_params& P);
+void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
 void cx_launch_emit_triangles(const cx_params& P, hipStream_t s);

@@ -17,8 +17,7 @@ struct cx_ctx {
     size_t grid_owned_bytes = 0;
     int64_t n0 = 0, n1 = 0, n2 = 0;
     // side tables of the march
-    uint8_t* emask8 = nullptr;
-    uint32_t* rowbase = nullptr;
+    uint64_t* celltab = nullptr;
     size_t tables_for = 0;
     // Level-0 outputs
     float4* verts = nullptr;
@@ -40,8 +39,5 @@ struct cx_ctx {
     evset events[256];
 };
 
-// cx_march3d_fast.hip
-bool cx_fast_classify_supported(const cx_params& P);
-void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);

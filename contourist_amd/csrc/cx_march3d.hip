@@ -1,232 +1,261 @@
 // cx_march3d.hip -- Level-0 kernels of the 3-D marching-tetrahedra voxel march for gfx950 (wave64).
 //
-// Reference semantics restated here (paths relative to the reference checkout, contourist/...):
-//   border_voxel                      tetrahedral.py:383-394
-//   enumerate_tetrahedron_triangles   tetrahedral.py:561-595
-//   contour_pair_interpolation        tetrahedral.py:471-487
-// Data layout / kernel plan: DESIGN.md.
-//
 // Lattice "cell" q = lattice point (i,j,k) seen as the lower corner of the voxel [q, q+1].
 // A cell OWNS the 7 lattice edges q -> q+d, d = 4di+2dj+dk in 1..7, and (when all 8 corners are
 // inside the array) the 6 Kuhn tetrahedra of its voxel.  Vertex id of an edge = (lin(q) << 3) | d.
-#include "cx_common.h"
+//
+// K1  cx_k_classify<FAST>   one pass over the samples
+//       phase A  every wave streams its share of the grid and pushes the ACTIVE cells (sign change
+//                among the corners) into a wave-private LDS queue, in linear-index order.
+//                FAST: lanes hold 4 consecutive k-samples (one 16-byte load per row); the sign
+//                bits of a row are the v_cmp result masks (SGPRs), a cell's 8 corner signs are bit
+//                shifts of 8 such masks, so inactive regions cost no VALU work and no LDS.
+//                generic: one lane per cell, 8 scalar loads (any shape / alignment).
+//       phase B  the wave re-reads the 8 corners of its queued cells (L1/L2 hits), classifies the
+//                tetrahedra, counts vertices/triangles; the workgroup reserves output space with ONE
+//                atomic per counter (same-address atomics saturate near 88/us on MI355X, so they
+//                must stay in the low thousands per launch), then the wave interpolates and writes
+//                vertex records, the per-cell lookup word and one record per active cell.
+// K2  cx_k_emit_triangles   one lane per active-cell record: expands the tetrahedra into index
+//                triples, looking vertex indices up in the per-cell table.
+#include "cx_cell.h"
 
 __device__ __constant__ uint8_t cx_d_tet_corners[6][4] = CX_TET_CORNERS_INIT;
 __device__ __constant__ uint64_t cx_d_tet_tris[6][16][2] = CX_TET_TRIS_INIT;
 __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 
-// corner masks of the 6 tetrahedra: bit c set <=> cube corner c is a vertex of tet t
-#define CX_TETMASK(t) (uint32_t)((1u << cx_d_tet_corners[t][0]) | (1u << cx_d_tet_corners[t][1]) | \
-                                  (1u << cx_d_tet_corners[t][2]) | (1u << cx_d_tet_corners[t][3]))
+#define CX_QCAP 2048u   // active cells a wave can queue before it has to flush on its own
+#define CX_RJ 4         // cell rows per wave in the FAST kernel (a workgroup covers 4*CX_RJ rows)
 
-__device__ __forceinline__ uint32_t lane_id() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-// number of set bits of `mask` below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
+struct cx_task {        // launch geometry of the FAST kernel
+    uint32_t ci;        // cell planes per task
+    uint32_t nks, njg, nic;
+};
 
-// exclusive prefix sum over the wave of a small per-lane count (< 2^NBITS), plus the wave total,
-// from NBITS ballots (no LDS, no cross-lane data movement).
-template <int NBITS>
-__device__ __forceinline__ uint32_t wave_prefix_small(uint32_t x, uint32_t& total) {
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (int b = 0; b < NBITS; b++) {
-        uint64_t m = __ballot((x >> b) & 1u);
-        pre += mbcnt(m) << b;
-        tot += (uint32_t)__popcll(m) << b;
-    }
-    total = tot;
-    return pre;
-}
+// ---- phase B --------------------------------------------------------------------------------------
+struct cx_run {
+    uint32_t v, t, c, b;   // running vertex / triangle / cell-record / border-voxel counts
+};
 
-// pattern of tet t inside a voxel sign mask: bit m set <=> tet vertex m is low
-__device__ __forceinline__ uint32_t tet_pattern(uint32_t sm, int t) {
-    return ((sm >> cx_d_tet_corners[t][0]) & 1u) | (((sm >> cx_d_tet_corners[t][1]) & 1u) << 1) |
-           (((sm >> cx_d_tet_corners[t][2]) & 1u) << 2) | (((sm >> cx_d_tet_corners[t][3]) & 1u) << 3);
-}
-
-__device__ __forceinline__ uint32_t tet_ntri(uint32_t pattern) {
-    uint32_t n = __popc(pattern);
-    return (n == 2) ? 2u : ((n == 1 || n == 3) ? 1u : 0u);
-}
-
-// np.allclose(value, f) for one sample (border_voxel, tetrahedral.py:391): |v-f| <= 1e-8 + 1e-5|f|
-__device__ __forceinline__ bool near_b(double f, double v) { return fabs(v - f) <= 1e-8 + 1e-5 * fabs(f); }
-
-// Is the crossing lattice edge (q, q+d) used by at least one emitted triangle?  Only reached when
-// both end points are within the reference's np.allclose tolerances of the isovalue, where the
-// reference may skip whole voxels (border_voxel) or single tetrahedra (tetrahedral.py:576).
-__device__ __noinline__ bool edge_used_slow(const cx_params& P, uint32_t i, uint32_t j, uint32_t k, uint32_t d) {
-    const float* A = P.grid;
-    const uint32_t n1 = P.n1, n2 = P.n2;
-    for (uint32_t o = 0; o < 8; o++) {
-        if (o & d) continue;  // q is corner o of voxel p = q - o, q+d is corner o|d
-        uint32_t oi = (o >> 2) & 1u, oj = (o >> 1) & 1u, ok = o & 1u;
-        if (i < oi || j < oj || k < ok) continue;
-        uint32_t pi = i - oi, pj = j - oj, pk = k - ok;
-        if (pi + 1 >= P.n0 || pj + 1 >= P.n1 || pk + 1 >= P.n2) continue;
-        uint32_t near_a = 0, all_b = 1;
-        for (uint32_t c = 0; c < 8; c++) {
-            double f = (double)A[((size_t)(pi + ((c >> 2) & 1u)) * n1 + (pj + ((c >> 1) & 1u))) * n2 + (pk + (c & 1u))];
-            if (fabs(f - P.value) <= P.tol_value) near_a |= 1u << c;
-            if (!near_b(f, P.value)) all_b = 0;
-        }
-        if (all_b) continue;  // not a border voxel: never enumerated
-        uint32_t c1 = o, c2 = o | d;
-        for (int t = 0; t < 6; t++) {
-            uint32_t tm = CX_TETMASK(t);
-            if (((tm >> c1) & 1u) && ((tm >> c2) & 1u) && (near_a & tm) != tm) return true;
-        }
-    }
-    return false;
-}
-
-// =================================================================================================
-// K1 (generic shapes): one lane per lattice cell, 64 consecutive linear indices per wave.
-// Classifies the cell, interpolates the edge crossings it owns, reserves output space with one
-// atomic per wave and counter, writes vertex records, the per-cell crossing mask, per-row vertex
-// bases and one record per active cell for the triangle kernel.
-// =================================================================================================
-__global__ __launch_bounds__(256) void cx_k_classify_generic(const cx_params P) {
-    const uint32_t lane = lane_id();
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * waves_per_block;
-    const uint32_t N = P.nsamples;
+// one sweep over the wave's queued cells.  emit == false: only count into `run` (from zero);
+// emit == true: `run` holds the reserved bases and advances as records are written.
+__device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint32_t* q, uint32_t n, uint32_t lane,
+                                                 bool emit, cx_run& run) {
     const uint32_t plane = P.n1 * P.n2;
-    const float* __restrict__ A = P.grid;
-
-    for (uint32_t base = wave * 64u; base < N; base += nwaves * 64u) {
-        const uint32_t lin = base + lane;
-        const bool in = lin < N;
-        const uint32_t linc = in ? lin : (N - 1);
-        const uint32_t i = cx_div(linc, P.div_plane);
-        const uint32_t r = linc - i * plane;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+        const uint32_t idx = b0 + lane;
+        const bool have = idx < n;
+        const uint32_t lin = have ? q[idx] : 0u;
+        const uint32_t i = cx_div(lin, P.div_plane);
+        const uint32_t r = lin - i * plane;
         const uint32_t j = cx_div(r, P.div_row);
         const uint32_t k = r - j * P.n2;
-        // corner validity and clamped offsets
-        const bool vi = (i + 1 < P.n0), vj = (j + 1 < P.n1), vk = (k + 1 < P.n2);
-        const uint32_t oi = vi ? plane : 0u, oj = vj ? P.n2 : 0u, ok = vk ? 1u : 0u;
         float f[8];
-        f[0] = A[linc];
-        f[1] = A[linc + ok];
-        f[2] = A[linc + oj];
-        f[3] = A[linc + oj + ok];
-        f[4] = A[linc + oi];
-        f[5] = A[linc + oi + ok];
-        f[6] = A[linc + oi + oj];
-        f[7] = A[linc + oi + oj + ok];
-        uint32_t vm = 1u | (vk ? 2u : 0u) | (vj ? 4u : 0u) | ((vj && vk) ? 8u : 0u);
-        vm |= vi ? (vm << 4) : 0u;
-        uint32_t sm = 0;
-#pragma unroll
-        for (int c = 0; c < 8; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
+        const uint32_t vm = cx_load_corners(P, lin, i, j, k, f);
+        const uint32_t sm = cx_sign_mask(P, f);
         const uint32_t smv = sm & vm;
-        const bool active = in && (smv != 0u) && (smv != vm);
-        const uint64_t act = __ballot(active);
-        if (act == 0) continue;  // wave-uniform: nothing crosses in these 64 cells
-
-        uint32_t emask = 0, ntri = 0, tetskip = 0, border = 0;
-        if (active) {
-            // crossing mask of the 7 owned edges: corner d valid and on the other side than corner 0
-            const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
-            emask = ((sm ^ s0) & vm) & 0xFEu;
-            // tolerance masks in float64, exactly as the reference evaluates them
-            uint32_t near_a = 0, nb = 0;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const double fc = (double)f[c];
-                near_a |= (fabs(fc - P.value) <= P.tol_value) ? (1u << c) : 0u;
-                nb |= near_b(fc, P.value) ? (1u << c) : 0u;
+        const bool active = have && smv != 0u && smv != vm;
+        cx_cell_info R;
+        R.sm = sm; R.emask = 0; R.ntri = 0; R.tetskip = 0; R.border = 0;
+        if (active) R = cx_classify_cell(P, f, vm, sm, i, j, k);
+        const uint32_t nv = __popc(R.emask);
+        const bool rec = active && (nv != 0u || R.ntri != 0u);
+        uint32_t vtot, ttot;
+        const uint32_t vpre = cx_wave_prefix_small<3>(nv, vtot);
+        const uint32_t tpre = cx_wave_prefix_small<4>(R.ntri, ttot);
+        const uint64_t recm = __ballot(rec);
+        const uint32_t ctot = (uint32_t)__popcll(recm);
+        const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
+        if (emit) {
+            const uint32_t vfirst = run.v + vpre;
+            if (nv && run.v + vtot <= P.vcap) {
+                cx_emit_vertices(P, f, R.emask, lin, i, j, k, vfirst);
+                P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
-            const bool real_voxel = (vm == 0xFFu);
-            if (real_voxel) {
-                if (nb == 0xFFu) {
-                    tetskip = 0x3Fu;  // border_voxel() false: np.allclose(value, function_values)
-                } else {
-                    border = 1;
-                    if (near_a == 0) {
-                        ntri = cx_d_voxel_ntri[sm];
-                    } else {
-                        for (int t = 0; t < 6; t++) {
-                            const uint32_t tm = CX_TETMASK(t);
-                            if ((near_a & tm) == tm) tetskip |= 1u << t;
-                            else ntri += tet_ntri(tet_pattern(sm, t));
-                        }
+            if (rec && run.c + ctot <= P.ccap) {
+                uint4 c4;
+                c4.x = lin;
+                c4.y = sm | (R.tetskip << 8) | (R.ntri << 16) | (R.emask << 24);
+                c4.z = run.t + tpre;
+                c4.w = vfirst;
+                P.cells[run.c + cx_mbcnt(recm)] = c4;
+            }
+        }
+        run.v += vtot; run.t += ttot; run.c += ctot; run.b += btot;
+    }
+}
+
+// FAST phase A bit layout: one u32 per lane and sample plane, 6 bits per sample row r (0..RJ):
+//   bit 6r+m (m=0..3) : sample (row r, k = k0 + 4*lane + m) < isovalue
+//   bit 6r+4          : the same for k+1 of m=3 (next lane's m=0, the halo sample, or a clamped repeat)
+#define CX_ROWBITS 6u
+#define CX_M0_MASK 0x01041041u     // bit 6r+0, r = 0..4
+#define CX_CELL_MASK 0x003CF3CFu   // bits 6r+0..3, r = 0..3  (the 16 cells of a lane: 4 rows x 4 k)
+
+// =================================================================================================
+// K1
+// =================================================================================================
+template <bool FAST>
+__global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx_task T, const uint32_t cells_per_block) {
+    __shared__ uint32_t s_queue[4][CX_QCAP];
+    __shared__ uint32_t s_tot[4][4];
+    __shared__ uint32_t s_base[4];
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* q = s_queue[wave];
+    uint32_t qn = 0;   // wave-uniform
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+
+    // ---- FAST task: block -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
+    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0;
+    bool lane_valid = false, halo_in = false;
+    // ---- generic task: contiguous range of linear cell indices per block
+    uint32_t gbase = 0, gend = 0;
+    bool streaming;
+    if (FAST) {
+        uint32_t b = blockIdx.x;
+        const uint32_t ks = b % T.nks; b /= T.nks;
+        const uint32_t jg = b % T.njg;
+        const uint32_t ic = b / T.njg;
+        k0 = ks * 256u;
+        j0 = jg * (4u * CX_RJ) + wave * CX_RJ;
+        p = ic * T.ci;
+        ib = min(p + T.ci, P.n0);
+        nrows = (j0 < P.n1) ? min((uint32_t)CX_RJ, P.n1 - j0) : 0u;
+        kofs = k0 + 4u * lane;
+        lane_valid = kofs < P.n2;                      // n2 % 4 == 0
+        last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
+        halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
+        streaming = nrows != 0u && p < ib;
+    } else {
+        gbase = blockIdx.x * cells_per_block + wave * 64u;
+        gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
+        streaming = gbase < gend;
+    }
+
+    // sign bits of one sample plane for this lane (FAST)
+    auto plane_bits = [&](uint32_t pp) -> uint32_t {
+        const uint32_t pc = min(pp, P.n0 - 1u);
+        float4 v[CX_RJ + 1];
+        float hv[CX_RJ + 1];
+#pragma unroll
+        for (int r = 0; r <= CX_RJ; r++) {
+            const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
+            const uint32_t rowofs = (pc * P.n1 + jr) * P.n2;
+            v[r] = lane_valid ? *reinterpret_cast<const float4*>(A + rowofs + kofs) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[r] = halo_in ? A[rowofs + k0 + 256u] : 0.f;          // wave-uniform address
+        }
+        uint32_t own = 0, halo = 0;
+#pragma unroll
+        for (int r = 0; r <= CX_RJ; r++) {
+            own |= (v[r].x < P.vcmp) ? (1u << (CX_ROWBITS * r + 0)) : 0u;
+            own |= (v[r].y < P.vcmp) ? (1u << (CX_ROWBITS * r + 1)) : 0u;
+            own |= (v[r].z < P.vcmp) ? (1u << (CX_ROWBITS * r + 2)) : 0u;
+            own |= (v[r].w < P.vcmp) ? (1u << (CX_ROWBITS * r + 3)) : 0u;
+            halo |= (hv[r] < P.vcmp) ? (1u << (CX_ROWBITS * r)) : 0u;
+        }
+        // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
+        // at the array edge, repeats its own m=3 (clamped corner)
+        uint32_t nb = (uint32_t)__shfl_down((int)own, 1) & CX_M0_MASK;
+        if (lane == last_lane) nb = halo_in ? halo : ((own >> 3) & CX_M0_MASK);
+        return own | (nb << 4);
+    };
+
+    if (FAST && streaming) wprev = plane_bits(p);
+
+    for (;;) {
+        // ---- phase A: stream until done or until the queue might not hold another step
+        if (FAST) {
+            while (streaming && qn + 16u * 64u <= CX_QCAP) {
+                const uint32_t wcur = plane_bits(p + 1u);
+                // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
+                const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
+                const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
+                const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
+                const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
+                uint32_t act = o & ~a & CX_CELL_MASK;
+                if (nrows < CX_RJ) act &= (1u << (CX_ROWBITS * nrows)) - 1u;
+                if (!lane_valid) act = 0;
+                if (__ballot(act != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
+                    uint32_t tot;
+                    const uint32_t pre = cx_wave_prefix_small<5>(__popc(act), tot);
+                    uint32_t pos = qn + pre;
+                    const uint32_t lin0 = (p * P.n1 + j0) * P.n2 + kofs;
+                    while (act) {
+                        const uint32_t bit = __ffs(act) - 1u;
+                        act &= act - 1u;
+                        const uint32_t r = bit / CX_ROWBITS, m = bit - r * CX_ROWBITS;
+                        q[pos++] = lin0 + r * P.n2 + m;
                     }
+                    qn += tot;
+                }
+                wprev = wcur;
+                p++;
+                streaming = p < ib;
+            }
+        } else {
+            while (streaming && qn + 64u <= CX_QCAP) {
+                const uint32_t lin = gbase + lane;
+                const bool in = lin < gend;
+                const uint32_t linc = in ? lin : (P.nsamples - 1u);
+                const uint32_t i = cx_div(linc, P.div_plane);
+                const uint32_t r = linc - i * plane;
+                const uint32_t j = cx_div(r, P.div_row);
+                const uint32_t k = r - j * P.n2;
+                float f[8];
+                const uint32_t vm = cx_load_corners(P, linc, i, j, k, f);
+                const uint32_t smv = cx_sign_mask(P, f) & vm;
+                const bool active = in && smv != 0u && smv != vm;
+                const uint64_t act = __ballot(active);
+                if (active) q[qn + cx_mbcnt(act)] = lin;
+                qn += (uint32_t)__popcll(act);
+                gbase += 256u;
+                streaming = gbase < gend;
+            }
+        }
+        // ---- phase B: count, reserve, emit.  The last round of a workgroup reserves once for all
+        // four waves; a wave whose queue filled up early reserves for itself (dense surfaces only).
+        const bool final_round = !streaming;
+        cx_run run = {0, 0, 0, 0};
+        for (int pass = 0; pass < 2; pass++) {
+            cx_process_queue(P, q, qn, lane, pass == 1, run);
+            if (pass == 1) break;
+            if (final_round) {
+                if (lane == 0) {
+                    s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const uint32_t v = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
+                    const uint32_t t = s_tot[0][1] + s_tot[1][1] + s_tot[2][1] + s_tot[3][1];
+                    const uint32_t c = s_tot[0][2] + s_tot[1][2] + s_tot[2][2] + s_tot[3][2];
+                    const uint32_t bb = s_tot[0][3] + s_tot[1][3] + s_tot[2][3] + s_tot[3][3];
+                    s_base[0] = v ? atomicAdd(&P.counters[CX_CNT_VERTS], v) : 0u;
+                    s_base[1] = t ? atomicAdd(&P.counters[CX_CNT_TRIS], t) : 0u;
+                    s_base[2] = c ? atomicAdd(&P.counters[CX_CNT_CELLS], c) : 0u;
+                    if (bb) atomicAdd(&P.counters[CX_CNT_BORDER], bb);
+                }
+                __syncthreads();
+                run.v = s_base[0]; run.t = s_base[1]; run.c = s_base[2];
+                for (uint32_t w = 0; w < wave; w++) {
+                    run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
                 }
             } else {
-                tetskip = 0x3Fu;  // no voxel here (upper array boundary): the cell only owns edges
-            }
-            // drop owned crossings that no emitted triangle uses (tolerance skips around them)
-            if (emask && ((near_a & 1u) || (nb & 1u))) {
-                for (uint32_t d = 1; d < 8; d++) {
-                    if (!((emask >> d) & 1u)) continue;
-                    const bool suspicious = (((near_a >> d) & near_a & 1u) | ((nb >> d) & nb & 1u)) != 0u;
-                    if (suspicious && !edge_used_slow(P, i, j, k, d)) emask &= ~(1u << d);
+                cx_run base = {0, 0, 0, 0};
+                if (lane == 0) {
+                    if (run.v) base.v = atomicAdd(&P.counters[CX_CNT_VERTS], run.v);
+                    if (run.t) base.t = atomicAdd(&P.counters[CX_CNT_TRIS], run.t);
+                    if (run.c) base.c = atomicAdd(&P.counters[CX_CNT_CELLS], run.c);
+                    if (run.b) atomicAdd(&P.counters[CX_CNT_BORDER], run.b);
                 }
+                run.v = __builtin_amdgcn_readfirstlane(base.v);
+                run.t = __builtin_amdgcn_readfirstlane(base.t);
+                run.c = __builtin_amdgcn_readfirstlane(base.c);
             }
         }
-        const uint32_t nv = __popc(emask);
-        const bool rec = active && (nv != 0u || ntri != 0u);
-        uint32_t vtot, ttot;
-        const uint32_t vpre = wave_prefix_small<3>(nv, vtot);
-        const uint32_t tpre = wave_prefix_small<4>(ntri, ttot);
-        const uint64_t recm = __ballot(rec);
-        const uint32_t cpre = mbcnt(recm);
-        const uint32_t ctot = (uint32_t)__popcll(recm);
-        const uint32_t btot = (uint32_t)__popcll(__ballot(border != 0));
-        uint32_t vbase = 0, tbase = 0, cbase = 0;
-        if (lane == 0) {
-            if (vtot) vbase = atomicAdd(&P.counters[CX_CNT_VERTS], vtot);
-            if (ttot) tbase = atomicAdd(&P.counters[CX_CNT_TRIS], ttot);
-            if (ctot) cbase = atomicAdd(&P.counters[CX_CNT_CELLS], ctot);
-            if (btot) atomicAdd(&P.counters[CX_CNT_BORDER], btot);
-        }
-        vbase = __builtin_amdgcn_readfirstlane(vbase);
-        tbase = __builtin_amdgcn_readfirstlane(tbase);
-        cbase = __builtin_amdgcn_readfirstlane(cbase);
-        const uint32_t vfirst = vbase + vpre;
-
-        // per-cell crossing masks and per-row bases for every 8-cell row that owns a vertex
-        const uint64_t owners = __ballot(nv != 0u);
-        const uint32_t rowbits = (uint32_t)(owners >> (lane & ~7u)) & 0xFFu;
-        if (in && rowbits) {
-            P.emask8[lin] = (uint8_t)emask;
-            if ((lane & 7u) == 0u) P.rowbase[lin >> 3] = vfirst;
-        }
-        if (nv && vbase + vtot <= P.vcap) {
-            const float fi = (float)i, fj = (float)j, fk = (float)k;
-            uint32_t slot = vfirst;
-#pragma unroll
-            for (uint32_t d = 1; d < 8; d++) {
-                if ((emask >> d) & 1u) {
-                    // fraction from the owning lattice point: (v - f(q)) / (f(q+d) - f(q)); the
-                    // reference interpolates from the low end with ratio=(v-flow)/(fhigh-flow),
-                    // or 0.5 when |fhigh-flow| <= 1e-8 -- identical in exact arithmetic.
-                    const double den = (double)f[d] - (double)f[0];
-                    float t = 0.5f;
-                    if (fabs(den) > 1e-8) t = (float)(P.value - (double)f[0]) / (float)den;
-                    float4 rec4;
-                    rec4.x = (d & 4u) ? fi + t : fi;
-                    rec4.y = (d & 2u) ? fj + t : fj;
-                    rec4.z = (d & 1u) ? fk + t : fk;
-                    rec4.w = __uint_as_float((lin << 3) | d);
-                    P.verts[slot++] = rec4;
-                }
-            }
-        }
-        if (rec && cbase + ctot <= P.ccap) {
-            uint4 c4;
-            c4.x = lin;
-            c4.y = sm | (tetskip << 8) | (ntri << 16) | (emask << 24);
-            c4.z = tbase + tpre;
-            c4.w = vfirst;
-            P.cells[cbase + cpre] = c4;
-        }
+        qn = 0;
+        if (final_round) break;
     }
 }
 
@@ -254,21 +283,14 @@ __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
     return s2 < s1;
 }
 
-// vertex index of edge ref e = (c1 << 3) | d, given per-corner first-vertex index and crossing mask
-struct corner_lut {
-    uint32_t vfirst[8];
-    uint32_t emask[8];
-};
-
 // =================================================================================================
 // K2: one lane per active-cell record; expands the 6 tetrahedra into index triples.
 // =================================================================================================
 __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P) {
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
-    const uint32_t ntris_total = P.counters[CX_CNT_TRIS];
-    if (ntris_total > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host will re-run with more room
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     const uint32_t plane = P.n1 * P.n2;
-    const uint64_t* __restrict__ emask64 = reinterpret_cast<const uint64_t*>(P.emask8);
+    const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncells; idx += gridDim.x * blockDim.x) {
         const uint4 c4 = P.cells[idx];
         const uint32_t ntri = (c4.y >> 16) & 0xFFu;
@@ -276,24 +298,25 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P) {
         const uint32_t lin = c4.x;
         const uint32_t sm = c4.y & 0xFFu, tetskip = (c4.y >> 8) & 0x3Fu;
         // first-vertex index and crossing mask of the 7 corners that can own an edge of this voxel
-        uint32_t vfirst[8], em[8];
+        uint32_t vfirst[7], em[7];
+        vfirst[0] = c4.w;
+        em[0] = c4.y >> 24;
 #pragma unroll
-        for (uint32_t c = 0; c < 7; c++) {
-            const uint32_t lc = lin + ((c & 4u) ? plane : 0u) + ((c & 2u) ? P.n2 : 0u) + (c & 1u);
-            // does corner c own a crossing edge of this voxel?  (some corner c2 > c, c subset of c2, other side)
+        for (uint32_t c = 1; c < 7; c++) {
+            // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
             const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
-            uint32_t sup = 0;  // corners that are strict supersets of c
+            uint32_t sup = 0;
 #pragma unroll
             for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
-            if (((sm ^ sc) & sup) == 0u) { vfirst[c] = 0; em[c] = 0; continue; }
-            const uint64_t m64 = emask64[lc >> 3];
-            const uint32_t sh = (lc & 7u) * 8u;
-            em[c] = (uint32_t)(m64 >> sh) & 0xFFu;
-            vfirst[c] = P.rowbase[lc >> 3] + (uint32_t)__popcll(m64 & ((1ULL << sh) - 1ULL));
+            vfirst[c] = 0; em[c] = 0;
+            if (((sm ^ sc) & sup) != 0u) {
+                const uint32_t lc = lin + ((c & 4u) ? plane : 0u) + ((c & 2u) ? P.n2 : 0u) + (c & 1u);
+                const uint64_t e = P.celltab[lc];
+                vfirst[c] = (uint32_t)e;
+                em[c] = (uint32_t)(e >> 32);
+            }
         }
-        vfirst[7] = 0; em[7] = 0;
         uint32_t ci = 0, cj = 0, ck = 0;
-        const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
         if (emulate) {
             ci = cx_div(lin, P.div_plane);
             const uint32_t r = lin - ci * plane;
@@ -303,25 +326,25 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P) {
         int32_t* out = P.tris + (size_t)c4.z * 3u;
         for (int t = 0; t < 6; t++) {
             if ((tetskip >> t) & 1u) continue;
-            const uint32_t pat = tet_pattern(sm, t);
+            const uint32_t pat = cx_tet_pattern(sm, t);
             uint32_t variant = 0;
             if (emulate && __popc(pat) == 2) {
                 // low set and high set, each in insertion (tet vertex) order
-                uint64_t hl[2], hh[2];
+                uint64_t hl[2] = {0, 0}, hh[2] = {0, 0};
                 int nl = 0, nh = 0;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const uint32_t c = cx_d_tet_corners[t][m];
                     const uint64_t h = py_tuplehash3(ci + ((c >> 2) & 1u), cj + ((c >> 1) & 1u), ck + (c & 1u));
-                    if ((pat >> m) & 1u) { if (nl < 2) hl[nl] = h; nl++; }
-                    else { if (nh < 2) hh[nh] = h; nh++; }
+                    if ((pat >> m) & 1u) { if (nl == 0) hl[0] = h; else hl[1] = h; nl++; }
+                    else { if (nh == 0) hh[0] = h; else hh[1] = h; nh++; }
                 }
                 variant = (py_set2_swapped(hl[0], hl[1]) != py_set2_swapped(hh[0], hh[1])) ? 1u : 0u;
             }
             const uint64_t e = cx_d_tet_tris[t][pat][variant];
             const uint32_t n = (uint32_t)(e >> 36) & 3u;
-            for (uint32_t q = 0; q < n; q++) {
-                const uint32_t tri = (uint32_t)(e >> (18u * q)) & 0x3FFFFu;
+            for (uint32_t qd = 0; qd < n; qd++) {
+                const uint32_t tri = (uint32_t)(e >> (18u * qd)) & 0x3FFFFu;
 #pragma unroll
                 for (uint32_t s = 0; s < 3; s++) {
                     const uint32_t ref = (tri >> (6u * s)) & 0x3Fu;
@@ -337,12 +360,36 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P) {
     }
 }
 
+// ---- launchers --------------------------------------------------------------------------------------
+bool cx_fast_classify_supported(const cx_params& P) {
+    return (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
+}
+
+void cx_launch_classify_fast(const cx_params& P, hipStream_t s) {
+    cx_task T;
+    T.nks = (P.n2 + 255u) / 256u;
+    T.njg = (P.n1 + 4u * CX_RJ - 1u) / (4u * CX_RJ);
+    // planes per task: aim at >= ~2048 workgroups, between 4 and 32 planes each
+    const uint32_t per_plane = T.nks * T.njg;
+    uint32_t want_chunks = (2048u + per_plane - 1u) / per_plane;
+    if (want_chunks < 1u) want_chunks = 1u;
+    uint32_t ci = (P.n0 + want_chunks - 1u) / want_chunks;
+    if (ci < 4u) ci = 4u;
+    if (ci > 32u) ci = 32u;
+    T.ci = ci;
+    T.nic = (P.n0 + ci - 1u) / ci;
+    const uint32_t blocks = T.nks * T.njg * T.nic;
+    hipLaunchKernelGGL(cx_k_classify<true>, dim3(blocks), dim3(256), 0, s, P, T, 0u);
+}
+
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s) {
-    const uint32_t chunks = (P.nsamples + 63u) / 64u;          // 64-cell wave chunks
-    uint32_t blocks = (chunks + 3u) / 4u;
-    const uint32_t cap = 256u * 16u;                          // 16 blocks per CU, grid-stride beyond
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(cx_k_classify_generic, dim3(blocks), dim3(256), 0, s, P);
+    cx_task T = {0, 0, 0, 0};
+    // contiguous cell ranges per block: multiples of 256, at least 16384, about 2048 blocks
+    uint32_t cpb = (P.nsamples + 2047u) / 2048u;
+    cpb = (cpb + 255u) & ~255u;
+    if (cpb < 16384u) cpb = 16384u;
+    const uint32_t blocks = (P.nsamples + cpb - 1u) / cpb;
+    hipLaunchKernelGGL(cx_k_classify<false>, dim3(blocks), dim3(256), 0, s, P, T, cpb);
 }
 
 void cx_launch_emit_triangles(const cx_params& P, hipStream_t s) {

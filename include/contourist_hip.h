@@ -45,7 +45,7 @@ typedef struct {
     int64_t n_cells;         /* lattice cells with a sign change among their corners */
     int64_t n_vertices;      /* interpolated edge crossings == len(interpolated_contour_pairs) */
     int64_t n_triangles;     /* == len(simplex_sets) before quantize_interpolations */
-    int64_t n_border_voxels; /* voxels for which GridContour.border_voxel() is true */
+    int64_t n_border_voxels; /* voxels with a sign change for which GridContour.border_voxel() is true */
 } cx_counts;
 
 /* ---- context --------------------------------------------------------------------------------- */

@@ -57,15 +57,15 @@ def march3d(A, value, diag_mode=1, vcap=None, tcap=None):
         pairs = np.zeros((vcap, 6), dtype=np.int32)
         xyz = np.zeros((vcap, 3), dtype=np.float64)
         tris = np.zeros((tcap, 3), dtype=np.int64)
-        counts = np.zeros(3, dtype=np.int64)
+        counts = np.zeros(4, dtype=np.int64)
         rc = lib().oracle_march3d(A.ctypes.data, *A.shape, float(value), int(diag_mode),
                                   pairs.ctypes.data, xyz.ctypes.data, vcap, tris.ctypes.data, tcap,
                                   counts.ctypes.data)
         if rc != 0:
             raise MemoryError("oracle_march3d")
-        nv, nt, nb = (int(c) for c in counts)
+        nv, nt, nb, nbm = (int(c) for c in counts)
         if nv <= vcap and nt <= tcap:
-            return dict(pairs=pairs[:nv].copy(), xyz=xyz[:nv].copy(), tris=tris[:nt].copy(), nborder=nb)
+            return dict(pairs=pairs[:nv].copy(), xyz=xyz[:nv].copy(), tris=tris[:nt].copy(), nborder=nb, nborder_mixed=nbm)
         vcap = max(vcap * 2, nv + 1)
         tcap = max(tcap * 2, nt + 1)
 
@@ -76,6 +76,8 @@ def edge_keys_from_pairs(pairs, shape):
     """unordered lattice edge -> int64 key = linear_index(lexicographically smaller endpoint)*8 + dir,
     dir = 4*di+2*dj+dk in 1..7 (the device's vertex id)."""
     pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 6)
+    if len(pairs) == 0:
+        return np.zeros(0, dtype=np.int64)
     lo = np.minimum(pairs[:, :3], pairs[:, 3:])
     hi = np.maximum(pairs[:, :3], pairs[:, 3:])
     d = hi - lo

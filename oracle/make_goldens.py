@@ -119,6 +119,9 @@ def fields():
     F["noise_14x20x26"] = dict(A=close_interior(B, float(B.min()) - 1.0), value=0.1)
     # tiny amplitude: exercises the 1e-8 absolute tolerances (np.allclose) of the reference
     F["tiny_amp16"] = dict(A=(close_interior(smooth_noise(16, 3, 2), -4.0) * np.float32(2e-9)), value=0.0)
+    F["tiny_amp16b"] = dict(A=(close_interior(smooth_noise(16, 3, 2), -4.0) * np.float32(1.2e-8)), value=0.0)
+    # relative tolerance regime: values ~100, differences ~1e-3 (1e-5 * 100)
+    F["rel_tol16"] = dict(A=(np.float32(100.0) + close_interior(smooth_noise(16, 4, 2), -4.0) * np.float32(1.2e-3)), value=100.0)
     # samples exactly equal to the isovalue (f == v counts as HIGH; strict search test differs)
     Q = np.round(close_interior(smooth_noise(18, 21, 2), -3.0) * 2.0) / 2.0
     F["quantised18"] = dict(A=Q.astype(np.float32), value=0.5)

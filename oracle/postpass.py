@@ -188,12 +188,17 @@ def orient(xyz, tris):
     ties: last wins in the reference's set order; here the largest triangle id), wind it so that
     component is positive (:99-103) and flood-fill across shared edges so that a neighbour traverses
     the shared edge in the opposite direction (:110-138).
-    returns (tris_oriented (T,3) in input order, component_label (T,))"""
+    returns (tris_oriented (T,3) in input order, component_label (T,), comp_flags (ncomp,) uint8)
+    comp_flags bit 0: the component is not an orientable edge-manifold (an edge with more than two
+    triangles, or the flood fill met a conflicting orientation) -> the reference's result depends on
+    its traversal order; bit 1: the start rule is ambiguous (several vertices share the largest x, or
+    several of their triangles share the largest |cross_x|, and they do not all imply the same
+    winding, or cross_x is exactly 0) -> the reference's result depends on its vertex numbering."""
     xyz = np.asarray(xyz, dtype=np.float64)
     tris = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
     T = len(tris)
     if T == 0:
-        return tris, np.zeros(0, np.int64)
+        return tris, np.zeros(0, np.int64), np.zeros(0, np.uint8)
     edge_tris = {}
     vert_tris = {}
     for t in range(T):
@@ -237,7 +242,35 @@ def orient(xyz, tris):
                         stack.append((t2, (i1, i2, i3)))
         ncomp += 1
     out = np.array([orientation[t] for t in range(T)], dtype=np.int64).reshape(-1, 3)
-    return out, label
+    flags = np.zeros(ncomp, dtype=np.uint8)
+    # bit 0: non-manifold / non-orientable
+    for e, ts in edge_tris.items():
+        if len(ts) > 2:
+            flags[label[ts[0]]] |= 1
+        elif len(ts) == 2:
+            def direction(t):
+                o = orientation[t]
+                for n in range(3):
+                    if {o[n], o[(n + 1) % 3]} == set(e):
+                        return (o[n], o[(n + 1) % 3])
+            if direction(ts[0]) == direction(ts[1]):
+                flags[label[ts[0]]] |= 1
+    # bit 1: ambiguous start
+    for cid in range(ncomp):
+        members = np.nonzero(label == cid)[0]
+        vs = np.unique(tris[members].reshape(-1))
+        xmax = xyz[vs, 0].max()
+        for v in vs[xyz[vs, 0] == xmax]:
+            cand = [t for t in vert_tris[int(v)] if label[t] == cid]
+            dots = []
+            for t in cand:
+                a, b, c = (xyz[i] for i in orientation[t])
+                dots.append(np.cross(a - b, a - c)[0])
+            m = max(abs(d) for d in dots)
+            for d in dots:
+                if abs(d) >= m * (1 - 1e-12) and d <= 0:
+                    flags[cid] |= 2
+    return out, label, flags
 
 
 def canonical_level1(grid_points, triangles, corner):
@@ -268,14 +301,81 @@ def level1_from_level0(keys, xyz, tris, corner):
     xyz = np.asarray(xyz, dtype=np.float64)
     rep, t1 = weld(keys, xyz, tris, corner)
     n_after_weld = len(t1)
-    sites = tiny_sites(xyz, t1, corner)
+    # where the reference's hash-order artefacts can act: welded groups (which member represents
+    # the bucket), tiny triangles (merge point), zero-area triangles (merge direction)
+    welded = np.nonzero(rep != np.arange(len(rep)))[0]
+    group = np.unique(np.concatenate([welded, rep[welded]])) if len(welded) else np.zeros(0, np.int64)
+    sites = np.concatenate([xyz[group].reshape(-1, 3), tiny_sites(xyz, t1, corner).reshape(-1, 3)], axis=0)
     xyz2, t2 = tiny_collapse(keys, xyz, t1, corner)
     n_after_tiny = len(t2)
     x3, t3, _ = extract(xyz2, t2)
+    # vertices of zero-area triangles: clean_triangles merges them in hash order (not contractual)
+    if len(t3):
+        Pc = x3[t3]
+        crossc = np.cross(Pc[:, 0] - Pc[:, 2], Pc[:, 1] - Pc[:, 2])
+        degenerate = np.all(np.abs(crossc) <= 1e-8, axis=1)
+        sites = np.concatenate([sites.reshape(-1, 3), Pc[degenerate].reshape(-1, 3)], axis=0)
     x4, t4 = clean(x3, t3)
-    t5, label = orient(x4, t4)
+    t5, label, comp_flags = orient(x4, t4)
     return dict(grid_points=x4, triangles=t5, n_after_weld=n_after_weld, n_after_tiny=n_after_tiny,
-                labels=label, sites=sites)
+                labels=label, comp_flags=comp_flags, sites=sites)
+
+
+def _unoriented(rows):
+    rows = np.asarray(rows, dtype=np.int64).reshape(-1, 3, 3)
+    out = []
+    for r in rows:
+        out.append(tuple(sorted(tuple(int(x) for x in b) for b in r)))
+    return out
+
+
+def compare_level1(oracle_L1, other_points, other_tris, corner, reach=2):
+    """Compare another Level-1 mesh (the reference's golden, or the HIP path's output) with the
+    oracle's canonical Level-1 result `oracle_L1` (dict of level1_from_level0).
+
+    Contract: same triangles as triples of weld buckets, same winding.  Not
+    contractual, hence excused: (a) rows touching a site where the reference's hash order picks a
+    weld representative / merge point (`sites`); (b) the winding of components whose orientation the
+    reference itself only fixes through traversal order or vertex numbering (comp_flags).
+    returns dict(missing, extra: unexcused unoriented rows on one side only;
+                 winding: unexcused winding mismatches; excused_rows, excused_winding)"""
+    o_rows = canonical_level1(oracle_L1["grid_points"], oracle_L1["triangles"], corner)
+    x_rows = canonical_level1(other_points, other_tris, corner)
+    # component flags of the oracle's triangles, keyed by unoriented row
+    q = weld_buckets(oracle_L1["grid_points"], corner)
+    o_tris = np.asarray(oracle_L1["triangles"], dtype=np.int64).reshape(-1, 3)
+    flag_of = {}
+    for t, lab in zip(o_tris, oracle_L1["labels"]):
+        key = tuple(sorted(tuple(int(x) for x in q[v]) for v in t))
+        flag_of[key] = int(oracle_L1["comp_flags"][lab])
+    o_un, x_un = _unoriented(o_rows), _unoriented(x_rows)
+    o_map = dict(zip(o_un, map(tuple, o_rows.tolist())))
+    x_map = dict(zip(x_un, map(tuple, x_rows.tolist())))
+    sites = oracle_L1["sites"]
+    sb = weld_buckets(np.asarray(sites, dtype=np.float64).reshape(-1, 3), corner) if len(sites) else np.zeros((0, 3), np.int64)
+
+    def near_site(un):
+        if len(sb) == 0:
+            return False
+        b = np.array(un, dtype=np.int64).reshape(3, 3)
+        d = np.abs(b[:, None, :] - sb[None, :, :]).max(axis=2)
+        return bool((d <= reach).any())
+    missing = [u for u in o_map if u not in x_map]
+    extra = [u for u in x_map if u not in o_map]
+    res = dict(excused_rows=0, excused_winding=0)
+    res["missing"] = [u for u in missing if not near_site(u)]
+    res["extra"] = [u for u in extra if not near_site(u)]
+    res["excused_rows"] = len(missing) + len(extra) - len(res["missing"]) - len(res["extra"])
+    winding = []
+    for u, row in o_map.items():
+        if u in x_map and x_map[u] != row:
+            if flag_of.get(u, 0) != 0 or near_site(u):
+                res["excused_winding"] += 1
+            else:
+                winding.append(u)
+    res["winding"] = winding
+    res["n_oracle"], res["n_other"] = len(o_rows), len(x_rows)
+    return res
 
 
 def compare_canonical(ref_rows, got_rows, sites, corner, reach=2):

@@ -46,19 +46,23 @@ def test_level1_canonical(name):
     assert L1["n_after_weld"] == int(G["n_tris_after_weld"])   # invariant through the weld
     band = G["l1_count_band"]
     n_tiny = L1["n_after_weld"] - L1["n_after_tiny"]
-    ref = postpass.canonical_level1(G["l1_grid_points"], G["l1_triangles"], corner)
-    got = postpass.canonical_level1(L1["grid_points"], L1["triangles"], corner)
-    if n_tiny == 0 and bool(G["l1_order_invariant"]):
+    nsites = len(L1["sites"])
+    cmp = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner)
+    # same triangles (as weld-bucket triples) and same winding, except where the reference's own
+    # hash order decides (weld representative, tiny-collapse merge point, ambiguous orientation)
+    assert not cmp["missing"] and not cmp["extra"], (cmp["missing"][:2], cmp["extra"][:2])
+    assert not cmp["winding"], cmp["winding"][:2]
+    assert cmp["excused_rows"] <= 20 * max(nsites, 1)
+    if nsites == 0:
         assert L1["n_after_tiny"] == int(G["n_tris_after_tiny"])
-        assert np.array_equal(ref, got)                        # same triangles, same winding, exact
+        assert cmp["n_oracle"] == cmp["n_other"] == len(G["l1_triangles"])
+        assert cmp["excused_rows"] == 0
     else:
-        # tiny-collapse merge points are the reference's hash-order artefacts (not contractual):
-        # everything away from the collapse sites must still agree exactly
-        assert abs(L1["n_after_tiny"] - int(G["n_tris_after_tiny"])) <= n_tiny
-        assert abs(len(L1["triangles"]) - len(G["l1_triangles"])) <= max(2 * n_tiny, band[1] - band[0])
-        bad_r, bad_g, excused = postpass.compare_canonical(ref, got, L1["sites"], corner)
-        assert not bad_r and not bad_g, (bad_r[:3], bad_g[:3])
-        assert excused <= 40 * max(n_tiny, 1)
+        assert abs(L1["n_after_tiny"] - int(G["n_tris_after_tiny"])) <= max(n_tiny, 2)
+        assert abs(len(L1["triangles"]) - len(G["l1_triangles"])) <= max(2 * n_tiny, band[1] - band[0], 4)
+    if name in ("sphere32", "inv_sphere20", "shells24", "blobs27", "noise24_v0", "noise32_v0"):
+        # well-behaved closed surfaces: nothing about the winding may need excusing
+        assert cmp["excused_winding"] == 0
 
 
 def test_two_dots_reference_golden():
