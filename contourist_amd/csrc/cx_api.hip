@@ -62,6 +62,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     free_outputs(ctx);
     if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
     if (ctx->celltab) (void)hipFree(ctx->celltab);
+    if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -193,6 +194,17 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
     P.counters = ctx->counters;
     ctx->last = P;
+    if ((flags & CX_DIAG_CPYTHON310) && (ctx->hash_xy_n0 != ctx->n0 || ctx->hash_xy_n1 != ctx->n1)) {
+        const size_t need = (size_t)(ctx->n0 * ctx->n1);
+        if (ctx->hash_xy_cap < need) {
+            if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
+            ctx->hash_xy = nullptr; ctx->hash_xy_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->hash_xy, need * sizeof(uint64_t)));
+            ctx->hash_xy_cap = need;
+        }
+        cx_launch_hash_xy(ctx->hash_xy, P.n0, P.n1, ctx->stream);
+        ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
+    }
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {
         if (ctx->nevents < (int)(sizeof(ctx->events) / sizeof(ctx->events[0]))) {
@@ -206,7 +218,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (!(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported(P)) cx_launch_classify_fast(P, ctx->stream);
     else cx_launch_classify_generic(P, ctx->stream);
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
-    cx_launch_emit_triangles(P, ctx->stream);
+    if (!(flags & CX_DBG_NO_EMIT)) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
     CX_HIP(ctx, hipGetLastError());
     ctx->extracted = true;

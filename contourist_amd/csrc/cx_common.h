@@ -49,6 +49,16 @@ struct cx_params {
     uint32_t* counters;    // [0] cells [1] verts [2] tris [3] border voxels
 };
 
+// debug / ablation flags (timing experiments only; results are wrong when set)
+#define CX_DBG_PHASE_A_ONLY 0x10000u   // classify kernel: stream + queue, skip phase B
+#define CX_DBG_COUNT_ONLY 0x20000u     // phase B: count pass only
+#define CX_DBG_NO_CELLTAB 0x40000u     // phase B: skip the per-cell table store
+#define CX_DBG_NO_VERTS 0x80000u       // phase B: skip vertex record stores
+#define CX_DBG_NO_CELLS 0x100000u      // phase B: skip cell record stores
+#define CX_DBG_NO_LOOKUP 0x200000u     // emit kernel: skip neighbour table lookups
+#define CX_DBG_NO_TRIS 0x400000u       // emit kernel: skip triangle stores
+#define CX_DBG_NO_EMIT 0x800000u       // skip the emit kernel
+
 enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_WORDS = 8 };
 
 // device tables (defined in cx_march3d.hip)
@@ -60,4 +70,5 @@ extern __device__ __constant__ uint8_t cx_d_voxel_ntri[256];
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s);
 bool cx_fast_classify_supported(const cx_params& P);
 void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
-void cx_launch_emit_triangles(const cx_params& P, hipStream_t s);
+void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
+void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, hipStream_t s);

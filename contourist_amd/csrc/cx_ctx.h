@@ -19,6 +19,9 @@ struct cx_ctx {
     // side tables of the march
     uint64_t* celltab = nullptr;
     size_t tables_for = 0;
+    uint64_t* hash_xy = nullptr;       // CPython tuple-hash prefix per (i,j), for CX_DIAG_CPYTHON310
+    size_t hash_xy_cap = 0;
+    int64_t hash_xy_n0 = 0, hash_xy_n1 = 0;
     // Level-0 outputs
     float4* verts = nullptr;
     uint4* cells = nullptr;

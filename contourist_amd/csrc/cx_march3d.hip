@@ -69,10 +69,10 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint3
         if (emit) {
             const uint32_t vfirst = run.v + vpre;
             if (nv && run.v + vtot <= P.vcap) {
-                cx_emit_vertices(P, f, R.emask, lin, i, j, k, vfirst);
-                P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+                if (!(P.flags & CX_DBG_NO_VERTS)) cx_emit_vertices(P, f, R.emask, lin, i, j, k, vfirst);
+                if (!(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
-            if (rec && run.c + ctot <= P.ccap) {
+            if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
                 uint4 c4;
                 c4.x = lin;
                 c4.y = sm | (R.tetskip << 8) | (R.ntri << 16) | (R.emask << 24);
@@ -83,6 +83,32 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint3
         }
         run.v += vtot; run.t += ttot; run.c += ctot; run.b += btot;
     }
+}
+
+// vertex / triangle / record / border counts of an active cell from its sign mask alone -- exact
+// unless a corner is within the reference's np.allclose tolerances of the isovalue (then phase B
+// recounts exactly).
+struct cx_cnt {
+    uint32_t v, t, c, b;
+};
+__device__ __forceinline__ void cx_count_from_signs(uint32_t sm, uint32_t vm, cx_cnt& acc) {
+    const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+    const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
+    const bool real_voxel = (vm == 0xFFu);
+    const uint32_t nt = real_voxel ? (uint32_t)cx_d_voxel_ntri[sm] : 0u;
+    acc.v += nv;
+    acc.t += nt;
+    acc.c += (nv | nt) ? 1u : 0u;
+    acc.b += real_voxel ? 1u : 0u;
+}
+// fp32 screen (superset of both float64 np.allclose tests): |f - v| <= s*(|f| + |v|) + c
+__device__ __forceinline__ bool cx_near_screen(const cx_params& P, float f) {
+    return fabsf(f - P.vcmp) <= fmaf(fabsf(f), P.near_screen, P.near_screen * P.vabs + 4e-8f);
+}
+__device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
+    return x;
 }
 
 // FAST phase A bit layout: one u32 per lane and sample plane, 6 bits per sample row r (0..RJ):
@@ -104,11 +130,13 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* q = s_queue[wave];
     uint32_t qn = 0;   // wave-uniform
+    cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the queued cells (from sign masks)
+    bool suspect = false;        // per-lane: a sample within the tolerance screen was seen
     const float* __restrict__ A = P.grid;
     const uint32_t plane = P.n1 * P.n2;
 
     // ---- FAST task: block -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
-    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0;
+    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0, mk = 0, mj = 0, mr = 0;
     bool lane_valid = false, halo_in = false;
     // ---- generic task: contiguous range of linear cell indices per block
     uint32_t gbase = 0, gend = 0;
@@ -128,6 +156,13 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
         last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
         halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
         streaming = nrows != 0u && p < ib;
+        // cells whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
+        mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
+        mk = mr;
+        if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << 3);       // m == 3 at the array edge
+        mj = 0;
+        for (uint32_t r = 0; r < CX_RJ; r++)
+            if (j0 + r + 1u < P.n1) mj |= 0xFu << (CX_ROWBITS * r);
     } else {
         gbase = blockIdx.x * cells_per_block + wave * 64u;
         gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
@@ -149,6 +184,8 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
         uint32_t own = 0, halo = 0;
 #pragma unroll
         for (int r = 0; r <= CX_RJ; r++) {
+            suspect |= (bool)((int)cx_near_screen(P, v[r].x) | (int)cx_near_screen(P, v[r].y) | (int)cx_near_screen(P, v[r].z) |
+                              (int)cx_near_screen(P, v[r].w) | (int)cx_near_screen(P, hv[r]));
             own |= (v[r].x < P.vcmp) ? (1u << (CX_ROWBITS * r + 0)) : 0u;
             own |= (v[r].y < P.vcmp) ? (1u << (CX_ROWBITS * r + 1)) : 0u;
             own |= (v[r].z < P.vcmp) ? (1u << (CX_ROWBITS * r + 2)) : 0u;
@@ -178,6 +215,7 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
                 if (nrows < CX_RJ) act &= (1u << (CX_ROWBITS * nrows)) - 1u;
                 if (!lane_valid) act = 0;
                 if (__ballot(act != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
+                    const uint32_t act0 = act;
                     uint32_t tot;
                     const uint32_t pre = cx_wave_prefix_small<5>(__popc(act), tot);
                     uint32_t pos = qn + pre;
@@ -188,6 +226,34 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
                         const uint32_t r = bit / CX_ROWBITS, m = bit - r * CX_ROWBITS;
                         q[pos++] = lin0 + r * P.n2 + m;
                     }
+                    // counts of this lane's 16 cells, all at once on the packed sign words: corner
+                    // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
+                    // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
+                    const uint32_t mi = ((p + 1u) < P.n0) ? mr : 0u;               // plane p+1 exists
+                    const uint32_t real = mk & mj & mi;                           // cells that are voxels
+                    const uint32_t b0 = wprev, b1 = wprev >> 1, b2 = wprev >> CX_ROWBITS, b3 = wprev >> (CX_ROWBITS + 1u);
+                    const uint32_t b4 = wcur, b5 = wcur >> 1, b6 = wcur >> CX_ROWBITS, b7 = wcur >> (CX_ROWBITS + 1u);
+                    const uint32_t x1 = (b0 ^ b1) & mk, x2 = (b0 ^ b2) & mj, x3 = (b0 ^ b3) & mk & mj;   // mk, mj subsets of mr
+                    const uint32_t x4 = (b0 ^ b4) & mi, x5 = (b0 ^ b5) & mk & mi, x6 = (b0 ^ b6) & mj & mi, x7 = (b0 ^ b7) & real;
+                    acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
+                    const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
+                    acc.c += __popc(owners | (act0 & real));
+                    acc.b += __popc(act0 & real);
+                    // triangles: per tetrahedron {0,7,c,d} the number of low corners n = b0+b7+bc+bd;
+                    // n odd -> 1 triangle, n == 2 -> 2 triangles  (only voxels emit)
+                    const uint32_t x07 = b0 ^ b7, y07 = b0 & b7;
+                    uint32_t nt = 0;
+#define CX_TET_COUNT(bc, bd)                                                          \
+    {                                                                                 \
+        const uint32_t xcd = (bc) ^ (bd);                                             \
+        const uint32_t s0 = x07 ^ xcd;                                                \
+        const uint32_t s1 = y07 ^ ((bc) & (bd)) ^ (x07 & xcd);                         \
+        nt += __popc(s0 & real) + 2u * __popc(s1 & ~s0 & real);                        \
+    }
+                    CX_TET_COUNT(b1, b3) CX_TET_COUNT(b3, b2) CX_TET_COUNT(b2, b6)
+                    CX_TET_COUNT(b6, b4) CX_TET_COUNT(b4, b5) CX_TET_COUNT(b5, b1)
+#undef CX_TET_COUNT
+                    acc.t += nt;
                     qn += tot;
                 }
                 wprev = wcur;
@@ -205,10 +271,16 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
                 const uint32_t k = r - j * P.n2;
                 float f[8];
                 const uint32_t vm = cx_load_corners(P, linc, i, j, k, f);
-                const uint32_t smv = cx_sign_mask(P, f) & vm;
+                const uint32_t sm = cx_sign_mask(P, f);
+                const uint32_t smv = sm & vm;
                 const bool active = in && smv != 0u && smv != vm;
                 const uint64_t act = __ballot(active);
-                if (active) q[qn + cx_mbcnt(act)] = lin;
+                if (active) {
+                    q[qn + cx_mbcnt(act)] = lin;
+                    cx_count_from_signs(sm, vm, acc);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) suspect |= cx_near_screen(P, f[c]);
+                }
                 qn += (uint32_t)__popcll(act);
                 gbase += 256u;
                 streaming = gbase < gend;
@@ -217,10 +289,21 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
         // ---- phase B: count, reserve, emit.  The last round of a workgroup reserves once for all
         // four waves; a wave whose queue filled up early reserves for itself (dense surfaces only).
         const bool final_round = !streaming;
+        if (P.flags & CX_DBG_PHASE_A_ONLY) {
+            if (final_round) break;
+            qn = 0;
+            continue;
+        }
         cx_run run = {0, 0, 0, 0};
+        const bool recount = __ballot(suspect) != 0ULL;   // wave-uniform
         for (int pass = 0; pass < 2; pass++) {
-            cx_process_queue(P, q, qn, lane, pass == 1, run);
-            if (pass == 1) break;
+            if (pass == 1 || recount) {
+                cx_process_queue(P, q, qn, lane, pass == 1, run);
+            } else {
+                run.v = cx_wave_sum(acc.v); run.t = cx_wave_sum(acc.t);
+                run.c = cx_wave_sum(acc.c); run.b = cx_wave_sum(acc.b);
+            }
+            if (pass == 1 || (P.flags & CX_DBG_COUNT_ONLY)) break;
             if (final_round) {
                 if (lane == 0) {
                     s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
@@ -255,21 +338,33 @@ __global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx
             }
         }
         qn = 0;
+        acc.v = acc.t = acc.c = acc.b = 0;
+        suspect = false;
         if (final_round) break;
     }
 }
 
 // ---- CPython 3.10 tuple hash + 8-slot set order, used only with
 // CX_DIAG_CPYTHON310 to reproduce the quad diagonal the reference picks (tetrahedral.py:592-595).
-__device__ __forceinline__ uint64_t py_tuplehash3(uint32_t x, uint32_t y, uint32_t z) {
-    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
-    uint64_t acc = P5;
-    acc += (uint64_t)x * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
-    acc += (uint64_t)y * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
-    acc += (uint64_t)z * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
-    acc += 3ULL ^ (P5 ^ 3527539ULL);
-    if (acc == ~0ULL) acc = 1546275796ULL;
-    return acc;
+// hash((x,y,z)) = finish(round(round(round(P5, x), y), z)); the first two rounds depend only on
+// (x,y) and come from a table built once per grid shape (cx_k_hash_xy).
+#define CX_PY_P1 11400714785074694791ULL
+#define CX_PY_P2 14029467366897019727ULL
+#define CX_PY_P5 2870177450012600261ULL
+__device__ __forceinline__ uint64_t py_round(uint64_t acc, uint32_t x) {
+    acc += (uint64_t)x * CX_PY_P2;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * CX_PY_P1;
+}
+__device__ __forceinline__ uint64_t py_finish3(uint64_t acc) {
+    acc += 3ULL ^ (CX_PY_P5 ^ 3527539ULL);
+    return (acc == ~0ULL) ? 1546275796ULL : acc;
+}
+__global__ void cx_k_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n0 * n1) return;
+    const uint32_t i = idx / n1, j = idx - i * n1;
+    table[idx] = py_round(py_round(CX_PY_P5, i), j);
 }
 // does a 2-element set {first inserted h1, then h2} iterate h2 first?
 __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
@@ -283,80 +378,129 @@ __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
     return s2 < s1;
 }
 
+// tet vertex m of tet t -> cube corner, as compile-time constants (same data as cx_d_tet_corners)
+__device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
+#define CX_TC_MASK(t) ((1u << CX_TC[t][0]) | (1u << CX_TC[t][1]) | (1u << CX_TC[t][2]) | (1u << CX_TC[t][3]))
+
 // =================================================================================================
-// K2: one lane per active-cell record; expands the 6 tetrahedra into index triples.
+// K2: one lane per active-cell record; expands the 6 tetrahedra into index triples.  A wave whose
+// 64 records own one contiguous triangle range stages its indices in LDS and writes them out as
+// full 256-byte rows; otherwise (range broken by a reservation boundary) lanes store directly.
 // =================================================================================================
-__global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P) {
+#define CX_K2_STAGE 1536u   // ints per wave (typical wave: ~1200); larger waves store directly
+__global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
+    __shared__ int32_t s_stage[4][CX_K2_STAGE];
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     const uint32_t plane = P.n1 * P.n2;
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncells; idx += gridDim.x * blockDim.x) {
-        const uint4 c4 = P.cells[idx];
-        const uint32_t ntri = (c4.y >> 16) & 0xFFu;
-        if (ntri == 0) continue;
-        const uint32_t lin = c4.x;
-        const uint32_t sm = c4.y & 0xFFu, tetskip = (c4.y >> 8) & 0x3Fu;
-        // first-vertex index and crossing mask of the 7 corners that can own an edge of this voxel
-        uint32_t vfirst[7], em[7];
-        vfirst[0] = c4.w;
-        em[0] = c4.y >> 24;
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;   // whole wave idle
+    const bool have = idx < ncells;
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (have) c4 = P.cells[idx];
+    const uint32_t ntri = have ? ((c4.y >> 16) & 0xFFu) : 0u;
+    const uint32_t lin = c4.x;
+    const uint32_t sm = c4.y & 0xFFu, tetskip = (c4.y >> 8) & 0x3Fu;
+    // first-vertex index and crossing mask of the 7 corners that can own an edge of this voxel
+    uint32_t vfirst[7], em[7];
+    vfirst[0] = c4.w;
+    em[0] = c4.y >> 24;
 #pragma unroll
-        for (uint32_t c = 1; c < 7; c++) {
-            // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
-            const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
-            uint32_t sup = 0;
+    for (uint32_t c = 1; c < 7; c++) {
+        // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
+        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
+        uint32_t sup = 0;
 #pragma unroll
-            for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
-            vfirst[c] = 0; em[c] = 0;
-            if (((sm ^ sc) & sup) != 0u) {
-                const uint32_t lc = lin + ((c & 4u) ? plane : 0u) + ((c & 2u) ? P.n2 : 0u) + (c & 1u);
-                const uint64_t e = P.celltab[lc];
-                vfirst[c] = (uint32_t)e;
-                em[c] = (uint32_t)(e >> 32);
-            }
+        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
+        vfirst[c] = 0; em[c] = 0;
+        if (ntri && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
+            const uint32_t lc = lin + ((c & 4u) ? plane : 0u) + ((c & 2u) ? P.n2 : 0u) + (c & 1u);
+            const uint64_t e = P.celltab[lc];
+            vfirst[c] = (uint32_t)e;
+            em[c] = (uint32_t)(e >> 32);
         }
-        uint32_t ci = 0, cj = 0, ck = 0;
-        if (emulate) {
-            ci = cx_div(lin, P.div_plane);
-            const uint32_t r = lin - ci * plane;
-            cj = cx_div(r, P.div_row);
-            ck = r - cj * P.n2;
-        }
-        int32_t* out = P.tris + (size_t)c4.z * 3u;
+    }
+    // quad diagonal variants of the 2-2 tetrahedra (bit t of `variants`)
+    uint32_t variants = 0;
+    if (emulate) {
+        uint32_t need = 0;   // corners whose hash is needed
+#pragma unroll
         for (int t = 0; t < 6; t++) {
-            if ((tetskip >> t) & 1u) continue;
-            const uint32_t pat = cx_tet_pattern(sm, t);
-            uint32_t variant = 0;
-            if (emulate && __popc(pat) == 2) {
+            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+            if (ntri && !((tetskip >> t) & 1u) && __popc(pat) == 2) need |= CX_TC_MASK(t);
+        }
+        if (__ballot(need != 0u) != 0ULL) {
+            const uint32_t ci = cx_div(lin, P.div_plane);
+            const uint32_t r = lin - ci * plane;
+            const uint32_t cj = cx_div(r, P.div_row);
+            const uint32_t ck = r - cj * P.n2;
+            uint64_t h[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) {
+                h[c] = 0;
+                if ((need >> c) & 1u) {
+                    const uint64_t hxy = hash_xy[(ci + ((c >> 2) & 1u)) * P.n1 + (cj + ((c >> 1) & 1u))];
+                    h[c] = py_finish3(py_round(hxy, ck + (c & 1u)));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                     (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+                if (__popc(pat) != 2) continue;
                 // low set and high set, each in insertion (tet vertex) order
-                uint64_t hl[2] = {0, 0}, hh[2] = {0, 0};
+                uint64_t hl0 = 0, hl1 = 0, hh0 = 0, hh1 = 0;
                 int nl = 0, nh = 0;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const uint32_t c = cx_d_tet_corners[t][m];
-                    const uint64_t h = py_tuplehash3(ci + ((c >> 2) & 1u), cj + ((c >> 1) & 1u), ck + (c & 1u));
-                    if ((pat >> m) & 1u) { if (nl == 0) hl[0] = h; else hl[1] = h; nl++; }
-                    else { if (nh == 0) hh[0] = h; else hh[1] = h; nh++; }
+                    const uint64_t hm = h[CX_TC[t][m]];
+                    if ((pat >> m) & 1u) { if (nl == 0) hl0 = hm; else hl1 = hm; nl++; }
+                    else { if (nh == 0) hh0 = hm; else hh1 = hm; nh++; }
                 }
-                variant = (py_set2_swapped(hl[0], hl[1]) != py_set2_swapped(hh[0], hh[1])) ? 1u : 0u;
-            }
-            const uint64_t e = cx_d_tet_tris[t][pat][variant];
-            const uint32_t n = (uint32_t)(e >> 36) & 3u;
-            for (uint32_t qd = 0; qd < n; qd++) {
-                const uint32_t tri = (uint32_t)(e >> (18u * qd)) & 0x3FFFFu;
-#pragma unroll
-                for (uint32_t s = 0; s < 3; s++) {
-                    const uint32_t ref = (tri >> (6u * s)) & 0x3Fu;
-                    const uint32_t c1 = ref >> 3, d = ref & 7u;
-                    // runtime-indexed small arrays: select with a compare chain to stay in registers
-                    uint32_t vf = 0, m = 0;
-#pragma unroll
-                    for (uint32_t c = 0; c < 7; c++) { vf = (c1 == c) ? vfirst[c] : vf; m = (c1 == c) ? em[c] : m; }
-                    *out++ = (int32_t)(vf + __popc(m & ((1u << d) - 1u)));
-                }
+                if (py_set2_swapped(hl0, hl1) != py_set2_swapped(hh0, hh1)) variants |= 1u << t;
             }
         }
+    }
+    // is this wave's triangle range contiguous?  (lane l+1 starts where lane l ends)
+    uint32_t ttot;
+    const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
+    const uint32_t tb0 = __builtin_amdgcn_readfirstlane(c4.z);   // lane 0 always has a record here
+    const bool contiguous = (ttot * 3u <= CX_K2_STAGE) && __ballot(ntri != 0u && c4.z != tb0 + tpre) == 0ULL;
+    int32_t* stage = s_stage[wave];
+    int32_t* direct = P.tris + (size_t)c4.z * 3u;
+    uint32_t w = tpre * 3u;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        if (ntri == 0u || ((tetskip >> t) & 1u)) continue;
+        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+        const uint64_t e = cx_d_tet_tris[t][pat][(variants >> t) & 1u];
+        const uint32_t n = (uint32_t)(e >> 36) & 3u;
+        for (uint32_t qd = 0; qd < n; qd++) {
+            const uint32_t tri = (uint32_t)(e >> (18u * qd)) & 0x3FFFFu;
+#pragma unroll
+            for (uint32_t sidx = 0; sidx < 3; sidx++) {
+                const uint32_t ref = (tri >> (6u * sidx)) & 0x3Fu;
+                const uint32_t c1 = ref >> 3, d = ref & 7u;
+                // runtime-indexed small arrays: select with a compare chain to stay in registers
+                uint32_t vf = 0, m = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 7; c++) { vf = (c1 == c) ? vfirst[c] : vf; m = (c1 == c) ? em[c] : m; }
+                const int32_t vi = (int32_t)(vf + __popc(m & ((1u << d) - 1u)));
+                if (contiguous) stage[w] = vi;
+                else if (!(P.flags & CX_DBG_NO_TRIS)) direct[w - tpre * 3u] = vi;
+                w++;
+            }
+        }
+    }
+    if (contiguous && !(P.flags & CX_DBG_NO_TRIS)) {
+        int32_t* out = P.tris + (size_t)tb0 * 3u;
+        const uint32_t total = ttot * 3u;
+        for (uint32_t o = lane; o < total; o += 64u) out[o] = stage[o];
     }
 }
 
@@ -392,6 +536,14 @@ void cx_launch_classify_generic(const cx_params& P, hipStream_t s) {
     hipLaunchKernelGGL(cx_k_classify<false>, dim3(blocks), dim3(256), 0, s, P, T, cpb);
 }
 
-void cx_launch_emit_triangles(const cx_params& P, hipStream_t s) {
-    hipLaunchKernelGGL(cx_k_emit_triangles, dim3(256u * 8u), dim3(256), 0, s, P);
+void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s) {
+    // one lane per record; the record count lives on the device, so launch for the capacity and let
+    // idle waves exit at once
+    const uint32_t blocks = (P.ccap + 255u) / 256u;
+    hipLaunchKernelGGL(cx_k_emit_triangles, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P, hash_xy);
+}
+
+void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, hipStream_t s) {
+    const uint32_t n = n0 * n1;
+    hipLaunchKernelGGL(cx_k_hash_xy, dim3((n + 255u) / 256u), dim3(256), 0, s, table, n0, n1);
 }
