@@ -35,6 +35,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, "lib", os.path.basename(src) + ".o")
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function"]
+        cmd += os.environ.get("CX_EXTRA_FLAGS", "").split()
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

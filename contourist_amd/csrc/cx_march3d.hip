@@ -24,7 +24,12 @@ __device__ __constant__ uint8_t cx_d_tet_corners[6][4] = CX_TET_CORNERS_INIT;
 __device__ __constant__ uint64_t cx_d_tet_tris[6][16][2] = CX_TET_TRIS_INIT;
 __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 
-#define CX_QCAP 2048u   // active cells a wave can queue before it has to flush on its own
+#ifndef CX_QCAP
+#define CX_QCAP 2048u
+#endif
+#ifndef CX_K1_MIN_WAVES
+#define CX_K1_MIN_WAVES 4
+#endif   // active cells a wave can queue before it has to flush on its own
 #define CX_RJ 4         // cell rows per wave in the FAST kernel (a workgroup covers 4*CX_RJ rows)
 
 struct cx_task {        // launch geometry of the FAST kernel
@@ -122,7 +127,7 @@ __device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
 // K1
 // =================================================================================================
 template <bool FAST>
-__global__ __launch_bounds__(256) void cx_k_classify(const cx_params P, const cx_task T, const uint32_t cells_per_block) {
+__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_params P, const cx_task T, const uint32_t cells_per_block) {
     __shared__ uint32_t s_queue[4][CX_QCAP];
     __shared__ uint32_t s_tot[4][4];
     __shared__ uint32_t s_base[4];

@@ -1,17 +1,766 @@
-// cx_post.hip -- Level-1 mesh post-passes (placeholder).
+// cx_post.hip -- Level-1 mesh post-passes on the device (surface-sized work).
+//
+// Reference semantics restated (paths relative to the reference checkout, contourist/...):
+//   quantize_interpolations   tetrahedral.py:190-215      weld by bucket trunc(p * int(10000/corner))
+//   remove_tiny_simplices     tetrahedral.py:353-375      drop tiny triangles, move their vertices together
+//   extract_surface_geometry  tetrahedral.py:604-621      compact used vertices
+//   clean_triangles           surface_geometry.py:14-50   drop zero-area triangles, merge their coincident vertices
+//   orient_triangles          surface_geometry.py:52-140  per component: max-x start rule + edge flood fill
+// Where the reference's result depends on Python set/dict order, a canonical choice is made (the
+// member with the smallest priority -- edge id in the pipeline, index for a caller's mesh --
+// represents a weld bucket / merge group; of triangles that become the same vertex set the one
+// with the smallest sorted priority triple survives).  oracle/postpass.py restates the same choices.
+//
+// Building blocks: open-addressing hash tables (64-bit keys, atomicCAS), lock-free union-find
+// (root = smallest priority; a parity bit per link carries the relative winding for the
+// orientation flood fill), pointer jumping, a three-kernel exclusive scan.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+
 #include "cx_ctx.h"
 
-void cx_post_free(cx_ctx*) {}
+#define CXP_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return (e__ == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;                      \
+        }                                                                                        \
+    } while (0)
 
-extern "C" int cx_postprocess3d(cx_ctx* ctx, uint32_t, int64_t*) {
-    if (ctx) ctx->err = "cx_postprocess3d: not built yet";
-    return CX_ERR_UNSUPPORTED;
+typedef unsigned long long u64;
+#define CXP_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define CXP_NONE 0xFFFFFFFFu
+
+struct cxp_dev {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct cx_post_state {
+    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
+    int64_t nv_out = 0, nt_out = 0;
+};
+
+static int cxp_reserve(cx_ctx* ctx, cxp_dev& d, size_t bytes) {
+    if (d.bytes >= bytes) return CX_OK;
+    if (d.p) (void)hipFree(d.p);
+    d.p = nullptr; d.bytes = 0;
+    CXP_HIP(ctx, hipMalloc(&d.p, bytes));
+    d.bytes = bytes;
+    return CX_OK;
 }
-extern "C" int cx_level1_download(cx_ctx* ctx, double*, int32_t*) {
-    if (ctx) ctx->err = "cx_level1_download: not built yet";
-    return CX_ERR_UNSUPPORTED;
+
+void cx_post_free(cx_ctx* ctx) {
+    if (!ctx->post) return;
+    cx_post_state* S = ctx->post;
+    cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
+                      &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc};
+    for (cxp_dev* d : all)
+        if (d->p) (void)hipFree(d->p);
+    delete S;
+    ctx->post = nullptr;
 }
-extern "C" int cx_surface_geometry(cx_ctx* ctx, double*, int64_t*, int32_t*, int64_t*, int) {
-    if (ctx) ctx->err = "cx_surface_geometry: not built yet";
-    return CX_ERR_UNSUPPORTED;
+
+// ---- device helpers --------------------------------------------------------------------------------
+__device__ __forceinline__ u64 cxp_mix(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+// total order on doubles as unsigned integers
+__device__ __forceinline__ u64 cxp_orderable(double x) {
+    u64 b = (u64)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+// union-find over 32-bit ids; parent word = (parity << 32) | parent id.  Root = smallest priority.
+__device__ __forceinline__ uint32_t cxp_find(const u64* parent, uint32_t x, uint32_t& parity) {
+    uint32_t par = 0;
+    for (;;) {
+        const u64 w = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t p = (uint32_t)w;
+        if (p == x) break;
+        par ^= (uint32_t)(w >> 32) & 1u;
+        x = p;
+    }
+    parity = par;
+    return x;
+}
+// link the sets of a and b; rel = parity between a and b (0: same winding class)
+__device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uint32_t a, uint32_t b, uint32_t rel) {
+    for (;;) {
+        uint32_t pa, pb;
+        uint32_t ra = cxp_find(parent, a, pa), rb = cxp_find(parent, b, pb);
+        if (ra == rb) return;
+        const uint32_t ka = prio ? prio[ra] : ra, kb = prio ? prio[rb] : rb;
+        const bool a_wins = (ka < kb) || (ka == kb && ra < rb);
+        const uint32_t win = a_wins ? ra : rb, lose = a_wins ? rb : ra;
+        const u64 expect = (u64)lose;                                  // still a root, parity 0
+        const u64 desired = ((u64)((pa ^ pb ^ rel) & 1u) << 32) | (u64)win;
+        if (atomicCAS(&parent[lose], expect, desired) == expect) return;
+    }
+}
+
+__global__ void cxp_k_iota64(u64* a, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (u64)i;
+}
+__global__ void cxp_k_fill64(u64* a, size_t n, u64 v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = v;
+}
+// pointer jumping with parity until every node points at its root
+__global__ void cxp_k_jump(u64* parent, uint32_t n, uint32_t* changed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 w = parent[i];
+    const uint32_t p = (uint32_t)w;
+    if (p == i) return;
+    const u64 wp = parent[p];
+    const uint32_t pp = (uint32_t)wp;
+    if (pp == p) return;
+    parent[i] = ((((w >> 32) ^ (wp >> 32)) & 1ULL) << 32) | (u64)pp;
+    *changed = 1u;
+}
+
+// ---- exclusive scan of u32 (n up to 2^32) ----------------------------------------------------------
+#define CXP_SCAN_BLOCK 1024u
+__global__ __launch_bounds__(256) void cxp_k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t* sums, uint32_t n) {
+    __shared__ uint32_t s[256];
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t v[4], t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        t += v[k];
+    }
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t run = s[threadIdx.x] - t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255) sums[blockIdx.x] = s[255];
+}
+__global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total) {
+    __shared__ uint32_t s[1024];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nb) ? sums[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < nb) sums[i] = carry + s[threadIdx.x] - v;
+        const uint32_t blocktot = s[1023];
+        __syncthreads();
+        carry += blocktot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void cxp_k_scan_add(uint32_t* out, const uint32_t* sums, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += sums[i / CXP_SCAN_BLOCK];
+}
+
+// ---- step kernels -------------------------------------------------------------------------------------
+// float64 vertex coordinates exactly as the reference computes them (tetrahedral.py:471-487)
+__global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, cx_fdiv dplane, cx_fdiv drow,
+                                   double value, const float4* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const uint32_t key = __float_as_uint(verts[v].w);
+    const uint32_t lin = key >> 3, d = key & 7u;
+    const uint32_t plane = n1 * n2;
+    const uint32_t i = cx_div(lin, dplane);
+    const uint32_t r = lin - i * plane;
+    const uint32_t j = cx_div(r, drow);
+    const uint32_t k = r - j * n2;
+    const uint32_t lin2 = lin + ((d & 4u) ? plane : 0u) + ((d & 2u) ? n2 : 0u) + (d & 1u);
+    const double f0 = (double)A[lin], f1 = (double)A[lin2];
+    const bool owner_low = !(f0 > f1);             // reference swaps when flow > fhigh
+    const double flow = owner_low ? f0 : f1, fhigh = owner_low ? f1 : f0;
+    double ratio = 0.5;
+    const double den = 1.0 * (fhigh - flow);
+    if (!(fabs(den) <= 1e-8)) ratio = (value - flow) / den;
+    const double q[3] = {(double)i, (double)j, (double)k};
+    const uint32_t db[3] = {(d >> 2) & 1u, (d >> 1) & 1u, d & 1u};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double low = owner_low ? q[a] : q[a] + (double)db[a];
+        const double high = owner_low ? q[a] + (double)db[a] : q[a];
+        pts[(size_t)v * 3 + a] = low + ratio * (high - low);
+    }
+    prio[v] = key;
+}
+
+__global__ void cxp_k_iota_prio(uint32_t* prio, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) prio[i] = i;
+}
+
+struct cxp_weld_params {
+    double ex[3];
+};
+
+// weld: bucket -> vertex with the smallest priority
+__global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint32_t nv, cxp_weld_params W, u64* tkeys, u64* tvals,
+                                  u64 mask) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
+    const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
+    const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
+    const u64 key = (q0 << 42) | (q1 << 21) | q2;
+    u64 slot = cxp_mix(key) & mask;
+    for (;;) {
+        const u64 cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key);
+        if (cur == CXP_EMPTY || cur == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&tvals[slot], ((u64)prio[v] << 32) | (u64)v);
+}
+__global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_params W, const u64* tkeys, const u64* tvals, u64 mask,
+                                  uint32_t* rep) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
+    const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
+    const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
+    const u64 key = (q0 << 42) | (q1 << 21) | q2;
+    u64 slot = cxp_mix(key) & mask;
+    while (tkeys[slot] != key) slot = (slot + 1) & mask;
+    rep[v] = (uint32_t)tvals[slot];
+}
+
+// remap triangles through `map` (optionally a union-find: map == nullptr), kill those with < 3 distinct vertices
+__global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uint32_t* map, const u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    uint32_t v[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t x = (uint32_t)tri[(size_t)t * 3 + s];
+        uint32_t par;
+        v[s] = map ? map[x] : cxp_find(parent, x, par);
+        tri[(size_t)t * 3 + s] = (int32_t)v[s];
+    }
+    if (v[0] == v[1] || v[0] == v[2] || v[1] == v[2]) alive[t] = 0;
+}
+
+// priority of a triangle = its sorted triple of ORIGINAL vertex priorities (compared lexicographically)
+struct cxp_tri3 {
+    uint32_t a, b, c;
+};
+__device__ __forceinline__ cxp_tri3 cxp_sorted3(uint32_t x, uint32_t y, uint32_t z) {
+    if (x > y) { const uint32_t t = x; x = y; y = t; }
+    if (y > z) { const uint32_t t = y; y = z; z = t; }
+    if (x > y) { const uint32_t t = x; x = y; y = t; }
+    cxp_tri3 r = {x, y, z};
+    return r;
+}
+__device__ __forceinline__ bool cxp_less3(const cxp_tri3& p, const cxp_tri3& q) {
+    if (p.a != q.a) return p.a < q.a;
+    if (p.b != q.b) return p.b < q.b;
+    return p.c < q.c;
+}
+
+// dedupe triangles that are the same vertex set: table slot holds the id of the current winner
+__global__ void cxp_k_dedupe_insert(const int32_t* tri, const uint32_t* tprio3, const uint8_t* alive, uint32_t nt, u64* table,
+                                    u64 mask) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const cxp_tri3 me = cxp_sorted3((uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]);
+    const cxp_tri3 mp = {tprio3[(size_t)t * 3], tprio3[(size_t)t * 3 + 1], tprio3[(size_t)t * 3 + 2]};
+    u64 slot = cxp_mix(((u64)me.a << 40) ^ ((u64)me.b << 20) ^ (u64)me.c ^ ((u64)me.c << 50)) & mask;
+    for (;;) {
+        u64 cur = atomicCAS(&table[slot], CXP_EMPTY, (u64)t);
+        if (cur == CXP_EMPTY) return;
+        for (;;) {   // slot occupied by triangle `cur`: same vertex set?
+            const uint32_t o = (uint32_t)cur;
+            const cxp_tri3 ot = cxp_sorted3((uint32_t)tri[(size_t)o * 3], (uint32_t)tri[(size_t)o * 3 + 1], (uint32_t)tri[(size_t)o * 3 + 2]);
+            if (ot.a != me.a || ot.b != me.b || ot.c != me.c) break;   // different set: probe on
+            const cxp_tri3 op = {tprio3[(size_t)o * 3], tprio3[(size_t)o * 3 + 1], tprio3[(size_t)o * 3 + 2]};
+            if (!cxp_less3(mp, op)) return;                            // the resident wins
+            const u64 seen = atomicCAS(&table[slot], cur, (u64)t);
+            if (seen == cur) return;                                   // replaced it
+            cur = seen;                                                // someone else got in: compare again
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void cxp_k_dedupe_resolve(const int32_t* tri, uint8_t* alive, uint32_t nt, const u64* table, u64 mask) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const cxp_tri3 me = cxp_sorted3((uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]);
+    u64 slot = cxp_mix(((u64)me.a << 40) ^ ((u64)me.b << 20) ^ (u64)me.c ^ ((u64)me.c << 50)) & mask;
+    for (;;) {
+        const uint32_t o = (uint32_t)table[slot];
+        if (o == t) return;
+        const cxp_tri3 ot = cxp_sorted3((uint32_t)tri[(size_t)o * 3], (uint32_t)tri[(size_t)o * 3 + 1], (uint32_t)tri[(size_t)o * 3 + 2]);
+        if (ot.a == me.a && ot.b == me.b && ot.c == me.c) { alive[t] = 0; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+// original priority triple of every triangle (sorted), taken before any remap
+__global__ void cxp_k_tri_prio(const int32_t* tri, const uint32_t* prio, uint32_t nt, uint32_t* tprio3) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const cxp_tri3 p = cxp_sorted3(prio[tri[(size_t)t * 3]], prio[tri[(size_t)t * 3 + 1]], prio[tri[(size_t)t * 3 + 2]]);
+    tprio3[(size_t)t * 3] = p.a; tprio3[(size_t)t * 3 + 1] = p.b; tprio3[(size_t)t * 3 + 2] = p.c;
+}
+
+__global__ void cxp_k_count_alive(const uint8_t* alive, uint32_t nt, uint32_t* counter) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool a = t < nt && alive[t];
+    const u64 m = __ballot(a);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
+// tiny triangles (tetrahedral.py:360-365): bbox * (1/corner) < epsilon on every axis
+__global__ void cxp_k_tiny(const int32_t* tri, uint8_t* alive, uint32_t nt, const double* pts, double ic0, double ic1, double ic2,
+                           double eps, u64* parent, const uint32_t* prio, uint8_t* moved) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const uint32_t v0 = tri[(size_t)t * 3], v1 = tri[(size_t)t * 3 + 1], v2 = tri[(size_t)t * 3 + 2];
+    const double ic[3] = {ic0, ic1, ic2};
+    double worst = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double x0 = pts[(size_t)v0 * 3 + a], x1 = pts[(size_t)v1 * 3 + a], x2 = pts[(size_t)v2 * 3 + a];
+        const double d = (fmax(x0, fmax(x1, x2)) - fmin(x0, fmin(x1, x2))) * ic[a];
+        worst = fmax(worst, d);
+    }
+    if (worst < eps) {
+        alive[t] = 0;
+        cxp_union(parent, prio, v0, v1, 0);
+        cxp_union(parent, prio, v0, v2, 0);
+        moved[v0] = moved[v1] = moved[v2] = 1;
+    }
+}
+// members of a tiny group take the coordinates of the group's root (tetrahedral.py:368-370, canonical root)
+__global__ void cxp_k_move(double* pts, const double* pts_src, const u64* parent, const uint8_t* moved, uint32_t nv) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || !moved[v]) return;
+    uint32_t par;
+    const uint32_t r = cxp_find(parent, v, par);
+#pragma unroll
+    for (int a = 0; a < 3; a++) pts[(size_t)v * 3 + a] = pts_src[(size_t)r * 3 + a];
+}
+
+// zero-area triangles (surface_geometry.py:33-43): drop, and merge their np.allclose vertex pairs
+__global__ void cxp_k_degenerate(const int32_t* tri, uint8_t* alive, uint32_t nt, const double* pts, u64* parent, const uint32_t* prio) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+    double P[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) P[s][a] = pts[(size_t)v[s] * 3 + a];
+    const double ux = P[0][0] - P[2][0], uy = P[0][1] - P[2][1], uz = P[0][2] - P[2][2];   // A - C
+    const double wx = P[1][0] - P[2][0], wy = P[1][1] - P[2][1], wz = P[1][2] - P[2][2];   // B - C
+    const double cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+    if (fabs(cx) <= 1e-8 && fabs(cy) <= 1e-8 && fabs(cz) <= 1e-8) {
+        alive[t] = 0;
+        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int i = pr[e][0], j = pr[e][1];
+            bool close = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++) close = close && (fabs(P[i][a] - P[j][a]) <= 1e-8 + 1e-5 * fabs(P[j][a]));
+            if (close) cxp_union(parent, prio, v[i], v[j], 0);
+        }
+    }
+}
+
+__global__ void cxp_k_mark_used(const int32_t* tri, const uint8_t* alive, uint32_t nt, uint32_t* used) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    used[tri[(size_t)t * 3]] = 1u; used[tri[(size_t)t * 3 + 1]] = 1u; used[tri[(size_t)t * 3 + 2]] = 1u;
+}
+__global__ void cxp_k_alive_u32(const uint8_t* alive, uint32_t nt, uint32_t* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nt) out[t] = alive[t] ? 1u : 0u;
+}
+__global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const uint32_t* newid, uint32_t nv, double* out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || !used[v]) return;
+#pragma unroll
+    for (int a = 0; a < 3; a++) out[(size_t)newid[v] * 3 + a] = pts[(size_t)v * 3 + a];
+}
+__global__ void cxp_k_compact_tri(const int32_t* tri, const uint8_t* alive, const uint32_t* tnew, const uint32_t* vnew, uint32_t nt,
+                                  int32_t* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+#pragma unroll
+    for (int s = 0; s < 3; s++) out[(size_t)tnew[t] * 3 + s] = (int32_t)vnew[tri[(size_t)t * 3 + s]];
+}
+
+// ---- orientation ---------------------------------------------------------------------------------------
+// edge table: key = (min vertex << 32) | max vertex, value = first triangle that inserted the edge.
+// Every later triangle on that edge is linked to the first with the parity of their relative winding
+// (surface_geometry.py:110-138: neighbours must run along the shared edge in opposite directions).
+__device__ __forceinline__ uint32_t cxp_edge_dir(const int32_t* tri, uint32_t t, uint32_t lo, uint32_t hi) {
+    // 1 if triangle t runs lo -> hi along its boundary cycle, 0 if hi -> lo
+    const uint32_t a = tri[(size_t)t * 3], b = tri[(size_t)t * 3 + 1], c = tri[(size_t)t * 3 + 2];
+    return ((a == lo && b == hi) || (b == lo && c == hi) || (c == lo && a == hi)) ? 1u : 0u;
+}
+__global__ void cxp_k_edges(const int32_t* tri, uint32_t nt, u64* ekeys, u64* evals, u64 mask, u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const uint32_t lo = min(p, q), hi = max(p, q);
+        const u64 key = ((u64)lo << 32) | (u64)hi;
+        u64 slot = cxp_mix(key) & mask;
+        for (;;) {
+            const u64 cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
+            if (cur == CXP_EMPTY || cur == key) break;
+            slot = (slot + 1) & mask;
+        }
+        const u64 first = atomicCAS(&evals[slot], CXP_EMPTY, (u64)t);
+        if (first != CXP_EMPTY && (uint32_t)first != t) {
+            const uint32_t o = (uint32_t)first;
+            const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;
+            cxp_union(parent, nullptr, t, o, same_dir);   // same direction = inconsistent winding = parity 1
+        }
+    }
+}
+// per component (root triangle): largest x over its vertices
+__global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t root = (uint32_t)parent[t];
+    u64 m = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) m = max(m, cxp_orderable(pts[(size_t)tri[(size_t)t * 3 + s] * 3]));
+    atomicMax(&cmaxx[root], m);
+}
+// among the vertices at that x: the one with the largest index (surface_geometry.py:79 max((x, index)))
+__global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, uint32_t* cmaxv) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t root = (uint32_t)parent[t];
+    const u64 m = cmaxx[root];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t v = tri[(size_t)t * 3 + s];
+        if (cxp_orderable(pts[(size_t)v * 3]) == m) atomicMax(&cmaxv[root], v);
+    }
+}
+// among that vertex's triangles: the largest |cross(a-b, a-c)[0]| (surface_geometry.py:88-94); the packed
+// word keeps the triangle id so that the next kernel can read its sign
+__device__ __forceinline__ double cxp_dotx(const int32_t* tri, uint32_t t, const double* pts) {
+    const uint32_t a = tri[(size_t)t * 3], b = tri[(size_t)t * 3 + 1], c = tri[(size_t)t * 3 + 2];
+    const double aby = pts[(size_t)a * 3 + 1] - pts[(size_t)b * 3 + 1], abz = pts[(size_t)a * 3 + 2] - pts[(size_t)b * 3 + 2];
+    const double acy = pts[(size_t)a * 3 + 1] - pts[(size_t)c * 3 + 1], acz = pts[(size_t)a * 3 + 2] - pts[(size_t)c * 3 + 2];
+    return aby * acz - abz * acy;
+}
+__global__ void cxp_k_comp_start(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cmaxv,
+                                 u64* cbest) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t root = (uint32_t)parent[t];
+    const uint32_t vm = cmaxv[root];
+    if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
+    atomicMax(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
+}
+__global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cmaxv,
+                                const u64* cbest, uint32_t* cstart) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t root = (uint32_t)parent[t];
+    const uint32_t vm = cmaxv[root];
+    if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
+    if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) atomicMax(&cstart[root], t);
+}
+// final winding: triangle parity relative to the root, and the root's flip so that the start triangle gets dotx > 0
+__global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, uint32_t* ncomp) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const u64 w = parent[t];
+    const uint32_t root = (uint32_t)w, par = (uint32_t)(w >> 32) & 1u;
+    if (root == t) atomicAdd(ncomp, 1u);
+    const uint32_t s = cstart[root];
+    const uint32_t spar = (uint32_t)(parent[s] >> 32) & 1u;
+    const uint32_t flip_root = ((cxp_dotx(tri, s, pts) < 0.0) ? 1u : 0u) ^ spar;   // in the root's frame
+    if ((par ^ flip_root) & 1u) {
+        const int32_t b = tri[(size_t)t * 3 + 1];
+        // reversed(orientation): (a,b,c) -> (c,b,a)
+        tri[(size_t)t * 3 + 1] = b;
+        const int32_t a = tri[(size_t)t * 3];
+        tri[(size_t)t * 3] = tri[(size_t)t * 3 + 2];
+        tri[(size_t)t * 3 + 2] = a;
+    }
+}
+
+// ---- host orchestration ----------------------------------------------------------------------------------
+static inline uint32_t cxp_blocks(size_t n, uint32_t b = 256) { return (uint32_t)((n + b - 1) / b); }
+static inline u64 cxp_table_size(size_t n) {
+    u64 s = 1024;
+    while (s < 2 * (u64)n + 16) s <<= 1;
+    return s;
+}
+
+static int cxp_scan(cx_ctx* ctx, cx_post_state* S, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev) {
+    const uint32_t nb = cxp_blocks(n, CXP_SCAN_BLOCK);
+    int rc = cxp_reserve(ctx, S->blocksums, (size_t)(nb + 1) * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t* sums = (uint32_t*)S->blocksums.p;
+    hipLaunchKernelGGL(cxp_k_scan_blocks, dim3(nb ? nb : 1), dim3(256), 0, ctx->stream, in, out, sums, n);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, total_dev);
+    hipLaunchKernelGGL(cxp_k_scan_add, dim3(cxp_blocks(n)), dim3(256), 0, ctx->stream, out, sums, n);
+    return CX_OK;
+}
+
+static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_dev) {
+    for (int it = 0; it < 64; it++) {
+        CXP_HIP(ctx, hipMemsetAsync(changed_dev, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(cxp_k_jump, dim3(cxp_blocks(n)), dim3(256), 0, ctx->stream, parent, n, changed_dev);
+        uint32_t changed = 0;
+        CXP_HIP(ctx, hipMemcpyAsync(&changed, changed_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!changed) return CX_OK;
+    }
+    ctx->err = "union-find did not flatten";
+    return CX_ERR_HIP;
+}
+
+// Shared tail: clean (optional) + compaction + orientation (optional) on S->pts (nv x 3 doubles),
+// S->tri (nt x 3), S->alive.  prio = vertex priorities.  Results in S->pts_out / S->tri_out.
+static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, bool do_clean, bool do_orient,
+                            uint32_t* tprio3, int64_t* out_counts) {
+    int rc;
+    double* pts = (double*)S->pts.p;
+    uint32_t* prio = (uint32_t*)S->prio.p;
+    int32_t* tri = (int32_t*)S->tri.p;
+    uint8_t* alive = (uint8_t*)S->alive.p;
+    uint32_t* misc = (uint32_t*)S->misc.p;   // [0] changed flag, [1..] counters
+    hipStream_t st = ctx->stream;
+    if (do_clean && nt) {
+        u64* parent2 = (u64*)S->parent2.p;
+        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent2, nv);
+        hipLaunchKernelGGL(cxp_k_degenerate, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, pts, parent2, prio);
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2);
+        const u64 tsz = cxp_table_size(nt);
+        if ((rc = cxp_reserve(ctx, S->tkeys, tsz * sizeof(u64)))) return rc;
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+    }
+    // ---- compaction of used vertices and living triangles
+    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
+    uint32_t* used = (uint32_t*)S->flags.p;
+    uint32_t* tflag = used + nv;
+    uint32_t* vnew = (uint32_t*)S->scan.p;
+    uint32_t* tnew = vnew + nv;
+    CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv * sizeof(uint32_t), st));
+    uint32_t nv2 = 0, nt2 = 0;
+    if (nt) {
+        hipLaunchKernelGGL(cxp_k_mark_used, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, used);
+        hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, tflag);
+        if ((rc = cxp_scan(ctx, S, used, vnew, nv, misc + 1))) return rc;
+        if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 2))) return rc;
+        uint32_t h[2];
+        CXP_HIP(ctx, hipMemcpyAsync(h, misc + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        nv2 = h[0]; nt2 = h[1];
+    }
+    if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(nv2 + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(nt2 + 1) * 3 * sizeof(int32_t)))) return rc;
+    double* pts2 = (double*)S->pts_out.p;
+    int32_t* tri2 = (int32_t*)S->tri_out.p;
+    if (nt2) {
+        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2);
+        hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, tnew, vnew, nt, tri2);
+    }
+    S->nv_out = nv2; S->nt_out = nt2;
+    uint32_t ncomp = 0;
+    if (do_orient && nt2) {
+        // ---- orientation: edge table + parity union-find over triangles
+        const u64 esz = cxp_table_size((size_t)nt2 * 3);
+        if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->parent, (size_t)nt2 * sizeof(u64)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t))))) return rc;
+        u64* ekeys = (u64*)S->tkeys.p;
+        u64* evals = (u64*)S->tvals.p;
+        u64* parent = (u64*)S->parent.p;
+        u64* cmaxx = (u64*)S->comp.p;
+        u64* cbest = cmaxx + nt2;
+        uint32_t* cmaxv = (uint32_t*)(cbest + nt2);
+        uint32_t* cstart = cmaxv + nt2;
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, evals, (size_t)esz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
+        hipLaunchKernelGGL(cxp_k_edges, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, ekeys, evals, esz - 1, parent);
+        if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
+        CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
+        CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx);
+        hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv);
+        hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest);
+        hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart);
+        hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, misc + 3);
+        CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+    }
+    CXP_HIP(ctx, hipGetLastError());
+    if (out_counts) {
+        out_counts[0] = nv2; out_counts[1] = nt2; out_counts[4] = ncomp;
+    }
+    return CX_OK;
+}
+
+static int cxp_state(cx_ctx* ctx, cx_post_state** out) {
+    if (!ctx->post) ctx->post = new (std::nothrow) cx_post_state();
+    if (!ctx->post) return CX_ERR_NOMEM;
+    *out = ctx->post;
+    return cxp_reserve(ctx, ctx->post->misc, 64 * sizeof(uint32_t));
+}
+
+extern "C" int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) { ctx->err = "cx_postprocess3d: no valid extraction"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)ctx->counts.n_vertices, nt = (uint32_t)ctx->counts.n_triangles;
+    const bool do_clean = !(flags & 1u);
+    hipStream_t st = ctx->stream;
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->rep, (size_t)(nv + 1) * (sizeof(uint32_t) + 1)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->tri, (size_t)(nt + 1) * 3 * sizeof(int32_t) * 2))) return rc;   // triangles + priority triples
+    if ((rc = cxp_reserve(ctx, S->alive, (size_t)nt + 16))) return rc;
+    if ((rc = cxp_reserve(ctx, S->parent, (size_t)(nv + 1) * sizeof(u64)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->parent2, (size_t)(nv + 1) * sizeof(u64)))) return rc;
+    double* pts = (double*)S->pts.p;
+    uint32_t* prio = (uint32_t*)S->prio.p;
+    uint32_t* rep = (uint32_t*)S->rep.p;
+    uint8_t* moved = (uint8_t*)(rep + nv + 1);
+    int32_t* tri = (int32_t*)S->tri.p;
+    uint32_t* tprio3 = (uint32_t*)(tri + (size_t)(nt + 1) * 3);
+    uint8_t* alive = (uint8_t*)S->alive.p;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    if (nv && nt) {
+        const cx_params& P = ctx->last;
+        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
+                           P.value, ctx->verts, nv, pts, prio);
+        CXP_HIP(ctx, hipMemcpyAsync(tri, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        CXP_HIP(ctx, hipMemsetAsync(alive, 1, nt, st));
+        hipLaunchKernelGGL(cxp_k_tri_prio, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, prio, nt, tprio3);
+        // ---- weld (tetrahedral.py:190-215): expander = int(10000 / corner)
+        cxp_weld_params W;
+        const double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
+        for (int a = 0; a < 3; a++) W.ex[a] = std::trunc((10000 * 1.0) / corner[a]);
+        const u64 wsz = cxp_table_size(nv);
+        if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->tvals, wsz * sizeof(u64)))) return rc;
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)wsz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1);
+        hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep);
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr);
+        const u64 tsz = cxp_table_size(nt);
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+        CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 4);
+        // ---- tiny collapse (tetrahedral.py:353-375), epsilon = 1e-4, scaled by 1/corner
+        u64* parent = (u64*)S->parent.p;
+        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent, nv);
+        CXP_HIP(ctx, hipMemsetAsync(moved, 0, nv, st));
+        hipLaunchKernelGGL(cxp_k_tiny, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, pts, 1.0 / corner[0], 1.0 / corner[1],
+                           1.0 / corner[2], 1e-4, parent, prio, moved);
+        // roots keep their own coordinates, so moving members in place is race free
+        hipLaunchKernelGGL(cxp_k_move, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, pts, parent, moved, nv);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 5);
+        uint32_t h[2];
+        CXP_HIP(ctx, hipMemcpyAsync(h, misc + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        counts[2] = h[0]; counts[3] = h[1];
+    }
+    if ((rc = cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts))) return rc;
+    ctx->post_valid = true;
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    return CX_OK;
+}
+
+extern "C" int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post_valid) { ctx->err = "cx_level1_download: run cx_postprocess3d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    if (points_xyz && S->nv_out)
+        CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->nv_out * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (tris && S->nt_out)
+        CXP_HIP(ctx, hipMemcpyAsync(tris, S->tri_out.p, (size_t)S->nt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+// SurfaceGeometry(vertices, triangles) on a caller's mesh.  mode: 0 = orient only, 1 = clean + orient, 2 = clean only.
+extern "C" int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv_io, int32_t* tris, int64_t* nt_io, int mode) {
+    if (!ctx || !points_xyz || !tris || !nv_io || !nt_io || mode < 0 || mode > 2) return CX_ERR_INVALID;
+    if (*nv_io < 0 || *nt_io < 0 || *nv_io > 0x7FFFFFF0LL || *nt_io > 0x7FFFFFF0LL) return CX_ERR_INVALID;
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)*nv_io, nt = (uint32_t)*nt_io;
+    for (int64_t n = 0; n < (int64_t)nt * 3; n++)
+        if (tris[n] < 0 || tris[n] >= (int64_t)nv) { ctx->err = "cx_surface_geometry: triangle index out of range"; return CX_ERR_INVALID; }
+    hipStream_t st = ctx->stream;
+    if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->tri, (size_t)(nt + 1) * 3 * sizeof(int32_t) * 2))) return rc;
+    if ((rc = cxp_reserve(ctx, S->alive, (size_t)nt + 16))) return rc;
+    if ((rc = cxp_reserve(ctx, S->parent2, (size_t)(nv + 1) * sizeof(u64)))) return rc;
+    int32_t* tri = (int32_t*)S->tri.p;
+    uint32_t* tprio3 = (uint32_t*)(tri + (size_t)(nt + 1) * 3);
+    if (nv) CXP_HIP(ctx, hipMemcpyAsync(S->pts.p, points_xyz, (size_t)nv * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (nt) CXP_HIP(ctx, hipMemcpyAsync(tri, tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (nv) hipLaunchKernelGGL(cxp_k_iota_prio, dim3(cxp_blocks(nv)), dim3(256), 0, st, (uint32_t*)S->prio.p, nv);
+    if (nt) {
+        CXP_HIP(ctx, hipMemsetAsync(S->alive.p, 1, nt, st));
+        hipLaunchKernelGGL(cxp_k_tri_prio, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, (const uint32_t*)S->prio.p, nt, tprio3);
+        // a caller's triangle may repeat a vertex: such rows are not triangles (surface_geometry.py:63)
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, (uint8_t*)S->alive.p, nt, (const uint32_t*)S->prio.p,
+                           (const u64*)nullptr);
+    }
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cxp_clean_orient(ctx, S, nv, nt, mode != 0, mode != 2, tprio3, counts))) return rc;
+    if (S->nv_out) CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->nv_out * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (S->nt_out) CXP_HIP(ctx, hipMemcpyAsync(tris, S->tri_out.p, (size_t)S->nt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    *nv_io = S->nv_out; *nt_io = S->nt_out;
+    ctx->post_valid = false;
+    return CX_OK;
 }

@@ -89,7 +89,8 @@ int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris);
  * Replaces GridContour.quantize_interpolations (tetrahedral.py:190-215), remove_tiny_simplices
  * (:353-375), GridContour3d.extract_surface_geometry (:604-621), SurfaceGeometry.clean_triangles
  * (surface_geometry.py:14-50) and SurfaceGeometry.orient_triangles (:52-140) on the device.
- * corner = grid_dimensions of the reference (= n-1 per axis).  out_counts: [0] vertices, [1] triangles,
+ * corner = grid_dimensions of the reference (= n-1 per axis).  flags bit 0: skip clean_triangles
+ * (the reference's clean=False).  out_counts (8 x int64): [0] vertices, [1] triangles,
  * [2] triangles after weld, [3] triangles after tiny collapse, [4] connected components. */
 int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
@@ -98,10 +99,11 @@ int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 /* ---- standalone SurfaceGeometry operator ---------------------------------------------------------
  * SurfaceGeometry(vertices, triangles).clean_triangles() / .orient_triangles()
  * (surface_geometry.py:6-12, 14-50, 52-140) on caller-supplied host arrays.
- * do_clean != 0 runs clean_triangles first.  Outputs are written in place: *nv / *nt are updated,
- * points (nv*3 doubles) and tris (nt*3 int32) are overwritten with the cleaned / oriented mesh. */
+ * mode 0 = orient_triangles only, 1 = clean_triangles then orient_triangles, 2 = clean_triangles only.
+ * Outputs are written in place: *nv / *nt are updated, points (nv*3 doubles) and tris (nt*3 int32)
+ * are overwritten with the cleaned / oriented mesh (vertices compacted to those still in use). */
 int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv, int32_t* tris, int64_t* nt,
-                        int do_clean);
+                        int mode);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.

@@ -88,7 +88,17 @@ def weld(keys, xyz, tris, corner):
         if s not in winners or pr < winners[s][0]:
             winners[s] = (pr, m)
     out = np.array([w[1] for w in winners.values()], dtype=np.int64).reshape(-1, 3)
-    return rep, out
+    tprio = np.array([w[0] for w in winners.values()], dtype=np.int64).reshape(-1, 3)
+    return rep, out, tprio
+
+
+def tiny_mask(xyz, tris, corner, epsilon=1e-4):
+    tris = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    if len(tris) == 0:
+        return np.zeros(0, dtype=bool)
+    P = np.asarray(xyz, dtype=np.float64)[tris]
+    delta = (P.max(axis=1) - P.min(axis=1)) * (1.0 / np.asarray(corner, dtype=np.float64))
+    return delta.max(axis=1) < epsilon
 
 
 def tiny_collapse(keys, xyz, tris, corner, epsilon=1e-4):
@@ -145,7 +155,7 @@ def extract(xyz, tris):
     return np.asarray(xyz)[used], remap[tris], used
 
 
-def clean(xyz, tris):
+def clean(xyz, tris, tprio=None):
     """A9.  SurfaceGeometry.clean_triangles: omit triangles with np.allclose(cross((A-C),(B-C)), 0)
     (:33-34) and merge those of their vertex pairs that are np.allclose (:38-43).
     Canonical form: all merges are collected first (union-find, root = smallest index), then every
@@ -169,14 +179,17 @@ def clean(xyz, tris):
                 uf.union(int(i), int(j))
     root = uf.roots()
     kept = {}
-    for t in tris[~degenerate]:
+    if tprio is None:
+        tprio = np.sort(tris, axis=1)
+    for t, pr in zip(tris[~degenerate], np.asarray(tprio)[~degenerate]):
         m = (int(root[t[0]]), int(root[t[1]]), int(root[t[2]]))
         if len(set(m)) < 3:
             continue
         s = tuple(sorted(m))
-        if s not in kept:
-            kept[s] = m
-    out = np.array(list(kept.values()), dtype=np.int64).reshape(-1, 3)
+        pr = tuple(int(x) for x in pr)
+        if s not in kept or pr < kept[s][0]:      # equal vertex sets: smallest original priority triple survives
+            kept[s] = (pr, m)
+    out = np.array([w[1] for w in kept.values()], dtype=np.int64).reshape(-1, 3)
     x2, t2, _ = extract(xyz, out)
     return x2, t2
 
@@ -299,14 +312,22 @@ def level1_from_level0(keys, xyz, tris, corner):
     returns dict(grid_points, triangles, n_after_weld, n_after_tiny, flipped)"""
     keys = np.asarray(keys, dtype=np.int64)
     xyz = np.asarray(xyz, dtype=np.float64)
-    rep, t1 = weld(keys, xyz, tris, corner)
+    tris = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    # canonical numbering: vertices in ascending edge-key order, so "smallest index" == "smallest key"
+    order = np.argsort(keys, kind="stable")
+    inv = np.empty(len(keys), dtype=np.int64)
+    inv[order] = np.arange(len(keys))
+    keys, xyz, tris = keys[order], xyz[order], (inv[tris] if len(tris) else tris)
+    rep, t1, p1 = weld(keys, xyz, tris, corner)
     n_after_weld = len(t1)
     # where the reference's hash-order artefacts can act: welded groups (which member represents
     # the bucket), tiny triangles (merge point), zero-area triangles (merge direction)
     welded = np.nonzero(rep != np.arange(len(rep)))[0]
     group = np.unique(np.concatenate([welded, rep[welded]])) if len(welded) else np.zeros(0, np.int64)
     sites = np.concatenate([xyz[group].reshape(-1, 3), tiny_sites(xyz, t1, corner).reshape(-1, 3)], axis=0)
+    keep = ~tiny_mask(xyz, t1, corner)
     xyz2, t2 = tiny_collapse(keys, xyz, t1, corner)
+    p2 = p1[keep]
     n_after_tiny = len(t2)
     x3, t3, _ = extract(xyz2, t2)
     # vertices of zero-area triangles: clean_triangles merges them in hash order (not contractual)
@@ -315,7 +336,7 @@ def level1_from_level0(keys, xyz, tris, corner):
         crossc = np.cross(Pc[:, 0] - Pc[:, 2], Pc[:, 1] - Pc[:, 2])
         degenerate = np.all(np.abs(crossc) <= 1e-8, axis=1)
         sites = np.concatenate([sites.reshape(-1, 3), Pc[degenerate].reshape(-1, 3)], axis=0)
-    x4, t4 = clean(x3, t3)
+    x4, t4 = clean(x3, t3, p2)
     t5, label, comp_flags = orient(x4, t4)
     return dict(grid_points=x4, triangles=t5, n_after_weld=n_after_weld, n_after_tiny=n_after_tiny,
                 labels=label, comp_flags=comp_flags, sites=sites)

@@ -1,0 +1,116 @@
+"""GPU: API-level (Level-1) parity of the device post-passes with the oracle's canonical restatement
+and with the outputs of the real reference (goldens), through the reference-shaped Python API."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_names
+
+pytestmark = pytest.mark.gpu
+
+WELL_BEHAVED = ("sphere32", "inv_sphere20", "shells24", "blobs27", "noise24_v0", "noise32_v0")
+
+
+def run_api(G):
+    from contourist_amd import tetrahedral
+    A, v = G["A"], float(G["value"])
+    mins = G["mins"] if "mins" in G.files else np.zeros(3)
+    delta = G["delta"] if "delta" in G.files else np.ones(3)
+    S = tetrahedral.TriangulatedIsosurfaces(list(mins), None, list(delta), A, v, [])
+    S.search_for_endpoints()
+    points, triangles = S.get_points_and_triangles()
+    grid_points = (np.asarray(points) - mins) / delta if len(points) else np.zeros((0, 3))
+    return S, np.asarray(points), grid_points, np.asarray(triangles)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_api_matches_oracle_and_reference(name):
+    from oracle import level0, postpass
+    G = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    corner = np.array(A.shape) - 1
+    S, points, grid_points, triangles = run_api(G)
+    post = S.contour_maker._post
+    O = level0.march3d(A, v, diag_mode=1)
+    L1 = postpass.level1_from_level0(level0.edge_keys_from_pairs(O["pairs"], A.shape), O["xyz"], O["tris"], corner)
+    # counts through the pipeline: identical to the oracle's canonical pipeline
+    assert post["n_after_weld"] == L1["n_after_weld"] == int(G["n_tris_after_weld"])
+    assert post["n_after_tiny"] == L1["n_after_tiny"]
+    assert len(triangles) == len(L1["triangles"])
+    assert triangles.shape[1] == 3 and points.shape[1] == 3
+    assert triangles.min(initial=0) >= 0 and triangles.max(initial=-1) < len(points)
+    # device vs oracle: same canonical choices => same triangles and winding (ambiguous components excused)
+    cmp = postpass.compare_level1(L1, grid_points, triangles, corner, reach=0)
+    assert not cmp["missing"] and not cmp["extra"] and not cmp["winding"], {k: (len(x) if isinstance(x, list) else x) for k, x in cmp.items()}
+    assert cmp["excused_rows"] == 0
+    # coordinates are the reference's float64 interpolation, bit for bit (every output point is a Level-0 point)
+    ref_pts = set(map(tuple, np.round(O["xyz"], 12).tolist()))
+    got_pts = set(map(tuple, np.round(grid_points, 12).tolist()))
+    assert got_pts <= ref_pts
+    # device vs the real reference's output
+    cmpr = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner)
+    assert not cmpr["missing"] and not cmpr["extra"] and not cmpr["winding"]
+    if name in WELL_BEHAVED:
+        assert cmp["excused_winding"] == 0 and cmpr["excused_winding"] == 0
+        # Level-1 canonical forms (bucket triples + winding) are then literally identical
+        ref = postpass.canonical_level1(G["l1_grid_points"], G["l1_triangles"], corner)
+        got = postpass.canonical_level1(grid_points, triangles, corner)
+        if len(L1["sites"]) == 0:
+            assert np.array_equal(ref, got)
+    # world coordinates (grid_field.py:89-93)
+    if "l1_points" in G.files and len(L1["sites"]) == 0 and len(points) == len(G["l1_points"]):
+        a = np.array(sorted(map(tuple, points.tolist())))
+        b = np.array(sorted(map(tuple, G["l1_points"].tolist())))
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+def test_config1_sphere_counts():
+    """BASELINE.json configs[0]: 32^3 sphere -> 6386 points / 12768 triangles, Euler characteristic 2"""
+    from contourist_amd import tetrahedral
+    d = 3.0 / 32
+    S = tetrahedral.TriangulatedIsosurfaces([-1.5] * 3, [1.5 - d] * 3, [d] * 3, lambda x, y, z: x * x + y * y + z * z, 1.0, [])
+    S.search_for_endpoints()
+    points, triangles = S.get_points_and_triangles()
+    assert len(points) == 6386 and len(triangles) == 12768
+    edges = set()
+    for t in triangles:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            edges.add((min(a, b), max(a, b)))
+    assert len(points) - len(edges) + len(triangles) == 2
+    # outward orientation: normals point away from the origin
+    P = points[triangles]
+    n = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    assert np.all(np.einsum("ij,ij->i", n, P.mean(axis=1)) > 0)
+    assert np.allclose(np.linalg.norm(points, axis=1), 1.0, atol=0.01)
+
+
+def test_surface_geometry_standalone():
+    """SurfaceGeometry(vertices, triangles).clean_triangles()/orient_triangles() on a caller's mesh with
+    scrambled winding"""
+    from contourist_amd import surface_geometry
+    from oracle import level0, postpass
+    G = np.load(os.path.join(GOLDEN_DIR, "shells24.npz"))
+    O = level0.march3d(G["A"], float(G["value"]), diag_mode=1)
+    rng = np.random.RandomState(0)
+    tris = O["tris"].copy()
+    flip = rng.rand(len(tris)) < 0.5
+    tris[flip] = tris[flip][:, ::-1]
+    sg = surface_geometry.SurfaceGeometry(list(O["xyz"]), [tuple(t) for t in tris])
+    got = np.asarray(sg.orient_triangles())
+    want, label, flags = postpass.orient(O["xyz"], O["tris"])
+    assert flags.max(initial=0) == 0
+
+    def canon(T):
+        T = np.asarray(T)
+        first = np.argmin(T, axis=1)
+        idx = (first[:, None] + np.arange(3)[None, :]) % 3
+        R = np.take_along_axis(T, idx, axis=1)
+        return R[np.lexsort((R[:, 2], R[:, 1], R[:, 0]))]
+    assert np.array_equal(canon(got), canon(want))
+    # clean: a mesh with an injected zero-area triangle and a duplicate vertex
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], dtype=float)
+    tri = [(0, 1, 2), (0, 1, 3), (1, 4, 2), (0, 2, 3), (4, 2, 3)]
+    sg2 = surface_geometry.SurfaceGeometry(list(pts), tri)
+    v2, t2 = sg2.clean_triangles()
+    assert len(t2) == 4 and len(v2) == 4      # (1,4,2) dropped, vertices 1 and 4 merged

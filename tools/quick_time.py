@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""K1/K2 timing of the full path (median of rounds), for A/B builds."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from contourist_amd import _ffi, synthetic
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+A = synthetic.smooth_noise_torch((size,) * 3, 1235, 1400, torch.device("cuda", 0))
+ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+print(ctx.extract3d(0.0, 1))
+for fl, name in ((1, "full"), (1 | 0x10000 | 0x800000, "phaseA")):
+    r = []
+    for rnd in range(7):
+        ctx.extract3d_async(0.0, fl)
+        ctx.timing_enable(True)
+        for _ in range(5):
+            ctx.extract3d_async(0.0, fl)
+        t = ctx.timing_read(); ctx.timing_enable(False)
+        r.append((t["classify_ms"] / t["n"], t["emit_ms"] / t["n"]))
+    k1 = sorted(x[0] for x in r); k2 = sorted(x[1] for x in r)
+    print("%s %-8s K1 med %.3f min %.3f | K2 med %.3f min %.3f" % (os.environ.get("TAG", ""), name, k1[3], k1[0], k2[3], k2[0]))
