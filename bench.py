@@ -59,6 +59,7 @@ def main():
     import torch
     import torch.distributed as dist
     from contourist_amd import _ffi, synthetic
+    from contourist_amd import distributed as cxdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,18 +88,12 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = _ffi.Context(local_rank, stream=stream.cuda_stream)
+    ctx.set_origin(rank * n, 0, 0)
     flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
 
     def halo_exchange(buf):
         """lower plane of rank r+1 -> halo plane of rank r (RCCL send/recv over xGMI)"""
-        ops = []
-        if rank > 0:
-            ops.append(dist.P2POp(dist.isend, buf[0], rank - 1))
-        if has_upper:
-            ops.append(dist.P2POp(dist.irecv, buf[n], rank + 1))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        cxdist.exchange_halo(buf, n, rank, world, dist)
 
     def step(i):
         buf = slabs[i % nrot]

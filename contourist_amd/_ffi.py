@@ -20,7 +20,7 @@ CX_KERNEL_GENERIC = 0x100
 # every symbol include/contourist_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
-    "cx_grid_upload", "cx_grid_adopt_device", "cx_reserve",
+    "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
     "cx_timing_enable", "cx_timing_read", "cx_version",
@@ -61,6 +61,7 @@ def load():
         "cx_synchronize": [vp],
         "cx_grid_upload": [vp, vp, i64, i64, i64],
         "cx_grid_adopt_device": [vp, vp, i64, i64, i64],
+        "cx_set_origin": [vp, i64, i64, i64],
         "cx_reserve": [vp, i64, i64, i64],
         "cx_extract3d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
         "cx_extract3d_async": [vp, dbl, u32],
@@ -136,6 +137,9 @@ class Context(object):
         self._check(self.lib.cx_grid_adopt_device(self.handle, ctypes.c_void_p(int(device_ptr)), *[int(n) for n in shape]))
         self.shape = tuple(int(n) for n in shape)
         self._keep = keepalive
+
+    def set_origin(self, o0=0, o1=0, o2=0):
+        self._check(self.lib.cx_set_origin(self.handle, int(o0), int(o1), int(o2)))
 
     def reserve(self, max_cells=0, max_vertices=0, max_triangles=0):
         self._check(self.lib.cx_reserve(self.handle, int(max_cells), int(max_vertices), int(max_triangles)))

@@ -132,6 +132,12 @@ extern "C" int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t
     return CX_OK;
 }
 
+extern "C" int cx_set_origin(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2) {
+    if (!ctx || o0 < 0 || o1 < 0 || o2 < 0 || o0 > 0x7FFFFFFFLL || o1 > 0x7FFFFFFFLL || o2 > 0x7FFFFFFFLL) return CX_ERR_INVALID;
+    ctx->origin[0] = o0; ctx->origin[1] = o1; ctx->origin[2] = o2;
+    return CX_OK;
+}
+
 extern "C" int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max_triangles) {
     if (!ctx || max_cells < 0 || max_vertices < 0 || max_triangles < 0) return CX_ERR_INVALID;
     if (max_cells > 0xFFFFFFF0LL || max_vertices > 0xFFFFFFF0LL || max_triangles > 0x7FFFFFF0LL)
@@ -194,7 +200,10 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
     P.counters = ctx->counters;
     ctx->last = P;
-    if ((flags & CX_DIAG_CPYTHON310) && (ctx->hash_xy_n0 != ctx->n0 || ctx->hash_xy_n1 != ctx->n1)) {
+    P.org0 = (uint32_t)ctx->origin[0]; P.org1 = (uint32_t)ctx->origin[1]; P.org2 = (uint32_t)ctx->origin[2];
+    ctx->last = P;
+    if ((flags & CX_DIAG_CPYTHON310) && (ctx->hash_xy_n0 != ctx->n0 || ctx->hash_xy_n1 != ctx->n1 ||
+                                         ctx->hash_xy_o0 != ctx->origin[0] || ctx->hash_xy_o1 != ctx->origin[1])) {
         const size_t need = (size_t)(ctx->n0 * ctx->n1);
         if (ctx->hash_xy_cap < need) {
             if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
@@ -202,8 +211,9 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             CX_HIP(ctx, hipMalloc(&ctx->hash_xy, need * sizeof(uint64_t)));
             ctx->hash_xy_cap = need;
         }
-        cx_launch_hash_xy(ctx->hash_xy, P.n0, P.n1, ctx->stream);
+        cx_launch_hash_xy(ctx->hash_xy, P.n0, P.n1, P.org0, P.org1, ctx->stream);
         ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
+        ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
     }
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {

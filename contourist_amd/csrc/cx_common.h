@@ -40,6 +40,7 @@ struct cx_params {
     double value;          // isovalue (float64, as the reference computes)
     double tol_value;      // 1e-8 + 1e-5*|value|   (np.allclose(values, value), tetrahedral.py:576)
     uint32_t flags;
+    uint32_t org0, org1, org2;   // lattice offset of this array inside a larger volume (hash order only)
     // outputs
     uint64_t* celltab;     // [nsamples] per lattice cell that owns a vertex: (crossing mask << 32) | first vertex index
     float4* verts;         // [vcap]  {x,y,z,bits(edge id)}
@@ -71,4 +72,4 @@ void cx_launch_classify_generic(const cx_params& P, hipStream_t s);
 bool cx_fast_classify_supported(const cx_params& P);
 void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
-void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, hipStream_t s);
+void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

@@ -21,7 +21,8 @@ struct cx_ctx {
     size_t tables_for = 0;
     uint64_t* hash_xy = nullptr;       // CPython tuple-hash prefix per (i,j), for CX_DIAG_CPYTHON310
     size_t hash_xy_cap = 0;
-    int64_t hash_xy_n0 = 0, hash_xy_n1 = 0;
+    int64_t hash_xy_n0 = 0, hash_xy_n1 = 0, hash_xy_o0 = -1, hash_xy_o1 = -1;
+    int64_t origin[3] = {0, 0, 0};
     // Level-0 outputs
     float4* verts = nullptr;
     uint4* cells = nullptr;

@@ -365,11 +365,11 @@ __device__ __forceinline__ uint64_t py_finish3(uint64_t acc) {
     acc += 3ULL ^ (CX_PY_P5 ^ 3527539ULL);
     return (acc == ~0ULL) ? 1546275796ULL : acc;
 }
-__global__ void cx_k_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1) {
+__global__ void cx_k_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n0 * n1) return;
     const uint32_t i = idx / n1, j = idx - i * n1;
-    table[idx] = py_round(py_round(CX_PY_P5, i), j);
+    table[idx] = py_round(py_round(CX_PY_P5, i + org0), j + org1);
 }
 // does a 2-element set {first inserted h1, then h2} iterate h2 first?
 __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
                 h[c] = 0;
                 if ((need >> c) & 1u) {
                     const uint64_t hxy = hash_xy[(ci + ((c >> 2) & 1u)) * P.n1 + (cj + ((c >> 1) & 1u))];
-                    h[c] = py_finish3(py_round(hxy, ck + (c & 1u)));
+                    h[c] = py_finish3(py_round(hxy, ck + (c & 1u) + P.org2));
                 }
             }
 #pragma unroll
@@ -548,7 +548,7 @@ void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipSt
     hipLaunchKernelGGL(cx_k_emit_triangles, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P, hash_xy);
 }
 
-void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, hipStream_t s) {
+void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {
     const uint32_t n = n0 * n1;
-    hipLaunchKernelGGL(cx_k_hash_xy, dim3((n + 255u) / 256u), dim3(256), 0, s, table, n0, n1);
+    hipLaunchKernelGGL(cx_k_hash_xy, dim3((n + 255u) / 256u), dim3(256), 0, s, table, n0, n1, org0, org1);
 }

@@ -1,0 +1,114 @@
+"""Slab-partitioned extraction over several GPUs of one node (one process per GPU).
+
+The volume is cut into contiguous slabs along array axis 0 (the reference's x, BASELINE.json's
+"z-slab").  Voxels are independent given their corners, so the only exchange on the data path is
+ONE sample plane per slab boundary: rank r receives the first plane of rank r+1 as its halo
+(`torch.distributed` send/recv: RCCL over xGMI with backend "nccl", gloo on CPU tensors).
+Edge ids are global by formula -- (global linear index of the lower lattice point << 3) | direction
+-- so slab meshes concatenate without any renumbering exchange; vertices that a slab sees only
+through its halo plane are owned (and emitted) by the upper neighbour.
+
+There is no counterpart in the reference (it is single-process Python); the slab rule follows
+SURVEY.md section 8e.
+"""
+import numpy as np
+
+
+def slab_bounds(n0, world, rank):
+    "planes [i0, i1) of axis 0 owned by `rank`"
+    return (rank * n0) // world, ((rank + 1) * n0) // world
+
+
+def exchange_halo(local, n_own, rank, world, dist=None):
+    """local: tensor of n_own (+1 if rank < world-1) planes.  Sends the first owned plane to
+    rank-1 and receives the halo plane local[n_own] from rank+1."""
+    if world == 1:
+        return
+    if dist is None:
+        import torch.distributed as dist
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, local[0].contiguous(), rank - 1))
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.irecv, local[n_own], rank + 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def hip_extract(device=0, diagonal_flags=1):
+    "default local extractor: the HIP Level-0 march. returns f(local_array_or_tensor, value, origin) -> (xyz, keys, tris)"
+    from . import _ffi
+    ctx = _ffi.Context(device)
+
+    def run(local, value, origin=(0, 0, 0)):
+        ctx.set_origin(*origin)
+        if type(local).__module__.split(".")[0] == "torch":
+            ctx.adopt_device_grid(local.data_ptr(), tuple(local.shape), keepalive=local)
+        else:
+            ctx.upload_grid(local)
+        counts = ctx.extract3d(value, diagonal_flags)
+        return ctx.download_level0(counts)
+    return run
+
+
+def local_to_global(xyz, keys, tris, local_shape, i0, n_own, has_halo):
+    """Level-0 mesh of one slab -> global ids.
+    returns (gkeys (V',) int64 of the vertices this rank OWNS, gxyz (V',3), tri_gkeys (T,3) int64)"""
+    n1, n2 = int(local_shape[1]), int(local_shape[2])
+    keys = np.asarray(keys).astype(np.int64)
+    offset = (np.int64(i0) * n1 * n2) << 3
+    gkeys = keys + offset
+    tri_gkeys = gkeys[np.asarray(tris, dtype=np.int64)] if len(tris) else np.zeros((0, 3), dtype=np.int64)
+    gxyz = np.asarray(xyz, dtype=np.float64).copy()
+    gxyz[:, 0] += i0
+    if has_halo:
+        owner_plane = (keys >> 3) // (n1 * n2)           # local plane of the owning lattice point
+        own = owner_plane < n_own
+        gkeys, gxyz = gkeys[own], gxyz[own]
+    return gkeys, gxyz, tri_gkeys
+
+
+def assemble(parts):
+    """parts: list of (gkeys, gxyz, tri_gkeys) from all ranks -> (keys sorted, xyz, triangles as indices)"""
+    keys = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
+    xyz = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, 3))
+    tk = np.concatenate([p[2] for p in parts]) if parts else np.zeros((0, 3), np.int64)
+    order = np.argsort(keys, kind="stable")
+    keys, xyz = keys[order], xyz[order]
+    if len(keys) > 1 and np.any(keys[1:] == keys[:-1]):
+        raise RuntimeError("a vertex was emitted by two slabs")
+    tris = np.searchsorted(keys, tk)
+    if len(tk) and not np.array_equal(keys[tris], tk):
+        raise RuntimeError("a triangle references a vertex no slab emitted")
+    return keys, xyz, tris
+
+
+def extract_slabs(own_planes, value, rank, world, extract_fn, global_shape, dist=None, gather=True):
+    """own_planes: this rank's planes [i0, i1) (numpy array or torch tensor, on CPU or GPU).
+    Runs halo exchange + local march + global id conversion; with gather=True rank 0 returns the
+    assembled (keys, xyz, triangles), other ranks None."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    n0 = int(global_shape[0])
+    i0, i1 = slab_bounds(n0, world, rank)
+    n_own = i1 - i0
+    has_halo = rank + 1 < world
+    t = own_planes if isinstance(own_planes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(own_planes, dtype=np.float32))
+    assert t.shape[0] == n_own, (t.shape, n_own)
+    local = torch.empty((n_own + (1 if has_halo else 0),) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+    local[:n_own] = t
+    exchange_halo(local, n_own, rank, world, dist)
+    arg = local if local.is_cuda else local.numpy()
+    xyz, keys, tris = extract_fn(arg, value, (i0, 0, 0))
+    part = local_to_global(xyz, keys, tris, tuple(local.shape), i0, n_own, has_halo)
+    if not gather:
+        return part
+    if world == 1:
+        return assemble([part])
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(part, gathered, dst=0)
+    if rank == 0:
+        return assemble(gathered)
+    return None

@@ -62,6 +62,12 @@ int cx_synchronize(cx_ctx* ctx);
 int cx_grid_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2);
 int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2);
 
+/* the grid is a sub-block of a larger volume starting at lattice point (o0,o1,o2) (slab partitions).
+ * Only CX_DIAG_CPYTHON310 depends on it: the reference's set order hashes ABSOLUTE lattice
+ * coordinates (tetrahedral.py:567-575), so slabs must hash global coordinates to agree with the
+ * undivided volume.  Edge ids stay local; the caller adds (o0*n1*n2 + ...) << 3. */
+int cx_set_origin(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2);
+
 /* optional: pre-size the output buffers (cells / vertices / triangles); 0 keeps the default. */
 int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max_triangles);
 

@@ -23,6 +23,9 @@ def lib():
         L.oracle_march3d.argtypes = [ctypes.c_void_p, i64, i64, i64, ctypes.c_double, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, i64,
                                      ctypes.c_void_p]
+        L.oracle_march3d_origin.restype = ctypes.c_int
+        L.oracle_march3d_origin.argtypes = [ctypes.c_void_p, i64, i64, i64, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p]
         L.oracle_count_crossings3d.restype = i64
         L.oracle_count_crossings3d.argtypes = [ctypes.c_void_p, i64, i64, i64, ctypes.c_double,
                                                ctypes.c_void_p]
@@ -41,7 +44,7 @@ def count_crossings(A, value):
     return int(n), float(mm[0]), float(mm[1])
 
 
-def march3d(A, value, diag_mode=1, vcap=None, tcap=None):
+def march3d(A, value, diag_mode=1, vcap=None, tcap=None, origin=(0, 0, 0)):
     """Level-0 dense march of fp32 array A at isovalue `value`.
 
     returns dict(pairs (V,6) int32 [low ijk, high ijk], xyz (V,3) float64 grid coords,
@@ -58,9 +61,10 @@ def march3d(A, value, diag_mode=1, vcap=None, tcap=None):
         xyz = np.zeros((vcap, 3), dtype=np.float64)
         tris = np.zeros((tcap, 3), dtype=np.int64)
         counts = np.zeros(4, dtype=np.int64)
-        rc = lib().oracle_march3d(A.ctypes.data, *A.shape, float(value), int(diag_mode),
-                                  pairs.ctypes.data, xyz.ctypes.data, vcap, tris.ctypes.data, tcap,
-                                  counts.ctypes.data)
+        org = np.array(origin, dtype=np.int64)
+        rc = lib().oracle_march3d_origin(A.ctypes.data, *A.shape, float(value), int(diag_mode), org.ctypes.data,
+                                         pairs.ctypes.data, xyz.ctypes.data, vcap, tris.ctypes.data, tcap,
+                                         counts.ctypes.data)
         if rc != 0:
             raise MemoryError("oracle_march3d")
         nv, nt, nb, nbm = (int(c) for c in counts)
