@@ -23,7 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
-    "cx_timing_enable", "cx_timing_read", "cx_version",
+    "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
 
 
@@ -71,6 +71,7 @@ def load():
         "cx_postprocess3d": [vp, u32, vp],
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
+        "cx_debug_stamps": [vp, i64, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }

@@ -190,8 +190,10 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.div_plane = cx_fdiv_make(P.n1 * P.n2);
     P.div_row = cx_fdiv_make(P.n2);
     P.vcmp = fp32_threshold(value);
-    P.vabs = std::nextafterf((float)std::fabs(value), INFINITY);
-    P.near_screen = 1.1e-5f;
+    // |f-v| <= 1e-8 + 1e-5*max(|f|,|v|)  =>  |f - vcmp| <= 2.2e-5*|v| + 4e-8  (vcmp within 1 ulp of v)
+    P.near_abs = std::nextafterf((float)(2.2e-5 * std::fabs(value) + 4e-8), INFINITY);
+    P.vhi = (float)value;
+    P.vlo = (float)(value - (double)P.vhi);
     P.value = value;
     P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
     P.flags = flags;
@@ -199,6 +201,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.verts = ctx->verts; P.cells = ctx->cells; P.tris = ctx->tris;
     P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
     P.counters = ctx->counters;
+    P.stamps = ctx->stamps;
     ctx->last = P;
     P.org0 = (uint32_t)ctx->origin[0]; P.org1 = (uint32_t)ctx->origin[1]; P.org2 = (uint32_t)ctx->origin[2];
     ctx->last = P;
@@ -298,6 +301,25 @@ extern "C" int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris
     if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
     if (verts_xyzk) *verts_xyzk = ctx->verts;
     if (tris) *tris = ctx->tris;
+    return CX_OK;
+}
+
+// diagnostic: allocate (words > 0) or drop (0) the per-wave stamp buffer; copy it out with host != NULL
+extern "C" int cx_debug_stamps(cx_ctx* ctx, int64_t words, unsigned long long* host) {
+    if (!ctx) return CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (host && ctx->stamps) {
+        CX_HIP(ctx, hipMemcpy(host, ctx->stamps, ctx->stamps_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return CX_OK;
+    }
+    if (ctx->stamps) (void)hipFree(ctx->stamps);
+    ctx->stamps = nullptr; ctx->stamps_words = 0;
+    if (words > 0) {
+        CX_HIP(ctx, hipMalloc(&ctx->stamps, (size_t)words * sizeof(unsigned long long)));
+        CX_HIP(ctx, hipMemset(ctx->stamps, 0, (size_t)words * sizeof(unsigned long long)));
+        ctx->stamps_words = (size_t)words;
+    }
     return CX_OK;
 }
 

@@ -35,8 +35,8 @@ struct cx_params {
     cx_fdiv div_plane;     // / (n1*n2)
     cx_fdiv div_row;       // / n2
     float vcmp;            // smallest fp32 >= value :  (double)f < value  <=>  f < vcmp
-    float vabs;            // >= |value| (fp32, rounded up)
-    float near_screen;     // fp32 screen factor (superset of the float64 np.allclose tests)
+    float near_abs;        // fp32 screen: |f - vcmp| <= near_abs is a superset of both float64 np.allclose tests
+    float vhi, vlo;        // isovalue as an unevaluated fp32 sum (vhi + vlo == value to ~2^-48 relative)
     double value;          // isovalue (float64, as the reference computes)
     double tol_value;      // 1e-8 + 1e-5*|value|   (np.allclose(values, value), tetrahedral.py:576)
     uint32_t flags;
@@ -48,6 +48,7 @@ struct cx_params {
     int32_t* tris;         // [tcap*3]
     uint32_t vcap, ccap, tcap;
     uint32_t* counters;    // [0] cells [1] verts [2] tris [3] border voxels
+    unsigned long long* stamps;   // diagnostic builds only: 4 s_memtime stamps per classify wave (else null)
 };
 
 // debug / ablation flags (timing experiments only; results are wrong when set)
@@ -64,7 +65,7 @@ enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, C
 
 // device tables (defined in cx_march3d.hip)
 extern __device__ __constant__ uint8_t cx_d_tet_corners[6][4];
-extern __device__ __constant__ uint64_t cx_d_tet_tris[6][16][2];
+extern __device__ __constant__ uint32_t cx_d_tet_tris[6][16][2];
 extern __device__ __constant__ uint8_t cx_d_voxel_ntri[256];
 
 // kernel launchers (cx_march3d.hip)

@@ -36,6 +36,8 @@ struct cx_ctx {
     // Level-1
     cx_post_state* post = nullptr;
     bool post_valid = false;
+    unsigned long long* stamps = nullptr;   // diagnostic stamps (cx_debug_stamps)
+    size_t stamps_words = 0;
     // timing
     struct evset { hipEvent_t e[3] = {nullptr, nullptr, nullptr}; };
     bool timing = false;

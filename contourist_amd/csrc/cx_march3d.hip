@@ -18,17 +18,19 @@
 //                vertex records, the per-cell lookup word and one record per active cell.
 // K2  cx_k_emit_triangles   one lane per active-cell record: expands the tetrahedra into index
 //                triples, looking vertex indices up in the per-cell table.
+#include <cstdlib>
+
 #include "cx_cell.h"
 
 __device__ __constant__ uint8_t cx_d_tet_corners[6][4] = CX_TET_CORNERS_INIT;
-__device__ __constant__ uint64_t cx_d_tet_tris[6][16][2] = CX_TET_TRIS_INIT;
+__device__ __constant__ uint32_t cx_d_tet_tris[6][16][2] = CX_TET_TRIS_INIT;
 __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 
 #ifndef CX_QCAP
-#define CX_QCAP 2048u
+#define CX_QCAP 1024u
 #endif
 #ifndef CX_K1_MIN_WAVES
-#define CX_K1_MIN_WAVES 4
+#define CX_K1_MIN_WAVES 3   // two sample planes in flight per wave need ~130 VGPRs (4 waves/SIMD would spill)
 #endif   // active cells a wave can queue before it has to flush on its own
 #define CX_RJ 4         // cell rows per wave in the FAST kernel (a workgroup covers 4*CX_RJ rows)
 
@@ -44,8 +46,9 @@ struct cx_run {
 
 // one sweep over the wave's queued cells.  emit == false: only count into `run` (from zero);
 // emit == true: `run` holds the reserved bases and advances as records are written.
+#define CX_VSTAGE 256u   // vertex records a wave stages in LDS per batch of 64 cells (typical: ~200)
 __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint32_t* q, uint32_t n, uint32_t lane,
-                                                 bool emit, cx_run& run) {
+                                                 bool emit, cx_run& run, float4* vstage) {
     const uint32_t plane = P.n1 * P.n2;
     for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
         const uint32_t idx = b0 + lane;
@@ -73,9 +76,17 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint3
         const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
         if (emit) {
             const uint32_t vfirst = run.v + vpre;
-            if (nv && run.v + vtot <= P.vcap) {
-                if (!(P.flags & CX_DBG_NO_VERTS)) cx_emit_vertices(P, f, R.emask, lin, i, j, k, vfirst);
-                if (!(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+            if (run.v + vtot <= P.vcap) {
+                if (vtot <= CX_VSTAGE) {
+                    // the wave's vertices of this batch are one contiguous run of the vertex array:
+                    // stage them in LDS, then write full 16-byte-per-lane rows
+                    if (nv) cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const float4& rec4) { vstage[vpre + r2] = rec4; });
+                    if (!(P.flags & CX_DBG_NO_VERTS))
+                        for (uint32_t o = lane; o < vtot; o += 64u) P.verts[run.v + o] = vstage[o];
+                } else if (nv && !(P.flags & CX_DBG_NO_VERTS)) {
+                    cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const float4& rec4) { P.verts[vfirst + r2] = rec4; });
+                }
+                if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
             if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
                 uint4 c4;
@@ -100,15 +111,11 @@ __device__ __forceinline__ void cx_count_from_signs(uint32_t sm, uint32_t vm, cx
     const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
     const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
     const bool real_voxel = (vm == 0xFFu);
-    const uint32_t nt = real_voxel ? (uint32_t)cx_d_voxel_ntri[sm] : 0u;
+    const uint32_t nt = real_voxel ? cx_voxel_ntri(sm) : 0u;
     acc.v += nv;
     acc.t += nt;
     acc.c += (nv | nt) ? 1u : 0u;
     acc.b += real_voxel ? 1u : 0u;
-}
-// fp32 screen (superset of both float64 np.allclose tests): |f - v| <= s*(|f| + |v|) + c
-__device__ __forceinline__ bool cx_near_screen(const cx_params& P, float f) {
-    return fabsf(f - P.vcmp) <= fmaf(fabsf(f), P.near_screen, P.near_screen * P.vabs + 4e-8f);
 }
 __device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
 #pragma unroll
@@ -129,19 +136,24 @@ __device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
 template <bool FAST>
 __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_params P, const cx_task T, const uint32_t cells_per_block) {
     __shared__ uint32_t s_queue[4][CX_QCAP];
+    __shared__ float4 s_vstage[4][CX_VSTAGE];
     __shared__ uint32_t s_tot[4][4];
     __shared__ uint32_t s_base[4];
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* q = s_queue[wave];
     uint32_t qn = 0;   // wave-uniform
+    unsigned long long* stamp = P.stamps ? P.stamps + ((size_t)blockIdx.x * 4u + wave) * 4u : nullptr;
+    if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the queued cells (from sign masks)
-    bool suspect = false;        // per-lane: a sample within the tolerance screen was seen
+    float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
+    uint32_t wcur = 0, act0 = 0;
+    bool pending = false;        // wave-uniform: a classified step is waiting for queue space
     const float* __restrict__ A = P.grid;
     const uint32_t plane = P.n1 * P.n2;
 
     // ---- FAST task: block -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
-    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0, mk = 0, mj = 0, mr = 0;
+    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0, mk = 0, mj = 0, mr = 0, kofs_c = 0;
     bool lane_valid = false, halo_in = false;
     // ---- generic task: contiguous range of linear cell indices per block
     uint32_t gbase = 0, gend = 0;
@@ -158,44 +170,54 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         nrows = (j0 < P.n1) ? min((uint32_t)CX_RJ, P.n1 - j0) : 0u;
         kofs = k0 + 4u * lane;
         lane_valid = kofs < P.n2;                      // n2 % 4 == 0
+        kofs_c = lane_valid ? kofs : (P.n2 - 4u);
         last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
         halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
         streaming = nrows != 0u && p < ib;
         // cells whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
         mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
+        if (!lane_valid) mr = 0;   // lanes right of the array hold re-read samples: they own no cells
         mk = mr;
         if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << 3);       // m == 3 at the array edge
         mj = 0;
         for (uint32_t r = 0; r < CX_RJ; r++)
             if (j0 + r + 1u < P.n1) mj |= 0xFu << (CX_ROWBITS * r);
+        mj &= mr;
     } else {
         gbase = blockIdx.x * cells_per_block + wave * 64u;
         gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
         streaming = gbase < gend;
     }
 
-    // sign bits of one sample plane for this lane (FAST)
-    auto plane_bits = [&](uint32_t pp) -> uint32_t {
-        const uint32_t pc = min(pp, P.n0 - 1u);
+    // one sample plane of this lane: RJ+1 rows x 4 consecutive k-samples, plus the sample right of the segment
+    struct plane_raw {
         float4 v[CX_RJ + 1];
         float hv[CX_RJ + 1];
+    };
+    auto load_plane = [&](uint32_t pp, plane_raw& R) {
+        const uint32_t pc = min(pp, P.n0 - 1u);
 #pragma unroll
         for (int r = 0; r <= CX_RJ; r++) {
             const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
             const uint32_t rowofs = (pc * P.n1 + jr) * P.n2;
-            v[r] = lane_valid ? *reinterpret_cast<const float4*>(A + rowofs + kofs) : make_float4(0.f, 0.f, 0.f, 0.f);
-            hv[r] = halo_in ? A[rowofs + k0 + 256u] : 0.f;          // wave-uniform address
+            R.v[r] = *reinterpret_cast<const float4*>(A + rowofs + kofs_c);      // lanes right of the array re-read its last 4 samples
+            R.hv[r] = A[rowofs + (halo_in ? k0 + 256u : 0u)];                    // wave-uniform address
         }
+    };
+    // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
+    // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
+    auto plane_bits = [&](const plane_raw& R) -> uint32_t {
         uint32_t own = 0, halo = 0;
 #pragma unroll
         for (int r = 0; r <= CX_RJ; r++) {
-            suspect |= (bool)((int)cx_near_screen(P, v[r].x) | (int)cx_near_screen(P, v[r].y) | (int)cx_near_screen(P, v[r].z) |
-                              (int)cx_near_screen(P, v[r].w) | (int)cx_near_screen(P, hv[r]));
-            own |= (v[r].x < P.vcmp) ? (1u << (CX_ROWBITS * r + 0)) : 0u;
-            own |= (v[r].y < P.vcmp) ? (1u << (CX_ROWBITS * r + 1)) : 0u;
-            own |= (v[r].z < P.vcmp) ? (1u << (CX_ROWBITS * r + 2)) : 0u;
-            own |= (v[r].w < P.vcmp) ? (1u << (CX_ROWBITS * r + 3)) : 0u;
-            halo |= (hv[r] < P.vcmp) ? (1u << (CX_ROWBITS * r)) : 0u;
+            const float dx = R.v[r].x - P.vcmp, dy = R.v[r].y - P.vcmp, dz = R.v[r].z - P.vcmp, dw = R.v[r].w - P.vcmp;
+            const float dh = R.hv[r] - P.vcmp;
+            own |= (__float_as_uint(dx) >> 31) << (CX_ROWBITS * r + 0);
+            own |= (__float_as_uint(dy) >> 31) << (CX_ROWBITS * r + 1);
+            own |= (__float_as_uint(dz) >> 31) << (CX_ROWBITS * r + 2);
+            own |= (__float_as_uint(dw) >> 31) << (CX_ROWBITS * r + 3);
+            halo |= (__float_as_uint(dh) >> 31) << (CX_ROWBITS * r);
+            dnear = fminf(dnear, fminf(fminf(fabsf(dx), fabsf(dy)), fminf(fabsf(dz), fminf(fabsf(dw), fabsf(dh)))));
         }
         // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
         // at the array edge, repeats its own m=3 (clamped corner)
@@ -204,25 +226,40 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         return own | (nb << 4);
     };
 
-    if (FAST && streaming) wprev = plane_bits(p);
+    plane_raw rawA, rawB;
+    bool odd = false;            // wave-uniform: which buffer holds plane p+1
+    if (FAST && streaming) {
+        load_plane(p, rawB);
+        load_plane(p + 1u, rawA);
+        wprev = plane_bits(rawB);
+    }
+
 
     for (;;) {
         // ---- phase A: stream until done or until the queue might not hold another step
         if (FAST) {
-            while (streaming && qn + 16u * 64u <= CX_QCAP) {
-                const uint32_t wcur = plane_bits(p + 1u);
-                // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
-                const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
-                const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
-                const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
-                const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
-                uint32_t act = o & ~a & CX_CELL_MASK;
-                if (nrows < CX_RJ) act &= (1u << (CX_ROWBITS * nrows)) - 1u;
-                if (!lane_valid) act = 0;
-                if (__ballot(act != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
-                    const uint32_t act0 = act;
+            // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
+            auto step = [&](const plane_raw& cur, plane_raw& nxt) -> bool {
+                if (!pending) {
+                    load_plane(p + 2u, nxt);
+                    wcur = plane_bits(cur);
+                    // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
+                    const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
+                    const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
+                    const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
+                    const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
+                    act0 = o & ~a & mr;
+                    if (!lane_valid) act0 = 0;
+                }
+                pending = false;
+                if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
                     uint32_t tot;
-                    const uint32_t pre = cx_wave_prefix_small<5>(__popc(act), tot);
+                    const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
+                    if (qn + tot > CX_QCAP) {          // wave-uniform: no room -> emit what is queued, then resume here
+                        pending = true;
+                        return false;
+                    }
+                    uint32_t act = act0;
                     uint32_t pos = qn + pre;
                     const uint32_t lin0 = (p * P.n1 + j0) * P.n2 + kofs;
                     while (act) {
@@ -264,6 +301,12 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
                 wprev = wcur;
                 p++;
                 streaming = p < ib;
+                return true;
+            };
+            while (streaming) {
+                const bool done = odd ? step(rawB, rawA) : step(rawA, rawB);
+                if (!done) break;
+                odd = !odd;
             }
         } else {
             while (streaming && qn + 64u <= CX_QCAP) {
@@ -284,7 +327,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
                     q[qn + cx_mbcnt(act)] = lin;
                     cx_count_from_signs(sm, vm, acc);
 #pragma unroll
-                    for (int c = 0; c < 8; c++) suspect |= cx_near_screen(P, f[c]);
+                    for (int c = 0; c < 8; c++) dnear = fminf(dnear, fabsf(f[c] - P.vcmp));
                 }
                 qn += (uint32_t)__popcll(act);
                 gbase += 256u;
@@ -293,17 +336,18 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         }
         // ---- phase B: count, reserve, emit.  The last round of a workgroup reserves once for all
         // four waves; a wave whose queue filled up early reserves for itself (dense surfaces only).
-        const bool final_round = !streaming;
+        const bool final_round = !streaming && !pending;
+        if (stamp && lane == 0 && final_round) stamp[1] = __builtin_amdgcn_s_memtime();
         if (P.flags & CX_DBG_PHASE_A_ONLY) {
             if (final_round) break;
             qn = 0;
             continue;
         }
         cx_run run = {0, 0, 0, 0};
-        const bool recount = __ballot(suspect) != 0ULL;   // wave-uniform
+        const bool recount = __ballot(dnear <= P.near_abs) != 0ULL;   // wave-uniform
         for (int pass = 0; pass < 2; pass++) {
             if (pass == 1 || recount) {
-                cx_process_queue(P, q, qn, lane, pass == 1, run);
+                cx_process_queue(P, q, qn, lane, pass == 1, run, s_vstage[wave]);
             } else {
                 run.v = cx_wave_sum(acc.v); run.t = cx_wave_sum(acc.t);
                 run.c = cx_wave_sum(acc.c); run.b = cx_wave_sum(acc.b);
@@ -329,6 +373,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
                 for (uint32_t w = 0; w < wave; w++) {
                     run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
                 }
+                if (stamp && lane == 0) stamp[2] = __builtin_amdgcn_s_memtime();
             } else {
                 cx_run base = {0, 0, 0, 0};
                 if (lane == 0) {
@@ -342,9 +387,10 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
                 run.c = __builtin_amdgcn_readfirstlane(base.c);
             }
         }
+        if (stamp && lane == 0 && final_round) stamp[3] = __builtin_amdgcn_s_memtime();
         qn = 0;
         acc.v = acc.t = acc.c = acc.b = 0;
-        suspect = false;
+        dnear = 3.0e38f;
         if (final_round) break;
     }
 }
@@ -393,10 +439,16 @@ __device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
 // full 256-byte rows; otherwise (range broken by a reservation boundary) lanes store directly.
 // =================================================================================================
 #define CX_K2_STAGE 1536u   // ints per wave (typical wave: ~1200); larger waves store directly
+__device__ constexpr uint8_t CX_EDGE[19][2] = CX_EDGES_INIT;
 __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
     __shared__ int32_t s_stage[4][CX_K2_STAGE];
+    __shared__ uint32_t s_lut[6 * 16 * 2];   // triangle LUT: per-lane lookups must not go to memory
+    __shared__ int32_t s_eidx[4][19][64];   // vertex index of each of the 19 voxel edges, per lane
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
+    if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
+    if (threadIdx.x < 6 * 16 * 2) s_lut[threadIdx.x] = (&cx_d_tet_tris[0][0][0])[threadIdx.x];
+    __syncthreads();
     const uint32_t plane = P.n1 * P.n2;
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
     const uint32_t lane = cx_lane_id();
@@ -443,14 +495,14 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
             const uint32_t r = lin - ci * plane;
             const uint32_t cj = cx_div(r, P.div_row);
             const uint32_t ck = r - cj * P.n2;
+            // hash prefixes of the 4 (i,j) columns of this voxel (clamped: pseudo cells never need them)
+            const uint32_t i1 = min(ci + 1u, P.n0 - 1u), j1 = min(cj + 1u, P.n1 - 1u);
+            const uint64_t hxy[4] = {hash_xy[ci * P.n1 + cj], hash_xy[ci * P.n1 + j1], hash_xy[i1 * P.n1 + cj], hash_xy[i1 * P.n1 + j1]};
             uint64_t h[8];
 #pragma unroll
             for (uint32_t c = 0; c < 8; c++) {
                 h[c] = 0;
-                if ((need >> c) & 1u) {
-                    const uint64_t hxy = hash_xy[(ci + ((c >> 2) & 1u)) * P.n1 + (cj + ((c >> 1) & 1u))];
-                    h[c] = py_finish3(py_round(hxy, ck + (c & 1u) + P.org2));
-                }
+                if ((need >> c) & 1u) h[c] = py_finish3(py_round(hxy[c >> 1], ck + (c & 1u) + P.org2));
             }
 #pragma unroll
             for (int t = 0; t < 6; t++) {
@@ -477,27 +529,32 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     const bool contiguous = (ttot * 3u <= CX_K2_STAGE) && __ballot(ntri != 0u && c4.z != tb0 + tpre) == 0ULL;
     int32_t* stage = s_stage[wave];
     int32_t* direct = P.tris + (size_t)c4.z * 3u;
+    // vertex index of every voxel edge (owner corner c1, direction d): first vertex of the owner +
+    // rank of d among the owner's crossing edges.  Static register indices; the table lives in LDS so
+    // that the runtime edge ids of the triangle LUT become one ds_read each.
+#pragma unroll
+    for (int e = 0; e < 19; e++) {
+        const uint32_t c1 = CX_EDGE[e][0], d = CX_EDGE[e][1];
+        s_eidx[wave][e][lane] = (int32_t)(vfirst[c1] + __popc(em[c1] & ((1u << d) - 1u)));
+    }
+    const int32_t* eidx = &s_eidx[wave][0][lane];
     uint32_t w = tpre * 3u;
+    const uint32_t w0 = w;
 #pragma unroll
     for (int t = 0; t < 6; t++) {
         if (ntri == 0u || ((tetskip >> t) & 1u)) continue;
         const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
                              (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-        const uint64_t e = cx_d_tet_tris[t][pat][(variants >> t) & 1u];
-        const uint32_t n = (uint32_t)(e >> 36) & 3u;
+        const uint32_t e = s_lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
+        const uint32_t n = e >> 30;
         for (uint32_t qd = 0; qd < n; qd++) {
-            const uint32_t tri = (uint32_t)(e >> (18u * qd)) & 0x3FFFFu;
+            const uint32_t tri = (e >> (15u * qd)) & 0x7FFFu;
 #pragma unroll
             for (uint32_t sidx = 0; sidx < 3; sidx++) {
-                const uint32_t ref = (tri >> (6u * sidx)) & 0x3Fu;
-                const uint32_t c1 = ref >> 3, d = ref & 7u;
-                // runtime-indexed small arrays: select with a compare chain to stay in registers
-                uint32_t vf = 0, m = 0;
-#pragma unroll
-                for (uint32_t c = 0; c < 7; c++) { vf = (c1 == c) ? vfirst[c] : vf; m = (c1 == c) ? em[c] : m; }
-                const int32_t vi = (int32_t)(vf + __popc(m & ((1u << d) - 1u)));
+                const uint32_t eid = (tri >> (5u * sidx)) & 0x1Fu;
+                const int32_t vi = eidx[eid * 64u];
                 if (contiguous) stage[w] = vi;
-                else if (!(P.flags & CX_DBG_NO_TRIS)) direct[w - tpre * 3u] = vi;
+                else if (!(P.flags & CX_DBG_NO_TRIS)) direct[w - w0] = vi;
                 w++;
             }
         }
@@ -520,11 +577,13 @@ void cx_launch_classify_fast(const cx_params& P, hipStream_t s) {
     T.njg = (P.n1 + 4u * CX_RJ - 1u) / (4u * CX_RJ);
     // planes per task: aim at >= ~2048 workgroups, between 4 and 32 planes each
     const uint32_t per_plane = T.nks * T.njg;
-    uint32_t want_chunks = (2048u + per_plane - 1u) / per_plane;
+    uint32_t target = 3072u;   // 12 workgroups per CU: measured best at 512^3 (tools/quick_time.py sweep)
+    if (const char* e = getenv("CX_TASKS")) target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : target;   // tuning knob
+    uint32_t want_chunks = (target + per_plane - 1u) / per_plane;
     if (want_chunks < 1u) want_chunks = 1u;
     uint32_t ci = (P.n0 + want_chunks - 1u) / want_chunks;
-    if (ci < 4u) ci = 4u;
-    if (ci > 32u) ci = 32u;
+    if (ci < 2u) ci = 2u;
+    if (ci > 64u) ci = 64u;
     T.ci = ci;
     T.nic = (P.n0 + ci - 1u) / ci;
     const uint32_t blocks = T.nks * T.njg * T.nic;

@@ -119,6 +119,10 @@ int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv, int32_t* t
 int cx_timing_enable(cx_ctx* ctx, int on);
 int cx_timing_read(cx_ctx* ctx, double ms[3], int* n);
 
+/* diagnostic builds only: per-wave s_memtime stamps of the classify kernel (4 per wave: start, end of
+ * streaming, after the reservation, end).  words > 0 allocates, host != NULL copies out, 0/NULL frees. */
+int cx_debug_stamps(cx_ctx* ctx, int64_t words, unsigned long long* host);
+
 /* library build info: "gfx950;<git describe or date>" */
 const char* cx_version(void);
 

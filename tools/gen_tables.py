@@ -12,8 +12,8 @@ contourist/pentatopes.py:15-30, 223-291).
 Conventions
 -----------
 3-D corner index  c = 4*di + 2*dj + dk      (array axes (i,j,k), k fastest)
-edge reference    e = (c1 << 3) | d         c1 = lower corner (bit subset of c2),
-                                            d  = c1 ^ c2 in 1..7  (edge direction)
+edge              (c1, d)                   c1 = lower corner (bit subset of c2), d = c1 ^ c2 in 1..7
+                                            (edge direction); edge id = index in the list of 19 edges
 A grid vertex q "owns" the 7 edges q -> q+d, so e names (owner corner, direction).
 tet pattern       bit m set <=> tet vertex m (reference order) has f < value.
 Triangles are wound so that (p1-p0)x(p2-p0) points from the low side (f<value)
@@ -42,10 +42,16 @@ def corner_xyz(c):
     return np.array([(c >> 2) & 1, (c >> 1) & 1, c & 1], dtype=float)
 
 
+# the 19 edges of the Kuhn-triangulated voxel: (owner corner c1, direction d), c1 a strict bit-subset of c1|d
+EDGES = [(c1, d) for c1 in range(7) for d in range(1, 8) if (c1 & d) == 0]
+EDGE_ID = {e: n for n, e in enumerate(EDGES)}
+assert len(EDGES) == 19
+
+
 def edge_ref(c1, c2):
     lo, hi = (c1, c2) if (c1 & c2) == c1 else (c2, c1)
     assert (lo & hi) == lo and lo != hi, (c1, c2)
-    return (lo << 3) | (lo ^ hi)
+    return EDGE_ID[(lo, lo ^ hi)]
 
 
 def edge_mid(c1, c2, t=0.5):
@@ -95,10 +101,10 @@ def tet_entry(tet, pattern, variant):
 
 
 def pack_tris(tris):
-    word = len(tris) << 36
+    word = len(tris) << 30
     for n, tri in enumerate(tris):
-        t = tri[0] | (tri[1] << 6) | (tri[2] << 12)
-        word |= t << (18 * n)
+        t = tri[0] | (tri[1] << 5) | (tri[2] << 10)
+        word |= t << (15 * n)
     return word
 
 
@@ -162,13 +168,18 @@ def main(out_path):
         a("  {%d,%d,%d,%d}, \\" % tuple(t))
     a("}")
     a("")
-    a("// [tet][pattern][variant] : bits 0..17 triangle 0 (3 x 6-bit edge refs), 18..35 triangle 1, 36..37 count")
+    a("// the 19 voxel edges: {owner corner c1, direction d}; edge id = index into this list")
+    a("#define CX_EDGES_INIT { \\")
+    a("  " + ",".join("{%d,%d}" % e for e in EDGES) + " \\")
+    a("}")
+    a("")
+    a("// [tet][pattern][variant] : bits 0..14 triangle 0 (3 x 5-bit edge ids), 15..29 triangle 1, 30..31 count")
     a("#define CX_TET_TRIS_INIT { \\")
     ntri_by_mask = []
     for t in TETS:
         rows = []
         for p in range(16):
-            rows.append("{0x%xULL,0x%xULL}" % (pack_tris(tet_entry(t, p, 0)), pack_tris(tet_entry(t, p, 1))))
+            rows.append("{0x%xu,0x%xu}" % (pack_tris(tet_entry(t, p, 0)), pack_tris(tet_entry(t, p, 1))))
         a("  {" + ",".join(rows) + "}, \\")
     a("}")
     a("")
