@@ -23,6 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
 
@@ -72,6 +73,11 @@ def load():
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
         "cx_debug_stamps": [vp, i64, vp],
+        "cx_grid4d_upload": [vp, vp, i64, i64, i64, i64],
+        "cx_grid4d_adopt_device": [vp, vp, i64, i64, i64, i64],
+        "cx_set_origin4d": [vp, i64, i64, i64, i64],
+        "cx_extract4d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
+        "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }
@@ -189,6 +195,33 @@ class Context(object):
         self._check(self.lib.cx_surface_geometry(self.handle, pts.ctypes.data, ctypes.byref(nv),
                                                  tris.ctypes.data, ctypes.byref(nt), int(bool(do_clean))))
         return pts[:nv.value].copy(), tris[:nt.value].copy()
+
+    # ---- 4-D ---------------------------------------------------------------------------------
+    def upload_grid4d(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        assert a.ndim == 4, "4-D sample array expected"
+        self._check(self.lib.cx_grid4d_upload(self.handle, a.ctypes.data, *a.shape))
+        self.shape4 = tuple(int(n) for n in a.shape)
+
+    def adopt_device_grid4d(self, device_ptr, shape, keepalive=None):
+        assert len(shape) == 4
+        self._check(self.lib.cx_grid4d_adopt_device(self.handle, ctypes.c_void_p(int(device_ptr)), *[int(n) for n in shape]))
+        self.shape4 = tuple(int(n) for n in shape)
+        self._keep4 = keepalive
+
+    def extract4d(self, value, flags=CX_DIAG_CPYTHON310):
+        c = CxCounts()
+        self._check(self.lib.cx_extract4d(self.handle, float(value), int(flags), ctypes.byref(c)))
+        return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
+
+    def download_level0_4d(self, counts):
+        "-> (xyzt (V,4) float32, edge ids (V,) uint32, tetrahedra (T,4) int32)"
+        nv, nt = int(counts["n_vertices"]), int(counts["n_tetrahedra"])
+        verts = np.empty((nv, 4), dtype=np.float32)
+        keys = np.empty(nv, dtype=np.uint32)
+        tets = np.empty((nt, 4), dtype=np.int32)
+        self._check(self.lib.cx_level0_4d_download(self.handle, verts.ctypes.data, keys.ctypes.data, tets.ctypes.data))
+        return verts, keys, tets
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

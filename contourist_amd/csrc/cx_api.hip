@@ -59,6 +59,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     cx_post_free(ctx);
+    cx_state4_free(ctx);
     free_outputs(ctx);
     if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
     if (ctx->celltab) (void)hipFree(ctx->celltab);

@@ -1,0 +1,247 @@
+// cx_api4d.hip -- C ABI of the 4-D (pentatope) march: grid binding, kernel sequencing, download.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "cx_ctx.h"
+
+// mirrors cx_march4d.hip
+struct cx_params4 {
+    const float* grid;
+    uint32_t n0, n1, n2, n3, nsamples;
+    cx_fdiv div3, div2, div1;
+    float vcmp, near_abs, vhi, vlo;
+    double value, tol_value;
+    uint32_t flags;
+    uint32_t org[4];
+    uint64_t* celltab;
+    float4* verts;
+    uint32_t* vkeys;
+    uint4* cells;
+    int32_t* tets;
+    uint32_t vcap, ccap, tcap;
+    uint32_t* counters;
+    const uint64_t* hash_xyz;
+    const uint64_t* lut;
+};
+void cx_launch_classify4d(const cx_params4& P, hipStream_t s);
+void cx_launch_emit_tets(const cx_params4& P, hipStream_t s);
+void cx_launch_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, const uint32_t org[4], hipStream_t s);
+const uint64_t* cx_pent_lut_device();
+
+struct cx_state4 {
+    const float* grid = nullptr;
+    float* grid_owned = nullptr;
+    size_t grid_owned_bytes = 0;
+    int64_t n[4] = {0, 0, 0, 0};
+    uint64_t* celltab = nullptr;
+    size_t celltab_for = 0;
+    float4* verts = nullptr;
+    uint32_t* vkeys = nullptr;
+    uint4* cells = nullptr;
+    int32_t* tets = nullptr;
+    uint32_t vcap = 0, ccap = 0, tcap = 0;
+    uint64_t* hash_xyz = nullptr;
+    size_t hash_cap = 0;
+    int64_t hash_key[7] = {-1, -1, -1, -1, -1, -1, -1};
+    int64_t origin[4] = {0, 0, 0, 0};
+    bool extracted = false;
+    cx_counts counts = {0, 0, 0, 0};
+};
+
+#define CX4_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return (e__ == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;                      \
+        }                                                                                        \
+    } while (0)
+
+void cx_state4_free(cx_ctx* ctx) {
+    cx_state4* S = ctx->s4;
+    if (!S) return;
+    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz};
+    for (void* p : all)
+        if (p) (void)hipFree(p);
+    delete S;
+    ctx->s4 = nullptr;
+}
+
+static int state4(cx_ctx* ctx, cx_state4** out) {
+    if (!ctx->s4) ctx->s4 = new (std::nothrow) cx_state4();
+    if (!ctx->s4) return CX_ERR_NOMEM;
+    *out = ctx->s4;
+    return CX_OK;
+}
+
+static int set_dims4(cx_ctx* ctx, cx_state4* S, int64_t n0, int64_t n1, int64_t n2, int64_t n3) {
+    if (n0 < 2 || n1 < 2 || n2 < 2 || n3 < 2) { ctx->err = "4-D grid needs at least 2 samples per axis"; return CX_ERR_INVALID; }
+    const int64_t N = n0 * n1 * n2 * n3;
+    if (N > (1LL << 28)) { ctx->err = "more than 2^28 samples in one 4-D grid: partition into slabs"; return CX_ERR_UNSUPPORTED; }
+    if (S->celltab_for < (size_t)N) {
+        if (S->celltab) (void)hipFree(S->celltab);
+        S->celltab = nullptr; S->celltab_for = 0;
+        CX4_HIP(ctx, hipMalloc(&S->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
+        S->celltab_for = (size_t)N;
+    }
+    S->n[0] = n0; S->n[1] = n1; S->n[2] = n2; S->n[3] = n3;
+    S->extracted = false;
+    return CX_OK;
+}
+
+extern "C" int cx_grid4d_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2, int64_t n3) {
+    if (!ctx || !host) return CX_ERR_INVALID;
+    CX4_HIP(ctx, hipSetDevice(ctx->device));
+    cx_state4* S;
+    int rc = state4(ctx, &S);
+    if (rc) return rc;
+    if ((rc = set_dims4(ctx, S, n0, n1, n2, n3))) return rc;
+    const size_t bytes = (size_t)(n0 * n1 * n2 * n3) * sizeof(float);
+    if (S->grid_owned_bytes < bytes) {
+        if (S->grid_owned) (void)hipFree(S->grid_owned);
+        S->grid_owned = nullptr; S->grid_owned_bytes = 0;
+        CX4_HIP(ctx, hipMalloc(&S->grid_owned, bytes));
+        S->grid_owned_bytes = bytes;
+    }
+    CX4_HIP(ctx, hipMemcpyAsync(S->grid_owned, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S->grid = S->grid_owned;
+    return CX_OK;
+}
+
+extern "C" int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2, int64_t n3) {
+    if (!ctx || !device_ptr) return CX_ERR_INVALID;
+    CX4_HIP(ctx, hipSetDevice(ctx->device));
+    cx_state4* S;
+    int rc = state4(ctx, &S);
+    if (rc) return rc;
+    if ((rc = set_dims4(ctx, S, n0, n1, n2, n3))) return rc;
+    S->grid = (const float*)device_ptr;
+    return CX_OK;
+}
+
+static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t nt) {
+    if (nc > 0xFFFFFFF0LL || nv > 0xFFFFFFF0LL || nt > 0x7FFFFFF0LL) { ctx->err = "capacity beyond 32-bit indices"; return CX_ERR_UNSUPPORTED; }
+    CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nc > (int64_t)S->ccap) {
+        if (S->cells) (void)hipFree(S->cells);
+        S->cells = nullptr; S->ccap = 0;
+        CX4_HIP(ctx, hipMalloc(&S->cells, (size_t)nc * sizeof(uint4)));
+        S->ccap = (uint32_t)nc;
+    }
+    if (nv > (int64_t)S->vcap) {
+        if (S->verts) (void)hipFree(S->verts);
+        if (S->vkeys) (void)hipFree(S->vkeys);
+        S->verts = nullptr; S->vkeys = nullptr; S->vcap = 0;
+        CX4_HIP(ctx, hipMalloc(&S->verts, (size_t)nv * sizeof(float4)));
+        CX4_HIP(ctx, hipMalloc(&S->vkeys, (size_t)nv * sizeof(uint32_t)));
+        S->vcap = (uint32_t)nv;
+    }
+    if (nt > (int64_t)S->tcap) {
+        if (S->tets) (void)hipFree(S->tets);
+        S->tets = nullptr; S->tcap = 0;
+        CX4_HIP(ctx, hipMalloc(&S->tets, (size_t)nt * 4 * sizeof(int32_t)));
+        S->tcap = (uint32_t)nt;
+    }
+    return CX_OK;
+}
+
+extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out) {
+    if (!ctx) return CX_ERR_INVALID;
+    CX4_HIP(ctx, hipSetDevice(ctx->device));
+    cx_state4* S;
+    int rc = state4(ctx, &S);
+    if (rc) return rc;
+    if (!S->grid) { ctx->err = "no 4-D grid: call cx_grid4d_upload or cx_grid4d_adopt_device first"; return CX_ERR_STATE; }
+    if (!(value == value)) { ctx->err = "isovalue is NaN"; return CX_ERR_INVALID; }
+    const int64_t N = S->n[0] * S->n[1] * S->n[2] * S->n[3];
+    if (!S->cells) {
+        if ((rc = reserve4(ctx, S, N / 8 + 4096, N / 2 + 4096, 4 * N + 4096))) return rc;
+    }
+    for (int d = 0; d < 4; d++) S->origin[d] = ctx->origin4[d];
+    for (int attempt = 0; attempt < 3; attempt++) {
+        cx_params4 P;
+        memset(&P, 0, sizeof(P));
+        P.grid = S->grid;
+        P.n0 = (uint32_t)S->n[0]; P.n1 = (uint32_t)S->n[1]; P.n2 = (uint32_t)S->n[2]; P.n3 = (uint32_t)S->n[3];
+        P.nsamples = (uint32_t)N;
+        P.div3 = cx_fdiv_make(P.n1 * P.n2 * P.n3);
+        P.div2 = cx_fdiv_make(P.n2 * P.n3);
+        P.div1 = cx_fdiv_make(P.n3);
+        float t = (float)value;
+        if ((double)t < value) t = std::nextafterf(t, INFINITY);
+        P.vcmp = t;
+        P.near_abs = std::nextafterf((float)(2.2e-5 * std::fabs(value) + 4e-8), INFINITY);
+        P.vhi = (float)value;
+        P.vlo = (float)(value - (double)P.vhi);
+        P.value = value;
+        P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
+        P.flags = flags;
+        for (int d = 0; d < 4; d++) P.org[d] = (uint32_t)S->origin[d];
+        P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
+        P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
+        P.counters = ctx->counters;
+        P.lut = cx_pent_lut_device();
+        if (!P.lut) { ctx->err = "pentatope table symbol not found"; return CX_ERR_HIP; }
+        if (flags & CX_DIAG_CPYTHON310) {
+            const int64_t key[7] = {S->n[0], S->n[1], S->n[2], S->origin[0], S->origin[1], S->origin[2], 1};
+            if (memcmp(key, S->hash_key, sizeof(key)) != 0) {
+                const size_t need = (size_t)(S->n[0] * S->n[1] * S->n[2]);
+                if (S->hash_cap < need) {
+                    if (S->hash_xyz) (void)hipFree(S->hash_xyz);
+                    S->hash_xyz = nullptr; S->hash_cap = 0;
+                    CX4_HIP(ctx, hipMalloc(&S->hash_xyz, need * sizeof(uint64_t)));
+                    S->hash_cap = need;
+                }
+                cx_launch_hash_xyz(S->hash_xyz, P.n0, P.n1, P.n2, P.org, ctx->stream);
+                memcpy(S->hash_key, key, sizeof(key));
+            }
+        }
+        P.hash_xyz = S->hash_xyz;
+        CX4_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
+        cx_launch_classify4d(P, ctx->stream);
+        cx_launch_emit_tets(P, ctx->stream);
+        CX4_HIP(ctx, hipGetLastError());
+        CX4_HIP(ctx, hipMemcpyAsync(ctx->counters_host, ctx->counters, CX_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        cx_counts c;
+        c.n_cells = ctx->counters_host[CX_CNT_CELLS];
+        c.n_vertices = ctx->counters_host[CX_CNT_VERTS];
+        c.n_triangles = ctx->counters_host[CX_CNT_TRIS];   // tetrahedra
+        c.n_border_voxels = ctx->counters_host[CX_CNT_BORDER];
+        S->counts = c;
+        if (out) *out = c;
+        if (c.n_cells <= S->ccap && c.n_vertices <= S->vcap && c.n_triangles <= S->tcap) {
+            S->extracted = true;
+            return CX_OK;
+        }
+        if ((rc = reserve4(ctx, S, c.n_cells + c.n_cells / 20 + 1024, c.n_vertices + c.n_vertices / 20 + 1024,
+                           c.n_triangles + c.n_triangles / 20 + 1024)))
+            return rc;
+    }
+    ctx->err = "4-D output buffers still too small after growing";
+    return CX_ERR_CAPACITY;
+}
+
+extern "C" int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, int32_t* tets) {
+    if (!ctx) return CX_ERR_INVALID;
+    cx_state4* S = ctx->s4;
+    if (!S || !S->extracted) { ctx->err = "no valid 4-D extraction"; return CX_ERR_STATE; }
+    CX4_HIP(ctx, hipSetDevice(ctx->device));
+    if (verts_xyzt && S->counts.n_vertices)
+        CX4_HIP(ctx, hipMemcpyAsync(verts_xyzt, S->verts, (size_t)S->counts.n_vertices * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (edge_ids && S->counts.n_vertices)
+        CX4_HIP(ctx, hipMemcpyAsync(edge_ids, S->vkeys, (size_t)S->counts.n_vertices * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (tets && S->counts.n_triangles)
+        CX4_HIP(ctx, hipMemcpyAsync(tets, S->tets, (size_t)S->counts.n_triangles * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+extern "C" int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3) {
+    if (!ctx || o0 < 0 || o1 < 0 || o2 < 0 || o3 < 0) return CX_ERR_INVALID;
+    ctx->origin4[0] = o0; ctx->origin4[1] = o1; ctx->origin4[2] = o2; ctx->origin4[3] = o3;
+    return CX_OK;
+}

@@ -5,6 +5,7 @@
 #include "cx_common.h"
 
 struct cx_post_state;  // Level-1 buffers (cx_post.hip)
+struct cx_state4;       // 4-D march state (cx_api4d.hip)
 
 struct cx_ctx {
     int device = 0;
@@ -23,6 +24,8 @@ struct cx_ctx {
     size_t hash_xy_cap = 0;
     int64_t hash_xy_n0 = 0, hash_xy_n1 = 0, hash_xy_o0 = -1, hash_xy_o1 = -1;
     int64_t origin[3] = {0, 0, 0};
+    int64_t origin4[4] = {0, 0, 0, 0};
+    cx_state4* s4 = nullptr;
     // Level-0 outputs
     float4* verts = nullptr;
     uint4* cells = nullptr;
@@ -47,3 +50,5 @@ struct cx_ctx {
 
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);
+// cx_api4d.hip
+void cx_state4_free(cx_ctx* ctx);

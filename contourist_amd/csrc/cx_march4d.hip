@@ -1,0 +1,467 @@
+// cx_march4d.hip -- Level-0 kernels of the 4-D marching-pentatopes hyper-voxel march (gfx950, wave64).
+//
+// Reference semantics restated (paths relative to the reference checkout, contourist/...):
+//   PENTATOPES / HYPERCUBE                       pentatopes.py:15-30
+//   enumerate_pentatope_tetrahedra                pentatopes.py:223-291
+//   border_voxel with box = HYPERCUBE             tetrahedral.py:383-394, pentatopes.py:94
+//   contour_pair_interpolation                    tetrahedral.py:471-487
+//
+// Same plan as the 3-D march (cx_march3d.hip): a lattice cell q = (i,j,k,l) owns the 15 edges q -> q+d,
+// d = 8di+4dj+2dk+dl in 1..15, and the 24 pentatopes of its hyper-voxel; vertex id = (lin(q) << 4) | d.
+//   K1  cx_k_classify4d   phase A: one lane per cell, active cells into a wave-private LDS queue;
+//                         phase B: per workgroup ONE reservation per counter, then vertex records
+//                         (x,y,z,t), edge ids, the per-cell lookup word and one record per active cell.
+//   K2  cx_k_emit_tets    one lane per record: 24 pentatopes -> tetrahedra as 4 vertex indices.
+// This first version streams with 16 scalar-pair loads per cell (any shape); the bit-packed fast path
+// of the 3-D kernel is the next step for this kernel.
+#include <cstdlib>
+
+#include "cx_cell.h"
+#include "cx_tables4d.h"
+
+struct cx_params4 {
+    const float* grid;
+    uint32_t n0, n1, n2, n3, nsamples;
+    cx_fdiv div3, div2, div1;   // / (n1*n2*n3), / (n2*n3), / n3
+    float vcmp, near_abs, vhi, vlo;
+    double value, tol_value;
+    uint32_t flags;
+    uint32_t org[4];
+    uint64_t* celltab;          // (crossing mask (bits 1..15) << 32) | first vertex index
+    float4* verts;              // {x, y, z, t} grid coordinates
+    uint32_t* vkeys;            // edge ids
+    uint4* cells;               // {lin, sign mask (16) | near flag << 16, first tet, first vertex}
+    int32_t* tets;              // 4 vertex indices per tetrahedron
+    uint32_t vcap, ccap, tcap;
+    uint32_t* counters;
+    const uint64_t* hash_xyz;   // CPython tuple-hash prefix per (i,j,k) (CX_DIAG_CPYTHON310)
+    const uint64_t* lut;        // [24][32][12][2] pentatope -> tetrahedra table
+};
+
+__device__ constexpr uint8_t CX_PC[24][5] = CX_PENT_CORNERS_INIT;
+#define CX_PENT_MASK(n) (uint32_t)((1u << CX_PC[n][0]) | (1u << CX_PC[n][1]) | (1u << CX_PC[n][2]) | (1u << CX_PC[n][3]) | (1u << CX_PC[n][4]))
+
+__device__ __forceinline__ void cx_unravel4(const cx_params4& P, uint32_t lin, uint32_t q[4]) {
+    q[0] = cx_div(lin, P.div3);
+    uint32_t r = lin - q[0] * (P.n1 * P.n2 * P.n3);
+    q[1] = cx_div(r, P.div2);
+    r -= q[1] * (P.n2 * P.n3);
+    q[2] = cx_div(r, P.div1);
+    q[3] = r - q[2] * P.n3;
+}
+
+// 16 corners (clamped onto the array); vm = validity mask (bit c: corner c inside the array)
+__device__ __forceinline__ uint32_t cx_load_corners4(const cx_params4& P, uint32_t lin, const uint32_t q[4], float f[16]) {
+    const float* __restrict__ A = P.grid;
+    const bool v0 = q[0] + 1 < P.n0, v1 = q[1] + 1 < P.n1, v2 = q[2] + 1 < P.n2, v3 = q[3] + 1 < P.n3;
+    const uint32_t o0 = v0 ? P.n1 * P.n2 * P.n3 : 0u, o1 = v1 ? P.n2 * P.n3 : 0u, o2 = v2 ? P.n3 : 0u;
+    const uint32_t base = v3 ? lin : lin - 1u;   // at the array edge in l read (l-1, l) and repeat l
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t ofs = ((c & 4u) ? o0 : 0u) + ((c & 2u) ? o1 : 0u) + ((c & 1u) ? o2 : 0u);
+        const cx_f2 p = *reinterpret_cast<const cx_f2*>(A + base + ofs);
+        f[2 * c] = v3 ? p.x : p.y;
+        f[2 * c + 1] = p.y;
+    }
+    uint32_t vm = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 16; c++) {
+        const bool ok = (!(c & 8u) || v0) && (!(c & 4u) || v1) && (!(c & 2u) || v2) && (!(c & 1u) || v3);
+        vm |= ok ? (1u << c) : 0u;
+    }
+    return vm;
+}
+
+__device__ __forceinline__ uint32_t cx_pent_pattern(uint32_t sm, int n) {
+    return ((sm >> CX_PC[n][0]) & 1u) | (((sm >> CX_PC[n][1]) & 1u) << 1) | (((sm >> CX_PC[n][2]) & 1u) << 2) |
+           (((sm >> CX_PC[n][3]) & 1u) << 3) | (((sm >> CX_PC[n][4]) & 1u) << 4);
+}
+// tetrahedra a pentatope with `nlow` low vertices emits (pentatopes.py:246-291)
+__device__ __forceinline__ uint32_t cx_pent_ntets(uint32_t nlow) {
+    return (nlow == 1u || nlow == 4u) ? 1u : ((nlow == 2u || nlow == 3u) ? 3u : 0u);
+}
+
+// exact tolerance handling of one active cell: which pentatopes the reference skips, which owned
+// crossings survive (used by some emitted tetrahedron)
+struct cx_cell4 {
+    uint32_t emask, ntets, pskip, border;
+};
+
+static __device__ __forceinline__ bool cx_edge_used_slow4(const cx_params4& P, const uint32_t q[4], uint32_t d) {
+    const float* A = P.grid;
+    for (uint32_t o = 0; o < 16; o++) {
+        if (o & d) continue;
+        const uint32_t oq[4] = {(o >> 3) & 1u, (o >> 2) & 1u, (o >> 1) & 1u, o & 1u};
+        if (q[0] < oq[0] || q[1] < oq[1] || q[2] < oq[2] || q[3] < oq[3]) continue;
+        const uint32_t p[4] = {q[0] - oq[0], q[1] - oq[1], q[2] - oq[2], q[3] - oq[3]};
+        if (p[0] + 1 >= P.n0 || p[1] + 1 >= P.n1 || p[2] + 1 >= P.n2 || p[3] + 1 >= P.n3) continue;
+        uint32_t near_a = 0, all_b = 1;
+        for (uint32_t c = 0; c < 16; c++) {
+            const size_t idx = (((size_t)(p[0] + ((c >> 3) & 1u)) * P.n1 + (p[1] + ((c >> 2) & 1u))) * P.n2 + (p[2] + ((c >> 1) & 1u))) * P.n3 +
+                               (p[3] + (c & 1u));
+            const double fv = (double)A[idx];
+            if (fabs(fv - P.value) <= P.tol_value) near_a |= 1u << c;
+            if (!cx_near_b(fv, P.value)) all_b = 0;
+        }
+        if (all_b) continue;
+        const uint32_t c1 = o, c2 = o | d;
+        for (int n = 0; n < 24; n++) {
+            const uint32_t pm = CX_PENT_MASK(n);
+            if (((pm >> c1) & 1u) && ((pm >> c2) & 1u) && (near_a & pm) != pm) return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ cx_cell4 cx_classify_cell4(const cx_params4& P, const float f[16], uint32_t vm, uint32_t sm,
+                                                      const uint32_t q[4]) {
+    cx_cell4 R;
+    R.pskip = 0; R.ntets = 0; R.border = 0;
+    const uint32_t s0 = (sm & 1u) ? 0xFFFFu : 0u;
+    R.emask = ((sm ^ s0) & vm) & 0xFFFEu;
+    float dmin = fabsf(f[0] - P.vcmp);
+#pragma unroll
+    for (int c = 1; c < 16; c++) dmin = fminf(dmin, fabsf(f[c] - P.vcmp));
+    const bool real_voxel = (vm == 0xFFFFu);
+    if (dmin > P.near_abs) {
+        if (real_voxel) {
+            R.border = 1;
+#pragma unroll
+            for (int n = 0; n < 24; n++) R.ntets += cx_pent_ntets(__popc(cx_pent_pattern(sm, n)));
+        } else {
+            R.pskip = 0xFFFFFFu;
+        }
+        return R;
+    }
+    uint32_t near_a = 0, nb = 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const double fc = (double)f[c];
+        near_a |= (fabs(fc - P.value) <= P.tol_value) ? (1u << c) : 0u;
+        nb |= cx_near_b(fc, P.value) ? (1u << c) : 0u;
+    }
+    if (real_voxel && nb != 0xFFFFu) {
+        R.border = 1;
+        for (int n = 0; n < 24; n++) {
+            const uint32_t pm = CX_PENT_MASK(n);
+            if ((near_a & pm) == pm) R.pskip |= 1u << n;
+            else R.ntets += cx_pent_ntets(__popc(cx_pent_pattern(sm, n)));
+        }
+    } else {
+        R.pskip = 0xFFFFFFu;
+    }
+    if (R.emask && ((near_a & 1u) || (nb & 1u))) {
+        for (uint32_t d = 1; d < 16; d++) {
+            if (!((R.emask >> d) & 1u)) continue;
+            const bool suspicious = (((near_a >> d) & near_a & 1u) | ((nb >> d) & nb & 1u)) != 0u;
+            if (suspicious && !cx_edge_used_slow4(P, q, d)) R.emask &= ~(1u << d);
+        }
+    }
+    return R;
+}
+
+#define CX4_QCAP 1024u
+
+struct cx_run4 {
+    uint32_t v, t, c, b;
+};
+
+__device__ __forceinline__ void cx_process_queue4(const cx_params4& P, const uint32_t* qq, uint32_t n, uint32_t lane, bool emit,
+                                                  cx_run4& run) {
+    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+        const uint32_t idx = b0 + lane;
+        const bool have = idx < n;
+        const uint32_t lin = have ? qq[idx] : 0u;
+        uint32_t q[4];
+        cx_unravel4(P, lin, q);
+        float f[16];
+        const uint32_t vm = cx_load_corners4(P, lin, q, f);
+        uint32_t sm = 0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
+        const uint32_t smv = sm & vm;
+        const bool active = have && smv != 0u && smv != vm;
+        cx_cell4 R;
+        R.emask = 0; R.ntets = 0; R.pskip = 0; R.border = 0;
+        if (active) R = cx_classify_cell4(P, f, vm, sm, q);
+        const uint32_t nv = __popc(R.emask);
+        const bool rec = active && (nv != 0u || R.ntets != 0u);
+        uint32_t vtot, ttot;
+        const uint32_t vpre = cx_wave_prefix_small<4>(nv, vtot);
+        const uint32_t tpre = cx_wave_prefix_small<7>(R.ntets, ttot);
+        const uint64_t recm = __ballot(rec);
+        const uint32_t ctot = (uint32_t)__popcll(recm);
+        const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
+        if (emit) {
+            const uint32_t vfirst = run.v + vpre;
+            if (nv && run.v + vtot <= P.vcap) {
+                const float num = (P.vhi - f[0]) + P.vlo;
+                uint32_t slot = vfirst;
+                for (uint32_t d = 1; d < 16; d++) {
+                    if (!((R.emask >> d) & 1u)) continue;
+                    float fd = f[0];
+#pragma unroll
+                    for (uint32_t c = 1; c < 16; c++) fd = (c == d) ? f[c] : fd;
+                    const float den = fd - f[0];
+                    float t = __fdividef(num, den);
+                    if (fabsf(den) <= 1.001e-8f) {
+                        const double dd = (double)fd - (double)f[0];
+                        t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f[0]) / dd);
+                    }
+                    float4 r4;
+                    r4.x = (float)q[0] + ((d & 8u) ? t : 0.f);
+                    r4.y = (float)q[1] + ((d & 4u) ? t : 0.f);
+                    r4.z = (float)q[2] + ((d & 2u) ? t : 0.f);
+                    r4.w = (float)q[3] + ((d & 1u) ? t : 0.f);
+                    P.verts[slot] = r4;
+                    P.vkeys[slot] = (lin << 4) | d;
+                    slot++;
+                }
+                P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+            }
+            if (rec && run.c + ctot <= P.ccap) {
+                uint4 c4;
+                c4.x = lin;
+                c4.y = sm | ((R.pskip != 0u) ? 0x10000u : 0u);
+                c4.z = run.t + tpre;
+                c4.w = vfirst;
+                P.cells[run.c + cx_mbcnt(recm)] = c4;
+            }
+        }
+        run.v += vtot; run.t += ttot; run.c += ctot; run.b += btot;
+    }
+}
+
+__global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const uint32_t cells_per_block) {
+    __shared__ uint32_t s_queue[4][CX4_QCAP];
+    __shared__ uint32_t s_tot[4][4];
+    __shared__ uint32_t s_base[4];
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* qq = s_queue[wave];
+    uint32_t qn = 0;
+    uint32_t gbase = blockIdx.x * cells_per_block + wave * 64u;
+    const uint32_t gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
+    bool streaming = gbase < gend;
+    for (;;) {
+        while (streaming && qn + 64u <= CX4_QCAP) {
+            const uint32_t lin = gbase + lane;
+            const bool in = lin < gend;
+            const uint32_t linc = in ? lin : (P.nsamples - 1u);
+            uint32_t q[4];
+            cx_unravel4(P, linc, q);
+            float f[16];
+            const uint32_t vm = cx_load_corners4(P, linc, q, f);
+            uint32_t sm = 0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
+            const uint32_t smv = sm & vm;
+            const bool active = in && smv != 0u && smv != vm;
+            const uint64_t act = __ballot(active);
+            if (active) qq[qn + cx_mbcnt(act)] = lin;
+            qn += (uint32_t)__popcll(act);
+            gbase += 256u;
+            streaming = gbase < gend;
+        }
+        const bool final_round = !streaming;
+        cx_run4 run = {0, 0, 0, 0};
+        for (int pass = 0; pass < 2; pass++) {
+            cx_process_queue4(P, qq, qn, lane, pass == 1, run);
+            if (pass == 1) break;
+            if (final_round) {
+                if (lane == 0) {
+                    s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const uint32_t v = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
+                    const uint32_t t = s_tot[0][1] + s_tot[1][1] + s_tot[2][1] + s_tot[3][1];
+                    const uint32_t c = s_tot[0][2] + s_tot[1][2] + s_tot[2][2] + s_tot[3][2];
+                    const uint32_t bb = s_tot[0][3] + s_tot[1][3] + s_tot[2][3] + s_tot[3][3];
+                    s_base[0] = v ? atomicAdd(&P.counters[CX_CNT_VERTS], v) : 0u;
+                    s_base[1] = t ? atomicAdd(&P.counters[CX_CNT_TRIS], t) : 0u;
+                    s_base[2] = c ? atomicAdd(&P.counters[CX_CNT_CELLS], c) : 0u;
+                    if (bb) atomicAdd(&P.counters[CX_CNT_BORDER], bb);
+                }
+                __syncthreads();
+                run.v = s_base[0]; run.t = s_base[1]; run.c = s_base[2];
+                for (uint32_t w = 0; w < wave; w++) {
+                    run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
+                }
+            } else {
+                cx_run4 base = {0, 0, 0, 0};
+                if (lane == 0) {
+                    if (run.v) base.v = atomicAdd(&P.counters[CX_CNT_VERTS], run.v);
+                    if (run.t) base.t = atomicAdd(&P.counters[CX_CNT_TRIS], run.t);
+                    if (run.c) base.c = atomicAdd(&P.counters[CX_CNT_CELLS], run.c);
+                    if (run.b) atomicAdd(&P.counters[CX_CNT_BORDER], run.b);
+                }
+                run.v = __builtin_amdgcn_readfirstlane(base.v);
+                run.t = __builtin_amdgcn_readfirstlane(base.t);
+                run.c = __builtin_amdgcn_readfirstlane(base.c);
+            }
+        }
+        qn = 0;
+        if (final_round) break;
+    }
+}
+
+// ---- CPython set order of 4-tuples ------------------------------------------------------------------------
+#define CX4_PY_P1 11400714785074694791ULL
+#define CX4_PY_P2 14029467366897019727ULL
+#define CX4_PY_P5 2870177450012600261ULL
+__device__ __forceinline__ uint64_t py_round4(uint64_t acc, uint32_t x) {
+    acc += (uint64_t)x * CX4_PY_P2;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * CX4_PY_P1;
+}
+__device__ __forceinline__ uint64_t py_finish4(uint64_t acc) {
+    acc += 4ULL ^ (CX4_PY_P5 ^ 3527539ULL);
+    return (acc == ~0ULL) ? 1546275796ULL : acc;
+}
+__global__ void cx_k_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t o0, uint32_t o1, uint32_t o2) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n0 * n1 * n2) return;
+    const uint32_t k = idx % n2, r = idx / n2, j = r % n1, i = r / n1;
+    table[idx] = py_round4(py_round4(py_round4(CX4_PY_P5, i + o0), j + o1), k + o2);
+}
+// slots of up to 3 hashes inserted in order into a fresh 8-slot set (setobject.c, mask 7)
+__device__ __forceinline__ void py_slots3(const uint64_t h[3], int m, uint32_t slot[3]) {
+    uint32_t used = 0;
+    for (int n = 0; n < m; n++) {
+        uint64_t perturb = h[n];
+        uint32_t i = (uint32_t)h[n] & 7u;
+        for (int guard = 0; guard < 32 && ((used >> i) & 1u); guard++) {
+            perturb >>= 5;
+            i = (uint32_t)((i * 5u + 1u + perturb) & 7u);
+        }
+        used |= 1u << i;
+        slot[n] = i;
+    }
+}
+
+// =================================================================================================
+// K2: one lane per record -> tetrahedra
+// =================================================================================================
+__global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
+    __shared__ uint32_t s_vf[4][16][64];
+    __shared__ uint16_t s_em[4][16][64];
+    __shared__ uint64_t s_h[4][16][64];
+    const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;
+    const bool have = idx < ncells;
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (have) c4 = P.cells[idx];
+    const uint32_t lin = c4.x, sm = c4.y & 0xFFFFu;
+    const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
+    uint32_t q[4];
+    cx_unravel4(P, lin, q);
+    const bool real_voxel = have && q[0] + 1 < P.n0 && q[1] + 1 < P.n1 && q[2] + 1 < P.n2 && q[3] + 1 < P.n3;
+    // pentatopes skipped by the reference's tolerances: recomputed exactly for the rare flagged records
+    uint32_t pskip = 0;
+    if (have && (c4.y & 0x10000u)) {
+        float f[16];
+        const uint32_t vm = cx_load_corners4(P, lin, q, f);
+        const cx_cell4 R = cx_classify_cell4(P, f, vm, sm, q);
+        pskip = R.pskip;
+    }
+    if (!real_voxel) pskip = 0xFFFFFFu;
+    // first-vertex index and crossing mask of the 15 corners that can own an edge of this hyper-voxel
+    const uint32_t st[4] = {P.n1 * P.n2 * P.n3, P.n2 * P.n3, P.n3, 1u};
+    for (uint32_t c = 0; c < 15; c++) {
+        uint32_t vf = 0, em = 0;
+        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFFFu : 0u;
+        uint32_t sup = 0;
+        for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
+        if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
+            const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
+            const uint64_t e = P.celltab[lc];
+            vf = (uint32_t)e;
+            em = (uint32_t)(e >> 32);
+        }
+        s_vf[wave][c][lane] = vf;
+        s_em[wave][c][lane] = (uint16_t)em;
+    }
+    // corner hashes (absolute lattice coordinates) for the set-order emulation
+    if (emulate) {
+        for (uint32_t c = 0; c < 16; c++) {
+            const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
+            const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
+            const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
+            s_h[wave][c][lane] = py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
+        }
+    }
+    int32_t* out = P.tets + (size_t)c4.z * 4u;
+    for (int n = 0; n < 24; n++) {
+        if (!real_voxel || ((pskip >> n) & 1u)) continue;
+        const uint32_t pat = cx_pent_pattern(sm, n);
+        const uint32_t nlow = __popc(pat);
+        if (nlow == 0u || nlow == 5u) continue;
+        uint32_t perm_id = 0;
+        if (emulate && (nlow == 2u || nlow == 3u)) {
+            // least = the 2-set, most = the 3-set, each in insertion (path) order
+            const bool low_is_two = (nlow == 2u);
+            uint64_t h2[3], h3[3];
+            int n2 = 0, n3 = 0;
+            for (int m = 0; m < 5; m++) {
+                const uint64_t hm = s_h[wave][CX_PC[n][m]][lane];
+                const bool is_low = (pat >> m) & 1u;
+                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                else { if (n3 < 3) h3[n3] = hm; n3++; }
+            }
+            uint32_t s2[3], s3[3];
+            py_slots3(h2, 2, s2);
+            py_slots3(h3, 3, s3);
+            const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
+            // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
+            uint32_t o0 = 0, o1 = 1, o2 = 2;
+            if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
+            if (s3[o1] > s3[o2]) { const uint32_t t = o1; o1 = o2; o2 = t; }
+            if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
+            const uint32_t p3 = o0 * 2u + ((o1 > o2) ? 1u : 0u);   // (0,1,2)=0 (0,2,1)=1 (1,0,2)=2 (1,2,0)=3 (2,0,1)=4 (2,1,0)=5
+            perm_id = (p3 << 1) | swapped;
+        }
+        const uint64_t* e = P.lut + (((size_t)n * 32u + pat) * 12u + perm_id) * 2u;
+        const uint64_t w0 = e[0], w1 = e[1];
+        const uint32_t nt = (uint32_t)(w1 >> 32) & 3u;
+        for (uint32_t k = 0; k < nt; k++) {
+            const uint32_t word = (k == 0) ? (uint32_t)w0 : ((k == 1) ? (uint32_t)(w0 >> 32) : (uint32_t)w1);
+#pragma unroll
+            for (uint32_t s = 0; s < 4; s++) {
+                const uint32_t ref = (word >> (8u * s)) & 0xFFu;
+                const uint32_t c1 = ref >> 4, d = ref & 15u;
+                const uint32_t vf = s_vf[wave][c1][lane], em = s_em[wave][c1][lane];
+                *out++ = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
+            }
+        }
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+__device__ uint64_t cx_d_pent_lut[24][32][12][2] = CX_PENT_TETS_INIT;
+
+const uint64_t* cx_pent_lut_device() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cx_d_pent_lut)) != hipSuccess) return nullptr;
+    return (const uint64_t*)p;
+}
+
+void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
+    uint32_t cpb = (P.nsamples + 3071u) / 3072u;
+    cpb = (cpb + 255u) & ~255u;
+    if (cpb < 4096u) cpb = 4096u;
+    const uint32_t blocks = (P.nsamples + cpb - 1u) / cpb;
+    hipLaunchKernelGGL(cx_k_classify4d, dim3(blocks), dim3(256), 0, s, P, cpb);
+}
+void cx_launch_emit_tets(const cx_params4& P, hipStream_t s) {
+    const uint32_t blocks = (P.ccap + 255u) / 256u;
+    hipLaunchKernelGGL(cx_k_emit_tets, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P);
+}
+void cx_launch_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, const uint32_t org[4], hipStream_t s) {
+    const uint32_t n = n0 * n1 * n2;
+    hipLaunchKernelGGL(cx_k_hash_xyz, dim3((n + 255u) / 256u), dim3(256), 0, s, table, n0, n1, n2, org[0], org[1], org[2]);
+}

@@ -1,0 +1,125 @@
+"""4-D isosurfaces ("morphing" 3-D surfaces) by marching pentatopes on MI355X -- host-side mirror of
+the reference's `contourist/pentatopes.py` (Delta4DContour :42-68, MorphingIsoSurfaces :71-89,
+GridContour4D :92-444).
+
+Built so far: the hyper-voxel march -- 16-corner border test,
+24 pentatopes per hyper-voxel, 1-4 / 2-3 splits into tetrahedra, 4-D edge interpolation -- as HIP
+kernels (cx_extract4d).  `GridContour4D.find_tetrahedra()` returns that Level-0 result.
+Not built yet (rows B3-B6): bin_times / drop_instant_tetrahedra / tiny collapse, the slicing of
+tetrahedra into morph triangles and their orientation; `collect_morph_triangles()` raises
+NotImplementedError instead of falling back to a CPU path.
+"""
+import itertools
+
+import numpy as np
+
+from . import _ffi
+from . import grid_field
+from . import tetrahedral
+
+
+def generate_simplex_vertices(permutation):
+    vertex = [0] * len(permutation)
+    yield vertex[:]
+    for index in permutation:
+        vertex[index] = 1
+        yield vertex[:]
+
+
+# the 24 pentatopes (monotone lattice paths, one per axis permutation), the 16 hypercube corners and the
+# 80-neighbourhood, in the reference's order (pentatopes.py:15-39)
+PENTATOPES = np.array([list(generate_simplex_vertices(p)) for p in itertools.permutations(range(4))], dtype=int)
+HYPERCUBE = np.array(list(itertools.product((0, 1), repeat=4)), dtype=int)
+OFFSETS4D = np.array([o for o in itertools.product((-1, 0, 1), repeat=4) if any(o)], dtype=int)
+
+
+def unpack_edge_ids4(keys, shape):
+    "edge id (lin << 4 | d) -> (lower lattice point (V,4), upper lattice point (V,4))"
+    keys = np.asarray(keys).astype(np.int64)
+    lin, d = keys >> 4, keys & 15
+    l = lin % shape[3]
+    r = lin // shape[3]
+    k = r % shape[2]
+    r //= shape[2]
+    j = r % shape[1]
+    i = r // shape[1]
+    lo = np.stack([i, j, k, l], axis=1)
+    hi = lo + np.stack([(d >> 3) & 1, (d >> 2) & 1, (d >> 1) & 1, d & 1], axis=1)
+    return lo, hi
+
+
+class GridContour4D(object):
+    "device-backed counterpart of GridContour4D (pentatopes.py:92-444), grid coordinates"
+
+    def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
+                 device=None, diagonal="cpython310", context=None):
+        self.corner = np.array(corner, dtype=int)
+        assert self.corner.shape == (4,), "dimension should be 4 " + repr(self.corner.shape)
+        if not linear_interpolate:
+            raise NotImplementedError("linear_interpolate=False needs f off the grid")
+        self.dimension = 4
+        self.value = float(value)
+        self.end_points = segment_endpoints
+        self.samples = samples
+        self.shape = tuple(int(n) for n in samples.shape)
+        assert self.shape == tuple(int(c) + 1 for c in self.corner), (self.shape, self.corner)
+        self.device = tetrahedral._DEFAULT_DEVICE[0] if device is None else int(device)
+        self.flags = {"cpython310": _ffi.CX_DIAG_CPYTHON310, "canonical": _ffi.CX_DIAG_CANONICAL}[diagonal]
+        self._ctx = context
+        self._counts = None
+
+    def context(self):
+        if self._ctx is None:
+            self._ctx = _ffi.Context(self.device)
+        return self._ctx
+
+    def find_tetrahedra(self):
+        """hyper-voxel march on the device.  returns dict(xyzt (V,4) f32 grid coords, keys (V,) u32 edge ids,
+        tetrahedra (T,4) i32, counts).  (The reference continues with bin_times / drop_instant_tetrahedra /
+        remove_tiny_simplices, pentatopes.py:107-125: not built yet.)"""
+        ctx = self.context()
+        s = self.samples
+        if grid_field._is_torch(s):
+            assert s.is_cuda and s.is_contiguous() and str(s.dtype) == "torch.float32"
+            ctx.adopt_device_grid4d(s.data_ptr(), self.shape, keepalive=s)
+        else:
+            ctx.upload_grid4d(s)
+        self._counts = ctx.extract4d(self.value, self.flags)
+        xyzt, keys, tets = ctx.download_level0_4d(self._counts)
+        return dict(xyzt=xyzt, keys=keys, tetrahedra=tets, counts=self._counts)
+
+    def collect_morph_triangles(self, epsilon=1e-7):
+        raise NotImplementedError("morph-triangle slicing (pentatopes.py:314-368) is not on the device path yet")
+
+
+class Delta4DContour(tetrahedral.Delta3DContour):
+    "world-coordinate facade (pentatopes.py:42-68)"
+
+    def get_contour_maker(self, grid_endpoints):
+        grid = self.grid
+        self.grid_endpoints = grid_endpoints
+        return GridContour4D(tuple(int(n) for n in grid.grid_dimensions), grid.dense_samples(), self.value, grid_endpoints,
+                             linear_interpolate=self.linear_interpolate, device=self.device)
+
+    def search_for_endpoints(self, skip=1):
+        self.contour_maker = self.get_contour_maker(None)
+
+    def collect_morph_triangles(self):
+        self.contour_maker.find_tetrahedra()
+        return self.contour_maker.collect_morph_triangles()
+
+
+class MorphingIsoSurfaces(Delta4DContour):
+    "MorphingIsoSurfaces(mins, maxes, delta, function, value, segment_endpoints, ...)  (pentatopes.py:71-89)"
+
+    def __init__(self, mins, maxes, delta, function, value, segment_endpoints, linear_interpolate=True, flatten=False,
+                 minimum_ratio=None, minimum_extent=None, smooth=None, device=None):
+        self.flatten = flatten
+        self.smooth = smooth
+        self.device = device
+        self.linear_interpolate = linear_interpolate
+        if callable(function):
+            self.grid = grid_field.FunctionGrid(mins, maxes, delta, function)
+        else:
+            self.grid = grid_field.FunctionGrid.from_array(function, mins, delta)
+        Delta4DContour.__init__(self, self.grid, value, segment_endpoints, linear_interpolate=linear_interpolate)

@@ -111,6 +111,21 @@ int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv, int32_t* tris, int64_t* nt,
                         int mode);
 
+/* ---- 4-D: marching pentatopes ------------------------------------------------------------------------
+ * Replaces, for a dense grid A[n0][n1][n2][n3] (last axis = t, fastest), GridContour4D's hyper-voxel
+ * march: find_initial_voxels/expand_voxels/border_voxel with the 16-corner HYPERCUBE (pentatopes.py:94-95,
+ * tetrahedral.py:383-469), enumerate_voxel_tetrahedra / enumerate_pentatope_tetrahedra
+ * (pentatopes.py:216-291) and the edge interpolation (tetrahedral.py:471-512).
+ * Result: vertex records float4 {x,y,z,t} in grid coordinates, edge ids
+ * (linear index of the lower lattice point << 4) | direction (1..15 = 8di+4dj+2dk+dl), and
+ * tetrahedra as 4 int32 vertex indices (cx_counts.n_triangles counts tetrahedra here).
+ * CX_DIAG_CPYTHON310 reproduces the reference's 2-3 split (set order of 4-tuples, pentatopes.py:255-256). */
+int cx_grid4d_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2, int64_t n3);
+int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2, int64_t n3);
+int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3);
+int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
+int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, int32_t* tets);
+
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.
  * cx_timing_read synchronises and returns the summed milliseconds since the last reset:

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""oracle/make_goldens4d.py -- TEST INFRASTRUCTURE ONLY; runs only where /root/reference exists.
+
+4-D goldens from the REAL reference.  contourist/pentatopes.py and morph_geometry.py are Python-2
+source, so the package is copied to a temp dir OUTSIDE the repo, translated there with lib2to3 and
+imported from there; only numbers are written to tests/golden4d/*.npz.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REFERENCE = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_DIR = os.path.normpath(os.path.join(HERE, "..", "tests", "golden4d"))
+sys.path.insert(0, os.path.normpath(os.path.join(HERE, "..")))
+_TMP = [None]
+
+
+def reference_modules4d():
+    if not os.path.isdir(REFERENCE):
+        raise RuntimeError("reference not present")
+    if _TMP[0] is None:
+        tmp = tempfile.mkdtemp(prefix="contourist_ref4d_")
+        shutil.copytree(os.path.join(REFERENCE, "contourist"), os.path.join(tmp, "contourist"))
+        pk = os.path.join(tmp, "contourist")
+        subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", "pentatopes.py", "morph_geometry.py", "field2d.py",
+                               "html_demo.py", "lasso.py"], cwd=pk, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        src = open(os.path.join(pk, "pentatopes.py")).read().replace("for l in 0,1]", "for l in (0,1)]")
+        open(os.path.join(pk, "pentatopes.py"), "w").write(src)
+        _TMP[0] = tmp
+    np.int = int
+    np.float = float
+    np.sometrue = np.any
+    sys.dont_write_bytecode = True
+    if _TMP[0] not in sys.path:
+        sys.path.insert(0, _TMP[0])
+    from contourist import pentatopes
+    return pentatopes
+
+
+def close4(A, fill):
+    """force the outermost 2 samples of every axis to `fill` so that no crossing touches the array
+    boundary (the reference evaluates f outside the array near boundary crossings)"""
+    A = A.copy()
+    for ax in range(4):
+        sl = [slice(None)] * 4
+        for idx in (0, 1, -1, -2):
+            sl[ax] = idx
+            A[tuple(sl)] = fill
+    return A
+
+
+def fields4d():
+    F = {}
+    g = np.arange(11, dtype=np.float64)
+    X, Y, Z, T = np.meshgrid(g, g, g, np.arange(9, dtype=np.float64), indexing="ij")
+    # sphere whose radius grows with t, closed interior in all four axes
+    A = ((X - 4.9) ** 2 + (Y - 5.1) ** 2 + (Z - 5.0) ** 2 - 0.9 * T)
+    F["paraboloid_11x11x11x9"] = dict(A=close4(A, 60.0).astype(np.float32), value=2.1)
+    rng = np.random.RandomState(3)
+    B = rng.standard_normal((9, 8, 10, 8))
+    for _ in range(2):
+        for ax in range(4):
+            B = 0.25 * np.roll(B, 1, ax) + 0.5 * B + 0.25 * np.roll(B, -1, ax)
+    B = B / B.std()
+    F["noise_9x8x10x8"] = dict(A=close4(B, float(B.min()) - 1.0).astype(np.float32), value=0.15)
+    # two blobs that merge over time
+    C = np.minimum((X - 3.7) ** 2 + (Y - 4.6) ** 2 + (Z - 4.8) ** 2, (X - 6.4) ** 2 + (Y - 5.4) ** 2 + (Z - 5.1) ** 2) - 0.45 * T
+    F["merge_11x11x11x9"] = dict(A=close4(C, 60.0).astype(np.float32), value=1.2)
+    return F
+
+
+def run_reference4d(A, value):
+    pentatopes = reference_modules4d()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    shape = A.shape
+    outside = float(A[0, 0, 0, 0])     # beyond the array the field continues with its boundary fill value
+
+    def f(x, y, z, t):
+        idx = (int(x), int(y), int(z), int(t))
+        if any(i < 0 or i >= n for i, n in zip(idx, shape)):
+            return float(outside)
+        return float(A[idx])
+    t0 = time.time()
+    M = pentatopes.MorphingIsoSurfaces([0.0] * 4, [n - 2 for n in shape], [1.0] * 4, f, float(value), [])
+    assert tuple(M.grid.grid_dimensions) == tuple(n - 1 for n in shape)
+    M.search_for_endpoints()
+    cm = M.contour_maker
+    cm.find_initial_voxels()
+    while cm.new_surface_voxels:
+        cm.expand_voxels()
+    for quad in cm.surface_voxels:
+        cm.enumerate_voxel_tetrahedra(quad)
+    pair_list = list(cm.interpolated_contour_pairs.keys())
+    pair_index = {p: n for n, p in enumerate(pair_list)}
+    out = dict(A=A, value=np.float64(value),
+               surface_voxels=np.array(sorted(cm.surface_voxels), dtype=np.int32).reshape(-1, 4),
+               l0_pairs=np.array([list(p[0]) + list(p[1]) for p in pair_list], dtype=np.int32).reshape(-1, 8),
+               l0_xyzt=np.array([cm.interpolated_contour_pairs[p] for p in pair_list], dtype=np.float64).reshape(-1, 4),
+               l0_tets=np.array([[pair_index[p] for p in s] for s in cm.simplex_sets], dtype=np.int64).reshape(-1, 4))
+    # B3: bin_times / drop_instant_tetrahedra / remove_tiny_simplices (pentatopes.py:107, 122-125)
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        cm.bin_times()
+        out["b3_xyzt_binned"] = np.array([cm.interpolated_contour_pairs[p] for p in pair_list], dtype=np.float64).reshape(-1, 4)
+        cm.drop_instant_tetrahedra()
+        out["n_tets_after_drop"] = np.int64(len(cm.simplex_sets))
+        cm.remove_tiny_simplices(epsilon=1e-3)
+        out["n_tets_after_tiny"] = np.int64(len(cm.simplex_sets))
+    out["t_total_s"] = np.float64(time.time() - t0)
+    return out
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    names = sys.argv[1:]
+    for name, spec in fields4d().items():
+        if names and name not in names:
+            continue
+        G = run_reference4d(spec["A"], spec["value"])
+        np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **G)
+        print("%-22s shape=%s v=%g  hypervoxels %d  verts %d  tets %d | after drop %d after tiny %d (%.1fs)" % (
+            name, spec["A"].shape, spec["value"], len(G["surface_voxels"]), len(G["l0_pairs"]), len(G["l0_tets"]),
+            G["n_tets_after_drop"], G["n_tets_after_tiny"], G["t_total_s"]))

@@ -1,0 +1,60 @@
+"""GPU: 4-D hyper-voxel march (pentatopes) through the C ABI vs the 4-D oracle and vs the vectors of the
+real reference: edge sets, tetrahedra sets (incl. the hash-order 2-3 splits) bit-exact, coordinates
+within 1e-6 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+G4 = os.path.join(ROOT, "tests", "golden4d")
+
+
+def names():
+    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")) if os.path.isdir(G4) else []
+
+
+def check(A, v, diagonal, diag_mode):
+    from contourist_amd import pentatopes
+    from oracle import level0_4d
+    corner = tuple(n - 1 for n in A.shape)
+    R = pentatopes.GridContour4D(corner, A, v, diagonal=diagonal).find_tetrahedra()
+    O = level0_4d.march4d(A, v, diag_mode=diag_mode)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    co = level0_4d.canonical4(ko, O["xyzt"], O["tets"])
+    ch = level0_4d.canonical4(R["keys"].astype(np.int64), R["xyzt"], R["tetrahedra"].astype(np.int64))
+    assert R["counts"]["n_vertices"] == len(ko) and R["counts"]["n_tetrahedra"] == len(O["tets"])
+    assert R["counts"]["n_border_voxels"] == O["nborder_mixed"]
+    assert np.array_equal(co[0], ch[0])
+    assert np.all(np.abs(ch[1] - co[1]) <= 1e-6 * np.abs(co[1]) + 1e-6)
+    assert np.array_equal(co[2], ch[2])
+    return R, ch
+
+
+@pytest.mark.parametrize("name", names())
+def test_golden4d(name):
+    from oracle import level0_4d
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    R, ch = check(A, v, "cpython310", 1)
+    check(A, v, "canonical", 0)
+    kr = level0_4d.edge_keys4(G["l0_pairs"], A.shape)
+    cr = level0_4d.canonical4(kr, G["l0_xyzt"], G["l0_tets"])
+    assert np.array_equal(cr[0], ch[0]) and np.array_equal(cr[2], ch[2])        # the real reference's snapshot
+
+
+@pytest.mark.parametrize("shape,seed", [((3, 4, 5, 6), 1), ((2, 2, 2, 2), 2), ((9, 5, 4, 7), 3), ((6, 6, 6, 17), 4)])
+def test_random_open_boundary_4d(shape, seed):
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal(shape).astype(np.float32)
+    check(A, 0.1, "cpython310", 1)
+
+
+def test_tolerances_4d():
+    rng = np.random.RandomState(5)
+    B = (rng.standard_normal((5, 6, 5, 6)) * 3e-9).astype(np.float32)
+    check(B, 0.0, "cpython310", 1)
+    C = np.round(rng.standard_normal((5, 5, 6, 6)) * 2) / 2
+    check(C.astype(np.float32), 0.5, "cpython310", 1)

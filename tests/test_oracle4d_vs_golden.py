@@ -1,0 +1,35 @@
+"""CPU: the 4-D oracle (oracle/march4d_oracle.c) against vectors produced by the real reference
+(oracle/make_goldens4d.py).  The reference has no test of its own for the pentatope path, so these
+goldens are the only pin."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import level0_4d
+
+G4 = os.path.join(ROOT, "tests", "golden4d")
+
+
+def names():
+    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")) if os.path.isdir(G4) else []
+
+
+@pytest.mark.parametrize("name", names())
+def test_level0_4d_exact(name):
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    assert O["nborder"] == len(G["surface_voxels"])
+    kr = level0_4d.edge_keys4(G["l0_pairs"], A.shape)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    cr = level0_4d.canonical4(kr, G["l0_xyzt"], G["l0_tets"])
+    co = level0_4d.canonical4(ko, O["xyzt"], O["tets"])
+    assert np.array_equal(cr[0], co[0])                      # crossing edges
+    assert np.array_equal(G["l0_pairs"][np.argsort(kr)], O["pairs"][np.argsort(ko)])   # low -> high orientation
+    assert np.array_equal(cr[1], co[1])                      # float64 coordinates, bit for bit
+    assert np.array_equal(cr[2], co[2])                      # tetrahedra incl. the hash-order 2-3 splits
+    O0 = level0_4d.march4d(A, v, diag_mode=0)
+    c0 = level0_4d.canonical4(level0_4d.edge_keys4(O0["pairs"], A.shape), O0["xyzt"], O0["tets"])
+    assert np.array_equal(level0_4d.pentatope_groups(cr[2], A.shape), level0_4d.pentatope_groups(c0[2], A.shape))
