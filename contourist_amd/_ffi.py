@@ -23,7 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
 
@@ -78,6 +78,8 @@ def load():
         "cx_set_origin4d": [vp, i64, i64, i64, i64],
         "cx_extract4d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
         "cx_level0_4d_download": [vp, vp, vp, vp],
+        "cx_postprocess4d": [vp, ctypes.c_int32, vp],
+        "cx_level1_4d_download": [vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }
@@ -222,6 +224,17 @@ class Context(object):
         tets = np.empty((nt, 4), dtype=np.int32)
         self._check(self.lib.cx_level0_4d_download(self.handle, verts.ctypes.data, keys.ctypes.data, tets.ctypes.data))
         return verts, keys, tets
+
+    def postprocess4d(self, nbins=100):
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cx_postprocess4d(self.handle, int(nbins), out.ctypes.data))
+        return dict(n_vertices=int(out[0]), n_tetrahedra=int(out[1]), n_after_drop=int(out[2]), n_after_tiny=int(out[3]))
+
+    def download_level1_4d(self, counts):
+        pts = np.empty((int(counts["n_vertices"]), 4), dtype=np.float64)
+        tets = np.empty((int(counts["n_tetrahedra"]), 4), dtype=np.int32)
+        self._check(self.lib.cx_level1_4d_download(self.handle, pts.ctypes.data, tets.ctypes.data))
+        return pts, tets
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

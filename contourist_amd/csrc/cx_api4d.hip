@@ -6,49 +6,7 @@
 
 #include "cx_ctx.h"
 
-// mirrors cx_march4d.hip
-struct cx_params4 {
-    const float* grid;
-    uint32_t n0, n1, n2, n3, nsamples;
-    cx_fdiv div3, div2, div1;
-    float vcmp, near_abs, vhi, vlo;
-    double value, tol_value;
-    uint32_t flags;
-    uint32_t org[4];
-    uint64_t* celltab;
-    float4* verts;
-    uint32_t* vkeys;
-    uint4* cells;
-    int32_t* tets;
-    uint32_t vcap, ccap, tcap;
-    uint32_t* counters;
-    const uint64_t* hash_xyz;
-    const uint64_t* lut;
-};
-void cx_launch_classify4d(const cx_params4& P, hipStream_t s);
-void cx_launch_emit_tets(const cx_params4& P, hipStream_t s);
-void cx_launch_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, const uint32_t org[4], hipStream_t s);
-const uint64_t* cx_pent_lut_device();
-
-struct cx_state4 {
-    const float* grid = nullptr;
-    float* grid_owned = nullptr;
-    size_t grid_owned_bytes = 0;
-    int64_t n[4] = {0, 0, 0, 0};
-    uint64_t* celltab = nullptr;
-    size_t celltab_for = 0;
-    float4* verts = nullptr;
-    uint32_t* vkeys = nullptr;
-    uint4* cells = nullptr;
-    int32_t* tets = nullptr;
-    uint32_t vcap = 0, ccap = 0, tcap = 0;
-    uint64_t* hash_xyz = nullptr;
-    size_t hash_cap = 0;
-    int64_t hash_key[7] = {-1, -1, -1, -1, -1, -1, -1};
-    int64_t origin[4] = {0, 0, 0, 0};
-    bool extracted = false;
-    cx_counts counts = {0, 0, 0, 0};
-};
+#include "cx_state4.h"
 
 #define CX4_HIP(ctx, call)                                                                       \
     do {                                                                                         \
@@ -215,6 +173,8 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         if (out) *out = c;
         if (c.n_cells <= S->ccap && c.n_vertices <= S->vcap && c.n_triangles <= S->tcap) {
             S->extracted = true;
+            S->post_valid = false;
+            S->value = value;
             return CX_OK;
         }
         if ((rc = reserve4(ctx, S, c.n_cells + c.n_cells / 20 + 1024, c.n_vertices + c.n_vertices / 20 + 1024,

@@ -17,26 +17,8 @@
 #include <cstdlib>
 
 #include "cx_cell.h"
+#include "cx_state4.h"
 #include "cx_tables4d.h"
-
-struct cx_params4 {
-    const float* grid;
-    uint32_t n0, n1, n2, n3, nsamples;
-    cx_fdiv div3, div2, div1;   // / (n1*n2*n3), / (n2*n3), / n3
-    float vcmp, near_abs, vhi, vlo;
-    double value, tol_value;
-    uint32_t flags;
-    uint32_t org[4];
-    uint64_t* celltab;          // (crossing mask (bits 1..15) << 32) | first vertex index
-    float4* verts;              // {x, y, z, t} grid coordinates
-    uint32_t* vkeys;            // edge ids
-    uint4* cells;               // {lin, sign mask (16) | near flag << 16, first tet, first vertex}
-    int32_t* tets;              // 4 vertex indices per tetrahedron
-    uint32_t vcap, ccap, tcap;
-    uint32_t* counters;
-    const uint64_t* hash_xyz;   // CPython tuple-hash prefix per (i,j,k) (CX_DIAG_CPYTHON310)
-    const uint64_t* lut;        // [24][32][12][2] pentatope -> tetrahedra table
-};
 
 __device__ constexpr uint8_t CX_PC[24][5] = CX_PENT_CORNERS_INIT;
 #define CX_PENT_MASK(n) (uint32_t)((1u << CX_PC[n][0]) | (1u << CX_PC[n][1]) | (1u << CX_PC[n][2]) | (1u << CX_PC[n][3]) | (1u << CX_PC[n][4]))

@@ -21,6 +21,7 @@
 #include <string>
 
 #include "cx_ctx.h"
+#include "cx_state4.h"
 
 #define CXP_HIP(ctx, call)                                                                       \
     do {                                                                                         \
@@ -762,5 +763,179 @@ extern "C" int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv_
     CXP_HIP(ctx, hipStreamSynchronize(st));
     *nv_io = S->nv_out; *nt_io = S->nt_out;
     ctx->post_valid = false;
+    return CX_OK;
+}
+
+
+// =====================================================================================================
+// 4-D: the post-steps of GridContour4D.find_tetrahedra
+//   bin_times(nbins=100)            pentatopes.py:162-169
+//   drop_instant_tetrahedra(1e-7)   pentatopes.py:171-189
+//   remove_tiny_simplices(1e-3)     tetrahedral.py:353-375 (called at pentatopes.py:125)
+// =====================================================================================================
+// float64 4-D vertex coordinates exactly as the reference interpolates them, with t snapped to its bin
+__global__ void cxp_k_vertices4_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, uint32_t n3, cx_fdiv d3, cx_fdiv d2, cx_fdiv d1,
+                                    double value, const uint32_t* __restrict__ vkeys, uint32_t nv, double min_interval, double* pts,
+                                    uint32_t* prio) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const uint32_t key = vkeys[v];
+    const uint32_t lin = key >> 4, d = key & 15u;
+    uint32_t q[4];
+    q[0] = cx_div(lin, d3);
+    uint32_t r = lin - q[0] * (n1 * n2 * n3);
+    q[1] = cx_div(r, d2);
+    r -= q[1] * (n2 * n3);
+    q[2] = cx_div(r, d1);
+    q[3] = r - q[2] * n3;
+    const uint32_t lin2 = lin + ((d & 8u) ? n1 * n2 * n3 : 0u) + ((d & 4u) ? n2 * n3 : 0u) + ((d & 2u) ? n3 : 0u) + (d & 1u);
+    const double f0 = (double)A[lin], f1 = (double)A[lin2];
+    const bool owner_low = !(f0 > f1);
+    const double flow = owner_low ? f0 : f1, fhigh = owner_low ? f1 : f0;
+    double ratio = 0.5;
+    const double den = 1.0 * (fhigh - flow);
+    if (!(fabs(den) <= 1e-8)) ratio = (value - flow) / den;
+    const uint32_t db[4] = {(d >> 3) & 1u, (d >> 2) & 1u, (d >> 1) & 1u, d & 1u};
+    double x[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const double low = owner_low ? (double)q[a] : (double)q[a] + (double)db[a];
+        const double high = owner_low ? (double)q[a] + (double)db[a] : (double)q[a];
+        x[a] = low + ratio * (high - low);
+    }
+    // bin_times: bin = int(t / min_interval); t = bin * min_interval
+    x[3] = (double)(long long)(x[3] / min_interval) * min_interval;
+#pragma unroll
+    for (int a = 0; a < 4; a++) pts[(size_t)v * 4 + a] = x[a];
+    prio[v] = key;
+}
+
+__global__ void cxp_k_drop_instant(const int32_t* tets, uint8_t* alive, uint32_t nt, const double* pts, double eps) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    double lo = pts[(size_t)tets[(size_t)t * 4] * 4 + 3], hi = lo;
+#pragma unroll
+    for (int s = 1; s < 4; s++) {
+        const double x = pts[(size_t)tets[(size_t)t * 4 + s] * 4 + 3];
+        lo = fmin(lo, x); hi = fmax(hi, x);
+    }
+    alive[t] = ((hi - lo) < eps) ? 0 : 1;
+}
+
+__global__ void cxp_k_tiny4(const int32_t* tets, uint8_t* alive, uint32_t nt, const double* pts, double ic0, double ic1, double ic2,
+                            double ic3, double eps, u64* parent, const uint32_t* prio, uint8_t* moved) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const double ic[4] = {ic0, ic1, ic2, ic3};
+    uint32_t v[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) v[s] = (uint32_t)tets[(size_t)t * 4 + s];
+    double worst = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        double lo = pts[(size_t)v[0] * 4 + a], hi = lo;
+#pragma unroll
+        for (int s = 1; s < 4; s++) {
+            const double x = pts[(size_t)v[s] * 4 + a];
+            lo = fmin(lo, x); hi = fmax(hi, x);
+        }
+        worst = fmax(worst, (hi - lo) * ic[a]);
+    }
+    if (worst < eps) {
+        alive[t] = 0;
+#pragma unroll
+        for (int s = 1; s < 4; s++) cxp_union(parent, prio, v[0], v[s], 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) moved[v[s]] = 1;
+    }
+}
+__global__ void cxp_k_move4(double* pts, const u64* parent, const uint8_t* moved, uint32_t nv) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || !moved[v]) return;
+    uint32_t par;
+    const uint32_t r = cxp_find(parent, v, par);
+    if (r == v) return;
+#pragma unroll
+    for (int a = 0; a < 4; a++) pts[(size_t)v * 4 + a] = pts[(size_t)r * 4 + a];
+}
+__global__ void cxp_k_compact_tets(const int32_t* tets, const uint8_t* alive, const uint32_t* tnew, uint32_t nt, int32_t* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+#pragma unroll
+    for (int s = 0; s < 4; s++) out[(size_t)tnew[t] * 4 + s] = tets[(size_t)t * 4 + s];
+}
+
+extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts) {
+    if (!ctx || nbins <= 0) return CX_ERR_INVALID;
+    cx_state4* G = ctx->s4;
+    if (!G || !G->extracted) { ctx->err = "cx_postprocess4d: no valid 4-D extraction"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)G->counts.n_vertices, nt = (uint32_t)G->counts.n_triangles;
+    hipStream_t st = ctx->stream;
+    if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv + 1) * 4 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->rep, (size_t)nv + 16))) return rc;
+    if ((rc = cxp_reserve(ctx, S->alive, (size_t)nt + 16))) return rc;
+    if ((rc = cxp_reserve(ctx, S->parent, (size_t)(nv + 1) * sizeof(u64)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
+    double* pts = (double*)S->pts.p;
+    uint32_t* prio = (uint32_t*)S->prio.p;
+    uint8_t* moved = (uint8_t*)S->rep.p;
+    uint8_t* alive = (uint8_t*)S->alive.p;
+    u64* parent = (u64*)S->parent.p;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nt2 = 0;
+    if (nv && nt) {
+        const uint32_t n1 = (uint32_t)G->n[1], n2 = (uint32_t)G->n[2], n3 = (uint32_t)G->n[3];
+        const double corner[4] = {(double)(G->n[0] - 1), (double)(G->n[1] - 1), (double)(G->n[2] - 1), (double)(G->n[3] - 1)};
+        const double min_interval = corner[3] * (1.0 / (double)nbins);
+        hipLaunchKernelGGL(cxp_k_vertices4_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, G->grid, n1, n2, n3, cx_fdiv_make(n1 * n2 * n3),
+                           cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio);
+        hipLaunchKernelGGL(cxp_k_drop_instant, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1e-7);
+        CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 4);
+        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent, nv);
+        CXP_HIP(ctx, hipMemsetAsync(moved, 0, nv, st));
+        hipLaunchKernelGGL(cxp_k_tiny4, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1.0 / corner[0], 1.0 / corner[1],
+                           1.0 / corner[2], 1.0 / corner[3], 1e-3, parent, prio, moved);
+        hipLaunchKernelGGL(cxp_k_move4, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, parent, moved, nv);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 5);
+        uint32_t* tflag = (uint32_t*)S->flags.p;
+        uint32_t* tnew = (uint32_t*)S->scan.p;
+        hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, tflag);
+        if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 2))) return rc;
+        uint32_t h[3];
+        CXP_HIP(ctx, hipMemcpyAsync(h, misc + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipMemcpyAsync(h + 2, misc + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        counts[2] = h[0]; counts[3] = h[1];
+        nt2 = h[2];
+        if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(nt2 + 1) * 4 * sizeof(int32_t)))) return rc;
+        hipLaunchKernelGGL(cxp_k_compact_tets, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, tnew, nt, (int32_t*)S->tri_out.p);
+        CXP_HIP(ctx, hipGetLastError());
+    }
+    S->nv_out = nv; S->nt_out = nt2;
+    counts[0] = nv; counts[1] = nt2;
+    G->post_valid = true;
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    return CX_OK;
+}
+
+extern "C" int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* tets) {
+    if (!ctx) return CX_ERR_INVALID;
+    cx_state4* G = ctx->s4;
+    if (!G || !G->post_valid || !ctx->post) { ctx->err = "cx_level1_4d_download: run cx_postprocess4d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    if (points_xyzt && S->nv_out)
+        CXP_HIP(ctx, hipMemcpyAsync(points_xyzt, S->pts.p, (size_t)S->nv_out * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (tets && S->nt_out)
+        CXP_HIP(ctx, hipMemcpyAsync(tets, S->tri_out.p, (size_t)S->nt_out * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CX_OK;
 }

@@ -2,12 +2,12 @@
 the reference's `contourist/pentatopes.py` (Delta4DContour :42-68, MorphingIsoSurfaces :71-89,
 GridContour4D :92-444).
 
-Built so far (SURVEY.md section 8a rows B1-B2): the hyper-voxel march -- 16-corner border test,
-24 pentatopes per hyper-voxel, 1-4 / 2-3 splits into tetrahedra, 4-D edge interpolation -- as HIP
-kernels (cx_extract4d).  `GridContour4D.find_tetrahedra()` returns that Level-0 result.
-Not built yet (rows B3-B6): bin_times / drop_instant_tetrahedra / tiny collapse, the slicing of
-tetrahedra into morph triangles and their orientation; `collect_morph_triangles()` raises
-NotImplementedError instead of falling back to a CPU path.
+Built so far (SURVEY.md section 8a rows B1-B3): the hyper-voxel march -- 16-corner border test,
+24 pentatopes per hyper-voxel, 1-4 / 2-3 splits into tetrahedra, 4-D edge interpolation -- and the
+post-steps of find_tetrahedra (bin_times, drop_instant_tetrahedra, tiny collapse), as HIP kernels
+(cx_extract4d, cx_postprocess4d).
+Not built yet (rows B4-B6): the slicing of tetrahedra into morph triangles and their orientation;
+`collect_morph_triangles()` raises NotImplementedError instead of falling back to a CPU path.
 """
 import itertools
 
@@ -73,10 +73,9 @@ class GridContour4D(object):
             self._ctx = _ffi.Context(self.device)
         return self._ctx
 
-    def find_tetrahedra(self):
-        """hyper-voxel march on the device.  returns dict(xyzt (V,4) f32 grid coords, keys (V,) u32 edge ids,
-        tetrahedra (T,4) i32, counts).  (The reference continues with bin_times / drop_instant_tetrahedra /
-        remove_tiny_simplices, pentatopes.py:107-125: not built yet.)"""
+    def march(self):
+        """Level 0: the hyper-voxel march alone.  returns dict(xyzt (V,4) f32 grid coords, keys (V,) u32 edge ids,
+        tetrahedra (T,4) i32, counts)"""
         ctx = self.context()
         s = self.samples
         if grid_field._is_torch(s):
@@ -87,6 +86,17 @@ class GridContour4D(object):
         self._counts = ctx.extract4d(self.value, self.flags)
         xyzt, keys, tets = ctx.download_level0_4d(self._counts)
         return dict(xyzt=xyzt, keys=keys, tetrahedra=tets, counts=self._counts)
+
+    def find_tetrahedra(self, nbins=100):
+        """GridContour4D.find_tetrahedra (pentatopes.py:101-125) on the device: march, bin_times(nbins),
+        drop_instant_tetrahedra, remove_tiny_simplices(1e-3).  returns dict(points4d (V,4) float64 grid
+        coordinates, keys (V,) edge ids, tetrahedra (T,4) int32, counts)"""
+        L = self.march()
+        ctx = self.context()
+        post = ctx.postprocess4d(nbins)
+        pts, tets = ctx.download_level1_4d(post)
+        self.post_counts = post
+        return dict(points4d=pts, keys=L["keys"], tetrahedra=tets, counts=post)
 
     def collect_morph_triangles(self, epsilon=1e-7):
         raise NotImplementedError("morph-triangle slicing (pentatopes.py:314-368) is not on the device path yet")

@@ -125,6 +125,12 @@ int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int6
 int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3);
 int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
 int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, int32_t* tets);
+/* GridContour4D.find_tetrahedra's post-steps on the device: bin_times(nbins) (pentatopes.py:162-169),
+ * drop_instant_tetrahedra(1e-7) (:171-189), remove_tiny_simplices(1e-3) (tetrahedral.py:353-375).
+ * out_counts (8 x int64): [0] vertices (unchanged numbering), [1] surviving tetrahedra,
+ * [2] after drop_instant, [3] after the tiny collapse.  Download: points = nv*4 doubles, tets = nt*4 int32. */
+int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts);
+int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* tets);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.

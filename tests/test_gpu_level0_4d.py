@@ -20,7 +20,7 @@ def check(A, v, diagonal, diag_mode):
     from contourist_amd import pentatopes
     from oracle import level0_4d
     corner = tuple(n - 1 for n in A.shape)
-    R = pentatopes.GridContour4D(corner, A, v, diagonal=diagonal).find_tetrahedra()
+    R = pentatopes.GridContour4D(corner, A, v, diagonal=diagonal).march()
     O = level0_4d.march4d(A, v, diag_mode=diag_mode)
     ko = level0_4d.edge_keys4(O["pairs"], A.shape)
     co = level0_4d.canonical4(ko, O["xyzt"], O["tets"])
@@ -58,3 +58,24 @@ def test_tolerances_4d():
     check(B, 0.0, "cpython310", 1)
     C = np.round(rng.standard_normal((5, 5, 6, 6)) * 2) / 2
     check(C.astype(np.float32), 0.5, "cpython310", 1)
+
+
+@pytest.mark.parametrize("name", names())
+def test_find_tetrahedra_post_steps(name):
+    """bin_times / drop_instant_tetrahedra / remove_tiny_simplices on the device vs the oracle and the reference"""
+    from contourist_amd import pentatopes
+    from oracle import level0_4d, postpass4d
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    corner = np.array(A.shape) - 1
+    R = pentatopes.GridContour4D(tuple(corner), A, v).find_tetrahedra()
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    W = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    assert R["counts"]["n_after_drop"] == W["n_after_drop"] == int(G["n_tets_after_drop"])
+    assert R["counts"]["n_after_tiny"] == W["n_after_tiny"] == int(G["n_tets_after_tiny"])
+    kh = R["keys"].astype(np.int64)
+    assert np.array_equal(R["points4d"][np.argsort(kh)], W["xyzt"][np.argsort(ko)])          # float64, bit for bit
+    got = level0_4d.canonical4(kh, R["points4d"], R["tetrahedra"].astype(np.int64))[2]
+    want = level0_4d.canonical4(ko, W["xyzt"], W["tets"])[2]
+    assert np.array_equal(got, want)

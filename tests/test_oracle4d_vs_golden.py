@@ -33,3 +33,19 @@ def test_level0_4d_exact(name):
     O0 = level0_4d.march4d(A, v, diag_mode=0)
     c0 = level0_4d.canonical4(level0_4d.edge_keys4(O0["pairs"], A.shape), O0["xyzt"], O0["tets"])
     assert np.array_equal(level0_4d.pentatope_groups(cr[2], A.shape), level0_4d.pentatope_groups(c0[2], A.shape))
+
+
+@pytest.mark.parametrize("name", names())
+def test_b3_post_steps(name):
+    """bin_times / drop_instant_tetrahedra / remove_tiny_simplices against the reference's own results"""
+    from oracle import postpass4d
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    corner = np.array(A.shape) - 1
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    R = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    kr = level0_4d.edge_keys4(G["l0_pairs"], A.shape)
+    assert np.array_equal(R["xyzt_binned"][np.argsort(ko)], G["b3_xyzt_binned"][np.argsort(kr)])   # bit for bit
+    assert R["n_after_drop"] == int(G["n_tets_after_drop"])
+    assert R["n_after_tiny"] == int(G["n_tets_after_tiny"])
