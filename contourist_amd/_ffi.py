@@ -23,7 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
 
@@ -80,6 +80,8 @@ def load():
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
         "cx_level1_4d_download": [vp, vp, vp],
+        "cx_morph_triangles": [vp, vp],
+        "cx_morph_download": [vp, vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }
@@ -235,6 +237,16 @@ class Context(object):
         tets = np.empty((int(counts["n_tetrahedra"]), 4), dtype=np.int32)
         self._check(self.lib.cx_level1_4d_download(self.handle, pts.ctypes.data, tets.ctypes.data))
         return pts, tets
+
+    def morph_triangles(self):
+        "-> (points4d (V,4) float64, segments (S,2) int32 low t -> high t, triangles (T,3) int32 oriented)"
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cx_morph_triangles(self.handle, out.ctypes.data))
+        pts = np.empty((int(out[0]), 4), dtype=np.float64)
+        segs = np.empty((int(out[1]), 2), dtype=np.int32)
+        tris = np.empty((int(out[2]), 3), dtype=np.int32)
+        self._check(self.lib.cx_morph_download(self.handle, pts.ctypes.data, segs.ctypes.data, tris.ctypes.data))
+        return pts, segs, tris, int(out[4])
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

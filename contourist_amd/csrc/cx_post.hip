@@ -43,7 +43,9 @@ struct cxp_dev {
 
 struct cx_post_state {
     cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
+    cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
+    int64_t ms_out = 0, mt_out = 0;
 };
 
 static int cxp_reserve(cx_ctx* ctx, cxp_dev& d, size_t bytes) {
@@ -59,7 +61,8 @@ void cx_post_free(cx_ctx* ctx) {
     if (!ctx->post) return;
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
-                      &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc};
+                      &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -936,6 +939,306 @@ extern "C" int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* 
         CXP_HIP(ctx, hipMemcpyAsync(points_xyzt, S->pts.p, (size_t)S->nv_out * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (tets && S->nt_out)
         CXP_HIP(ctx, hipMemcpyAsync(tets, S->tri_out.p, (size_t)S->nt_out * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+
+// =====================================================================================================
+// 4-D rows B4 / B5: morph triangles
+//   GridContour4D.collect_morph_triangles                     pentatopes.py:314-368
+//   MorphGeometry.triangulate_tetrahedron_at_midpoints / add_tetrahedron / interpolate_pair_3d
+//                                                             morph_geometry.py:145-237
+//   MorphTriangles.__init__ / orient_triangles / compute_triangle_stats / time_compatible_triangles
+//                                                             morph_geometry.py:7-22, 49-89
+// Canonical numbering: the 4 vertices of a tetrahedron are ordered by edge id (the reference orders them by
+// its dict numbering, which only decides how a 4-segment slice is split).
+// =====================================================================================================
+__global__ void cxp_k_minmax_t(const double* pts, uint32_t nv, u64* mm) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const u64 o = cxp_orderable(pts[(size_t)v * 4 + 3]);
+    atomicMin(&mm[0], o);
+    atomicMax(&mm[1], o);
+}
+__device__ __forceinline__ double cxp_from_orderable(u64 o) {
+    const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+    return __longlong_as_double((long long)b);
+}
+
+// slices of one tetrahedron: calls emit(p0, p1, p2) with vertex-index pairs packed (i << 32 | j), i before j in
+// canonical order; returns the number of triangles
+template <typename Emit>
+__device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32_t t, const double* pts, const uint32_t* prio, double t_eps,
+                                                     Emit emit) {
+    uint32_t v[4];
+    double tv[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) v[s] = (uint32_t)tets[(size_t)t * 4 + s];
+    // (a,b,c,d) = vertices in ascending priority (sorting network)
+#define CXP_CSWAP(x, y) if (prio[v[x]] > prio[v[y]]) { const uint32_t tmp = v[x]; v[x] = v[y]; v[y] = tmp; }
+    CXP_CSWAP(0, 1) CXP_CSWAP(2, 3) CXP_CSWAP(0, 2) CXP_CSWAP(1, 3) CXP_CSWAP(1, 2)
+#undef CXP_CSWAP
+#pragma unroll
+    for (int s = 0; s < 4; s++) tv[s] = pts[(size_t)v[s] * 4 + 3];
+    double ts[4] = {tv[0], tv[1], tv[2], tv[3]};
+#define CXP_DSWAP(x, y) if (ts[x] > ts[y]) { const double tmp = ts[x]; ts[x] = ts[y]; ts[y] = tmp; }
+    CXP_DSWAP(0, 1) CXP_DSWAP(2, 3) CXP_DSWAP(0, 2) CXP_DSWAP(1, 3) CXP_DSWAP(1, 2)
+#undef CXP_DSWAP
+    const int PI[6] = {0, 0, 0, 1, 1, 2}, PJ[6] = {1, 2, 3, 2, 3, 3};   // scan order (a,b)(a,c)(a,d)(b,c)(b,d)(c,d)
+    uint32_t n = 0;
+    for (int g = 0; g < 3; g++) {
+        if (!((ts[g + 1] - ts[g]) > 1e-4)) continue;               // morph_geometry.py:150
+        const double mid = 0.5 * (ts[g + 1] + ts[g]);
+        u64 sp[6];
+        bool zero[6];
+        int m = 0;
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            double v1 = tv[PI[e]], v2 = tv[PJ[e]];
+            if (v1 > v2) { const double tmp = v1; v1 = v2; v2 = tmp; }
+            if (mid + 1e-5 < v1 || mid - 1e-5 > v2) continue;      // morph_geometry.py:218
+            sp[m] = ((u64)v[PI[e]] << 32) | (u64)v[PJ[e]];
+            zero[m] = fabs(tv[PI[e]] - tv[PJ[e]]) <= t_eps;        // pentatopes.py:341-345
+            m++;
+        }
+        if (m == 3) {
+            if (!(zero[0] || zero[1] || zero[2])) { emit(sp[0], sp[1], sp[2]); n++; }
+        } else if (m == 4) {                                       // morph_geometry.py:176-186
+            int p2 = -1;
+            for (int e = 1; e < 4; e++) {
+                const uint32_t a0 = (uint32_t)(sp[0] >> 32), a1 = (uint32_t)sp[0], b0 = (uint32_t)(sp[e] >> 32), b1 = (uint32_t)sp[e];
+                if (a0 != b0 && a0 != b1 && a1 != b0 && a1 != b1) p2 = e;
+            }
+            for (int e = 1; e < 4; e++) {
+                if (e == p2 || p2 < 0) continue;
+                if (!(zero[0] || zero[p2] || zero[e])) { emit(sp[0], sp[p2], sp[e]); n++; }
+            }
+        }
+    }
+    return n;
+}
+
+__global__ void cxp_k_morph_count(const int32_t* tets, uint32_t nt, const double* pts, const uint32_t* prio, const u64* mm, uint32_t* counts) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const double t_eps = 1e-7 * (cxp_from_orderable(mm[1]) - cxp_from_orderable(mm[0]));
+    counts[t] = cxp_morph_slices(tets, t, pts, prio, t_eps, [](u64, u64, u64) {});
+}
+__global__ void cxp_k_morph_emit(const int32_t* tets, uint32_t nt, const double* pts, const uint32_t* prio, const u64* mm,
+                                 const uint32_t* offsets, u64* pairs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const double t_eps = 1e-7 * (cxp_from_orderable(mm[1]) - cxp_from_orderable(mm[0]));
+    u64* out = pairs + (size_t)offsets[t] * 3;
+    cxp_morph_slices(tets, t, pts, prio, t_eps, [&](u64 p0, u64 p1, u64 p2) { out[0] = p0; out[1] = p1; out[2] = p2; out += 3; });
+}
+// segments = distinct vertex pairs
+__global__ void cxp_k_seg_insert(const u64* pairs, size_t n, u64* tkeys, u64 mask) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = pairs[i];
+    u64 slot = cxp_mix(key) & mask;
+    for (;;) {
+        const u64 cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key);
+        if (cur == CXP_EMPTY || cur == key) break;
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void cxp_k_slot_flags(const u64* tkeys, size_t n, uint32_t* flags) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (tkeys[i] != CXP_EMPTY) ? 1u : 0u;
+}
+// segment records: (i,j) pointing from low t to high t (morph_geometry.py:12-18), and the 3-D midpoint
+__global__ void cxp_k_seg_write(const u64* tkeys, const uint32_t* ids, size_t n, const double* pts, int32_t* segs, double* mid, double* stime) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n || tkeys[i] == CXP_EMPTY) return;
+    uint32_t a = (uint32_t)(tkeys[i] >> 32), b = (uint32_t)tkeys[i];
+    if (pts[(size_t)a * 4 + 3] > pts[(size_t)b * 4 + 3]) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t s = ids[i];
+    segs[(size_t)s * 2] = (int32_t)a; segs[(size_t)s * 2 + 1] = (int32_t)b;
+#pragma unroll
+    for (int c = 0; c < 3; c++) mid[(size_t)s * 3 + c] = 0.5 * (pts[(size_t)a * 4 + c] + pts[(size_t)b * 4 + c]);
+    stime[(size_t)s * 2] = pts[(size_t)a * 4 + 3]; stime[(size_t)s * 2 + 1] = pts[(size_t)b * 4 + 3];
+}
+// triangles as segment-id triples + their time range (morph_geometry.py:69-89)
+__global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tkeys, const uint32_t* ids, u64 mask, const double* stime,
+                                   const u64* mm, int32_t* tris, double* ttime) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    double lo = cxp_from_orderable(mm[0]), hi = cxp_from_orderable(mm[1]);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const u64 key = pairs[(size_t)t * 3 + e];
+        u64 slot = cxp_mix(key) & mask;
+        while (tkeys[slot] != key) slot = (slot + 1) & mask;
+        const uint32_t s = ids[slot];
+        tris[(size_t)t * 3 + e] = (int32_t)s;
+        lo = fmax(lo, stime[(size_t)s * 2]);
+        hi = fmin(hi, stime[(size_t)s * 2 + 1]);
+    }
+    ttime[(size_t)t * 2] = lo; ttime[(size_t)t * 2 + 1] = hi;
+}
+// edge table with a linked list of the triangles on each edge (an "edge" = pair of segment ids)
+__global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u64* eheads, u64 mask, uint32_t* next) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const u64 key = ((u64)min(p, q) << 32) | (u64)max(p, q);
+        u64 slot = cxp_mix(key) & mask;
+        for (;;) {
+            const u64 cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
+            if (cur == CXP_EMPTY || cur == key) break;
+            slot = (slot + 1) & mask;
+        }
+        const u64 old = atomicExch(&eheads[slot], (u64)(t * 3u + (uint32_t)e));
+        next[t * 3u + (uint32_t)e] = (old == CXP_EMPTY) ? CXP_NONE : (uint32_t)old;
+    }
+}
+// link every pair of time-compatible triangles on a common edge (morph_geometry.py:61-67, surface_geometry.py:117-128)
+__global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u64* ekeys, const u64* eheads, u64 mask, const uint32_t* next,
+                                        const double* ttime, u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+    const double lo = ttime[(size_t)t * 2], hi = ttime[(size_t)t * 2 + 1];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const uint32_t elo = min(p, q), ehi = max(p, q);
+        const u64 key = ((u64)elo << 32) | (u64)ehi;
+        u64 slot = cxp_mix(key) & mask;
+        while (ekeys[slot] != key) slot = (slot + 1) & mask;
+        for (uint32_t it = (uint32_t)eheads[slot]; it != CXP_NONE; it = next[it]) {
+            const uint32_t o = it / 3u;
+            if (o >= t) continue;                                  // each unordered pair once
+            const double l2 = fmax(lo, ttime[(size_t)o * 2]), h2 = fmin(hi, ttime[(size_t)o * 2 + 1]);
+            if (!(l2 < h2)) continue;
+            const uint32_t same_dir = (cxp_edge_dir(tri, t, elo, ehi) == cxp_edge_dir(tri, o, elo, ehi)) ? 1u : 0u;
+            cxp_union(parent, nullptr, t, o, same_dir);
+        }
+    }
+}
+
+extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
+    if (!ctx) return CX_ERR_INVALID;
+    cx_state4* G = ctx->s4;
+    if (!G || !G->post_valid || !ctx->post) { ctx->err = "cx_morph_triangles: run cx_postprocess4d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    hipStream_t st = ctx->stream;
+    const uint32_t nv = (uint32_t)S->nv_out, nt = (uint32_t)S->nt_out;   // vertices / surviving tetrahedra
+    const double* pts = (const double*)S->pts.p;
+    const uint32_t* prio = (const uint32_t*)S->prio.p;
+    const int32_t* tets = (const int32_t*)S->tri_out.p;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    u64* mm = (u64*)(misc + 16);
+    int rc;
+    int64_t counts[8] = {nv, 0, 0, 0, 0, 0, 0, 0};
+    S->ms_out = 0; S->mt_out = 0;
+    if (nv && nt) {
+        const u64 init[2] = {~0ULL, 0ULL};
+        CXP_HIP(ctx, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(cxp_k_minmax_t, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, mm);
+        if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
+        uint32_t* cnt = (uint32_t*)S->flags.p;
+        uint32_t* off = (uint32_t*)S->scan.p;
+        hipLaunchKernelGGL(cxp_k_morph_count, dim3(cxp_blocks(nt)), dim3(256), 0, st, tets, nt, pts, prio, mm, cnt);
+        if ((rc = cxp_scan(ctx, S, cnt, off, nt, misc + 1))) return rc;
+        uint32_t ntri = 0;
+        CXP_HIP(ctx, hipMemcpyAsync(&ntri, misc + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        if (ntri) {
+            if ((rc = cxp_reserve(ctx, S->mpairs, (size_t)ntri * 3 * sizeof(u64)))) return rc;
+            u64* pairs = (u64*)S->mpairs.p;
+            hipLaunchKernelGGL(cxp_k_morph_emit, dim3(cxp_blocks(nt)), dim3(256), 0, st, tets, nt, pts, prio, mm, off, pairs);
+            // ---- segments
+            const size_t np = (size_t)ntri * 3;
+            const u64 ssz = cxp_table_size(np);
+            if ((rc = cxp_reserve(ctx, S->tkeys, ssz * sizeof(u64)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->flags, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
+            u64* skeys = (u64*)S->tkeys.p;
+            uint32_t* sflag = (uint32_t*)S->flags.p;
+            uint32_t* sid = (uint32_t*)S->scan.p;
+            hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, skeys, (size_t)ssz, CXP_EMPTY);
+            hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np)), dim3(256), 0, st, pairs, np, skeys, ssz - 1);
+            hipLaunchKernelGGL(cxp_k_slot_flags, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, (size_t)ssz, sflag);
+            if ((rc = cxp_scan(ctx, S, sflag, sid, (uint32_t)ssz, misc + 2))) return rc;
+            uint32_t nseg = 0;
+            CXP_HIP(ctx, hipMemcpyAsync(&nseg, misc + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CXP_HIP(ctx, hipStreamSynchronize(st));
+            if ((rc = cxp_reserve(ctx, S->msegs, (size_t)(nseg + 1) * 2 * sizeof(int32_t)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->mmid, (size_t)(nseg + 1) * 3 * sizeof(double)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->mtime, ((size_t)(nseg + 1) * 2 + (size_t)(ntri + 1) * 2) * sizeof(double)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->mtris, (size_t)(ntri + 1) * 3 * sizeof(int32_t)))) return rc;
+            int32_t* segs = (int32_t*)S->msegs.p;
+            double* mid = (double*)S->mmid.p;
+            double* stime = (double*)S->mtime.p;
+            double* ttime = stime + (size_t)(nseg + 1) * 2;
+            int32_t* tris = (int32_t*)S->mtris.p;
+            hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
+            hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, stime, mm, tris, ttime);
+            CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
+            // ---- orientation on the segment midpoints, time-compatible neighbours only
+            const u64 esz = cxp_table_size((size_t)ntri * 3);
+            if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->parent, (size_t)ntri * sizeof(u64)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->mnext, (size_t)ntri * 3 * sizeof(uint32_t)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->comp, (size_t)ntri * (2 * sizeof(u64) + 2 * sizeof(uint32_t))))) return rc;
+            u64* ekeys = (u64*)S->tkeys.p;
+            u64* eheads = (u64*)S->tvals.p;
+            u64* parent = (u64*)S->parent.p;
+            uint32_t* next = (uint32_t*)S->mnext.p;
+            u64* cmaxx = (u64*)S->comp.p;
+            u64* cbest = cmaxx + ntri;
+            uint32_t* cmaxv = (uint32_t*)(cbest + ntri);
+            uint32_t* cstart = cmaxv + ntri;
+            hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
+            hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, eheads, (size_t)esz, CXP_EMPTY);
+            hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(ntri)), dim3(256), 0, st, parent, ntri);
+            hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, next);
+            hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, next, ttime, parent);
+            if ((rc = cxp_flatten(ctx, parent, ntri, misc))) return rc;
+            CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
+            CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx);
+            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv);
+            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest);
+            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart);
+            hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, misc + 3);
+            uint32_t ncomp = 0;
+            CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CXP_HIP(ctx, hipStreamSynchronize(st));
+            CXP_HIP(ctx, hipGetLastError());
+            S->ms_out = nseg; S->mt_out = ntri;
+            counts[1] = nseg; counts[2] = ntri; counts[4] = ncomp;
+        }
+        // min / max t of all points (MorphTriangles.min_value / max_value)
+        u64 h[2];
+        CXP_HIP(ctx, hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        memcpy(&counts[5], &h[0], 8); memcpy(&counts[6], &h[1], 8);   // orderable encodings, decoded by the host side
+    }
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    return CX_OK;
+}
+
+extern "C" int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32_t* triangles) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    if (points_xyzt && S->nv_out)
+        CXP_HIP(ctx, hipMemcpyAsync(points_xyzt, S->pts.p, (size_t)S->nv_out * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (segments && S->ms_out)
+        CXP_HIP(ctx, hipMemcpyAsync(segments, S->msegs.p, (size_t)S->ms_out * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (triangles && S->mt_out)
+        CXP_HIP(ctx, hipMemcpyAsync(triangles, S->mtris.p, (size_t)S->mt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CX_OK;
 }

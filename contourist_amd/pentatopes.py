@@ -2,12 +2,12 @@
 the reference's `contourist/pentatopes.py` (Delta4DContour :42-68, MorphingIsoSurfaces :71-89,
 GridContour4D :92-444).
 
-Built so far: the hyper-voxel march -- 16-corner border test,
-24 pentatopes per hyper-voxel, 1-4 / 2-3 splits into tetrahedra, 4-D edge interpolation -- and the
-post-steps of find_tetrahedra (bin_times, drop_instant_tetrahedra, tiny collapse), as HIP kernels
-(cx_extract4d, cx_postprocess4d).
-Not built yet (rows B4-B6): the slicing of tetrahedra into morph triangles and their orientation;
-`collect_morph_triangles()` raises NotImplementedError instead of falling back to a CPU path.
+Device kernels: the hyper-voxel march -- 16-corner border test,
+24 pentatopes per hyper-voxel, 1-4 / 2-3 splits into tetrahedra, 4-D edge interpolation (cx_extract4d);
+the post-steps of find_tetrahedra -- bin_times, drop_instant_tetrahedra, tiny collapse
+(cx_postprocess4d); the slicing of tetrahedra into morph triangles and their time-aware orientation
+(cx_morph_triangles).  Row B6, evaluating the surface at a time t, is MorphTriangles.triangles_at
+(the consumer-side lerp of misc/morph_triangles.js).
 """
 import itertools
 
@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _ffi
 from . import grid_field
+from . import morph_geometry
 from . import tetrahedral
 
 
@@ -99,7 +100,15 @@ class GridContour4D(object):
         return dict(points4d=pts, keys=L["keys"], tetrahedra=tets, counts=post)
 
     def collect_morph_triangles(self, epsilon=1e-7):
-        raise NotImplementedError("morph-triangle slicing (pentatopes.py:314-368) is not on the device path yet")
+        """slice the tetrahedra into morph triangles and orient them (pentatopes.py:314-368) on the device.
+        Call find_tetrahedra() first (as Delta4DContour.collect_morph_triangles does).
+        returns morph_geometry.MorphTriangles in GRID coordinates."""
+        assert epsilon == 1e-7, "the device path implements the reference's default epsilon"
+        if getattr(self, "post_counts", None) is None:
+            self.find_tetrahedra()
+        pts, segs, tris, ncomp = self.context().morph_triangles()
+        self.n_components = ncomp
+        return morph_geometry.MorphTriangles(pts, segs, tris)
 
 
 class Delta4DContour(tetrahedral.Delta3DContour):
@@ -115,8 +124,16 @@ class Delta4DContour(tetrahedral.Delta3DContour):
         self.contour_maker = self.get_contour_maker(None)
 
     def collect_morph_triangles(self):
-        self.contour_maker.find_tetrahedra()
-        return self.contour_maker.collect_morph_triangles()
+        "MorphTriangles in world coordinates (pentatopes.py:64-68)"
+        contour_maker = self.contour_maker
+        contour_maker.find_tetrahedra()
+        grid_morph_triangles = contour_maker.collect_morph_triangles()
+        return grid_morph_triangles.from_grid_coordinates(self.grid)
+
+    def to_json(self):
+        "pentatopes.py:85-89"
+        morph_triangles = self.collect_morph_triangles()
+        return morph_triangles.to_json(min_value=self.grid.mins[-1], max_value=self.grid.maxes[-1])
 
 
 class MorphingIsoSurfaces(Delta4DContour):

@@ -284,3 +284,28 @@ class TriangulatedIsosurfaces(Delta3DContour):
         else:
             grid = grid_field.FunctionGrid.from_array(function, mins, delta)
         Delta3DContour.__init__(self, grid, value, segment_endpoints, linear_interpolate=linear_interpolate)
+
+
+class MultiLevelIsosurfaces(object):
+    """Several isovalues of ONE field (BASELINE.json config 5; the reference has this only in 2-D,
+    contourist/multiple_2d_contour.py:17-75).  The dense samples are bound to the device once and every
+    level is marched against the resident grid; levels run back to back on one stream because they share
+    the per-cell lookup table.  `levels()` yields (value, points, triangles) in ascending value order."""
+
+    def __init__(self, mins, maxes, delta, function, values, device=None):
+        self.values = sorted(float(v) for v in values)
+        if callable(function):
+            self.grid = grid_field.FunctionGrid(mins, maxes, delta, function)
+        else:
+            self.grid = grid_field.FunctionGrid.from_array(function, mins, delta)
+        self.device = _DEFAULT_DEVICE[0] if device is None else int(device)
+        self._ctx = _ffi.Context(self.device)
+
+    def levels(self, clean=True):
+        samples = self.grid.dense_samples()
+        corner = tuple(int(n) for n in self.grid.grid_dimensions)
+        for v in self.values:
+            maker = GridContour3d(corner, samples, v, None, context=self._ctx)
+            grid_points, triangles = maker.get_points_and_triangles(clean)
+            points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
+            yield (v, points, triangles)

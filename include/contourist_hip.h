@@ -131,6 +131,15 @@ int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, in
  * [2] after drop_instant, [3] after the tiny collapse.  Download: points = nv*4 doubles, tets = nt*4 int32. */
 int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts);
 int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* tets);
+/* GridContour4D.collect_morph_triangles (pentatopes.py:314-368) + MorphTriangles.orient_triangles
+ * (morph_geometry.py:49-89) on the tetrahedra left by cx_postprocess4d: every tetrahedron is sliced at the
+ * midpoints between its distinct vertex times into 1-2 triangles whose corners are SEGMENTS (pairs of 4-D
+ * points, stored low t -> high t); triangles are oriented per connected component, propagating only between
+ * triangles whose time ranges overlap.  out_counts (8 x int64): [0] points, [1] segments, [2] triangles,
+ * [4] components.  Download: points nv*4 doubles, segments ns*2 int32 (point indices), triangles nt*3 int32
+ * (segment indices). */
+int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts);
+int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32_t* triangles);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.

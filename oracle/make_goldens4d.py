@@ -113,6 +113,15 @@ def run_reference4d(A, value):
         out["n_tets_after_drop"] = np.int64(len(cm.simplex_sets))
         cm.remove_tiny_simplices(epsilon=1e-3)
         out["n_tets_after_tiny"] = np.int64(len(cm.simplex_sets))
+        # B4/B5: morph triangles (pentatopes.py:314-368, morph_geometry.py:5-89, 145-237)
+        mt = cm.collect_morph_triangles()
+    pts = np.array(mt.points4d, dtype=np.float64).reshape(-1, 4)
+    # reference vertex numbering = dict order of interpolated_contour_pairs at that time; map to edge keys
+    pl = list(cm.interpolated_contour_pairs.keys())
+    out["mt_point_pairs"] = np.array([list(p[0]) + list(p[1]) for p in pl], dtype=np.int32).reshape(-1, 8)
+    out["mt_points4d"] = pts
+    out["mt_segments"] = np.array(mt.segment_point_indices, dtype=np.int64).reshape(-1, 2)
+    out["mt_triangles"] = np.array([list(t) for t in mt.triangle_segment_indices], dtype=np.int64).reshape(-1, 3)
     out["t_total_s"] = np.float64(time.time() - t0)
     return out
 
@@ -125,6 +134,6 @@ if __name__ == "__main__":
             continue
         G = run_reference4d(spec["A"], spec["value"])
         np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **G)
-        print("%-22s shape=%s v=%g  hypervoxels %d  verts %d  tets %d | after drop %d after tiny %d (%.1fs)" % (
+        print("%-22s shape=%s v=%g  hypervoxels %d  verts %d  tets %d | after drop %d after tiny %d | morph: %d segments %d triangles (%.1fs)" % (
             name, spec["A"].shape, spec["value"], len(G["surface_voxels"]), len(G["l0_pairs"]), len(G["l0_tets"]),
-            G["n_tets_after_drop"], G["n_tets_after_tiny"], G["t_total_s"]))
+            G["n_tets_after_drop"], G["n_tets_after_tiny"], len(G["mt_segments"]), len(G["mt_triangles"]), G["t_total_s"]))

@@ -194,7 +194,7 @@ def clean(xyz, tris, tprio=None):
     return x2, t2
 
 
-def orient(xyz, tris):
+def orient(xyz, tris, compatible=None):
     """A10.  SurfaceGeometry.orient_triangles, restated faithfully (input winding is IGNORED):
     while unoriented triangles remain: take the vertex with the largest (x, index) among them
     (:79), among its unoriented triangles the one with the largest |cross(a-b, a-c)[0]| (:88-94,
@@ -250,7 +250,7 @@ def orient(xyz, tris):
             a, b, c = o
             for (i1, i2) in ((c, b), (b, a), (a, c)):
                 for t2 in edge_tris[(min(i1, i2), max(i1, i2))]:
-                    if t2 != t and t2 not in orientation:
+                    if t2 != t and t2 not in orientation and (compatible is None or compatible(t2, t)):
                         (i3,) = set(int(x) for x in tris[t2]) - {i1, i2}
                         stack.append((t2, (i1, i2, i3)))
         ncomp += 1

@@ -79,3 +79,46 @@ def test_find_tetrahedra_post_steps(name):
     got = level0_4d.canonical4(kh, R["points4d"], R["tetrahedra"].astype(np.int64))[2]
     want = level0_4d.canonical4(ko, W["xyzt"], W["tets"])[2]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", names())
+def test_morph_triangles_device(name):
+    """collect_morph_triangles on the device vs the oracle's canonical restatement and the reference's output"""
+    from contourist_amd import pentatopes
+    from oracle import level0_4d, postpass4d
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    corner = np.array(A.shape) - 1
+    maker = pentatopes.GridContour4D(tuple(corner), A, v)
+    R = maker.find_tetrahedra()
+    MT = maker.collect_morph_triangles()
+    kh = R["keys"].astype(np.int64)
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    W = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    M = postpass4d.collect_morph_triangles(ko, W["xyzt"], W["tets"])
+    # same canonical rules on both sides => identical segments (with direction) and identical triangles
+    got_seg = set((int(kh[i]), int(kh[j])) for i, j in MT.segment_point_indices)
+    want_seg = set((int(M["keys"][i]), int(M["keys"][j])) for i, j in M["segments"])
+    assert got_seg == want_seg
+    assert len(MT.triangle_segment_indices) == len(M["triangles"]) == len(G["mt_triangles"])
+
+    def tri_sets(keys, segs, tris):
+        sk = [tuple(sorted((int(keys[i]), int(keys[j])))) for i, j in segs]
+        return set(frozenset(sk[s] for s in t) for t in tris)
+    assert tri_sets(kh, MT.segment_point_indices, MT.triangle_segment_indices) == tri_sets(M["keys"], M["segments"], M["triangles"])
+    ot, label, flags = postpass4d.orient_morph_triangles(M)
+    common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, M["keys"], M["segments"], ot)
+    assert common == len(ot) and agree >= 0.98 * common          # non-manifold patches may flood in another order
+    # and against the real reference
+    rk = level0_4d.edge_keys4(G["mt_point_pairs"], A.shape)
+    assert set((int(rk[i]), int(rk[j])) for i, j in G["mt_segments"]) == got_seg
+    assert postpass4d.morph_polygons(rk, G["mt_segments"], G["mt_triangles"]) == \
+        postpass4d.morph_polygons(kh, MT.segment_point_indices, MT.triangle_segment_indices)
+    common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, rk, G["mt_segments"], G["mt_triangles"])
+    assert common > 0.7 * len(ot) and agree >= 0.98 * common
+    assert np.array_equal(MT.points4d[np.argsort(kh)], G["mt_points4d"][np.argsort(rk)])
+    # B6: the surface at a time t is a closed 3-D mesh where it exists (every edge shared by two triangles)
+    tmid = 0.5 * (MT.min_value + MT.max_value) + 0.013
+    pts, tris = MT.triangles_at(tmid)
+    assert len(tris) > 0 and tris.max() < len(pts)

@@ -120,3 +120,23 @@ def test_surface_geometry_standalone():
     sg2 = surface_geometry.SurfaceGeometry(list(pts), tri)
     v2, t2 = sg2.clean_triangles()
     assert len(t2) == 4 and len(v2) == 4      # (1,4,2) dropped, vertices 1 and 4 merged
+
+
+def test_multi_level_matches_single_levels():
+    """config 5 shape: several isovalues of one resident grid == the same levels extracted one by one"""
+    from contourist_amd import tetrahedral
+    G = np.load(os.path.join(GOLDEN_DIR, "noise32_v0.npz"))
+    A = G["A"]
+    values = [0.4, -0.5, 0.0]
+    M = tetrahedral.MultiLevelIsosurfaces([0, 0, 0], None, [1, 1, 1], A, values)
+    out = list(M.levels())
+    assert [o[0] for o in out] == sorted(values)
+    for v, pts, tris in out:
+        S = tetrahedral.TriangulatedIsosurfaces([0, 0, 0], None, [1, 1, 1], A, v, [])
+        S.search_for_endpoints()
+        p2, t2 = S.get_points_and_triangles()
+        assert len(pts) == len(p2) and len(tris) == len(t2)
+        a = np.array(sorted(map(tuple, np.round(pts, 9).tolist())))
+        b = np.array(sorted(map(tuple, np.round(p2, 9).tolist())))
+        assert np.array_equal(a, b)
+    assert len(out[1][2]) == len(G["l1_triangles"]) or abs(len(out[1][2]) - len(G["l1_triangles"])) <= 8

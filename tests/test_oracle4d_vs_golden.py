@@ -49,3 +49,29 @@ def test_b3_post_steps(name):
     assert np.array_equal(R["xyzt_binned"][np.argsort(ko)], G["b3_xyzt_binned"][np.argsort(kr)])   # bit for bit
     assert R["n_after_drop"] == int(G["n_tets_after_drop"])
     assert R["n_after_tiny"] == int(G["n_tets_after_tiny"])
+
+
+@pytest.mark.parametrize("name", names())
+def test_morph_triangles_b4_b5(name):
+    """collect_morph_triangles + orient_triangles: segments (with direction), slice polygons and points equal the
+    reference's; windings agree on every triangle both produce (the split of 4-segment slices follows the
+    reference's dict numbering and is not contractual)."""
+    from oracle import postpass4d
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    corner = np.array(A.shape) - 1
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    W = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    M = postpass4d.collect_morph_triangles(ko, W["xyzt"], W["tets"])
+    rk = level0_4d.edge_keys4(G["mt_point_pairs"], A.shape)
+    assert np.array_equal(G["mt_points4d"][np.argsort(rk)], M["points4d"])
+    ref_seg = set((int(rk[i]), int(rk[j])) for i, j in G["mt_segments"])
+    got_seg = set((int(M["keys"][i]), int(M["keys"][j])) for i, j in M["segments"])
+    assert ref_seg == got_seg                                           # same segments, same low-t -> high-t direction
+    assert len(G["mt_triangles"]) == len(M["triangles"])
+    assert postpass4d.morph_polygons(rk, G["mt_segments"], G["mt_triangles"]) == \
+        postpass4d.morph_polygons(M["keys"], M["segments"], M["triangles"])
+    ot, label, flags = postpass4d.orient_morph_triangles(M)
+    common, agree = postpass4d.winding_agreement(rk, G["mt_segments"], G["mt_triangles"], M["keys"], M["segments"], ot)
+    assert common > 0.7 * len(ot) and agree == common
