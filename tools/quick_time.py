@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K1/K2 timing of the full path (median of rounds), for A/B builds."""
+"""K1/K2 timing of the full path (median of rounds), for A/B builds and modes."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
