@@ -22,7 +22,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -70,6 +70,7 @@ def load():
         "cx_level0_download": [vp, vp, vp],
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_postprocess3d": [vp, u32, vp],
+        "cx_postprocess3d_ex": [vp, u32, dbl, vp],
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
         "cx_debug_stamps": [vp, i64, vp],
@@ -179,9 +180,9 @@ class Context(object):
         keys = verts[:, 3].copy().view(np.uint32)
         return verts[:, :3].copy(), keys, tris
 
-    def postprocess3d(self, flags=0):
+    def postprocess3d(self, flags=0, smooth=0.0):
         out = np.zeros(8, dtype=np.int64)
-        self._check(self.lib.cx_postprocess3d(self.handle, int(flags), out.ctypes.data))
+        self._check(self.lib.cx_postprocess3d_ex(self.handle, int(flags), float(smooth or 0.0), out.ctypes.data))
         return dict(n_vertices=int(out[0]), n_triangles=int(out[1]), n_after_weld=int(out[2]),
                     n_after_tiny=int(out[3]), n_components=int(out[4]))
 

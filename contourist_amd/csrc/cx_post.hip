@@ -646,7 +646,54 @@ static int cxp_state(cx_ctx* ctx, cx_post_state** out) {
     return cxp_reserve(ctx, ctx->post->misc, 64 * sizeof(uint32_t));
 }
 
+// ---- smooth_interpolations(factor) (tetrahedral.py:329-351): every vertex that is part of a triangle moves by
+// `factor` towards the mean of the vertices of its triangles (itself included, each neighbour once)
+__global__ void cxp_k_unique_edges(const int32_t* tri, const uint8_t* alive, uint32_t nt, u64* ekeys, u64 mask) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt || !alive[t]) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+    for (int e = 0; e < 3; e++) {
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const u64 key = ((u64)min(p, q) << 32) | (u64)max(p, q);
+        u64 slot = cxp_mix(key) & mask;
+        for (;;) {
+            const u64 cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
+            if (cur == CXP_EMPTY || cur == key) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+__global__ void cxp_k_smooth_accumulate(const u64* ekeys, size_t n, const double* pts, double* sum, uint32_t* cnt) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n || ekeys[i] == CXP_EMPTY) return;
+    const uint32_t a = (uint32_t)(ekeys[i] >> 32), b = (uint32_t)ekeys[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        atomicAdd(&sum[(size_t)a * 3 + c], pts[(size_t)b * 3 + c]);
+        atomicAdd(&sum[(size_t)b * 3 + c], pts[(size_t)a * 3 + c]);
+    }
+    atomicAdd(&cnt[a], 1u);
+    atomicAdd(&cnt[b], 1u);
+}
+__global__ void cxp_k_smooth_apply(double* pts, const double* sum, const uint32_t* cnt, uint32_t nv, double factor) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || cnt[v] == 0u) return;
+    const double inv = 1.0 / (double)(cnt[v] + 1u);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double p = pts[(size_t)v * 3 + c];
+        const double avg = (sum[(size_t)v * 3 + c] + p) * inv;
+        pts[(size_t)v * 3 + c] = p - factor * (p - avg);
+    }
+}
+
+extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts);
+
 extern "C" int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts) {
+    return cx_postprocess3d_ex(ctx, flags, 0.0, out_counts);
+}
+
+extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {
     if (!ctx) return CX_ERR_INVALID;
     if (!ctx->extracted) { ctx->err = "cx_postprocess3d: no valid extraction"; return CX_ERR_STATE; }
     CXP_HIP(ctx, hipSetDevice(ctx->device));
@@ -697,6 +744,21 @@ extern "C" int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts
         hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
         CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 4);
+        if (smooth > 0.0) {
+            // ---- smooth_interpolations (tetrahedral.py:547-550), between the weld and the tiny collapse
+            const u64 esz = cxp_table_size((size_t)nt * 3);
+            if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(nv + 1) * 3 * sizeof(double)))) return rc;
+            if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
+            double* sum = (double*)S->pts_out.p;
+            uint32_t* cnt = (uint32_t*)S->flags.p;
+            CXP_HIP(ctx, hipMemsetAsync(sum, 0, (size_t)nv * 3 * sizeof(double), st));
+            CXP_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)nv * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)esz, CXP_EMPTY);
+            hipLaunchKernelGGL(cxp_k_unique_edges, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, esz - 1);
+            hipLaunchKernelGGL(cxp_k_smooth_accumulate, dim3(cxp_blocks(esz)), dim3(256), 0, st, (const u64*)S->tkeys.p, (size_t)esz, pts, sum, cnt);
+            hipLaunchKernelGGL(cxp_k_smooth_apply, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, sum, cnt, nv, smooth);
+        }
         // ---- tiny collapse (tetrahedral.py:353-375), epsilon = 1e-4, scaled by 1/corner
         u64* parent = (u64*)S->parent.p;
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent, nv);

@@ -114,10 +114,10 @@ class GridContour3d(object):
         if self.flatten:
             raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
         if self.smooth:
-            raise NotImplementedError("smooth is not on the device path yet")
+            assert self.smooth > 0 and self.smooth <= 1
         ctx = self.context()
         if self._post is None:
-            self._post = ctx.postprocess3d(0 if clean else 1)
+            self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0)
         pts, tris = ctx.download_level1(self._post)
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
 

@@ -99,6 +99,9 @@ int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris);
  * (the reference's clean=False).  out_counts (8 x int64): [0] vertices, [1] triangles,
  * [2] triangles after weld, [3] triangles after tiny collapse, [4] connected components. */
 int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts);
+/* same with GridContour.smooth_interpolations(smooth) (tetrahedral.py:329-351, 547-550) between the weld and
+ * the tiny collapse; 0 < smooth <= 1, smooth == 0 disables it */
+int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 

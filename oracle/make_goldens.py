@@ -122,6 +122,9 @@ def fields():
     F["tiny_amp16b"] = dict(A=(close_interior(smooth_noise(16, 3, 2), -4.0) * np.float32(1.2e-8)), value=0.0)
     # relative tolerance regime: values ~100, differences ~1e-3 (1e-5 * 100)
     F["rel_tol16"] = dict(A=(np.float32(100.0) + close_interior(smooth_noise(16, 4, 2), -4.0) * np.float32(1.2e-3)), value=100.0)
+    # smooth_interpolations (tetrahedral.py:329-351)
+    F["sphere32_smooth05"] = dict(A=F["sphere32"]["A"], value=1.0, mins=[-1.5] * 3, delta=[d] * 3, smooth=0.5)
+    F["noise24_v07_smooth03"] = dict(A=F["noise24_v07"]["A"], value=0.7, smooth=0.3)
     # samples exactly equal to the isovalue (f == v counts as HIGH; strict search test differs)
     Q = np.round(close_interior(smooth_noise(18, 21, 2), -3.0) * 2.0) / 2.0
     F["quantised18"] = dict(A=Q.astype(np.float32), value=0.5)
@@ -130,7 +133,7 @@ def fields():
 
 # ---- staged reference run ----------------------------------------------------------------------
 
-def run_reference(A, value, order="native", seed=0, mins=None, delta=None):
+def run_reference(A, value, order="native", seed=0, mins=None, delta=None, smooth=None):
     grid_field, surface_geometry, tetrahedral, triangulated = reference_modules()
     A = np.ascontiguousarray(A, dtype=np.float32)
     shape = A.shape
@@ -145,7 +148,7 @@ def run_reference(A, value, order="native", seed=0, mins=None, delta=None):
         return fa(round((x - mins[0]) / delta[0]), round((y - mins[1]) / delta[1]), round((z - mins[2]) / delta[2]))
     maxes = mins + delta * (np.array(shape) - 2)      # grid_dimensions = shape-1  (grid_field.py:26-27)
     t0 = time.time()
-    S = tetrahedral.TriangulatedIsosurfaces(list(mins), list(maxes), list(delta), f, float(value), [])
+    S = tetrahedral.TriangulatedIsosurfaces(list(mins), list(maxes), list(delta), f, float(value), [], smooth=smooth)
     assert tuple(S.grid.grid_dimensions) == tuple(n - 1 for n in shape), (S.grid.grid_dimensions, shape)
     S.search_for_endpoints()
     n_crossing_segments = len(S.grid_endpoints)
@@ -177,6 +180,9 @@ def run_reference(A, value, order="native", seed=0, mins=None, delta=None):
     # ---- post passes
     cm.quantize_interpolations()
     out["n_tris_after_weld"] = np.int64(len(cm.simplex_sets))
+    if smooth:
+        cm.smooth_interpolations(smooth)          # tetrahedral.py:547-550
+        out["smooth"] = np.float64(smooth)
     cm.remove_tiny_simplices()
     out["n_tris_after_tiny"] = np.int64(len(cm.simplex_sets))
     geometry = cm.extract_surface_geometry(True)
@@ -199,7 +205,7 @@ def l1_canonical(grid_points, triangles, shape):
 
 def make(name, spec, outdir=GOLDEN_DIR):
     A, value = spec["A"], spec["value"]
-    kw = dict(mins=spec.get("mins"), delta=spec.get("delta"))
+    kw = dict(mins=spec.get("mins"), delta=spec.get("delta"), smooth=spec.get("smooth"))
     base = run_reference(A, value, "native", **kw)
     canon0 = l1_canonical(base["l1_grid_points"], base["l1_triangles"], A.shape)
     invariant = True

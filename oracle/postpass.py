@@ -286,6 +286,21 @@ def orient(xyz, tris, compatible=None):
     return out, label, flags
 
 
+_QSCALE = [None]     # when set: compare by coordinates rounded to 1/scale instead of by weld buckets
+
+
+def set_compare_scale(scale):
+    """smoothed meshes put many coordinates exactly ON weld-bucket boundaries (symmetric averages), where the
+    order of a float64 sum decides the bucket; such fixtures are compared by rounded coordinates instead"""
+    _QSCALE[0] = scale
+
+
+def _compare_ids(points, corner):
+    if _QSCALE[0] is None:
+        return weld_buckets(points, corner)
+    return np.rint(np.asarray(points, dtype=np.float64) * _QSCALE[0]).astype(np.int64)
+
+
 def canonical_level1(grid_points, triangles, corner):
     """order-independent Level-1 form: every triangle as a triple of weld-bucket ids
     of its (final) vertex coordinates, rotated so the smallest bucket comes first (winding kept),
@@ -294,7 +309,7 @@ def canonical_level1(grid_points, triangles, corner):
     triangles = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
     if len(triangles) == 0:
         return np.zeros((0, 9), dtype=np.int64)
-    q = weld_buckets(grid_points, corner)
+    q = _compare_ids(grid_points, corner)
     # scalar bucket id for ordering
     big = int(q.max()) + 2
     sid = (q[:, 0] * big + q[:, 1]) * big + q[:, 2]
@@ -307,7 +322,22 @@ def canonical_level1(grid_points, triangles, corner):
     return rows[order]
 
 
-def level1_from_level0(keys, xyz, tris, corner):
+def smooth_interpolations(xyz, tris, factor):
+    """GridContour.smooth_interpolations (tetrahedral.py:329-351): every vertex of a triangle moves by `factor`
+    towards the mean of the vertices of its triangles (the vertex itself included, each neighbour once)."""
+    xyz = np.array(xyz, dtype=np.float64)
+    adj = {}
+    for t in np.asarray(tris, dtype=np.int64).reshape(-1, 3):
+        for v in t:
+            adj.setdefault(int(v), set()).update(int(x) for x in t)
+    new = xyz.copy()
+    for v, nb in adj.items():
+        avg = xyz[sorted(nb)].mean(axis=0)
+        new[v] = xyz[v] - factor * (xyz[v] - avg)
+    return new
+
+
+def level1_from_level0(keys, xyz, tris, corner, smooth=None):
     """full canonical post-pass chain on a Level-0 mesh (input winding is irrelevant).
     returns dict(grid_points, triangles, n_after_weld, n_after_tiny, flipped)"""
     keys = np.asarray(keys, dtype=np.int64)
@@ -320,6 +350,8 @@ def level1_from_level0(keys, xyz, tris, corner):
     keys, xyz, tris = keys[order], xyz[order], (inv[tris] if len(tris) else tris)
     rep, t1, p1 = weld(keys, xyz, tris, corner)
     n_after_weld = len(t1)
+    if smooth:
+        xyz = smooth_interpolations(xyz, t1, smooth)
     # where the reference's hash-order artefacts can act: welded groups (which member represents
     # the bucket), tiny triangles (merge point), zero-area triangles (merge direction)
     welded = np.nonzero(rep != np.arange(len(rep)))[0]
@@ -363,7 +395,7 @@ def compare_level1(oracle_L1, other_points, other_tris, corner, reach=2):
     o_rows = canonical_level1(oracle_L1["grid_points"], oracle_L1["triangles"], corner)
     x_rows = canonical_level1(other_points, other_tris, corner)
     # component flags of the oracle's triangles, keyed by unoriented row
-    q = weld_buckets(oracle_L1["grid_points"], corner)
+    q = _compare_ids(oracle_L1["grid_points"], corner)
     o_tris = np.asarray(oracle_L1["triangles"], dtype=np.int64).reshape(-1, 3)
     flag_of = {}
     for t, lab in zip(o_tris, oracle_L1["labels"]):
@@ -373,7 +405,9 @@ def compare_level1(oracle_L1, other_points, other_tris, corner, reach=2):
     o_map = dict(zip(o_un, map(tuple, o_rows.tolist())))
     x_map = dict(zip(x_un, map(tuple, x_rows.tolist())))
     sites = oracle_L1["sites"]
-    sb = weld_buckets(np.asarray(sites, dtype=np.float64).reshape(-1, 3), corner) if len(sites) else np.zeros((0, 3), np.int64)
+    sb = _compare_ids(np.asarray(sites, dtype=np.float64).reshape(-1, 3), corner) if len(sites) else np.zeros((0, 3), np.int64)
+    if _QSCALE[0] is not None:
+        reach = int(reach * _QSCALE[0] / float(np.min(expander_for(corner)))) + 1
 
     def near_site(un):
         if len(sb) == 0:

@@ -17,7 +17,8 @@ def run_api(G):
     A, v = G["A"], float(G["value"])
     mins = G["mins"] if "mins" in G.files else np.zeros(3)
     delta = G["delta"] if "delta" in G.files else np.ones(3)
-    S = tetrahedral.TriangulatedIsosurfaces(list(mins), None, list(delta), A, v, [])
+    smooth = float(G["smooth"]) if "smooth" in G.files else None
+    S = tetrahedral.TriangulatedIsosurfaces(list(mins), None, list(delta), A, v, [], smooth=smooth)
     S.search_for_endpoints()
     points, triangles = S.get_points_and_triangles()
     grid_points = (np.asarray(points) - mins) / delta if len(points) else np.zeros((0, 3))
@@ -33,7 +34,9 @@ def test_api_matches_oracle_and_reference(name):
     S, points, grid_points, triangles = run_api(G)
     post = S.contour_maker._post
     O = level0.march3d(A, v, diag_mode=1)
-    L1 = postpass.level1_from_level0(level0.edge_keys_from_pairs(O["pairs"], A.shape), O["xyz"], O["tris"], corner)
+    smooth = float(G["smooth"]) if "smooth" in G.files else None
+    postpass.set_compare_scale(1e8 if smooth else None)
+    L1 = postpass.level1_from_level0(level0.edge_keys_from_pairs(O["pairs"], A.shape), O["xyz"], O["tris"], corner, smooth=smooth)
     # counts through the pipeline: identical to the oracle's canonical pipeline
     assert post["n_after_weld"] == L1["n_after_weld"] == int(G["n_tris_after_weld"])
     assert post["n_after_tiny"] == L1["n_after_tiny"]
@@ -45,11 +48,20 @@ def test_api_matches_oracle_and_reference(name):
     assert not cmp["missing"] and not cmp["extra"] and not cmp["winding"], {k: (len(x) if isinstance(x, list) else x) for k, x in cmp.items()}
     assert cmp["excused_rows"] == 0
     # coordinates are the reference's float64 interpolation, bit for bit (every output point is a Level-0 point)
-    ref_pts = set(map(tuple, np.round(O["xyz"], 12).tolist()))
-    got_pts = set(map(tuple, np.round(grid_points, 12).tolist()))
-    assert got_pts <= ref_pts
+    if smooth is None:
+        ref_pts = set(map(tuple, np.round(O["xyz"], 12).tolist()))
+        got_pts = set(map(tuple, np.round(grid_points, 12).tolist()))
+        assert got_pts <= ref_pts
+    else:
+        # smoothed coordinates: same values as the oracle's up to the order of the float64 sums
+        def rows(P):          # order by coordinates rounded to 1e-7 so that 1e-15 differences cannot reorder rows
+            R = np.round(P, 7)
+            return P[np.lexsort((R[:, 2], R[:, 1], R[:, 0]))]
+        a, b = rows(grid_points), rows(L1["grid_points"])
+        assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=1e-9)
     # device vs the real reference's output
-    cmpr = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner)
+    reach = 2 * int(postpass.expander_for(corner).max()) if smooth else 2
+    cmpr = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner, reach=reach)
     assert not cmpr["missing"] and not cmpr["extra"] and not cmpr["winding"]
     if name in WELL_BEHAVED:
         if L1["comp_flags"].max(initial=0) == 0 and len(L1["sites"]) == 0:
@@ -66,9 +78,10 @@ def test_api_matches_oracle_and_reference(name):
             assert np.array_equal(ref, got)
     # world coordinates (grid_field.py:89-93)
     if "l1_points" in G.files and len(L1["sites"]) == 0 and len(points) == len(G["l1_points"]):
-        a = np.array(sorted(map(tuple, points.tolist())))
-        b = np.array(sorted(map(tuple, G["l1_points"].tolist())))
-        assert np.allclose(a, b, rtol=1e-12, atol=1e-12)
+        def wrows(P):
+            R = np.round(P, 7)
+            return P[np.lexsort((R[:, 2], R[:, 1], R[:, 0]))]
+        assert np.allclose(wrows(points), wrows(G["l1_points"]), rtol=0, atol=1e-9 if smooth else 1e-12)
 
 
 def test_config1_sphere_counts():
@@ -139,4 +152,4 @@ def test_multi_level_matches_single_levels():
         a = np.array(sorted(map(tuple, np.round(pts, 9).tolist())))
         b = np.array(sorted(map(tuple, np.round(p2, 9).tolist())))
         assert np.array_equal(a, b)
-    assert len(out[1][2]) == len(G["l1_triangles"]) or abs(len(out[1][2]) - len(G["l1_triangles"])) <= 8
+    assert abs(len(out[1][2]) - len(G["l1_triangles"])) <= 0.002 * len(G["l1_triangles"])   # v=0: the golden's level

@@ -42,17 +42,21 @@ def test_level1_canonical(name):
     corner = np.array(A.shape) - 1
     O = level0.march3d(A, v, diag_mode=1)
     keys = level0.edge_keys_from_pairs(O["pairs"], A.shape)
-    L1 = postpass.level1_from_level0(keys, O["xyz"], O["tris"], corner)
+    smooth = float(G["smooth"]) if "smooth" in G.files else None
+    postpass.set_compare_scale(1e8 if smooth else None)
+    L1 = postpass.level1_from_level0(keys, O["xyz"], O["tris"], corner, smooth=smooth)
     assert L1["n_after_weld"] == int(G["n_tris_after_weld"])   # invariant through the weld
     band = G["l1_count_band"]
     n_tiny = L1["n_after_weld"] - L1["n_after_tiny"]
     nsites = len(L1["sites"])
-    cmp = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner)
+    # smoothing spreads a welded group's representative choice over its 1-ring: excuse ~2 voxels around sites
+    reach = 2 * int(postpass.expander_for(corner).max()) if smooth else 2
+    cmp = postpass.compare_level1(L1, G["l1_grid_points"], G["l1_triangles"], corner, reach=reach)
     # same triangles (as weld-bucket triples) and same winding, except where the reference's own
     # hash order decides (weld representative, tiny-collapse merge point, ambiguous orientation)
     assert not cmp["missing"] and not cmp["extra"], (cmp["missing"][:2], cmp["extra"][:2])
     assert not cmp["winding"], cmp["winding"][:2]
-    assert cmp["excused_rows"] <= 20 * max(nsites, 1)
+    assert cmp["excused_rows"] <= (200 if smooth else 20) * max(nsites, 1)
     if nsites == 0:
         assert L1["n_after_tiny"] == int(G["n_tris_after_tiny"])
         assert cmp["n_oracle"] == cmp["n_other"] == len(G["l1_triangles"])
