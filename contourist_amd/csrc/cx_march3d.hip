@@ -32,7 +32,9 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #ifndef CX_K1_MIN_WAVES
 #define CX_K1_MIN_WAVES 3   // two sample planes in flight per wave need ~130 VGPRs (4 waves/SIMD would spill)
 #endif   // active cells a wave can queue before it has to flush on its own
+#ifndef CX_RJ
 #define CX_RJ 4         // cell rows per wave in the FAST kernel (a workgroup covers 4*CX_RJ rows)
+#endif
 
 struct cx_task {        // launch geometry of the FAST kernel
     uint32_t ci;        // cell planes per task
@@ -127,8 +129,13 @@ __device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
 //   bit 6r+m (m=0..3) : sample (row r, k = k0 + 4*lane + m) < isovalue
 //   bit 6r+4          : the same for k+1 of m=3 (next lane's m=0, the halo sample, or a clamped repeat)
 #define CX_ROWBITS 6u
-#define CX_M0_MASK 0x01041041u     // bit 6r+0, r = 0..4
-#define CX_CELL_MASK 0x003CF3CFu   // bits 6r+0..3, r = 0..3  (the 16 cells of a lane: 4 rows x 4 k)
+constexpr uint32_t cx_rowmask(int rows, uint32_t bits) {
+    uint32_t m = 0;
+    for (int r = 0; r < rows; r++) m |= bits << (6 * r);
+    return m;
+}
+#define CX_M0_MASK cx_rowmask(CX_RJ + 1, 1u)    // bit 6r+0, r = 0..RJ
+#define CX_CELL_MASK cx_rowmask(CX_RJ, 0xFu)    // bits 6r+0..3, r = 0..RJ-1  (the 4*RJ cells of a lane)
 
 // =================================================================================================
 // K1
@@ -240,17 +247,15 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         if (FAST) {
             // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
             auto step = [&](const plane_raw& cur, plane_raw& nxt) -> bool {
-                if (!pending) {
-                    load_plane(p + 2u, nxt);
-                    wcur = plane_bits(cur);
-                    // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
-                    const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
-                    const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
-                    const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
-                    const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
-                    act0 = o & ~a & mr;
-                    if (!lane_valid) act0 = 0;
-                }
+                load_plane(p + 2u, nxt);
+                wcur = plane_bits(cur);
+                // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
+                const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
+                const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
+                const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
+                const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
+                act0 = o & ~a & mr;
+                if (!lane_valid) act0 = 0;
                 pending = false;
                 if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
                     uint32_t tot;
@@ -392,6 +397,13 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         acc.v = acc.t = acc.c = acc.b = 0;
         dnear = 3.0e38f;
         if (final_round) break;
+        if (FAST) {
+            // a wave that had to emit in the middle of its task dropped its prefetched planes (so that
+            // they do not occupy registers during phase B): fetch plane p+1 again and redo the step
+            load_plane(p + 1u, rawA);
+            odd = false;
+            pending = false;
+        }
     }
 }
 
@@ -438,7 +450,7 @@ __device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
 // 64 records own one contiguous triangle range stages its indices in LDS and writes them out as
 // full 256-byte rows; otherwise (range broken by a reservation boundary) lanes store directly.
 // =================================================================================================
-#define CX_K2_STAGE 1536u   // ints per wave (typical wave: ~1200); larger waves store directly
+#define CX_K2_STAGE 832u    // ints per wave and round (typical: ~600); larger waves store directly
 __device__ constexpr uint8_t CX_EDGE[19][2] = CX_EDGES_INIT;
 __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
     __shared__ int32_t s_stage[4][CX_K2_STAGE];
@@ -522,11 +534,26 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
             }
         }
     }
-    // is this wave's triangle range contiguous?  (lane l+1 starts where lane l ends)
-    uint32_t ttot;
+    // The wave's triangles are written in two rounds (tetrahedra 0-2, then 3-5) so that the LDS stage only has to
+    // hold half of them: round g goes to [tb0 + (g ? T0 : 0) + prefix_g(lane), ...).  The order of triangles inside
+    // the wave's range is free (c4.z only serves this kernel).  A wave whose records do not own one contiguous
+    // range (reservation boundary inside the wave) or that is too large for the stage stores directly, per cell.
+    uint32_t nround[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+        const uint32_t np = __popc(pat);
+        const uint32_t nt = (ntri == 0u || ((tetskip >> t) & 1u)) ? 0u : ((np == 2u) ? 2u : (np & 1u));
+        nround[t / 3] += nt;
+    }
+    uint32_t ttot, T0, T1;
     const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
+    const uint32_t pre0 = cx_wave_prefix_small<3>(nround[0], T0);
+    const uint32_t pre1 = cx_wave_prefix_small<3>(nround[1], T1);
     const uint32_t tb0 = __builtin_amdgcn_readfirstlane(c4.z);   // lane 0 always has a record here
-    const bool contiguous = (ttot * 3u <= CX_K2_STAGE) && __ballot(ntri != 0u && c4.z != tb0 + tpre) == 0ULL;
+    const bool contiguous = (T0 * 3u <= CX_K2_STAGE) && (T1 * 3u <= CX_K2_STAGE) &&
+                            __ballot(ntri != 0u && c4.z != tb0 + tpre) == 0ULL;
     int32_t* stage = s_stage[wave];
     int32_t* direct = P.tris + (size_t)c4.z * 3u;
     // vertex index of every voxel edge (owner corner c1, direction d): first vertex of the owner +
@@ -538,31 +565,34 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
         s_eidx[wave][e][lane] = (int32_t)(vfirst[c1] + __popc(em[c1] & ((1u << d) - 1u)));
     }
     const int32_t* eidx = &s_eidx[wave][0][lane];
-    uint32_t w = tpre * 3u;
-    const uint32_t w0 = w;
+    uint32_t wd = 0;   // running position of the direct path (per cell)
 #pragma unroll
-    for (int t = 0; t < 6; t++) {
-        if (ntri == 0u || ((tetskip >> t) & 1u)) continue;
-        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-        const uint32_t e = s_lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
-        const uint32_t n = e >> 30;
-        for (uint32_t qd = 0; qd < n; qd++) {
-            const uint32_t tri = (e >> (15u * qd)) & 0x7FFFu;
+    for (int g = 0; g < 2; g++) {
+        uint32_t w = (g ? pre1 : pre0) * 3u;
 #pragma unroll
-            for (uint32_t sidx = 0; sidx < 3; sidx++) {
-                const uint32_t eid = (tri >> (5u * sidx)) & 0x1Fu;
-                const int32_t vi = eidx[eid * 64u];
-                if (contiguous) stage[w] = vi;
-                else if (!(P.flags & CX_DBG_NO_TRIS)) direct[w - w0] = vi;
-                w++;
+        for (int tt = 0; tt < 3; tt++) {
+            const int t = g * 3 + tt;
+            if (ntri == 0u || ((tetskip >> t) & 1u)) continue;
+            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+            const uint32_t e = s_lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
+            const uint32_t n = e >> 30;
+            for (uint32_t qd = 0; qd < n; qd++) {
+                const uint32_t tri = (e >> (15u * qd)) & 0x7FFFu;
+#pragma unroll
+                for (uint32_t sidx = 0; sidx < 3; sidx++) {
+                    const uint32_t eid = (tri >> (5u * sidx)) & 0x1Fu;
+                    const int32_t vi = eidx[eid * 64u];
+                    if (contiguous) stage[w++] = vi;
+                    else if (!(P.flags & CX_DBG_NO_TRIS)) direct[wd++] = vi;
+                }
             }
         }
-    }
-    if (contiguous && !(P.flags & CX_DBG_NO_TRIS)) {
-        int32_t* out = P.tris + (size_t)tb0 * 3u;
-        const uint32_t total = ttot * 3u;
-        for (uint32_t o = lane; o < total; o += 64u) out[o] = stage[o];
+        if (contiguous && !(P.flags & CX_DBG_NO_TRIS)) {
+            int32_t* out = P.tris + ((size_t)tb0 + (g ? T0 : 0u)) * 3u;
+            const uint32_t total = (g ? T1 : T0) * 3u;
+            for (uint32_t o = lane; o < total; o += 64u) out[o] = stage[o];
+        }
     }
 }
 
