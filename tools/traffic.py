@@ -7,7 +7,8 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = {}
 vals = collections.defaultdict(dict)
 for name in ("fetch", "write"):
-    for f in glob.glob(os.path.join(root, name, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(root, name, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:          # the latest pass only
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
