@@ -1,0 +1,53 @@
+"""CPU: host-side behaviour of the reference-shaped API that needs no device: constructor argument
+handling, assertions where the reference asserts, loud failure without a GPU (no CPU fallback)."""
+import numpy as np
+import pytest
+
+from contourist_amd import _ffi, grid_field, pentatopes, tetrahedral
+
+
+def sphere(x, y, z):
+    return x * x + y * y + z * z
+
+
+def test_constructors_and_attributes():
+    d = 0.25
+    S = tetrahedral.TriangulatedIsosurfaces([-1] * 3, [1] * 3, [d] * 3, sphere, 0.5, [])
+    assert isinstance(S.grid, grid_field.FunctionGrid) and S.value == 0.5
+    assert S.grid_endpoints is None                       # [] -> grid search (triangulated.py:100-102)
+    assert isinstance(S.contour_maker, tetrahedral.GridContour3d)
+    assert tuple(S.contour_maker.corner) == tuple(S.grid.grid_dimensions)
+    assert S.contour_maker.samples.shape == tuple(n + 1 for n in S.grid.grid_dimensions)
+    # 3-D endpoints are accepted (the reference's ctor asserts len == 2, a 2-D leftover)
+    T = tetrahedral.TriangulatedIsosurfaces([-1] * 3, [1] * 3, [d] * 3, sphere, 0.5, [((0, 0, 0), (1, 1, 1))])
+    assert T.grid_endpoints is not None and len(T.grid_endpoints) == 1
+    p, q = T.grid_endpoints[0]
+    assert (T.grid.grid_function(*p) - 0.5) * (T.grid.grid_function(*q) - 0.5) <= 0
+    assert tetrahedral.CUBE.shape == (8, 3) and tetrahedral.TETRAHEDRA.shape == (6, 4, 3) and tetrahedral.OFFSETS.shape == (26, 3)
+    assert pentatopes.PENTATOPES.shape == (24, 5, 4) and pentatopes.HYPERCUBE.shape == (16, 4) and pentatopes.OFFSETS4D.shape == (80, 4)
+
+
+def test_reference_asserts_and_unsupported_options():
+    A = np.zeros((5, 5, 5), dtype=np.float32)
+    with pytest.raises(AssertionError):                    # tetrahedral.py:526 sanity_check
+        tetrahedral.GridContour3d((4, 4), A[0], 0.0)
+    with pytest.raises(AssertionError):                    # tetrahedral.py:153-155 endpoint dimension
+        tetrahedral.GridContour3d((4, 4, 4), A, 0.0, [((0, 0), (1, 1))])
+    with pytest.raises(NotImplementedError):
+        tetrahedral.GridContour3d((4, 4, 4), A, 0.0, linear_interpolate=False)
+    with pytest.raises(NotImplementedError):
+        tetrahedral.TriangulatedIsosurfaces([0] * 3, [4] * 3, [1] * 3, A, 0.0, [], flatten=True)
+    with pytest.raises(AssertionError):
+        pentatopes.GridContour4D((4, 4, 4), A, 0.0)
+
+
+def test_no_gpu_fails_loudly():
+    """on a host without a HIP device the product path raises; it never falls back to a CPU implementation"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.CxError):
+        _ffi.Context(0)
+    S = tetrahedral.TriangulatedIsosurfaces([-1] * 3, [1] * 3, [0.5] * 3, sphere, 0.5, [])
+    with pytest.raises(_ffi.CxError):
+        S.search_for_endpoints()
