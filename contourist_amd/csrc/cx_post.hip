@@ -82,6 +82,17 @@ __device__ __forceinline__ u64 cxp_orderable(double x) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
 }
 
+// monotonic maximum with a plain read first: once the running maximum is established almost every caller
+// sees that its value cannot raise it and skips the atomic (same-address atomics serialise at ~88/us)
+__device__ __forceinline__ void cxp_max64(u64* addr, u64 v) {
+    if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
+    atomicMax(addr, v);
+}
+__device__ __forceinline__ void cxp_max32(uint32_t* addr, uint32_t v) {
+    if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
+    atomicMax(addr, v);
+}
+
 // union-find over 32-bit ids; parent word = (parity << 32) | parent id.  Root = smallest priority.
 __device__ __forceinline__ uint32_t cxp_find(const u64* parent, uint32_t x, uint32_t& parity) {
     uint32_t par = 0;
@@ -332,11 +343,17 @@ __global__ void cxp_k_tri_prio(const int32_t* tri, const uint32_t* prio, uint32_
     tprio3[(size_t)t * 3] = p.a; tprio3[(size_t)t * 3 + 1] = p.b; tprio3[(size_t)t * 3 + 2] = p.c;
 }
 
-__global__ void cxp_k_count_alive(const uint8_t* alive, uint32_t nt, uint32_t* counter) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool a = t < nt && alive[t];
-    const u64 m = __ballot(a);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+__global__ __launch_bounds__(256) void cxp_k_count_alive(const uint8_t* alive, uint32_t nt, uint32_t* counter) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t n = 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) n += alive[t] ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(counter, s_n);
 }
 
 // tiny triangles (tetrahedral.py:360-365): bbox * (1/corner) < epsilon on every axis
@@ -460,7 +477,7 @@ __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* p
     u64 m = 0;
 #pragma unroll
     for (int s = 0; s < 3; s++) m = max(m, cxp_orderable(pts[(size_t)tri[(size_t)t * 3 + s] * 3]));
-    atomicMax(&cmaxx[root], m);
+    cxp_max64(&cmaxx[root], m);
 }
 // among the vertices at that x: the one with the largest index (surface_geometry.py:79 max((x, index)))
 __global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, uint32_t* cmaxv) {
@@ -471,7 +488,7 @@ __global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* p
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const uint32_t v = tri[(size_t)t * 3 + s];
-        if (cxp_orderable(pts[(size_t)v * 3]) == m) atomicMax(&cmaxv[root], v);
+        if (cxp_orderable(pts[(size_t)v * 3]) == m) cxp_max32(&cmaxv[root], v);
     }
 }
 // among that vertex's triangles: the largest |cross(a-b, a-c)[0]| (surface_geometry.py:88-94); the packed
@@ -489,7 +506,7 @@ __global__ void cxp_k_comp_start(const int32_t* tri, uint32_t nt, const double* 
     const uint32_t root = (uint32_t)parent[t];
     const uint32_t vm = cmaxv[root];
     if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
-    atomicMax(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
+    cxp_max64(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
 }
 __global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cmaxv,
                                 const u64* cbest, uint32_t* cstart) {
@@ -498,7 +515,7 @@ __global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* p
     const uint32_t root = (uint32_t)parent[t];
     const uint32_t vm = cmaxv[root];
     if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
-    if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) atomicMax(&cstart[root], t);
+    if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) cxp_max32(&cstart[root], t);
 }
 // final winding: triangle parity relative to the root, and the root's flip so that the start triangle gets dotx > 0
 __global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, uint32_t* ncomp) {
@@ -743,7 +760,7 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
         hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1);
         hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
         CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 4);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 4);
         if (smooth > 0.0) {
             // ---- smooth_interpolations (tetrahedral.py:547-550), between the weld and the tiny collapse
             const u64 esz = cxp_table_size((size_t)nt * 3);
@@ -767,7 +784,7 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
                            1.0 / corner[2], 1e-4, parent, prio, moved);
         // roots keep their own coordinates, so moving members in place is race free
         hipLaunchKernelGGL(cxp_k_move, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, pts, parent, moved, nv);
-        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 5);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 5);
         uint32_t h[2];
         CXP_HIP(ctx, hipMemcpyAsync(h, misc + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
@@ -963,13 +980,13 @@ extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts)
                            cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio);
         hipLaunchKernelGGL(cxp_k_drop_instant, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1e-7);
         CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 4);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 4);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent, nv);
         CXP_HIP(ctx, hipMemsetAsync(moved, 0, nv, st));
         hipLaunchKernelGGL(cxp_k_tiny4, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1.0 / corner[0], 1.0 / corner[1],
                            1.0 / corner[2], 1.0 / corner[3], 1e-3, parent, prio, moved);
         hipLaunchKernelGGL(cxp_k_move4, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, parent, moved, nv);
-        hipLaunchKernelGGL(cxp_k_count_alive, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, misc + 5);
+        hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 5);
         uint32_t* tflag = (uint32_t*)S->flags.p;
         uint32_t* tnew = (uint32_t*)S->scan.p;
         hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, tflag);
@@ -1020,8 +1037,8 @@ __global__ void cxp_k_minmax_t(const double* pts, uint32_t nv, u64* mm) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     const u64 o = cxp_orderable(pts[(size_t)v * 4 + 3]);
-    atomicMin(&mm[0], o);
-    atomicMax(&mm[1], o);
+    if (__hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > o) atomicMin(&mm[0], o);
+    cxp_max64(&mm[1], o);
 }
 __device__ __forceinline__ double cxp_from_orderable(u64 o) {
     const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
