@@ -68,10 +68,16 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % ndev            # one rank per GPU; ranks only share a GPU in the 1-GPU rehearsal
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n = args.size
     nrot = args.rotate or (1 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
 
@@ -87,7 +93,7 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
-    ctx = _ffi.Context(local_rank, stream=stream.cuda_stream)
+    ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
     ctx.set_origin(rank * n, 0, 0)
     flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
 
@@ -129,7 +135,7 @@ def main():
     timing = ctx.timing_read()
     final = ctx.counts()           # also verifies that the last extract fitted its buffers
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -26,14 +26,22 @@ def exchange_halo(local, n_own, rank, world, dist=None):
         return
     if dist is None:
         import torch.distributed as dist
+    staged = local.is_cuda and dist.get_backend() == "gloo"      # gloo moves host memory: stage the plane
+    send = local[0].contiguous()
+    recv = local[n_own] if rank + 1 < world else None
+    if staged:
+        send = send.cpu()
+        recv = recv.cpu() if recv is not None else None
     ops = []
     if rank > 0:
-        ops.append(dist.P2POp(dist.isend, local[0].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.isend, send, rank - 1))
     if rank + 1 < world:
-        ops.append(dist.P2POp(dist.irecv, local[n_own], rank + 1))
+        ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if staged and recv is not None:
+        local[n_own].copy_(recv)
 
 
 def hip_extract(device=0, diagonal_flags=1):
