@@ -253,7 +253,8 @@ class Context(object):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))
 
     def timing_read(self):
-        ms = (ctypes.c_double * 3)()
+        ms = (ctypes.c_double * 8)()
         n = ctypes.c_int()
         self._check(self.lib.cx_timing_read(self.handle, ms, ctypes.byref(n)))
-        return dict(classify_ms=ms[0], emit_ms=ms[1], total_ms=ms[2], n=n.value)
+        return dict(classify_ms=ms[0], emit_ms=ms[1], total_ms=ms[2], stream_ms=ms[3], scan_ms=ms[4],
+                    cells_ms=ms[5], n=n.value)

@@ -63,11 +63,16 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     free_outputs(ctx);
     if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
     if (ctx->celltab) (void)hipFree(ctx->celltab);
+    if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->wsum) (void)hipFree(ctx->wsum);
+    if (ctx->wbase) (void)hipFree(ctx->wbase);
+    if (ctx->brec) (void)hipFree(ctx->brec);
+    if (ctx->flat) (void)hipFree(ctx->flat);
     if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
-        for (int n = 0; n < 3; n++)
+        for (int n = 0; n < 5; n++)
             if (ev.e[n]) (void)hipEventDestroy(ev.e[n]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -219,21 +224,76 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
         ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
     }
+    const bool staged = !(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported(P);
+    cx_task T;
+    memset(&T, 0, sizeof(T));
+    if (staged) {
+        T = cx_fast_task(P.n0, P.n1, P.n2);
+        const size_t nw = (size_t)T.nblocks * 4u, need = nw * T.wcap;
+        if (ctx->queue_cap < need) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->queue) (void)hipFree(ctx->queue);
+            ctx->queue = nullptr; ctx->queue_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->queue, need * sizeof(uint32_t)));
+            ctx->queue_cap = need;
+        }
+        if (ctx->waves_cap < nw) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->wsum) (void)hipFree(ctx->wsum);
+            if (ctx->wbase) (void)hipFree(ctx->wbase);
+            ctx->wsum = nullptr; ctx->wbase = nullptr; ctx->waves_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->wsum, nw * sizeof(cx_wsum)));
+            CX_HIP(ctx, hipMalloc(&ctx->wbase, nw * sizeof(cx_wbase)));
+            ctx->waves_cap = nw;
+        }
+        const size_t nbrec = nw * T.bcap;
+        if (ctx->brec_cap < nbrec) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->brec) (void)hipFree(ctx->brec);
+            ctx->brec = nullptr; ctx->brec_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->brec, nbrec * sizeof(cx_brec)));
+            ctx->brec_cap = nbrec;
+        }
+        // batches: at most one short batch per streaming wave plus one per CX_BATCH_MIN (128) queued cells; queued
+        // cells = cell records + array-boundary cells without vertices.  Sized from the cell capacity, so a
+        // surface that fits the cell capacity fits here (cx_counts_get reports CX_ERR_CAPACITY otherwise).
+        const size_t boundary = (size_t)(ctx->n0 * ctx->n1 + ctx->n0 * ctx->n2 + ctx->n1 * ctx->n2);
+        const size_t nflat = nw + (size_t)ctx->ccap / 64u + boundary / 128u + 4096u;
+        if (ctx->flat_cap < nflat) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->flat) (void)hipFree(ctx->flat);
+            ctx->flat = nullptr; ctx->flat_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->flat, nflat * sizeof(cx_bdesc)));
+            ctx->flat_cap = nflat;
+        }
+        P.queue = ctx->queue; P.wsum = ctx->wsum; P.wbase = ctx->wbase; P.brec = ctx->brec;
+        P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
+        ctx->last = P;
+    }
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {
         if (ctx->nevents < (int)(sizeof(ctx->events) / sizeof(ctx->events[0]))) {
             ev = &ctx->events[ctx->nevents++];
-            for (int n = 0; n < 3; n++)
+            for (int n = 0; n < 5; n++)
                 if (!ev->e[n]) CX_HIP(ctx, hipEventCreate(&ev->e[n]));
         }
     }
     CX_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[0], ctx->stream));
-    if (!(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported(P)) cx_launch_classify_fast(P, ctx->stream);
-    else cx_launch_classify_generic(P, ctx->stream);
-    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
-    if (!(flags & CX_DBG_NO_EMIT)) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
-    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    if (staged) {
+        cx_launch_stream(P, T, ctx->stream);
+        if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
+        if (!(flags & CX_DBG_PHASE_A_ONLY)) cx_launch_scan_waves(P, T, ctx->stream);
+        if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
+        if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_vertices(P, T, ctx->stream);
+    } else {
+        cx_launch_classify_generic(P, ctx->stream);
+        if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
+        if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    }
+    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[3], ctx->stream));
+    if (!(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
+    if (ev) CX_HIP(ctx, hipEventRecord(ev->e[4], ctx->stream));
     CX_HIP(ctx, hipGetLastError());
     ctx->extracted = true;
     ctx->post_valid = false;
@@ -258,7 +318,8 @@ extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
     out->n_triangles = ctx->counters_host[CX_CNT_TRIS];
     out->n_border_voxels = ctx->counters_host[CX_CNT_BORDER];
     ctx->counts = *out;
-    if (out->n_cells > ctx->ccap || out->n_vertices > ctx->vcap || out->n_triangles > ctx->tcap) {
+    if (out->n_cells > ctx->ccap || out->n_vertices > ctx->vcap || out->n_triangles > ctx->tcap ||
+        (ctx->last.flat && ctx->counters_host[CX_CNT_BATCHES] > ctx->last.fcap)) {
         ctx->extracted = false;
         return fail(ctx, CX_ERR_CAPACITY, "output buffers too small for this isosurface");
     }
@@ -331,16 +392,16 @@ extern "C" int cx_timing_enable(cx_ctx* ctx, int on) {
     return CX_OK;
 }
 
-extern "C" int cx_timing_read(cx_ctx* ctx, double ms[3], int* n) {
+extern "C" int cx_timing_read(cx_ctx* ctx, double ms[8], int* n) {
     if (!ctx || !ms) return CX_ERR_INVALID;
     CX_HIP(ctx, hipSetDevice(ctx->device));
     CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ms[0] = ms[1] = ms[2] = 0.0;
+    for (int k = 0; k < 8; k++) ms[k] = 0.0;
     for (int i = 0; i < ctx->nevents; i++) {
-        float a = 0, b = 0;
-        CX_HIP(ctx, hipEventElapsedTime(&a, ctx->events[i].e[0], ctx->events[i].e[1]));
-        CX_HIP(ctx, hipEventElapsedTime(&b, ctx->events[i].e[1], ctx->events[i].e[2]));
-        ms[0] += a; ms[1] += b; ms[2] += a + b;
+        float d[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) CX_HIP(ctx, hipEventElapsedTime(&d[k], ctx->events[i].e[k], ctx->events[i].e[k + 1]));
+        ms[0] += d[0] + d[1] + d[2]; ms[1] += d[3]; ms[2] += d[0] + d[1] + d[2] + d[3];
+        ms[3] += d[0]; ms[4] += d[1]; ms[5] += d[2];
     }
     if (n) *n = ctx->nevents;
     ctx->nevents = 0;

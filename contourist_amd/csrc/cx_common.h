@@ -49,6 +49,44 @@ struct cx_params {
     uint32_t vcap, ccap, tcap;
     uint32_t* counters;    // [0] cells [1] verts [2] tris [3] border voxels
     unsigned long long* stamps;   // diagnostic builds only: 4 s_memtime stamps per classify wave (else null)
+    // staged pipeline (stream -> scan -> vertices -> triangles)
+    uint32_t* queue;          // [nwaves * wcap] packed active-cell entries, one region per streaming wave
+    struct cx_brec* brec;     // [nwaves * bcap] batch records of each streaming wave
+    struct cx_wsum* wsum;     // [nwaves] what each streaming wave found
+    struct cx_wbase* wbase;   // [nwaves] first vertex / triangle / record / batch index of each wave
+    struct cx_bdesc* flat;    // [fcap] all batches, self-contained
+    uint32_t fcap;
+};
+
+struct cx_wsum {   // 32 bytes
+    uint32_t nb;           // batches
+    uint32_t v, t, c, b;   // vertices, triangles, cell records, border voxels of the wave's cells
+    uint32_t nq;           // queued cells
+    uint32_t near;         // a sample of the wave's region lies inside the tolerance screen: per-cell path
+    uint32_t pad;
+};
+struct cx_wbase {  // 16 bytes
+    uint32_t v, t, c, boff;
+};
+struct cx_brec {   // 32 bytes: cells [qoff, qoff+n) of the wave's queue and what precedes them in the wave
+    uint32_t qoff, n, vpre, tpre, cpre, near, pad0, pad1;
+};
+
+struct cx_bdesc {  // 32 bytes: one batch as the emit kernel needs it
+    uint32_t w;            // streaming wave (-> tile geometry)
+    uint32_t qofs, n;      // its cells: queue[qofs .. qofs+n)
+    uint32_t vbase, tbase, cbase;   // first vertex / triangle / cell record
+    uint32_t near, pad;
+};
+
+// launch geometry of the staged pipeline: workgroup -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
+struct cx_task {
+    uint32_t ci;           // cell planes per task
+    uint32_t nks, njg, nic;
+    uint32_t nblocks;      // nks * njg * nic
+    uint32_t chunk;        // tasks per XCD (grid = 8 * chunk workgroups)
+    uint32_t wcap;         // queue entries per wave (every cell of its task)
+    uint32_t bcap;         // batch records per wave
 };
 
 // debug / ablation flags (timing experiments only; results are wrong when set)
@@ -60,8 +98,9 @@ struct cx_params {
 #define CX_DBG_NO_LOOKUP 0x200000u     // emit kernel: skip neighbour table lookups
 #define CX_DBG_NO_TRIS 0x400000u       // emit kernel: skip triangle stores
 #define CX_DBG_NO_EMIT 0x800000u       // skip the emit kernel
+#define CX_DBG_NO_VLOADS 0x1000000u    // phase B (packed entries): no sample loads for the vertices
 
-enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_WORDS = 8 };
+enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4, CX_CNT_WORDS = 8 };
 
 // device tables (defined in cx_march3d.hip)
 extern __device__ __constant__ uint8_t cx_d_tet_corners[6][4];
@@ -71,6 +110,9 @@ extern __device__ __constant__ uint8_t cx_d_voxel_ntri[256];
 // kernel launchers (cx_march3d.hip)
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s);
 bool cx_fast_classify_supported(const cx_params& P);
-void cx_launch_classify_fast(const cx_params& P, hipStream_t s);
+cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2);
+void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s);
+void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
+void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

@@ -20,6 +20,15 @@ struct cx_ctx {
     // side tables of the march
     uint64_t* celltab = nullptr;
     size_t tables_for = 0;
+    uint32_t* queue = nullptr;         // staged pipeline: per-wave queues, totals and offsets
+    size_t queue_cap = 0;
+    cx_wsum* wsum = nullptr;
+    cx_wbase* wbase = nullptr;
+    size_t waves_cap = 0;
+    cx_brec* brec = nullptr;
+    size_t brec_cap = 0;
+    cx_bdesc* flat = nullptr;
+    size_t flat_cap = 0;
     uint64_t* hash_xy = nullptr;       // CPython tuple-hash prefix per (i,j), for CX_DIAG_CPYTHON310
     size_t hash_xy_cap = 0;
     int64_t hash_xy_n0 = 0, hash_xy_n1 = 0, hash_xy_o0 = -1, hash_xy_o1 = -1;
@@ -42,7 +51,7 @@ struct cx_ctx {
     unsigned long long* stamps = nullptr;   // diagnostic stamps (cx_debug_stamps)
     size_t stamps_words = 0;
     // timing
-    struct evset { hipEvent_t e[3] = {nullptr, nullptr, nullptr}; };
+    struct evset { hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     bool timing = false;
     int nevents = 0;
     evset events[256];

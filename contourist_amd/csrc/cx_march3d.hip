@@ -4,20 +4,19 @@
 // A cell OWNS the 7 lattice edges q -> q+d, d = 4di+2dj+dk in 1..7, and (when all 8 corners are
 // inside the array) the 6 Kuhn tetrahedra of its voxel.  Vertex id of an edge = (lin(q) << 3) | d.
 //
-// K1  cx_k_classify<FAST>   one pass over the samples
-//       phase A  every wave streams its share of the grid and pushes the ACTIVE cells (sign change
-//                among the corners) into a wave-private LDS queue, in linear-index order.
-//                FAST: lanes hold 4 consecutive k-samples (one 16-byte load per row); the sign
-//                bits of a row are the v_cmp result masks (SGPRs), a cell's 8 corner signs are bit
-//                shifts of 8 such masks, so inactive regions cost no VALU work and no LDS.
-//                generic: one lane per cell, 8 scalar loads (any shape / alignment).
-//       phase B  the wave re-reads the 8 corners of its queued cells (L1/L2 hits), classifies the
-//                tetrahedra, counts vertices/triangles; the workgroup reserves output space with ONE
-//                atomic per counter (same-address atomics saturate near 88/us on MI355X, so they
-//                must stay in the low thousands per launch), then the wave interpolates and writes
-//                vertex records, the per-cell lookup word and one record per active cell.
-// K2  cx_k_emit_triangles   one lane per active-cell record: expands the tetrahedra into index
-//                triples, looking vertex indices up in the per-cell table.
+// Staged pipeline (rows of n2 % 4 == 0 samples, 16-byte aligned grid) -- no atomics, no barriers:
+//   S1  cx_k_stream            one pass over the samples: sign bits packed per lane, active cells (sign
+//                              change among the 8 corners) appended to a per-wave queue in global memory
+//                              as packed entries; the queue is cut into batches of >= CX_BATCH_MIN cells
+//                              with the vertex / triangle counts that precede them (from the packed words).
+//   S2  cx_k_scan_waves        exclusive scan of the per-wave totals -> output offsets, counters, and a
+//                              flat list of all batches.
+//   S3  cx_k_emit_vertices     one wave per batch: vertex records (one lane per vertex), per-cell table,
+//                              cell records.
+//   K2  cx_k_emit_triangles    one lane per cell record: expands the tetrahedra into index triples, looking
+//                              vertex indices up in the per-cell table.
+// Any other shape: cx_k_classify_generic (one lane per cell, LDS queue, one reservation atomic per
+// workgroup and counter -- same-address atomics saturate near 88/us on MI355X) followed by K2.
 #include <cstdlib>
 
 #include "cx_cell.h"
@@ -27,35 +26,35 @@ __device__ __constant__ uint32_t cx_d_tet_tris[6][16][2] = CX_TET_TRIS_INIT;
 __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 
 #ifndef CX_QCAP
-#define CX_QCAP 1024u
+#define CX_QCAP 1024u       // generic kernel: active cells a wave can queue in LDS before it flushes on its own
 #endif
 #ifndef CX_K1_MIN_WAVES
-#define CX_K1_MIN_WAVES 3   // two sample planes in flight per wave need ~130 VGPRs (4 waves/SIMD would spill)
-#endif   // active cells a wave can queue before it has to flush on its own
+#define CX_K1_MIN_WAVES 3   // stream kernel: two sample planes in flight per wave
+#endif
 #ifndef CX_RJ
-#define CX_RJ 4         // cell rows per wave in the FAST kernel (a workgroup covers 4*CX_RJ rows)
+#define CX_RJ 4             // cell rows per wave in the stream kernel (a workgroup covers 4*CX_RJ rows)
+#endif
+#ifndef CX_BATCH_MIN
+#define CX_BATCH_MIN 128u   // a streaming wave closes a batch once it holds this many cells
 #endif
 
-struct cx_task {        // launch geometry of the FAST kernel
-    uint32_t ci;        // cell planes per task
-    uint32_t nks, njg, nic;
-};
-
-// ---- phase B --------------------------------------------------------------------------------------
+// ---- per-cell path ------------------------------------------------------------------------------
 struct cx_run {
     uint32_t v, t, c, b;   // running vertex / triangle / cell-record / border-voxel counts
 };
 
-// one sweep over the wave's queued cells.  emit == false: only count into `run` (from zero);
-// emit == true: `run` holds the reserved bases and advances as records are written.
+// one sweep over queued cells, re-reading their corners and applying the reference's tolerance rules
+// exactly.  emit == false: only count into `run` (from zero); emit == true: `run` holds the bases and
+// advances as vertex records and table entries (RECORDS: and cell records) are written.
 #define CX_VSTAGE 256u   // vertex records a wave stages in LDS per batch of 64 cells (typical: ~200)
-__device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint32_t* q, uint32_t n, uint32_t lane,
+template <bool RECORDS, typename LinOf>
+__device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_of, uint32_t n, uint32_t lane,
                                                  bool emit, cx_run& run, float4* vstage) {
     const uint32_t plane = P.n1 * P.n2;
     for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
         const uint32_t idx = b0 + lane;
         const bool have = idx < n;
-        const uint32_t lin = have ? q[idx] : 0u;
+        const uint32_t lin = have ? lin_of(idx) : 0u;
         const uint32_t i = cx_div(lin, P.div_plane);
         const uint32_t r = lin - i * plane;
         const uint32_t j = cx_div(r, P.div_row);
@@ -90,7 +89,7 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint3
                 }
                 if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
-            if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            if (RECORDS && rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
                 uint4 c4;
                 c4.x = lin;
                 c4.y = sm | (R.tetskip << 8) | (R.ntri << 16) | (R.emask << 24);
@@ -100,6 +99,133 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, const uint3
             }
         }
         run.v += vtot; run.t += ttot; run.c += ctot; run.b += btot;
+    }
+}
+
+// ---- packed queue entries of the staged pipeline (one u32 per active cell):
+//   bits 0-9    corner signs as extracted from the packed plane words: bits 0,1 = corners 0,1;
+//               bits 2,3 = corners 4,5; bits 6,7 = corners 2,3; bits 8,9 = corners 6,7
+//   bits 10-14  position of the cell inside its lane's packed word (6*row + m)
+//   bits 15-20  streaming lane (k = k0 + 4*lane + m)
+//   bits 21-27  plane offset inside the task
+#ifndef CX_VR
+#define CX_VR 4u          // rounds of 64 vertices whose loads are issued together
+#endif
+struct cx_fast_geom {
+    uint32_t pstart, j0, k0;
+};
+__device__ __forceinline__ void cx_decode_entry(const cx_params& P, const cx_fast_geom& G, uint32_t e, uint32_t& i,
+                                                uint32_t& j, uint32_t& k) {
+    const uint32_t bit = (e >> 10) & 31u;
+    const uint32_t r = (bit * 11u) >> 6;   // bit / 6 for bit < 32
+    i = G.pstart + ((e >> 21) & 127u);
+    j = G.j0 + r;
+    k = G.k0 + 4u * ((e >> 15) & 63u) + (bit - 6u * r);
+}
+__device__ __forceinline__ uint32_t cx_entry_lin(const cx_params& P, const cx_fast_geom& G, uint32_t e) {
+    uint32_t i, j, k;
+    cx_decode_entry(P, G, e, i, j, k);
+    return (i * P.n1 + j) * P.n2 + k;
+}
+__device__ __forceinline__ uint32_t cx_entry_signs(uint32_t e) {
+    return (e & 3u) | ((e >> 4) & 0xCu) | ((e << 2) & 0x30u) | ((e >> 2) & 0xC0u);
+}
+// validity mask of the 8 corners of cell (i,j,k)
+__device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t i, uint32_t j, uint32_t k) {
+    const bool vi = (i + 1u < P.n0), vj = (j + 1u < P.n1), vk = (k + 1u < P.n2);
+    uint32_t vm = 1u | (vk ? 2u : 0u) | (vj ? 4u : 0u) | ((vj && vk) ? 8u : 0u);
+    vm |= vi ? (vm << 4) : 0u;
+    return vm;
+}
+
+// vertex records, per-cell table entries and cell records of n queued cells, common case (no sample of
+// the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
+// entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
+// one coalesced 16-byte store) -- no divergent per-direction loop.
+__device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
+                                                   uint32_t lane, cx_run run, uint32_t* slot, const uint8_t* ntri_lut) {
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+    uint32_t e_next = (lane < n) ? q[lane] : 0u;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+        const uint32_t idx = b0 + lane;
+        const bool have = idx < n;
+        const uint32_t e = e_next;
+        e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+        uint32_t i, j, k;
+        cx_decode_entry(P, G, e, i, j, k);
+        const uint32_t lin = (i * P.n1 + j) * P.n2 + k;
+        const uint32_t sm = cx_entry_signs(e);
+        const uint32_t vm = cx_corner_valid(P, i, j, k);
+        const bool real_voxel = have && (vm == 0xFFu);
+        const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+        const uint32_t emask = have ? (((sm ^ s0) & vm) & 0xFEu) : 0u;
+        const uint32_t ntri = real_voxel ? (uint32_t)ntri_lut[sm] : 0u;
+        const uint32_t nv = __popc(emask);
+        const bool rec = (nv | ntri) != 0u;
+        uint32_t vtot, ttot;
+        const uint32_t vpre = cx_wave_prefix_small<3>(nv, vtot);
+        const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
+        const uint64_t recm = __ballot(rec);
+        const uint32_t ctot = (uint32_t)__popcll(recm);
+        const uint32_t vfirst = run.v + vpre;
+        if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            uint4 c4;
+            c4.x = lin;
+            c4.y = sm | ((real_voxel ? 0u : 0x3Fu) << 8) | (ntri << 16) | (emask << 24);
+            c4.z = run.t + tpre;
+            c4.w = vfirst;
+            P.cells[run.c + cx_mbcnt(recm)] = c4;
+        }
+        if (run.v + vtot <= P.vcap) {   // wave-uniform
+            if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)emask << 32) | (uint64_t)vfirst;
+            // vertex o of this batch (o = vpre + rank of d in emask) -> (cell lane, direction d)
+#pragma unroll
+            for (uint32_t d = 1; d < 8; d++)
+                if ((emask >> d) & 1u) slot[vpre + __popc(emask & ((1u << d) - 1u))] = (lane << 3) | d;
+            __builtin_amdgcn_wave_barrier();
+            // all lanes stay active in this loop (the shuffles read any lane); up to CX_VR rounds of 64
+            // vertices have their sample loads in flight together
+            for (uint32_t o0 = 0; o0 < vtot; o0 += 64u * CX_VR) {
+                uint32_t e2[CX_VR], sl[CX_VR];
+                float f0[CX_VR], f1[CX_VR];
+#pragma unroll
+                for (uint32_t r = 0; r < CX_VR; r++) {
+                    if (o0 + 64u * r >= vtot) break;   // wave-uniform
+                    const uint32_t o = o0 + 64u * r + lane;
+                    sl[r] = slot[(o < vtot) ? o : 0u];
+                    e2[r] = (uint32_t)__shfl((int)e, (int)(sl[r] >> 3));
+                    const uint32_t d = sl[r] & 7u;
+                    const uint32_t lin2 = cx_entry_lin(P, G, e2[r]);
+                    if (P.flags & CX_DBG_NO_VLOADS) {
+                        f0[r] = -1.0f; f1[r] = (float)lin2;
+                    } else {
+                        f0[r] = A[lin2];
+                        f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
+                    }
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < CX_VR; r++) {
+                    if (o0 + 64u * r >= vtot) break;
+                    const uint32_t o = o0 + 64u * r + lane;
+                    const uint32_t d = sl[r] & 7u;
+                    uint32_t i2, j2, k2;
+                    cx_decode_entry(P, G, e2[r], i2, j2, k2);
+                    const uint32_t lin2 = (i2 * P.n1 + j2) * P.n2 + k2;
+                    // same arithmetic as cx_emit_vertices; |f1 - f0| > 8e-8 here (both ends outside the screen)
+                    const float t = __fdividef((P.vhi - f0[r]) + P.vlo, f1[r] - f0[r]);
+                    const float fi = (float)i2, fj = (float)j2, fk = (float)k2;
+                    float4 rec4;
+                    rec4.x = (d & 4u) ? fi + t : fi;
+                    rec4.y = (d & 2u) ? fj + t : fj;
+                    rec4.z = (d & 1u) ? fk + t : fk;
+                    rec4.w = __uint_as_float((lin2 << 3) | d);
+                    if (o < vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[run.v + o] = rec4;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        run.v += vtot; run.t += ttot; run.c += ctot;
     }
 }
 
@@ -138,10 +264,10 @@ constexpr uint32_t cx_rowmask(int rows, uint32_t bits) {
 #define CX_CELL_MASK cx_rowmask(CX_RJ, 0xFu)    // bits 6r+0..3, r = 0..RJ-1  (the 4*RJ cells of a lane)
 
 // =================================================================================================
-// K1
+// generic classify kernel (any shape / alignment): one lane per cell, wave-private LDS queue, the
+// workgroup reserves output space with ONE atomic per counter, then emits (per-cell path).
 // =================================================================================================
-template <bool FAST>
-__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_params P, const cx_task T, const uint32_t cells_per_block) {
+__global__ __launch_bounds__(256) void cx_k_classify_generic(const cx_params P, const uint32_t cells_per_block) {
     __shared__ uint32_t s_queue[4][CX_QCAP];
     __shared__ float4 s_vstage[4][CX_VSTAGE];
     __shared__ uint32_t s_tot[4][4];
@@ -150,146 +276,257 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* q = s_queue[wave];
     uint32_t qn = 0;   // wave-uniform
-    unsigned long long* stamp = P.stamps ? P.stamps + ((size_t)blockIdx.x * 4u + wave) * 4u : nullptr;
-    if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the queued cells (from sign masks)
-    float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
-    uint32_t wcur = 0, act0 = 0;
-    bool pending = false;        // wave-uniform: a classified step is waiting for queue space
-    const float* __restrict__ A = P.grid;
+    float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the corners of the queued cells
     const uint32_t plane = P.n1 * P.n2;
+    uint32_t gbase = blockIdx.x * cells_per_block + wave * 64u;
+    const uint32_t gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
+    bool streaming = gbase < gend;
+    for (;;) {
+        // ---- phase A: stream until done or until the queue might not hold another step
+        while (streaming && qn + 64u <= CX_QCAP) {
+            const uint32_t lin = gbase + lane;
+            const bool in = lin < gend;
+            const uint32_t linc = in ? lin : (P.nsamples - 1u);
+            const uint32_t i = cx_div(linc, P.div_plane);
+            const uint32_t r = linc - i * plane;
+            const uint32_t j = cx_div(r, P.div_row);
+            const uint32_t k = r - j * P.n2;
+            float f[8];
+            const uint32_t vm = cx_load_corners(P, linc, i, j, k, f);
+            const uint32_t sm = cx_sign_mask(P, f);
+            const uint32_t smv = sm & vm;
+            const bool active = in && smv != 0u && smv != vm;
+            const uint64_t act = __ballot(active);
+            if (active) {
+                q[qn + cx_mbcnt(act)] = lin;
+                cx_count_from_signs(sm, vm, acc);
+#pragma unroll
+                for (int c = 0; c < 8; c++) dnear = fminf(dnear, fabsf(f[c] - P.vcmp));
+            }
+            qn += (uint32_t)__popcll(act);
+            gbase += 256u;
+            streaming = gbase < gend;
+        }
+        // ---- phase B: count, reserve, emit.  The last round of a workgroup reserves once for all
+        // four waves; a wave whose queue filled up early reserves for itself (dense surfaces only).
+        const bool final_round = !streaming;
+        if (P.flags & CX_DBG_PHASE_A_ONLY) {
+            if (final_round) break;
+            qn = 0;
+            continue;
+        }
+        cx_run run = {0, 0, 0, 0};
+        auto lin_of = [&](uint32_t x) { return q[x]; };
+        if (__ballot(dnear <= P.near_abs) != 0ULL) {   // wave-uniform: a sample inside the tolerance screen, count exactly
+            cx_process_queue<true>(P, lin_of, qn, lane, false, run, s_vstage[wave]);
+        } else {
+            run.v = cx_wave_sum(acc.v); run.t = cx_wave_sum(acc.t);
+            run.c = cx_wave_sum(acc.c); run.b = cx_wave_sum(acc.b);
+        }
+        acc.v = acc.t = acc.c = acc.b = 0;
+        dnear = 3.0e38f;
+        if (P.flags & CX_DBG_COUNT_ONLY) {
+            if (final_round) break;
+            qn = 0;
+            continue;
+        }
+        if (final_round) {
+            if (lane == 0) {
+                s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t v = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
+                const uint32_t t = s_tot[0][1] + s_tot[1][1] + s_tot[2][1] + s_tot[3][1];
+                const uint32_t c = s_tot[0][2] + s_tot[1][2] + s_tot[2][2] + s_tot[3][2];
+                const uint32_t bb = s_tot[0][3] + s_tot[1][3] + s_tot[2][3] + s_tot[3][3];
+                s_base[0] = v ? atomicAdd(&P.counters[CX_CNT_VERTS], v) : 0u;
+                s_base[1] = t ? atomicAdd(&P.counters[CX_CNT_TRIS], t) : 0u;
+                s_base[2] = c ? atomicAdd(&P.counters[CX_CNT_CELLS], c) : 0u;
+                if (bb) atomicAdd(&P.counters[CX_CNT_BORDER], bb);
+            }
+            __syncthreads();
+            run.v = s_base[0]; run.t = s_base[1]; run.c = s_base[2];
+            for (uint32_t w = 0; w < wave; w++) {
+                run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
+            }
+        } else {
+            cx_run base = {0, 0, 0, 0};
+            if (lane == 0) {
+                if (run.v) base.v = atomicAdd(&P.counters[CX_CNT_VERTS], run.v);
+                if (run.t) base.t = atomicAdd(&P.counters[CX_CNT_TRIS], run.t);
+                if (run.c) base.c = atomicAdd(&P.counters[CX_CNT_CELLS], run.c);
+                if (run.b) atomicAdd(&P.counters[CX_CNT_BORDER], run.b);
+            }
+            run.v = __builtin_amdgcn_readfirstlane(base.v);
+            run.t = __builtin_amdgcn_readfirstlane(base.t);
+            run.c = __builtin_amdgcn_readfirstlane(base.c);
+        }
+        cx_process_queue<true>(P, lin_of, qn, lane, true, run, s_vstage[wave]);
+        qn = 0;
+        if (final_round) break;
+    }
+}
 
-    // ---- FAST task: block -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
-    uint32_t k0 = 0, j0 = 0, ib = 0, nrows = 0, kofs = 0, last_lane = 0, p = 0, wprev = 0, mk = 0, mj = 0, mr = 0, kofs_c = 0;
-    bool lane_valid = false, halo_in = false;
-    // ---- generic task: contiguous range of linear cell indices per block
-    uint32_t gbase = 0, gend = 0;
-    bool streaming;
-    if (FAST) {
-        uint32_t b = blockIdx.x;
-        const uint32_t ks = b % T.nks; b /= T.nks;
-        const uint32_t jg = b % T.njg;
-        const uint32_t ic = b / T.njg;
-        k0 = ks * 256u;
-        j0 = jg * (4u * CX_RJ) + wave * CX_RJ;
-        p = ic * T.ci;
-        ib = min(p + T.ci, P.n0);
-        nrows = (j0 < P.n1) ? min((uint32_t)CX_RJ, P.n1 - j0) : 0u;
-        kofs = k0 + 4u * lane;
-        lane_valid = kofs < P.n2;                      // n2 % 4 == 0
-        kofs_c = lane_valid ? kofs : (P.n2 - 4u);
-        last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
-        halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
-        streaming = nrows != 0u && p < ib;
+// =================================================================================================
+// staged pipeline:  S1 stream -> S2 scan -> S3 vertices -> S4 triangles
+// Every streaming wave owns a queue region in global memory (one u32 per cell of its task, written
+// densely from the front) and a list of batch records; nothing waits for anything inside a kernel.
+// =================================================================================================
+// logical task of a workgroup: the hardware deals workgroups round-robin to the 8 XCDs, each with
+// its own L2; give every XCD one contiguous range of tasks so that neighbours (which share halo
+// rows and planes) run on the same XCD at about the same time.
+__device__ __forceinline__ uint32_t cx_task_of_block(const cx_task& T) {
+    return (blockIdx.x & 7u) * T.chunk + (blockIdx.x >> 3);
+}
+struct cx_tile {     // what a wave covers: planes [p, ib), rows j0.., samples k0 + 4*lane..
+    uint32_t k0, j0, p, ib, nrows;
+};
+__device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task& T, uint32_t b, uint32_t wave) {
+    cx_tile t;
+    const uint32_t ks = b % T.nks; b /= T.nks;
+    const uint32_t jg = b % T.njg;
+    const uint32_t ic = b / T.njg;
+    t.k0 = ks * 256u;
+    t.j0 = jg * (4u * CX_RJ) + wave * CX_RJ;
+    t.p = ic * T.ci;
+    t.ib = min(t.p + T.ci, P.n0);
+    t.nrows = (t.j0 < P.n1) ? min((uint32_t)CX_RJ, P.n1 - t.j0) : 0u;
+    return t;
+}
+
+// ---- S1: one pass over the samples.  Lanes hold 4 consecutive k-samples of RJ+1 rows (one 16-byte
+// load per row and plane, two planes in flight); the 20 sign bits of a plane go into ONE u32 per lane,
+// a cell's activity and the per-lane vertex / triangle / record counts come from bitwise ops on two
+// such words for 16 cells at a time.
+__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
+    const uint32_t b = cx_task_of_block(T);
+    if (b >= T.nblocks) return;
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t w = b * 4u + wave;
+    unsigned long long* stamp = P.stamps ? P.stamps + (size_t)w * 4u : nullptr;
+    if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+    const cx_tile tile = cx_tile_of(P, T, b, wave);
+    const uint32_t k0 = tile.k0, j0 = tile.j0, ib = tile.ib, nrows = tile.nrows;
+    uint32_t p = tile.p;
+    uint32_t* __restrict__ gq = P.queue + (size_t)w * T.wcap;
+    cx_brec* __restrict__ brec = P.brec + (size_t)w * T.bcap;
+    const float* __restrict__ A = P.grid;
+    cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the cells queued since the last batch record (b: all)
+    uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
+    uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
+    float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
+    cx_fast_geom G;
+    G.pstart = p; G.j0 = j0; G.k0 = k0;
+    auto close_batch = [&]() {
+        const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
+        if (lane == 0) {
+            cx_brec R;
+            R.qoff = qstart; R.n = qn - qstart; R.vpre = rv; R.tpre = rt; R.cpre = rc; R.near = 0; R.pad0 = 0; R.pad1 = 0;
+            brec[nb] = R;
+        }
+        nb++; rv += bv; rt += bt; rc += bc;
+        qstart = qn;
+        acc.v = acc.t = acc.c = 0;
+    };
+    if (nrows != 0u && p < ib) {
+        const uint32_t kofs = k0 + 4u * lane;
+        const bool lane_valid = kofs < P.n2;                      // n2 % 4 == 0
+        const uint32_t kofs_c = lane_valid ? kofs : (P.n2 - 4u);
+        const uint32_t last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
+        const bool halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
         // cells whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
-        mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
+        uint32_t mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
         if (!lane_valid) mr = 0;   // lanes right of the array hold re-read samples: they own no cells
-        mk = mr;
+        uint32_t mk = mr;
         if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << 3);       // m == 3 at the array edge
-        mj = 0;
+        uint32_t mj = 0;
         for (uint32_t r = 0; r < CX_RJ; r++)
             if (j0 + r + 1u < P.n1) mj |= 0xFu << (CX_ROWBITS * r);
         mj &= mr;
-    } else {
-        gbase = blockIdx.x * cells_per_block + wave * 64u;
-        gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
-        streaming = gbase < gend;
-    }
 
-    // one sample plane of this lane: RJ+1 rows x 4 consecutive k-samples, plus the sample right of the segment
-    struct plane_raw {
-        float4 v[CX_RJ + 1];
-        float hv[CX_RJ + 1];
-    };
-    auto load_plane = [&](uint32_t pp, plane_raw& R) {
-        const uint32_t pc = min(pp, P.n0 - 1u);
+        // one sample plane of this lane: RJ+1 rows x 4 consecutive k-samples, plus the sample right of the segment
+        struct plane_raw {
+            float4 v[CX_RJ + 1];
+            float hv[CX_RJ + 1];
+        };
+        auto load_plane = [&](uint32_t pp, plane_raw& R) {
+            const uint32_t pc = min(pp, P.n0 - 1u);
 #pragma unroll
-        for (int r = 0; r <= CX_RJ; r++) {
-            const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
-            const uint32_t rowofs = (pc * P.n1 + jr) * P.n2;
-            R.v[r] = *reinterpret_cast<const float4*>(A + rowofs + kofs_c);      // lanes right of the array re-read its last 4 samples
-            R.hv[r] = A[rowofs + (halo_in ? k0 + 256u : 0u)];                    // wave-uniform address
-        }
-    };
-    // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
-    // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
-    auto plane_bits = [&](const plane_raw& R) -> uint32_t {
-        uint32_t own = 0, halo = 0;
+            for (int r = 0; r <= CX_RJ; r++) {
+                const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
+                const uint32_t rowofs = (pc * P.n1 + jr) * P.n2;
+                R.v[r] = *reinterpret_cast<const float4*>(A + rowofs + kofs_c);      // lanes right of the array re-read its last 4 samples
+                R.hv[r] = A[rowofs + (halo_in ? k0 + 256u : 0u)];                    // wave-uniform address
+            }
+        };
+        // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
+        // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
+        auto plane_bits = [&](const plane_raw& R) -> uint32_t {
+            uint32_t own = 0, halo = 0;
 #pragma unroll
-        for (int r = 0; r <= CX_RJ; r++) {
-            const float dx = R.v[r].x - P.vcmp, dy = R.v[r].y - P.vcmp, dz = R.v[r].z - P.vcmp, dw = R.v[r].w - P.vcmp;
-            const float dh = R.hv[r] - P.vcmp;
-            own |= (__float_as_uint(dx) >> 31) << (CX_ROWBITS * r + 0);
-            own |= (__float_as_uint(dy) >> 31) << (CX_ROWBITS * r + 1);
-            own |= (__float_as_uint(dz) >> 31) << (CX_ROWBITS * r + 2);
-            own |= (__float_as_uint(dw) >> 31) << (CX_ROWBITS * r + 3);
-            halo |= (__float_as_uint(dh) >> 31) << (CX_ROWBITS * r);
-            dnear = fminf(dnear, fminf(fminf(fabsf(dx), fabsf(dy)), fminf(fabsf(dz), fminf(fabsf(dw), fabsf(dh)))));
-        }
-        // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
-        // at the array edge, repeats its own m=3 (clamped corner)
-        uint32_t nb = (uint32_t)__shfl_down((int)own, 1) & CX_M0_MASK;
-        if (lane == last_lane) nb = halo_in ? halo : ((own >> 3) & CX_M0_MASK);
-        return own | (nb << 4);
-    };
+            for (int r = 0; r <= CX_RJ; r++) {
+                const float dx = R.v[r].x - P.vcmp, dy = R.v[r].y - P.vcmp, dz = R.v[r].z - P.vcmp, dw = R.v[r].w - P.vcmp;
+                const float dh = R.hv[r] - P.vcmp;
+                own |= (__float_as_uint(dx) >> 31) << (CX_ROWBITS * r + 0);
+                own |= (__float_as_uint(dy) >> 31) << (CX_ROWBITS * r + 1);
+                own |= (__float_as_uint(dz) >> 31) << (CX_ROWBITS * r + 2);
+                own |= (__float_as_uint(dw) >> 31) << (CX_ROWBITS * r + 3);
+                halo |= (__float_as_uint(dh) >> 31) << (CX_ROWBITS * r);
+                dnear = fminf(dnear, fminf(fminf(fabsf(dx), fabsf(dy)), fminf(fabsf(dz), fminf(fabsf(dw), fabsf(dh)))));
+            }
+            // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
+            // at the array edge, repeats its own m=3 (clamped corner)
+            uint32_t nbr = (uint32_t)__shfl_down((int)own, 1) & CX_M0_MASK;
+            if (lane == last_lane) nbr = halo_in ? halo : ((own >> 3) & CX_M0_MASK);
+            return own | (nbr << 4);
+        };
 
-    plane_raw rawA, rawB;
-    bool odd = false;            // wave-uniform: which buffer holds plane p+1
-    if (FAST && streaming) {
+        plane_raw rawA, rawB;
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
-        wprev = plane_bits(rawB);
-    }
-
-
-    for (;;) {
-        // ---- phase A: stream until done or until the queue might not hold another step
-        if (FAST) {
-            // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
-            auto step = [&](const plane_raw& cur, plane_raw& nxt) -> bool {
-                load_plane(p + 2u, nxt);
-                wcur = plane_bits(cur);
-                // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
-                const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
-                const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
-                const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
-                const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
-                act0 = o & ~a & mr;
-                if (!lane_valid) act0 = 0;
-                pending = false;
-                if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
-                    uint32_t tot;
-                    const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
-                    if (qn + tot > CX_QCAP) {          // wave-uniform: no room -> emit what is queued, then resume here
-                        pending = true;
-                        return false;
-                    }
-                    uint32_t act = act0;
-                    uint32_t pos = qn + pre;
-                    const uint32_t lin0 = (p * P.n1 + j0) * P.n2 + kofs;
-                    while (act) {
-                        const uint32_t bit = __ffs(act) - 1u;
-                        act &= act - 1u;
-                        const uint32_t r = bit / CX_ROWBITS, m = bit - r * CX_ROWBITS;
-                        q[pos++] = lin0 + r * P.n2 + m;
-                    }
-                    // counts of this lane's 16 cells, all at once on the packed sign words: corner
-                    // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
-                    // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
-                    const uint32_t mi = ((p + 1u) < P.n0) ? mr : 0u;               // plane p+1 exists
-                    const uint32_t real = mk & mj & mi;                           // cells that are voxels
-                    const uint32_t b0 = wprev, b1 = wprev >> 1, b2 = wprev >> CX_ROWBITS, b3 = wprev >> (CX_ROWBITS + 1u);
-                    const uint32_t b4 = wcur, b5 = wcur >> 1, b6 = wcur >> CX_ROWBITS, b7 = wcur >> (CX_ROWBITS + 1u);
-                    const uint32_t x1 = (b0 ^ b1) & mk, x2 = (b0 ^ b2) & mj, x3 = (b0 ^ b3) & mk & mj;   // mk, mj subsets of mr
-                    const uint32_t x4 = (b0 ^ b4) & mi, x5 = (b0 ^ b5) & mk & mi, x6 = (b0 ^ b6) & mj & mi, x7 = (b0 ^ b7) & real;
-                    acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
-                    const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
-                    acc.c += __popc(owners | (act0 & real));
-                    acc.b += __popc(act0 & real);
-                    // triangles: per tetrahedron {0,7,c,d} the number of low corners n = b0+b7+bc+bd;
-                    // n odd -> 1 triangle, n == 2 -> 2 triangles  (only voxels emit)
-                    const uint32_t x07 = b0 ^ b7, y07 = b0 & b7;
-                    uint32_t nt = 0;
+        uint32_t wprev = plane_bits(rawB);
+        // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
+        auto step = [&](const plane_raw& cur, plane_raw& nxt) {
+            load_plane(p + 2u, nxt);
+            const uint32_t wcur = plane_bits(cur);
+            // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
+            const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
+            const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
+            const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
+            const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
+            const uint32_t act0 = o & ~a & mr;
+            if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
+                uint32_t tot;
+                const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
+                uint32_t act = act0;
+                uint32_t pos = qn + pre;
+                const uint32_t ebase = (lane << 15) | ((p - G.pstart) << 21);
+                while (act) {
+                    const uint32_t bit = __ffs(act) - 1u;
+                    act &= act - 1u;
+                    // corners (k,k+1) of rows (r,r+1): bits (bit, bit+1, bit+6, bit+7) of the two plane words
+                    gq[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
+                }
+                // counts of this lane's 16 cells, all at once on the packed sign words: corner
+                // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
+                // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
+                const uint32_t mi = ((p + 1u) < P.n0) ? mr : 0u;               // plane p+1 exists
+                const uint32_t real = mk & mj & mi;                           // cells that are voxels
+                const uint32_t b0 = wprev, b1 = wprev >> 1, b2 = wprev >> CX_ROWBITS, b3 = wprev >> (CX_ROWBITS + 1u);
+                const uint32_t b4 = wcur, b5 = wcur >> 1, b6 = wcur >> CX_ROWBITS, b7 = wcur >> (CX_ROWBITS + 1u);
+                const uint32_t x1 = (b0 ^ b1) & mk, x2 = (b0 ^ b2) & mj, x3 = (b0 ^ b3) & mk & mj;   // mk, mj subsets of mr
+                const uint32_t x4 = (b0 ^ b4) & mi, x5 = (b0 ^ b5) & mk & mi, x6 = (b0 ^ b6) & mj & mi, x7 = (b0 ^ b7) & real;
+                acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
+                const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
+                acc.c += __popc(owners | (act0 & real));
+                acc.b += __popc(act0 & real);
+                // triangles: per tetrahedron {0,7,c,d} the number of low corners n = b0+b7+bc+bd;
+                // n odd -> 1 triangle, n == 2 -> 2 triangles  (only voxels emit)
+                const uint32_t x07 = b0 ^ b7, y07 = b0 & b7;
+                uint32_t nt = 0;
 #define CX_TET_COUNT(bc, bd)                                                          \
     {                                                                                 \
         const uint32_t xcd = (bc) ^ (bd);                                             \
@@ -297,113 +534,171 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_classify(const cx_p
         const uint32_t s1 = y07 ^ ((bc) & (bd)) ^ (x07 & xcd);                         \
         nt += __popc(s0 & real) + 2u * __popc(s1 & ~s0 & real);                        \
     }
-                    CX_TET_COUNT(b1, b3) CX_TET_COUNT(b3, b2) CX_TET_COUNT(b2, b6)
-                    CX_TET_COUNT(b6, b4) CX_TET_COUNT(b4, b5) CX_TET_COUNT(b5, b1)
+                CX_TET_COUNT(b1, b3) CX_TET_COUNT(b3, b2) CX_TET_COUNT(b2, b6)
+                CX_TET_COUNT(b6, b4) CX_TET_COUNT(b4, b5) CX_TET_COUNT(b5, b1)
 #undef CX_TET_COUNT
-                    acc.t += nt;
-                    qn += tot;
-                }
-                wprev = wcur;
-                p++;
-                streaming = p < ib;
-                return true;
-            };
-            while (streaming) {
-                const bool done = odd ? step(rawB, rawA) : step(rawA, rawB);
-                if (!done) break;
-                odd = !odd;
+                acc.t += nt;
+                qn += tot;
+                if (qn - qstart >= CX_BATCH_MIN) close_batch();
             }
-        } else {
-            while (streaming && qn + 64u <= CX_QCAP) {
-                const uint32_t lin = gbase + lane;
-                const bool in = lin < gend;
-                const uint32_t linc = in ? lin : (P.nsamples - 1u);
-                const uint32_t i = cx_div(linc, P.div_plane);
-                const uint32_t r = linc - i * plane;
-                const uint32_t j = cx_div(r, P.div_row);
-                const uint32_t k = r - j * P.n2;
-                float f[8];
-                const uint32_t vm = cx_load_corners(P, linc, i, j, k, f);
-                const uint32_t sm = cx_sign_mask(P, f);
-                const uint32_t smv = sm & vm;
-                const bool active = in && smv != 0u && smv != vm;
-                const uint64_t act = __ballot(active);
-                if (active) {
-                    q[qn + cx_mbcnt(act)] = lin;
-                    cx_count_from_signs(sm, vm, acc);
+            wprev = wcur;
+            p++;
+        };
+        while (p < ib) {
+            step(rawA, rawB);
+            if (p >= ib) break;
+            step(rawB, rawA);
+        }
+    }
+    if (qn > qstart) close_batch();
+    if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+    cx_run run;
+    run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
+    const bool near = __ballot(dnear <= P.near_abs) != 0ULL;   // wave-uniform
+    if (near && qn != 0u) {
+        // a sample inside the screen: the reference's tolerance rules may drop tetrahedra or vertices.
+        // Count exactly (per-cell path over the wave's own queue; its stores are complete after the
+        // fence) and hand the whole queue over as ONE batch that takes the per-cell path downstream.
+        __threadfence();
+        run.v = run.t = run.c = run.b = 0;
+        cx_process_queue<false>(P, [&](uint32_t x) { return cx_entry_lin(P, G, __builtin_nontemporal_load(gq + x)); }, qn, lane, false, run, nullptr);
+        nb = 1;
+        if (lane == 0) {
+            cx_brec R;
+            R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
+            brec[0] = R;
+        }
+    }
+    if (lane == 0) {
+        cx_wsum S;
+        S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = near ? 1u : 0u; S.pad = 0;
+        P.wsum[w] = S;
+    }
+}
+
+// ---- S2: exclusive scan of the per-wave totals (one workgroup of 16 waves; coalesced loads of
+// CX_SC chunks of 1024 waves at a time), output offsets per wave, the flat batch list, the counters.
+#define CX_SC 4
+// inclusive prefix sum over the wave with DPP row shifts / broadcasts (no LDS crossbar round trips)
+__device__ __forceinline__ uint32_t cx_wave_incl_scan(uint32_t x, uint32_t lane) {
+    (void)lane;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__global__ __launch_bounds__(1024) void cx_k_scan_waves(const cx_params P, const uint32_t nw) {
+    __shared__ uint32_t s_part[5][CX_SC * 16];   // per (chunk, wave) totals, then their exclusive prefixes
+    __shared__ uint32_t s_total[5];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = tid >> 6;
+    uint32_t carry[5] = {0, 0, 0, 0, 0};   // v, t, c, b, nb of everything before this super-chunk
+    for (uint32_t base = 0; base < nw; base += 1024u * CX_SC) {
+        uint32_t x[CX_SC][5], inc[CX_SC][5];
 #pragma unroll
-                    for (int c = 0; c < 8; c++) dnear = fminf(dnear, fabsf(f[c] - P.vcmp));
-                }
-                qn += (uint32_t)__popcll(act);
-                gbase += 256u;
-                streaming = gbase < gend;
+        for (int k = 0; k < CX_SC; k++) {
+            const uint32_t w = base + (uint32_t)k * 1024u + tid;
+            cx_wsum S;
+            S.nb = S.v = S.t = S.c = S.b = 0;
+            if (w < nw) S = P.wsum[w];
+            x[k][0] = S.v; x[k][1] = S.t; x[k][2] = S.c; x[k][3] = S.b; x[k][4] = S.nb;
+        }
+#pragma unroll
+        for (int k = 0; k < CX_SC; k++)
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                inc[k][m] = cx_wave_incl_scan(x[k][m], lane);
+                if (lane == 63u) s_part[m][k * 16 + wave] = inc[k][m];
+            }
+        __syncthreads();
+        if (wave == 0) {   // exclusive scan of the CX_SC*16 partial totals: CX_SC*16/64 consecutive items per lane
+            constexpr int PER = CX_SC * 16 / 64;
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                uint32_t loc[PER], sum = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { loc[q] = s_part[m][lane * PER + q]; sum += loc[q]; }
+                const uint32_t incl = cx_wave_incl_scan(sum, lane);
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { s_part[m][lane * PER + q] = run; run += loc[q]; }
+                if (lane == 63u) s_total[m] = incl;
             }
         }
-        // ---- phase B: count, reserve, emit.  The last round of a workgroup reserves once for all
-        // four waves; a wave whose queue filled up early reserves for itself (dense surfaces only).
-        const bool final_round = !streaming && !pending;
-        if (stamp && lane == 0 && final_round) stamp[1] = __builtin_amdgcn_s_memtime();
-        if (P.flags & CX_DBG_PHASE_A_ONLY) {
-            if (final_round) break;
-            qn = 0;
-            continue;
-        }
-        cx_run run = {0, 0, 0, 0};
-        const bool recount = __ballot(dnear <= P.near_abs) != 0ULL;   // wave-uniform
-        for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1 || recount) {
-                cx_process_queue(P, q, qn, lane, pass == 1, run, s_vstage[wave]);
-            } else {
-                run.v = cx_wave_sum(acc.v); run.t = cx_wave_sum(acc.t);
-                run.c = cx_wave_sum(acc.c); run.b = cx_wave_sum(acc.b);
-            }
-            if (pass == 1 || (P.flags & CX_DBG_COUNT_ONLY)) break;
-            if (final_round) {
-                if (lane == 0) {
-                    s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const uint32_t v = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
-                    const uint32_t t = s_tot[0][1] + s_tot[1][1] + s_tot[2][1] + s_tot[3][1];
-                    const uint32_t c = s_tot[0][2] + s_tot[1][2] + s_tot[2][2] + s_tot[3][2];
-                    const uint32_t bb = s_tot[0][3] + s_tot[1][3] + s_tot[2][3] + s_tot[3][3];
-                    s_base[0] = v ? atomicAdd(&P.counters[CX_CNT_VERTS], v) : 0u;
-                    s_base[1] = t ? atomicAdd(&P.counters[CX_CNT_TRIS], t) : 0u;
-                    s_base[2] = c ? atomicAdd(&P.counters[CX_CNT_CELLS], c) : 0u;
-                    if (bb) atomicAdd(&P.counters[CX_CNT_BORDER], bb);
-                }
-                __syncthreads();
-                run.v = s_base[0]; run.t = s_base[1]; run.c = s_base[2];
-                for (uint32_t w = 0; w < wave; w++) {
-                    run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
-                }
-                if (stamp && lane == 0) stamp[2] = __builtin_amdgcn_s_memtime();
-            } else {
-                cx_run base = {0, 0, 0, 0};
-                if (lane == 0) {
-                    if (run.v) base.v = atomicAdd(&P.counters[CX_CNT_VERTS], run.v);
-                    if (run.t) base.t = atomicAdd(&P.counters[CX_CNT_TRIS], run.t);
-                    if (run.c) base.c = atomicAdd(&P.counters[CX_CNT_CELLS], run.c);
-                    if (run.b) atomicAdd(&P.counters[CX_CNT_BORDER], run.b);
-                }
-                run.v = __builtin_amdgcn_readfirstlane(base.v);
-                run.t = __builtin_amdgcn_readfirstlane(base.t);
-                run.c = __builtin_amdgcn_readfirstlane(base.c);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CX_SC; k++) {
+            const uint32_t w = base + (uint32_t)k * 1024u + tid;
+            if (w < nw) {
+                uint32_t ex[5];
+#pragma unroll
+                for (int m = 0; m < 5; m++) ex[m] = carry[m] + s_part[m][k * 16 + wave] + inc[k][m] - x[k][m];
+                cx_wbase B;
+                B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
+                P.wbase[w] = B;
             }
         }
-        if (stamp && lane == 0 && final_round) stamp[3] = __builtin_amdgcn_s_memtime();
-        qn = 0;
-        acc.v = acc.t = acc.c = acc.b = 0;
-        dnear = 3.0e38f;
-        if (final_round) break;
-        if (FAST) {
-            // a wave that had to emit in the middle of its task dropped its prefetched planes (so that
-            // they do not occupy registers during phase B): fetch plane p+1 again and redo the step
-            load_plane(p + 1u, rawA);
-            odd = false;
-            pending = false;
-        }
+#pragma unroll
+        for (int m = 0; m < 5; m++) carry[m] += s_total[m];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.counters[CX_CNT_VERTS] = carry[0]; P.counters[CX_CNT_TRIS] = carry[1];
+        P.counters[CX_CNT_CELLS] = carry[2]; P.counters[CX_CNT_BORDER] = carry[3];
+        P.counters[CX_CNT_BATCHES] = carry[4];
+    }
+}
+
+// the flat batch list: self-contained descriptors (one thread per streaming wave; spread over many CUs --
+// the scattered stores of a single workgroup would take longer than the scan)
+__global__ __launch_bounds__(256) void cx_k_list_batches(const cx_params P, const cx_task T, const uint32_t nw) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= nw) return;
+    const uint32_t nb = P.wsum[w].nb;
+    if (nb == 0u) return;
+    const cx_wbase B = P.wbase[w];
+    for (uint32_t i = 0; i < nb; i++) {
+        if (B.boff + i >= P.fcap) break;
+        const cx_brec R = P.brec[(size_t)w * T.bcap + i];
+        cx_bdesc D;
+        D.w = w; D.qofs = w * T.wcap + R.qoff; D.n = R.n; D.near = R.near;
+        D.vbase = B.v + R.vpre; D.tbase = B.t + R.tpre; D.cbase = B.c + R.cpre; D.pad = 0;
+        P.flat[B.boff + i] = D;
+    }
+}
+
+// ---- S3: vertex records, per-cell table entries and cell records; one wave per batch, grid-stride
+__global__ __launch_bounds__(256) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
+    __shared__ float4 s_vstage[4][CX_VSTAGE];
+    __shared__ uint8_t s_ntri[256];
+    s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t f = blockIdx.x * 4u + wave;
+    if (f >= nbatches) return;
+    cx_bdesc D = P.flat[f];
+    for (;;) {   // waves are independent
+        const uint32_t fn = f + stride;
+        cx_bdesc Dn = D;
+        if (fn < nbatches) Dn = P.flat[fn];   // next descriptor in flight while this batch is processed
+        const cx_tile tile = cx_tile_of(P, T, D.w >> 2, D.w & 3u);
+        cx_fast_geom G;
+        G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
+        const uint32_t* __restrict__ q = P.queue + D.qofs;
+        cx_run run;
+        run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
+        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri);
+        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave]);
+        if (fn >= nbatches) break;
+        f = fn;
+        D = Dn;
     }
 }
 
@@ -446,37 +741,28 @@ __device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
 #define CX_TC_MASK(t) ((1u << CX_TC[t][0]) | (1u << CX_TC[t][1]) | (1u << CX_TC[t][2]) | (1u << CX_TC[t][3]))
 
 // =================================================================================================
-// K2: one lane per active-cell record; expands the 6 tetrahedra into index triples.  A wave whose
-// 64 records own one contiguous triangle range stages its indices in LDS and writes them out as
-// full 256-byte rows; otherwise (range broken by a reservation boundary) lanes store directly.
+// triangles: one lane per cell; expands the 6 tetrahedra into index triples.  A wave whose cells own
+// one contiguous triangle range stages its indices in LDS and writes them out as full 256-byte rows;
+// otherwise (range broken by a reservation boundary, generic path only) lanes store directly.
 // =================================================================================================
 #define CX_K2_STAGE 832u    // ints per wave and round (typical: ~600); larger waves store directly
 __device__ constexpr uint8_t CX_EDGE[19][2] = CX_EDGES_INIT;
-__global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
-    __shared__ int32_t s_stage[4][CX_K2_STAGE];
-    __shared__ uint32_t s_lut[6 * 16 * 2];   // triangle LUT: per-lane lookups must not go to memory
-    __shared__ int32_t s_eidx[4][19][64];   // vertex index of each of the 19 voxel edges, per lane
-    const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
-    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
-    if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
-    if (threadIdx.x < 6 * 16 * 2) s_lut[threadIdx.x] = (&cx_d_tet_tris[0][0][0])[threadIdx.x];
-    __syncthreads();
+struct cx_tri_lds {
+    int32_t stage[4][CX_K2_STAGE];
+    uint32_t lut[6 * 16 * 2];   // triangle LUT: per-lane lookups must not go to memory
+    int32_t eidx[4][19][64];    // vertex index of each of the 19 voxel edges, per lane
+};
+// one cell per lane: lin, corner signs sm, skipped tetrahedra, triangle count, first triangle index,
+// first vertex / crossing mask of the cell itself (vfirst0, em0)
+__device__ __forceinline__ void cx_cell_triangles(const cx_params& P, const uint64_t* __restrict__ hash_xy, cx_tri_lds& L,
+                                                  uint32_t lane, uint32_t wave, uint32_t lin, uint32_t sm, uint32_t tetskip,
+                                                  uint32_t ntri, uint32_t tri_first, uint32_t vfirst0, uint32_t em0) {
     const uint32_t plane = P.n1 * P.n2;
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    const uint32_t lane = cx_lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;   // whole wave idle
-    const bool have = idx < ncells;
-    uint4 c4 = make_uint4(0, 0, 0, 0);
-    if (have) c4 = P.cells[idx];
-    const uint32_t ntri = have ? ((c4.y >> 16) & 0xFFu) : 0u;
-    const uint32_t lin = c4.x;
-    const uint32_t sm = c4.y & 0xFFu, tetskip = (c4.y >> 8) & 0x3Fu;
     // first-vertex index and crossing mask of the 7 corners that can own an edge of this voxel
     uint32_t vfirst[7], em[7];
-    vfirst[0] = c4.w;
-    em[0] = c4.y >> 24;
+    vfirst[0] = vfirst0;
+    em[0] = em0;
 #pragma unroll
     for (uint32_t c = 1; c < 7; c++) {
         // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
@@ -536,7 +822,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     }
     // The wave's triangles are written in two rounds (tetrahedra 0-2, then 3-5) so that the LDS stage only has to
     // hold half of them: round g goes to [tb0 + (g ? T0 : 0) + prefix_g(lane), ...).  The order of triangles inside
-    // the wave's range is free (c4.z only serves this kernel).  A wave whose records do not own one contiguous
+    // the wave's range is free.  A wave whose records do not own one contiguous
     // range (reservation boundary inside the wave) or that is too large for the stage stores directly, per cell.
     uint32_t nround[2] = {0u, 0u};
 #pragma unroll
@@ -551,20 +837,23 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
     const uint32_t pre0 = cx_wave_prefix_small<3>(nround[0], T0);
     const uint32_t pre1 = cx_wave_prefix_small<3>(nround[1], T1);
-    const uint32_t tb0 = __builtin_amdgcn_readfirstlane(c4.z);   // lane 0 always has a record here
+    const uint32_t tb0 = __builtin_amdgcn_readfirstlane(tri_first);   // lane 0 always has a record here
     const bool contiguous = (T0 * 3u <= CX_K2_STAGE) && (T1 * 3u <= CX_K2_STAGE) &&
-                            __ballot(ntri != 0u && c4.z != tb0 + tpre) == 0ULL;
-    int32_t* stage = s_stage[wave];
-    int32_t* direct = P.tris + (size_t)c4.z * 3u;
+                            __ballot(ntri != 0u && tri_first != tb0 + tpre) == 0ULL;
+    int32_t* stage = L.stage[wave];
+    int32_t* direct = P.tris + (size_t)tri_first * 3u;
     // vertex index of every voxel edge (owner corner c1, direction d): first vertex of the owner +
     // rank of d among the owner's crossing edges.  Static register indices; the table lives in LDS so
     // that the runtime edge ids of the triangle LUT become one ds_read each.
 #pragma unroll
     for (int e = 0; e < 19; e++) {
         const uint32_t c1 = CX_EDGE[e][0], d = CX_EDGE[e][1];
-        s_eidx[wave][e][lane] = (int32_t)(vfirst[c1] + __popc(em[c1] & ((1u << d) - 1u)));
+        L.eidx[wave][e][lane] = (int32_t)(vfirst[c1] + __popc(em[c1] & ((1u << d) - 1u)));
     }
-    const int32_t* eidx = &s_eidx[wave][0][lane];
+    const int32_t* eidx = &L.eidx[wave][0][lane];
+    // Branch-free expansion: per tetrahedron the LUT word names up to 2 triangles x 3 voxel edges; all six
+    // vertex indices are read from the LDS table back to back (unused slots name edge 0), then stored under
+    // a predicate -- no LDS round trip sits inside a data-dependent loop.
     uint32_t wd = 0;   // running position of the direct path (per cell)
 #pragma unroll
     for (int g = 0; g < 2; g++) {
@@ -572,20 +861,22 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
 #pragma unroll
         for (int tt = 0; tt < 3; tt++) {
             const int t = g * 3 + tt;
-            if (ntri == 0u || ((tetskip >> t) & 1u)) continue;
             const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
                                  (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-            const uint32_t e = s_lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
+            uint32_t e = L.lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
+            if (ntri == 0u || ((tetskip >> t) & 1u)) e = 0u;
             const uint32_t n = e >> 30;
-            for (uint32_t qd = 0; qd < n; qd++) {
-                const uint32_t tri = (e >> (15u * qd)) & 0x7FFFu;
+            int32_t vi[6];
 #pragma unroll
-                for (uint32_t sidx = 0; sidx < 3; sidx++) {
-                    const uint32_t eid = (tri >> (5u * sidx)) & 0x1Fu;
-                    const int32_t vi = eidx[eid * 64u];
-                    if (contiguous) stage[w++] = vi;
-                    else if (!(P.flags & CX_DBG_NO_TRIS)) direct[wd++] = vi;
-                }
+            for (uint32_t sidx = 0; sidx < 6; sidx++) vi[sidx] = eidx[((e >> (5u * sidx)) & 0x1Fu) * 64u];
+            if (contiguous) {
+                if (n >= 1u) { stage[w] = vi[0]; stage[w + 1u] = vi[1]; stage[w + 2u] = vi[2]; }
+                if (n == 2u) { stage[w + 3u] = vi[3]; stage[w + 4u] = vi[4]; stage[w + 5u] = vi[5]; }
+                w += 3u * n;
+            } else if (!(P.flags & CX_DBG_NO_TRIS)) {
+                if (n >= 1u) { direct[wd] = vi[0]; direct[wd + 1u] = vi[1]; direct[wd + 2u] = vi[2]; }
+                if (n == 2u) { direct[wd + 3u] = vi[3]; direct[wd + 4u] = vi[4]; direct[wd + 5u] = vi[5]; }
+                wd += 3u * n;
             }
         }
         if (contiguous && !(P.flags & CX_DBG_NO_TRIS)) {
@@ -596,38 +887,82 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     }
 }
 
+// one lane per cell record
+__global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
+    __shared__ cx_tri_lds L;
+    const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
+    if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
+    if (threadIdx.x < 6 * 16 * 2) L.lut[threadIdx.x] = (&cx_d_tet_tris[0][0][0])[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;   // whole wave idle
+    const bool have = idx < ncells;
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (have) c4 = P.cells[idx];
+    const uint32_t ntri = have ? ((c4.y >> 16) & 0xFFu) : 0u;
+    cx_cell_triangles(P, hash_xy, L, lane, wave, c4.x, c4.y & 0xFFu, (c4.y >> 8) & 0x3Fu, ntri, c4.z, c4.w, c4.y >> 24);
+}
+
 // ---- launchers --------------------------------------------------------------------------------------
 bool cx_fast_classify_supported(const cx_params& P) {
     return (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
 }
 
-void cx_launch_classify_fast(const cx_params& P, hipStream_t s) {
+cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
     cx_task T;
-    T.nks = (P.n2 + 255u) / 256u;
-    T.njg = (P.n1 + 4u * CX_RJ - 1u) / (4u * CX_RJ);
-    // planes per task: aim at >= ~2048 workgroups, between 4 and 32 planes each
+    T.nks = (n2 + 255u) / 256u;
+    T.njg = (n1 + 4u * CX_RJ - 1u) / (4u * CX_RJ);
+    // planes per task: aim at ~3000 workgroups (12 per CU: measured best at 512^3), 2..64 planes each
     const uint32_t per_plane = T.nks * T.njg;
-    uint32_t target = 3072u;   // 12 workgroups per CU: measured best at 512^3 (tools/quick_time.py sweep)
+    uint32_t target = 3072u;
     if (const char* e = getenv("CX_TASKS")) target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : target;   // tuning knob
     uint32_t want_chunks = (target + per_plane - 1u) / per_plane;
     if (want_chunks < 1u) want_chunks = 1u;
-    uint32_t ci = (P.n0 + want_chunks - 1u) / want_chunks;
+    uint32_t ci = (n0 + want_chunks - 1u) / want_chunks;
     if (ci < 2u) ci = 2u;
     if (ci > 64u) ci = 64u;
     T.ci = ci;
-    T.nic = (P.n0 + ci - 1u) / ci;
-    const uint32_t blocks = T.nks * T.njg * T.nic;
-    hipLaunchKernelGGL(cx_k_classify<true>, dim3(blocks), dim3(256), 0, s, P, T, 0u);
+    T.nic = (n0 + ci - 1u) / ci;
+    T.nblocks = T.nks * T.njg * T.nic;
+    T.chunk = (T.nblocks + 7u) / 8u;
+    T.wcap = CX_RJ * 256u * ci;
+    T.bcap = T.wcap / CX_BATCH_MIN + 1u;
+    return T;
 }
 
+void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
+    hipLaunchKernelGGL(cx_k_stream, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
+}
+
+void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {
+    const uint32_t nw = T.nblocks * 4u;
+    hipLaunchKernelGGL(cx_k_scan_waves, dim3(1), dim3(1024), 0, s, P, nw);
+    hipLaunchKernelGGL(cx_k_list_batches, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
+}
+
+// one wave per batch, grid-stride: the batch count lives on the device, so launch what fills the chip
+// a few times over (256 CUs) and let every wave walk the list
+static uint32_t cx_batch_grid(const cx_params& P, uint32_t per_cu) {
+    uint32_t g = 256u * per_cu;
+    if (const char* e = getenv("CX_BGRID")) g = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g;   // tuning knob
+    const uint32_t most = (P.fcap + 3u) / 4u;
+    return g < most ? g : most;
+}
+void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s) {
+    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(cx_batch_grid(P, 16u)), dim3(256), 0, s, P, T);
+}
+
+
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s) {
-    cx_task T = {0, 0, 0, 0};
     // contiguous cell ranges per block: multiples of 256, at least 16384, about 2048 blocks
     uint32_t cpb = (P.nsamples + 2047u) / 2048u;
     cpb = (cpb + 255u) & ~255u;
     if (cpb < 16384u) cpb = 16384u;
     const uint32_t blocks = (P.nsamples + cpb - 1u) / cpb;
-    hipLaunchKernelGGL(cx_k_classify<false>, dim3(blocks), dim3(256), 0, s, P, T, cpb);
+    hipLaunchKernelGGL(cx_k_classify_generic, dim3(blocks), dim3(256), 0, s, P, cpb);
 }
 
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s) {

@@ -147,10 +147,11 @@ int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.
  * cx_timing_read synchronises and returns the summed milliseconds since the last reset:
- * ms[0] classify+vertex kernel, ms[1] triangle emit kernel, ms[2] whole extract (incl. memset),
- * *n = number of extracts accumulated. */
+ * ms[0] classify + vertex stage (all of its kernels), ms[1] triangle emit kernel, ms[2] whole extract,
+ * ms[3] stream kernel, ms[4] scan kernel, ms[5] cell / vertex emit kernel (staged pipeline; the generic
+ * classify kernel is reported in ms[3]), ms[6..7] reserved.  *n = number of extracts accumulated. */
 int cx_timing_enable(cx_ctx* ctx, int on);
-int cx_timing_read(cx_ctx* ctx, double ms[3], int* n);
+int cx_timing_read(cx_ctx* ctx, double ms[8], int* n);
 
 /* diagnostic builds only: per-wave s_memtime stamps of the classify kernel (4 per wave: start, end of
  * streaming, after the reservation, end).  words > 0 allocates, host != NULL copies out, 0/NULL frees. */

@@ -18,6 +18,9 @@ VARIANTS = [
     ("no_celltab", 0x40000),
     ("no_verts", 0x80000),
     ("no_cells_no_emit", 0x100000 | 0x800000),
+    ("no_vloads", 0x1000000),
+    ("no_vloads_no_verts", 0x1000000 | 0x80000),
+    ("no_vloads_no_stores", 0x1000000 | 0x40000 | 0x80000 | 0x100000 | 0x800000),
     ("no_stores_K1", 0x40000 | 0x80000 | 0x100000 | 0x800000),
     ("emit_no_lookup", 0x200000),
     ("emit_no_tris", 0x400000),
@@ -45,8 +48,7 @@ for rnd in range(args.rounds):
             ctx.extract3d_async(0.0, fl)
         t = ctx.timing_read()
         ctx.timing_enable(False)
-        res[name].append((t["classify_ms"] / t["n"], t["emit_ms"] / t["n"]))
+        res[name].append(tuple(t[k] / t["n"] for k in ("classify_ms", "emit_ms", "stream_ms", "scan_ms", "cells_ms")))
 for name, _ in VARIANTS:
-    k1 = sorted(x[0] for x in res[name])
-    k2 = sorted(x[1] for x in res[name])
-    print("%-24s K1 med %.3f min %.3f ms | K2 med %.3f min %.3f ms" % (name, k1[len(k1) // 2], k1[0], k2[len(k2) // 2], k2[0]))
+    med = [sorted(x[c] for x in res[name])[len(res[name]) // 2] for c in range(5)]
+    print("%-24s K1 %.3f (stream %.3f scan %.3f verts %.3f) | K2 %.3f ms" % (name, med[0], med[2], med[3], med[4], med[1]))

@@ -17,6 +17,7 @@ for fl, name in ((1, "full"), (1 | 0x10000 | 0x800000, "phaseA")):
         for _ in range(5):
             ctx.extract3d_async(0.0, fl)
         t = ctx.timing_read(); ctx.timing_enable(False)
-        r.append((t["classify_ms"] / t["n"], t["emit_ms"] / t["n"]))
-    k1 = sorted(x[0] for x in r); k2 = sorted(x[1] for x in r)
-    print("%s %-8s K1 med %.3f min %.3f | K2 med %.3f min %.3f" % (os.environ.get("TAG", ""), name, k1[3], k1[0], k2[3], k2[0]))
+        r.append(tuple(t[k] / t["n"] for k in ("classify_ms", "emit_ms", "stream_ms", "scan_ms", "cells_ms")))
+    med = [sorted(x[c] for x in r)[3] for c in range(5)]
+    print("%s %-8s K1 %.3f (stream %.3f scan %.3f verts %.3f) | K2 %.3f | sum %.3f" % (
+        os.environ.get("TAG", ""), name, med[0], med[2], med[3], med[4], med[1], med[0] + med[1]))
