@@ -142,14 +142,44 @@ __device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t
 // the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
 // entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
 // one coalesced 16-byte store) -- no divergent per-direction loop.
+// store flavours (A/B): CX_NT_* = nontemporal
+typedef float cx_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t cx_v4u __attribute__((ext_vector_type(4)));
+#ifdef CX_NT_VERTS
+#define CX_STORE_VERT(ptr, val) __builtin_nontemporal_store(cx_v4f{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4f*>(ptr))
+#else
+#define CX_STORE_VERT(ptr, val) (*(ptr) = (val))
+#endif
+#ifdef CX_NT_TAB
+#define CX_STORE_TAB(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define CX_STORE_TAB(ptr, val) (*(ptr) = (val))
+#endif
+#ifdef CX_NT_CELLS
+#define CX_STORE_CELL(ptr, val) __builtin_nontemporal_store(cx_v4u{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4u*>(ptr))
+#else
+#define CX_STORE_CELL(ptr, val) (*(ptr) = (val))
+#endif
+#ifdef CX_S3_STAMPS   // diagnostic build: where a vertex-stage wave spends its time (tools/stamps3.py)
+#define CX_T(k) { asm volatile("" ::: "memory"); const unsigned long long now__ = __builtin_amdgcn_s_memtime(); if (tacc) tacc[k] += now__ - tlast__; tlast__ = __builtin_amdgcn_s_memtime(); }
+#define CX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CX_T(k)
+#define CX_DRAIN()
+#endif
 __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
-                                                   uint32_t lane, cx_run run, uint32_t* slot, const uint8_t* ntri_lut) {
+                                                   uint32_t lane, cx_run run, uint32_t* slot, const uint8_t* ntri_lut,
+                                                   unsigned long long* tacc = nullptr) {
+#ifdef CX_S3_STAMPS
+    unsigned long long tlast__ = __builtin_amdgcn_s_memtime();
+#endif
     const float* __restrict__ A = P.grid;
     const uint32_t plane = P.n1 * P.n2;
     uint32_t e_next = (lane < n) ? q[lane] : 0u;
     for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
         const uint32_t idx = b0 + lane;
         const bool have = idx < n;
+        CX_DRAIN(); CX_T(0)   // entries of this round (requested one round ago) + drain of the previous stores
         const uint32_t e = e_next;
         e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
         uint32_t i, j, k;
@@ -169,21 +199,15 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
         const uint64_t recm = __ballot(rec);
         const uint32_t ctot = (uint32_t)__popcll(recm);
         const uint32_t vfirst = run.v + vpre;
-        if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
-            uint4 c4;
-            c4.x = lin;
-            c4.y = sm | ((real_voxel ? 0u : 0x3Fu) << 8) | (ntri << 16) | (emask << 24);
-            c4.z = run.t + tpre;
-            c4.w = vfirst;
-            P.cells[run.c + cx_mbcnt(recm)] = c4;
-        }
+        // all loads of this round are issued before its stores: vmcnt retires in issue order, so a
+        // load behind a store would wait for the store's round trip
         if (run.v + vtot <= P.vcap) {   // wave-uniform
-            if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)emask << 32) | (uint64_t)vfirst;
             // vertex o of this batch (o = vpre + rank of d in emask) -> (cell lane, direction d)
 #pragma unroll
             for (uint32_t d = 1; d < 8; d++)
                 if ((emask >> d) & 1u) slot[vpre + __popc(emask & ((1u << d) - 1u))] = (lane << 3) | d;
             __builtin_amdgcn_wave_barrier();
+            CX_T(1)   // decode, prefix sums, slot table
             // all lanes stay active in this loop (the shuffles read any lane); up to CX_VR rounds of 64
             // vertices have their sample loads in flight together
             for (uint32_t o0 = 0; o0 < vtot; o0 += 64u * CX_VR) {
@@ -204,6 +228,8 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
                         f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
                     }
                 }
+                CX_T(2)   // sample loads issued
+                CX_DRAIN(); CX_T(3)   // sample loads back
 #pragma unroll
                 for (uint32_t r = 0; r < CX_VR; r++) {
                     if (o0 + 64u * r >= vtot) break;
@@ -220,13 +246,26 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
                     rec4.y = (d & 2u) ? fj + t : fj;
                     rec4.z = (d & 1u) ? fk + t : fk;
                     rec4.w = __uint_as_float((lin2 << 3) | d);
-                    if (o < vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[run.v + o] = rec4;
+                    if (o < vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[run.v + o], rec4);
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) CX_STORE_TAB(&P.celltab[lin], ((uint64_t)emask << 32) | (uint64_t)vfirst);
+        }
+        if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            uint4 c4;
+            c4.x = lin;
+            c4.y = sm | ((real_voxel ? 0u : 0x3Fu) << 8) | (ntri << 16) | (emask << 24);
+            c4.z = run.t + tpre;
+            c4.w = vfirst;
+            CX_STORE_CELL(&P.cells[run.c + cx_mbcnt(recm)], c4);
         }
         run.v += vtot; run.t += ttot; run.c += ctot;
+        CX_T(4)   // interpolation, stores issued
     }
+#ifdef CX_S3_STAMPS
+    if (tacc) tacc[6] += (n + 63u) / 64u;
+#endif
 }
 
 // vertex / triangle / record / border counts of an active cell from its sign mask alone -- exact
@@ -400,13 +439,27 @@ __device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task&
 // load per row and plane, two planes in flight); the 20 sign bits of a plane go into ONE u32 per lane,
 // a cell's activity and the per-lane vertex / triangle / record counts come from bitwise ops on two
 // such words for 16 cells at a time.
+// Queue entries and batch records are staged in LDS and copied out in bulk: `s_waitcnt vmcnt` retires
+// loads, stores and atomics in issue order, so a store issued between two plane loads would make the
+// second wait for the store's round trip (measured: +45 % kernel time with one store per active step).
+#define CX_SQ 1024u     // queue entries a wave stages (one step adds at most 1024)
+#define CX_SBR 32u      // batch records a wave stages
 __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
+    __shared__ uint32_t s_q[4][CX_SQ];
+    __shared__ uint32_t s_br[4][CX_SBR][5];
     const uint32_t b = cx_task_of_block(T);
     if (b >= T.nblocks) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* q = s_q[wave];
+    uint32_t ql = 0, qflushed = 0;      // wave-uniform: entries staged / already in global memory
+    uint32_t nbl = 0, nbflushed = 0;    // the same for batch records
     const uint32_t w = b * 4u + wave;
+#ifdef CX_S3_STAMPS
+    unsigned long long* stamp = nullptr;   // the buffer belongs to the vertex stage in this build
+#else
     unsigned long long* stamp = P.stamps ? P.stamps + (size_t)w * 4u : nullptr;
+#endif
     if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     const cx_tile tile = cx_tile_of(P, T, b, wave);
     const uint32_t k0 = tile.k0, j0 = tile.j0, ib = tile.ib, nrows = tile.nrows;
@@ -420,14 +473,33 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
+    auto flush_queue = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t o = lane; o < ql; o += 64u) gq[qflushed + o] = q[o];
+        __builtin_amdgcn_wave_barrier();
+        qflushed += ql;
+        ql = 0;
+    };
+    auto flush_brec = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nbl) {
+            cx_brec R;
+            R.qoff = s_br[wave][lane][0]; R.n = s_br[wave][lane][1]; R.vpre = s_br[wave][lane][2];
+            R.tpre = s_br[wave][lane][3]; R.cpre = s_br[wave][lane][4]; R.near = 0; R.pad0 = 0; R.pad1 = 0;
+            brec[nbflushed + lane] = R;
+        }
+        __builtin_amdgcn_wave_barrier();
+        nbflushed += nbl;
+        nbl = 0;
+    };
     auto close_batch = [&]() {
         const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
+        if (nbl == CX_SBR) flush_brec();
         if (lane == 0) {
-            cx_brec R;
-            R.qoff = qstart; R.n = qn - qstart; R.vpre = rv; R.tpre = rt; R.cpre = rc; R.near = 0; R.pad0 = 0; R.pad1 = 0;
-            brec[nb] = R;
+            s_br[wave][nbl][0] = qstart; s_br[wave][nbl][1] = qn - qstart; s_br[wave][nbl][2] = rv;
+            s_br[wave][nbl][3] = rt; s_br[wave][nbl][4] = rc;
         }
-        nb++; rv += bv; rt += bt; rc += bc;
+        nbl++; nb++; rv += bv; rt += bt; rc += bc;
         qstart = qn;
         acc.v = acc.t = acc.c = 0;
     };
@@ -501,15 +573,17 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
             if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
                 uint32_t tot;
                 const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
+                if (ql + tot > CX_SQ) flush_queue();   // wave-uniform, dense surfaces only
                 uint32_t act = act0;
-                uint32_t pos = qn + pre;
+                uint32_t pos = ql + pre;
                 const uint32_t ebase = (lane << 15) | ((p - G.pstart) << 21);
                 while (act) {
                     const uint32_t bit = __ffs(act) - 1u;
                     act &= act - 1u;
                     // corners (k,k+1) of rows (r,r+1): bits (bit, bit+1, bit+6, bit+7) of the two plane words
-                    gq[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
+                    q[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
                 }
+                ql += tot;
                 // counts of this lane's 16 cells, all at once on the packed sign words: corner
                 // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
                 // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
@@ -551,10 +625,12 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         }
     }
     if (qn > qstart) close_batch();
+    flush_queue();
+    flush_brec();
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
     cx_run run;
     run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
-    const bool near = __ballot(dnear <= P.near_abs) != 0ULL;   // wave-uniform
+    const bool near = __ballot(dnear <= P.near_abs) != 0ULL && !(P.flags & CX_DBG_NO_NEAR);   // wave-uniform
     if (near && qn != 0u) {
         // a sample inside the screen: the reference's tolerance rules may drop tetrahedra or vertices.
         // Count exactly (per-cell path over the wave's own queue; its stores are complete after the
@@ -694,7 +770,19 @@ __global__ __launch_bounds__(256) void cx_k_emit_vertices(const cx_params P, con
         const uint32_t* __restrict__ q = P.queue + D.qofs;
         cx_run run;
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
+#ifdef CX_S3_STAMPS
+        unsigned long long tloc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long tb__ = __builtin_amdgcn_s_memtime();
+        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, tloc);
+        if (P.stamps && lane == 0) {
+            unsigned long long* dst = P.stamps + ((size_t)(blockIdx.x * 4u + wave)) * 8u;
+            for (int k = 0; k < 7; k++) dst[k] += tloc[k];
+            dst[5] += __builtin_amdgcn_s_memtime() - tb__;   // whole batch
+            dst[7] += 1;                                      // batches
+        }
+#else
         if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri);
+#endif
         else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave]);
         if (fn >= nbatches) break;
         f = fn;
@@ -887,7 +975,7 @@ __device__ __forceinline__ void cx_cell_triangles(const cx_params& P, const uint
     }
 }
 
-// one lane per cell record
+// one lane per cell record; waves walk the record array grid-stride (the record count lives on the device)
 __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
     __shared__ cx_tri_lds L;
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
@@ -897,13 +985,20 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;   // whole wave idle
-    const bool have = idx < ncells;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     uint4 c4 = make_uint4(0, 0, 0, 0);
-    if (have) c4 = P.cells[idx];
-    const uint32_t ntri = have ? ((c4.y >> 16) & 0xFFu) : 0u;
-    cx_cell_triangles(P, hash_xy, L, lane, wave, c4.x, c4.y & 0xFFu, (c4.y >> 8) & 0x3Fu, ntri, c4.z, c4.w, c4.y >> 24);
+    if (idx < ncells) c4 = P.cells[idx];
+    while (idx - lane < ncells) {   // wave-uniform
+        const bool have = idx < ncells;
+        const uint4 cur = c4;
+        const uint32_t nxt = idx + stride;
+        if (nxt < ncells) c4 = P.cells[nxt];   // next record in flight while this one is expanded
+        const uint32_t ntri = have ? ((cur.y >> 16) & 0xFFu) : 0u;
+        cx_cell_triangles(P, hash_xy, L, lane, wave, cur.x, cur.y & 0xFFu, (cur.y >> 8) & 0x3Fu, ntri, cur.z, cur.w, cur.y >> 24);
+        __builtin_amdgcn_wave_barrier();
+        idx = nxt;
+    }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------
@@ -952,7 +1047,7 @@ static uint32_t cx_batch_grid(const cx_params& P, uint32_t per_cu) {
     return g < most ? g : most;
 }
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s) {
-    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(cx_batch_grid(P, 16u)), dim3(256), 0, s, P, T);
+    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(cx_batch_grid(P, 10u)), dim3(256), 0, s, P, T);
 }
 
 
@@ -966,10 +1061,12 @@ void cx_launch_classify_generic(const cx_params& P, hipStream_t s) {
 }
 
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s) {
-    // one lane per record; the record count lives on the device, so launch for the capacity and let
-    // idle waves exit at once
-    const uint32_t blocks = (P.ccap + 255u) / 256u;
-    hipLaunchKernelGGL(cx_k_emit_triangles, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P, hash_xy);
+    // one lane per record, grid-stride: launch what fills the chip a few times over
+    uint32_t g = 256u * 8u;
+    if (const char* e = getenv("CX_TGRID")) g = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g;   // tuning knob
+    const uint32_t most = (P.ccap + 255u) / 256u;
+    if (g > most) g = most;
+    hipLaunchKernelGGL(cx_k_emit_triangles, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {

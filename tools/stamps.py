@@ -17,9 +17,14 @@ ctx._check(ctx.lib.cx_debug_stamps(ctx.handle, nw, buf.ctypes.data))
 S = buf.reshape(-1, 4).astype(np.int64)
 S = S[S[:, 0] > 0]
 t0 = S[:, 0].min()
-print("waves", len(S), "kernel span (ticks)", S[:, 3].max() - t0)
-for name, a, b in (("phaseA", 0, 1), ("barrier+reserve", 1, 2), ("emit", 2, 3), ("life", 0, 3)):
-    d = S[:, b] - S[:, a]
-    print("%-16s mean %9.0f  p50 %9.0f  p90 %9.0f  max %9.0f" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+d = S[:, 1] - S[:, 0]
+print("stream waves", len(S), "span", S[:, 1].max() - t0)
+print("wave life: mean %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (d.mean(), *np.percentile(d, [10, 50, 90, 99]), d.max()))
 st = S[:, 0] - t0
-print("start time p50 %d p90 %d max %d" % (np.median(st), np.percentile(st, 90), st.max()))
+en = S[:, 1] - t0
+print("start p50 %d p90 %d max %d | end p50 %d p90 %d p99 %d max %d" % (np.median(st), np.percentile(st, 90), st.max(), np.median(en), np.percentile(en, 90), np.percentile(en, 99), en.max()))
+# waves still running over time (20 bins)
+T = en.max()
+for k in range(0, 20):
+    t = T * (k + 0.5) / 20
+    print("t=%5.1f%%  running %5d" % (100 * (k + 0.5) / 20, int(((st <= t) & (en > t)).sum())))
