@@ -829,28 +829,49 @@ __device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
 #define CX_TC_MASK(t) ((1u << CX_TC[t][0]) | (1u << CX_TC[t][1]) | (1u << CX_TC[t][2]) | (1u << CX_TC[t][3]))
 
 // =================================================================================================
-// triangles: one lane per cell; expands the 6 tetrahedra into index triples.  A wave whose cells own
-// one contiguous triangle range stages its indices in LDS and writes them out as full 256-byte rows;
-// otherwise (range broken by a reservation boundary, generic path only) lanes store directly.
+// K2 triangles.  Phase 1, one lane per cell record: the (first vertex, crossing mask) pairs of the 7
+// corners that can own an edge of the voxel go to LDS, and every triangle of the cell gets a slot word
+// (cell lane, LUT entry, which of its 2 triangles, rank in the cell).  Phase 2, one lane per TRIANGLE:
+// three (owner corner, direction) pairs from the LUT -> three vertex indices -> one 12-byte store,
+// consecutive lanes writing consecutive triangles.  No divergent per-tetrahedron expansion.
 // =================================================================================================
-#define CX_K2_STAGE 832u    // ints per wave and round (typical: ~600); larger waves store directly
-__device__ constexpr uint8_t CX_EDGE[19][2] = CX_EDGES_INIT;
+__device__ constexpr uint32_t CX_TRI_CD[6][16][2][2] = CX_TET_TRIS_CD_INIT;
+#ifndef CX_VE_ROW
+#define CX_VE_ROW 65
+#endif
 struct cx_tri_lds {
-    int32_t stage[4][CX_K2_STAGE];
-    uint32_t lut[6 * 16 * 2];   // triangle LUT: per-lane lookups must not go to memory
-    int32_t eidx[4][19][64];    // vertex index of each of the 19 voxel edges, per lane
+    uint2 ve[4][7][CX_VE_ROW];   // per wave: (first vertex, crossing mask) of corner c of each cell (rows padded: bank spread)
+    uint16_t slot[4][12 * 64];   // per wave: one word per triangle
+    uint32_t tfirst[4][64];      // per wave: first triangle index of each cell minus its rank in the wave
+    uint32_t lut[6 * 16 * 2 * 2];
 };
-// one cell per lane: lin, corner signs sm, skipped tetrahedra, triangle count, first triangle index,
-// first vertex / crossing mask of the cell itself (vfirst0, em0)
-__device__ __forceinline__ void cx_cell_triangles(const cx_params& P, const uint64_t* __restrict__ hash_xy, cx_tri_lds& L,
-                                                  uint32_t lane, uint32_t wave, uint32_t lin, uint32_t sm, uint32_t tetskip,
-                                                  uint32_t ntri, uint32_t tri_first, uint32_t vfirst0, uint32_t em0) {
+// slot word: bits 0-5 cell lane, 6 second triangle of the entry, 7-14 LUT entry (tet*32 + pattern*2 + variant)
+
+// everything of one cell record that comes from memory.  The loads of record n+1 are issued before
+// record n is expanded and are waited for BEFORE the triangle stores of record n are issued:
+// `s_waitcnt vmcnt` retires loads and stores in issue order, so a load behind a store waits for the
+// store's round trip as well.
+struct cx_tri_in {
+    uint4 rec;            // cell record (zero: no record)
+    uint2 nb[6];          // table entries (first vertex, crossing mask) of corners 1..6
+    uint64_t hxy[4];      // CPython hash prefixes of the 4 (i,j) columns of the voxel (CX_DIAG_CPYTHON310)
+    uint32_t ck;          // k of the cell
+};
+__device__ __forceinline__ uint32_t cx_need_hash(uint32_t sm, uint32_t tetskip, uint32_t ntri) {
+    uint32_t need = 0;   // corners whose hash decides a quad diagonal
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+        if (ntri && !((tetskip >> t) & 1u) && __popc(pat) == 2) need |= CX_TC_MASK(t);
+    }
+    return need;
+}
+__device__ __forceinline__ void cx_tri_fetch(const cx_params& P, const uint64_t* __restrict__ hash_xy, const uint4& rec,
+                                             cx_tri_in& I) {
     const uint32_t plane = P.n1 * P.n2;
-    const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    // first-vertex index and crossing mask of the 7 corners that can own an edge of this voxel
-    uint32_t vfirst[7], em[7];
-    vfirst[0] = vfirst0;
-    em[0] = em0;
+    I.rec = rec;
+    const uint32_t lin = rec.x, sm = rec.y & 0xFFu, tetskip = (rec.y >> 8) & 0x3Fu, ntri = (rec.y >> 16) & 0xFFu;
 #pragma unroll
     for (uint32_t c = 1; c < 7; c++) {
         // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
@@ -858,37 +879,51 @@ __device__ __forceinline__ void cx_cell_triangles(const cx_params& P, const uint
         uint32_t sup = 0;
 #pragma unroll
         for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
-        vfirst[c] = 0; em[c] = 0;
+        uint2 pr = make_uint2(0u, 0u);
         if (ntri && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
             const uint32_t lc = lin + ((c & 4u) ? plane : 0u) + ((c & 2u) ? P.n2 : 0u) + (c & 1u);
             const uint64_t e = P.celltab[lc];
-            vfirst[c] = (uint32_t)e;
-            em[c] = (uint32_t)(e >> 32);
+            pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
         }
+        I.nb[c - 1u] = pr;
     }
+    I.ck = 0;
+    I.hxy[0] = I.hxy[1] = I.hxy[2] = I.hxy[3] = 0;
+    if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(sm, tetskip, ntri) != 0u) {
+        const uint32_t ci = cx_div(lin, P.div_plane);
+        const uint32_t r = lin - ci * plane;
+        const uint32_t cj = cx_div(r, P.div_row);
+        I.ck = r - cj * P.n2;
+        // hash prefixes of the 4 (i,j) columns of this voxel (clamped: pseudo cells never need them)
+        const uint32_t i1 = min(ci + 1u, P.n0 - 1u), j1 = min(cj + 1u, P.n1 - 1u);
+        I.hxy[0] = hash_xy[ci * P.n1 + cj]; I.hxy[1] = hash_xy[ci * P.n1 + j1];
+        I.hxy[2] = hash_xy[i1 * P.n1 + cj]; I.hxy[3] = hash_xy[i1 * P.n1 + j1];
+    }
+}
+// the loads behind I (and the next record) have to be complete here
+__device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
+    asm volatile("" : "+v"(I.rec.x), "+v"(I.rec.y), "+v"(I.rec.z), "+v"(I.rec.w), "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) :: "memory");
+    asm volatile("" : "+v"(I.nb[0].x), "+v"(I.nb[0].y), "+v"(I.nb[1].x), "+v"(I.nb[1].y), "+v"(I.nb[2].x), "+v"(I.nb[2].y) :: "memory");
+    asm volatile("" : "+v"(I.nb[3].x), "+v"(I.nb[3].y), "+v"(I.nb[4].x), "+v"(I.nb[4].y), "+v"(I.nb[5].x), "+v"(I.nb[5].y) :: "memory");
+    asm volatile("" : "+v"(I.hxy[0]), "+v"(I.hxy[1]), "+v"(I.hxy[2]), "+v"(I.hxy[3]), "+v"(I.ck) :: "memory");
+}
+
+// phase 1 of one record per lane: LDS tables and slot words; returns the wave's triangle count
+__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
+    const uint32_t sm = I.rec.y & 0xFFu, tetskip = (I.rec.y >> 8) & 0x3Fu, ntri = (I.rec.y >> 16) & 0xFFu;
+    L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
+#pragma unroll
+    for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u];
     // quad diagonal variants of the 2-2 tetrahedra (bit t of `variants`)
     uint32_t variants = 0;
-    if (emulate) {
-        uint32_t need = 0;   // corners whose hash is needed
-#pragma unroll
-        for (int t = 0; t < 6; t++) {
-            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-            if (ntri && !((tetskip >> t) & 1u) && __popc(pat) == 2) need |= CX_TC_MASK(t);
-        }
+    if (P.flags & CX_DIAG_CPYTHON310) {
+        const uint32_t need = cx_need_hash(sm, tetskip, ntri);
         if (__ballot(need != 0u) != 0ULL) {
-            const uint32_t ci = cx_div(lin, P.div_plane);
-            const uint32_t r = lin - ci * plane;
-            const uint32_t cj = cx_div(r, P.div_row);
-            const uint32_t ck = r - cj * P.n2;
-            // hash prefixes of the 4 (i,j) columns of this voxel (clamped: pseudo cells never need them)
-            const uint32_t i1 = min(ci + 1u, P.n0 - 1u), j1 = min(cj + 1u, P.n1 - 1u);
-            const uint64_t hxy[4] = {hash_xy[ci * P.n1 + cj], hash_xy[ci * P.n1 + j1], hash_xy[i1 * P.n1 + cj], hash_xy[i1 * P.n1 + j1]};
             uint64_t h[8];
 #pragma unroll
             for (uint32_t c = 0; c < 8; c++) {
                 h[c] = 0;
-                if ((need >> c) & 1u) h[c] = py_finish3(py_round(hxy[c >> 1], ck + (c & 1u) + P.org2));
+                if ((need >> c) & 1u) h[c] = py_finish3(py_round(I.hxy[c >> 1], I.ck + (c & 1u) + P.org2));
             }
 #pragma unroll
             for (int t = 0; t < 6; t++) {
@@ -908,71 +943,46 @@ __device__ __forceinline__ void cx_cell_triangles(const cx_params& P, const uint
             }
         }
     }
-    // The wave's triangles are written in two rounds (tetrahedra 0-2, then 3-5) so that the LDS stage only has to
-    // hold half of them: round g goes to [tb0 + (g ? T0 : 0) + prefix_g(lane), ...).  The order of triangles inside
-    // the wave's range is free.  A wave whose records do not own one contiguous
-    // range (reservation boundary inside the wave) or that is too large for the stage stores directly, per cell.
-    uint32_t nround[2] = {0u, 0u};
+    // slot words of this cell's triangles, in tetrahedron order
+    uint32_t ttot;
+    const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
+    L.tfirst[wave][lane] = I.rec.z - tpre;   // triangle j of the wave goes to tfirst[cell] + j
+    uint32_t pos = tpre;
 #pragma unroll
     for (int t = 0; t < 6; t++) {
         const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
                              (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
         const uint32_t np = __popc(pat);
         const uint32_t nt = (ntri == 0u || ((tetskip >> t) & 1u)) ? 0u : ((np == 2u) ? 2u : (np & 1u));
-        nround[t / 3] += nt;
+        const uint32_t word = lane | (((uint32_t)t * 32u + pat * 2u + ((variants >> t) & 1u)) << 7);
+        if (nt >= 1u) L.slot[wave][pos] = (uint16_t)word;
+        if (nt == 2u) L.slot[wave][pos + 1u] = (uint16_t)(word | (1u << 6));
+        pos += nt;
     }
-    uint32_t ttot, T0, T1;
-    const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
-    const uint32_t pre0 = cx_wave_prefix_small<3>(nround[0], T0);
-    const uint32_t pre1 = cx_wave_prefix_small<3>(nround[1], T1);
-    const uint32_t tb0 = __builtin_amdgcn_readfirstlane(tri_first);   // lane 0 always has a record here
-    const bool contiguous = (T0 * 3u <= CX_K2_STAGE) && (T1 * 3u <= CX_K2_STAGE) &&
-                            __ballot(ntri != 0u && tri_first != tb0 + tpre) == 0ULL;
-    int32_t* stage = L.stage[wave];
-    int32_t* direct = P.tris + (size_t)tri_first * 3u;
-    // vertex index of every voxel edge (owner corner c1, direction d): first vertex of the owner +
-    // rank of d among the owner's crossing edges.  Static register indices; the table lives in LDS so
-    // that the runtime edge ids of the triangle LUT become one ds_read each.
+    __builtin_amdgcn_wave_barrier();
+    return ttot;
+}
+// phase 2, one lane per triangle: stores only
+__device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, uint32_t ttot) {
+    for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
+        const uint32_t j = j0 + lane;
+        const bool ok = j < ttot;
+        const uint32_t w = L.slot[wave][ok ? j : 0u];
+        const uint32_t cell = w & 63u;
+        const uint32_t tw = L.lut[((w >> 7) & 0xFFu) * 2u + ((w >> 6) & 1u)];
+        int32_t vi[3];
 #pragma unroll
-    for (int e = 0; e < 19; e++) {
-        const uint32_t c1 = CX_EDGE[e][0], d = CX_EDGE[e][1];
-        L.eidx[wave][e][lane] = (int32_t)(vfirst[c1] + __popc(em[c1] & ((1u << d) - 1u)));
-    }
-    const int32_t* eidx = &L.eidx[wave][0][lane];
-    // Branch-free expansion: per tetrahedron the LUT word names up to 2 triangles x 3 voxel edges; all six
-    // vertex indices are read from the LDS table back to back (unused slots name edge 0), then stored under
-    // a predicate -- no LDS round trip sits inside a data-dependent loop.
-    uint32_t wd = 0;   // running position of the direct path (per cell)
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-        uint32_t w = (g ? pre1 : pre0) * 3u;
-#pragma unroll
-        for (int tt = 0; tt < 3; tt++) {
-            const int t = g * 3 + tt;
-            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-            uint32_t e = L.lut[(t * 16 + pat) * 2 + ((variants >> t) & 1u)];
-            if (ntri == 0u || ((tetskip >> t) & 1u)) e = 0u;
-            const uint32_t n = e >> 30;
-            int32_t vi[6];
-#pragma unroll
-            for (uint32_t sidx = 0; sidx < 6; sidx++) vi[sidx] = eidx[((e >> (5u * sidx)) & 0x1Fu) * 64u];
-            if (contiguous) {
-                if (n >= 1u) { stage[w] = vi[0]; stage[w + 1u] = vi[1]; stage[w + 2u] = vi[2]; }
-                if (n == 2u) { stage[w + 3u] = vi[3]; stage[w + 4u] = vi[4]; stage[w + 5u] = vi[5]; }
-                w += 3u * n;
-            } else if (!(P.flags & CX_DBG_NO_TRIS)) {
-                if (n >= 1u) { direct[wd] = vi[0]; direct[wd + 1u] = vi[1]; direct[wd + 2u] = vi[2]; }
-                if (n == 2u) { direct[wd + 3u] = vi[3]; direct[wd + 4u] = vi[4]; direct[wd + 5u] = vi[5]; }
-                wd += 3u * n;
-            }
+        for (uint32_t sidx = 0; sidx < 3; sidx++) {
+            const uint32_t cd = (tw >> (6u * sidx)) & 63u;
+            const uint2 pr = L.ve[wave][cd & 7u][cell];
+            vi[sidx] = (int32_t)(pr.x + __popc(pr.y & ((1u << (cd >> 3)) - 1u)));
         }
-        if (contiguous && !(P.flags & CX_DBG_NO_TRIS)) {
-            int32_t* out = P.tris + ((size_t)tb0 + (g ? T0 : 0u)) * 3u;
-            const uint32_t total = (g ? T1 : T0) * 3u;
-            for (uint32_t o = lane; o < total; o += 64u) out[o] = stage[o];
+        if (ok && !(P.flags & CX_DBG_NO_TRIS)) {
+            int32_t* out = P.tris + ((size_t)L.tfirst[wave][cell] + j) * 3u;
+            out[0] = vi[0]; out[1] = vi[1]; out[2] = vi[2];
         }
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // one lane per cell record; waves walk the record array grid-stride (the record count lives on the device)
@@ -981,23 +991,27 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
-    if (threadIdx.x < 6 * 16 * 2) L.lut[threadIdx.x] = (&cx_d_tet_tris[0][0][0])[threadIdx.x];
+    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
     __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    uint4 c4 = make_uint4(0, 0, 0, 0);
-    if (idx < ncells) c4 = P.cells[idx];
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    cx_tri_in Ia, Ib;
+    cx_tri_fetch(P, hash_xy, (idx < ncells) ? P.cells[idx] : zero, Ia);
+    uint4 rec_b = (idx + stride < ncells) ? P.cells[idx + stride] : zero;
+    cx_tri_pin(Ia, rec_b);          // nothing is in flight when the loop is entered
     while (idx - lane < ncells) {   // wave-uniform
-        const bool have = idx < ncells;
-        const uint4 cur = c4;
-        const uint32_t nxt = idx + stride;
-        if (nxt < ncells) c4 = P.cells[nxt];   // next record in flight while this one is expanded
-        const uint32_t ntri = have ? ((cur.y >> 16) & 0xFFu) : 0u;
-        cx_cell_triangles(P, hash_xy, L, lane, wave, cur.x, cur.y & 0xFFu, (cur.y >> 8) & 0x3Fu, ntri, cur.z, cur.w, cur.y >> 24);
-        __builtin_amdgcn_wave_barrier();
-        idx = nxt;
+        const uint32_t nidx = idx + stride;
+        cx_tri_fetch(P, hash_xy, rec_b, Ib);                                    // loads of the next record ...
+        uint4 rec_c = (nidx + stride < ncells) ? P.cells[nidx + stride] : zero;   // ... and the record after it
+        const uint32_t ttot = cx_tri_phase1(P, L, lane, wave, Ia);
+        cx_tri_pin(Ib, rec_c);                                                  // ... are back before the stores go out
+        cx_tri_phase2(P, L, lane, wave, ttot);
+        Ia = Ib;
+        rec_b = rec_c;
+        idx = nidx;
     }
 }
 

@@ -41,6 +41,7 @@ print("counts", c)
 res = {name: [] for name, _ in VARIANTS}
 for rnd in range(args.rounds):
     for name, fl in VARIANTS:
+        print("round", rnd, name, flush=True)
         fl = 0 if fl == -1 else (1 | fl)
         ctx.extract3d_async(0.0, fl)       # warm
         ctx.timing_enable(True)

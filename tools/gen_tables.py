@@ -183,6 +183,28 @@ def main(out_path):
         a("  {" + ",".join(rows) + "}, \\")
     a("}")
     a("")
+    a("// [tet][pattern][variant][triangle] : 3 x 6 bits (owner corner c1 | direction d << 3) of the triangle's")
+    a("// voxel edges, wound like CX_TET_TRIS_INIT; bits 30..31 of both words: triangle count of the entry")
+    a("#define CX_TET_TRIS_CD_INIT { \\")
+    for t in TETS:
+        rows = []
+        for p in range(16):
+            ent = []
+            for v in range(2):
+                tris = tet_entry(t, p, v)
+                words = []
+                for n in range(2):
+                    w = len(tris) << 30
+                    if n < len(tris):
+                        for s_, eid in enumerate(tris[n]):
+                            c1, d = EDGES[eid]
+                            w |= (c1 | (d << 3)) << (6 * s_)
+                    words.append("0x%xu" % w)
+                ent.append("{" + ",".join(words) + "}")
+            rows.append("{" + ",".join(ent) + "}")
+        a("  {" + ",".join(rows) + "}, \\")
+    a("}")
+    a("")
     # per-voxel triangle count (no tolerance skips): sign mask bit c set <=> corner c low
     for mask in range(256):
         n = 0

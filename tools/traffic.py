@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 PMC passes of tools/pmc.sh into profiles/traffic.json (HBM bytes per launch of the
-classify and emit kernels, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB-like
+Level-0 kernels, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB-like
 units of 1024 B; on gfx950 FETCH_SIZE counts wide coalesced streaming reads at half their bytes)."""
 import collections, csv, glob, json, os, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
@@ -13,20 +13,20 @@ for name in ("fetch", "write"):
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in acc.items():
-            kk = "classify" if "cx_k_classify" in k else ("emit" if "cx_k_emit_triangles" in k else None)
-            if kk:
+            kk = k.split("(")[0].strip()
+            if kk.startswith("cx_k_"):
                 vals[kk][c] = sum(v[1:]) / max(len(v) - 1, 1)
 for kk, d in vals.items():
     fetch_raw = d.get("FETCH_SIZE", 0.0) * 1024.0
     write = d.get("WRITE_SIZE", 0.0) * 1024.0
     out[kk + "_512"] = {
         "fetch_bytes_raw": fetch_raw, "write_bytes": write,
-        # classify: the streamed grid is read with 16-B-per-lane loads (counted at 1/2); the rest of its reads are
-        # 8-byte gathers whose calibration is unknown, so both bounds are given
+        # 16-B-per-lane streaming loads (grid rows, cell records) are counted at 1/2; narrower gathers are
+        # uncalibrated, so both bounds are given
         "hbm_bytes_low": fetch_raw + write, "hbm_bytes_high": 2.0 * fetch_raw + write,
         "note": "FETCH_SIZE*1024 (+ x2 upper bound for 16-B/lane streams on gfx950) + WRITE_SIZE*1024, mean of launches 2..N",
     }
 json.dump(out, open("profiles/traffic_detail.json", "w"), indent=1)
-# the number bench.py reports as roofline.traffic: upper-bound HBM bytes of the classify kernel per launch
-json.dump({"classify_512": out.get("classify_512", {}).get("hbm_bytes_high")}, open("profiles/traffic.json", "w"))
+# the numbers bench.py reports as roofline.traffic: upper-bound HBM bytes per launch, per kernel
+json.dump({k: v["hbm_bytes_high"] for k, v in out.items()}, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
