@@ -142,130 +142,146 @@ __device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t
 // the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
 // entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
 // one coalesced 16-byte store) -- no divergent per-direction loop.
-// store flavours (A/B): CX_NT_* = nontemporal
-typedef float cx_v4f __attribute__((ext_vector_type(4)));
-typedef uint32_t cx_v4u __attribute__((ext_vector_type(4)));
-#ifdef CX_NT_VERTS
-#define CX_STORE_VERT(ptr, val) __builtin_nontemporal_store(cx_v4f{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4f*>(ptr))
-#else
-#define CX_STORE_VERT(ptr, val) (*(ptr) = (val))
-#endif
-#ifdef CX_NT_TAB
-#define CX_STORE_TAB(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define CX_STORE_TAB(ptr, val) (*(ptr) = (val))
-#endif
-#ifdef CX_NT_CELLS
-#define CX_STORE_CELL(ptr, val) __builtin_nontemporal_store(cx_v4u{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4u*>(ptr))
-#else
-#define CX_STORE_CELL(ptr, val) (*(ptr) = (val))
-#endif
-#ifdef CX_S3_STAMPS   // diagnostic build: where a vertex-stage wave spends its time (tools/stamps3.py)
-#define CX_T(k) { asm volatile("" ::: "memory"); const unsigned long long now__ = __builtin_amdgcn_s_memtime(); if (tacc) tacc[k] += now__ - tlast__; tlast__ = __builtin_amdgcn_s_memtime(); }
-#define CX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define CX_T(k)
-#define CX_DRAIN()
-#endif
-__device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
-                                                   uint32_t lane, cx_run run, uint32_t* slot, const uint8_t* ntri_lut,
-                                                   unsigned long long* tacc = nullptr) {
-#ifdef CX_S3_STAMPS
-    unsigned long long tlast__ = __builtin_amdgcn_s_memtime();
-#endif
+// one round of 64 queued cells, as the vertex stage carries it from its front half (decode, prefix
+// sums, slot table, sample loads issued) to its back half (interpolation, stores)
+struct cx_vround {
+    uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, ctot, real_voxel;
+    uint64_t recm;
+    cx_run base;                       // first vertex / triangle / record of the round
+    uint32_t e2[CX_VR], sl[CX_VR];     // per vertex of the first CX_VR x 64: source cell entry, slot word
+    float f0[CX_VR], f1[CX_VR];        // ... and its two samples
+    uint32_t e_next;                   // entries of the following round
+};
+__device__ __forceinline__ void cx_vround_front(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n, uint32_t b0,
+                                                uint32_t lane, uint32_t e, const cx_run& base, uint32_t* slot,
+                                                const uint8_t* ntri_lut, cx_vround& R) {
     const float* __restrict__ A = P.grid;
     const uint32_t plane = P.n1 * P.n2;
-    uint32_t e_next = (lane < n) ? q[lane] : 0u;
-    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
-        const uint32_t idx = b0 + lane;
-        const bool have = idx < n;
-        CX_DRAIN(); CX_T(0)   // entries of this round (requested one round ago) + drain of the previous stores
-        const uint32_t e = e_next;
-        e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
-        uint32_t i, j, k;
-        cx_decode_entry(P, G, e, i, j, k);
-        const uint32_t lin = (i * P.n1 + j) * P.n2 + k;
-        const uint32_t sm = cx_entry_signs(e);
-        const uint32_t vm = cx_corner_valid(P, i, j, k);
-        const bool real_voxel = have && (vm == 0xFFu);
-        const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
-        const uint32_t emask = have ? (((sm ^ s0) & vm) & 0xFEu) : 0u;
-        const uint32_t ntri = real_voxel ? (uint32_t)ntri_lut[sm] : 0u;
-        const uint32_t nv = __popc(emask);
-        const bool rec = (nv | ntri) != 0u;
-        uint32_t vtot, ttot;
-        const uint32_t vpre = cx_wave_prefix_small<3>(nv, vtot);
-        const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
-        const uint64_t recm = __ballot(rec);
-        const uint32_t ctot = (uint32_t)__popcll(recm);
-        const uint32_t vfirst = run.v + vpre;
-        // all loads of this round are issued before its stores: vmcnt retires in issue order, so a
-        // load behind a store would wait for the store's round trip
-        if (run.v + vtot <= P.vcap) {   // wave-uniform
-            // vertex o of this batch (o = vpre + rank of d in emask) -> (cell lane, direction d)
+    const uint32_t idx = b0 + lane;
+    const bool have = idx < n;
+    R.e = e;
+    R.e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+    uint32_t i, j, k;
+    cx_decode_entry(P, G, e, i, j, k);
+    R.lin = (i * P.n1 + j) * P.n2 + k;
+    R.sm = cx_entry_signs(e);
+    const uint32_t vm = cx_corner_valid(P, i, j, k);
+    R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
+    const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
+    R.emask = have ? (((R.sm ^ s0) & vm) & 0xFEu) : 0u;
+    R.ntri = R.real_voxel ? (uint32_t)ntri_lut[R.sm] : 0u;
+    const uint32_t nv = __popc(R.emask);
+    R.vpre = cx_wave_prefix_small<3>(nv, R.vtot);
+    R.tpre = cx_wave_prefix_small<4>(R.ntri, R.ttot);
+    R.recm = __ballot((nv | R.ntri) != 0u);
+    R.ctot = (uint32_t)__popcll(R.recm);
+    R.base = base;
+    // vertex o of this round (o = vpre + rank of d in emask) -> (cell lane, direction d)
 #pragma unroll
-            for (uint32_t d = 1; d < 8; d++)
-                if ((emask >> d) & 1u) slot[vpre + __popc(emask & ((1u << d) - 1u))] = (lane << 3) | d;
-            __builtin_amdgcn_wave_barrier();
-            CX_T(1)   // decode, prefix sums, slot table
-            // all lanes stay active in this loop (the shuffles read any lane); up to CX_VR rounds of 64
-            // vertices have their sample loads in flight together
-            for (uint32_t o0 = 0; o0 < vtot; o0 += 64u * CX_VR) {
-                uint32_t e2[CX_VR], sl[CX_VR];
-                float f0[CX_VR], f1[CX_VR];
+    for (uint32_t d = 1; d < 8; d++)
+        if ((R.emask >> d) & 1u) slot[R.vpre + __popc(R.emask & ((1u << d) - 1u))] = (lane << 3) | d;
+    __builtin_amdgcn_wave_barrier();
+    // sample loads of the first CX_VR x 64 vertices (all lanes stay active: the shuffles read any lane)
 #pragma unroll
-                for (uint32_t r = 0; r < CX_VR; r++) {
-                    if (o0 + 64u * r >= vtot) break;   // wave-uniform
-                    const uint32_t o = o0 + 64u * r + lane;
-                    sl[r] = slot[(o < vtot) ? o : 0u];
-                    e2[r] = (uint32_t)__shfl((int)e, (int)(sl[r] >> 3));
-                    const uint32_t d = sl[r] & 7u;
-                    const uint32_t lin2 = cx_entry_lin(P, G, e2[r]);
-                    if (P.flags & CX_DBG_NO_VLOADS) {
-                        f0[r] = -1.0f; f1[r] = (float)lin2;
-                    } else {
-                        f0[r] = A[lin2];
-                        f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
-                    }
-                }
-                CX_T(2)   // sample loads issued
-                CX_DRAIN(); CX_T(3)   // sample loads back
-#pragma unroll
-                for (uint32_t r = 0; r < CX_VR; r++) {
-                    if (o0 + 64u * r >= vtot) break;
-                    const uint32_t o = o0 + 64u * r + lane;
-                    const uint32_t d = sl[r] & 7u;
-                    uint32_t i2, j2, k2;
-                    cx_decode_entry(P, G, e2[r], i2, j2, k2);
-                    const uint32_t lin2 = (i2 * P.n1 + j2) * P.n2 + k2;
-                    // same arithmetic as cx_emit_vertices; |f1 - f0| > 8e-8 here (both ends outside the screen)
-                    const float t = __fdividef((P.vhi - f0[r]) + P.vlo, f1[r] - f0[r]);
-                    const float fi = (float)i2, fj = (float)j2, fk = (float)k2;
-                    float4 rec4;
-                    rec4.x = (d & 4u) ? fi + t : fi;
-                    rec4.y = (d & 2u) ? fj + t : fj;
-                    rec4.z = (d & 1u) ? fk + t : fk;
-                    rec4.w = __uint_as_float((lin2 << 3) | d);
-                    if (o < vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[run.v + o], rec4);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) CX_STORE_TAB(&P.celltab[lin], ((uint64_t)emask << 32) | (uint64_t)vfirst);
+    for (uint32_t r = 0; r < CX_VR; r++) {
+        R.sl[r] = 0; R.e2[r] = 0; R.f0[r] = 0.0f; R.f1[r] = 1.0f;
+        if (64u * r >= R.vtot) continue;   // wave-uniform
+        const uint32_t o = 64u * r + lane;
+        R.sl[r] = slot[(o < R.vtot) ? o : 0u];
+        R.e2[r] = (uint32_t)__shfl((int)e, (int)(R.sl[r] >> 3));
+        const uint32_t d = R.sl[r] & 7u;
+        const uint32_t lin2 = cx_entry_lin(P, G, R.e2[r]);
+        if (P.flags & CX_DBG_NO_VLOADS) {
+            R.f0[r] = -1.0f; R.f1[r] = (float)lin2;
+        } else {
+            R.f0[r] = A[lin2];
+            R.f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
         }
-        if (rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
-            uint4 c4;
-            c4.x = lin;
-            c4.y = sm | ((real_voxel ? 0u : 0x3Fu) << 8) | (ntri << 16) | (emask << 24);
-            c4.z = run.t + tpre;
-            c4.w = vfirst;
-            CX_STORE_CELL(&P.cells[run.c + cx_mbcnt(recm)], c4);
-        }
-        run.v += vtot; run.t += ttot; run.c += ctot;
-        CX_T(4)   // interpolation, stores issued
     }
-#ifdef CX_S3_STAMPS
-    if (tacc) tacc[6] += (n + 63u) / 64u;
-#endif
+}
+// the loads issued by the front half have to be complete here
+__device__ __forceinline__ void cx_vround_pin(cx_vround& R) {
+#pragma unroll
+    for (uint32_t r = 0; r < CX_VR; r++) asm volatile("" : "+v"(R.f0[r]), "+v"(R.f1[r]) :: "memory");
+    asm volatile("" : "+v"(R.e_next) :: "memory");
+}
+__device__ __forceinline__ float4 cx_vertex_record(const cx_params& P, const cx_fast_geom& G, uint32_t e2, uint32_t d, float f0, float f1) {
+    uint32_t i2, j2, k2;
+    cx_decode_entry(P, G, e2, i2, j2, k2);
+    const uint32_t lin2 = (i2 * P.n1 + j2) * P.n2 + k2;
+    // same arithmetic as cx_emit_vertices; |f1 - f0| > 8e-8 here (both ends outside the screen)
+    const float t = __fdividef((P.vhi - f0) + P.vlo, f1 - f0);
+    const float fi = (float)i2, fj = (float)j2, fk = (float)k2;
+    float4 rec4;
+    rec4.x = (d & 4u) ? fi + t : fi;
+    rec4.y = (d & 2u) ? fj + t : fj;
+    rec4.z = (d & 1u) ? fk + t : fk;
+    rec4.w = __uint_as_float((lin2 << 3) | d);
+    return rec4;
+}
+
+// vertex records, per-cell table entries and cell records of n queued cells, common case (no sample of
+// the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
+// entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
+// one coalesced 16-byte store) -- no divergent per-direction loop.  Rounds of 64 cells are software-
+// pipelined: the sample loads of round s+1 are issued, and waited for, before the stores of round s go
+// out (`s_waitcnt vmcnt` retires loads and stores in issue order: a load behind a store waits for it).
+__device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
+                                                   uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut) {
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+    cx_vround Ra, Rb;
+    uint32_t e0 = (lane < n) ? q[lane] : 0u;
+    asm volatile("" : "+v"(e0) :: "memory");
+    cx_vround_front(P, G, q, n, 0u, lane, e0, run, slot2, ntri_lut, Ra);
+    cx_vround_pin(Ra);
+    uint32_t par = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+        const bool more = b0 + 64u < n;   // wave-uniform
+        if (more) {
+            cx_run nb = Ra.base;
+            nb.v += Ra.vtot; nb.t += Ra.ttot; nb.c += Ra.ctot;
+            cx_vround_front(P, G, q, n, b0 + 64u, lane, Ra.e_next, nb, slot2 + (par ^ 1u) * 448u, ntri_lut, Rb);
+        }
+        // back half of round b0: interpolate what is loaded ...
+        const bool vroom = Ra.base.v + Ra.vtot <= P.vcap;   // wave-uniform
+        float4 rec4[CX_VR];
+#pragma unroll
+        for (uint32_t r = 0; r < CX_VR; r++) rec4[r] = cx_vertex_record(P, G, Ra.e2[r], Ra.sl[r] & 7u, Ra.f0[r], Ra.f1[r]);
+        if (more) cx_vround_pin(Rb);
+        // ... then the stores
+        if (vroom) {
+#pragma unroll
+            for (uint32_t r = 0; r < CX_VR; r++) {
+                const uint32_t o = 64u * r + lane;
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[Ra.base.v + o] = rec4[r];
+            }
+            const uint32_t* slot = slot2 + par * 448u;
+            for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
+                const uint32_t o = o0 + lane;
+                const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
+                const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)(sl >> 3));
+                const uint32_t d = sl & 7u;
+                const uint32_t lin2 = cx_entry_lin(P, G, e2);
+                const float f0 = A[lin2];
+                const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
+                const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[Ra.base.v + o] = r4;
+            }
+            if (Ra.emask && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[Ra.lin] = ((uint64_t)Ra.emask << 32) | (uint64_t)(Ra.base.v + Ra.vpre);
+        }
+        if ((Ra.emask | Ra.ntri) != 0u && Ra.base.c + Ra.ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            uint4 c4;
+            c4.x = Ra.lin;
+            c4.y = Ra.sm | ((Ra.real_voxel ? 0u : 0x3Fu) << 8) | (Ra.ntri << 16) | (Ra.emask << 24);
+            c4.z = Ra.base.t + Ra.tpre;
+            c4.w = Ra.base.v + Ra.vpre;
+            P.cells[Ra.base.c + cx_mbcnt(Ra.recm)] = c4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) Ra = Rb;
+        par ^= 1u;
+    }
 }
 
 // vertex / triangle / record / border counts of an active cell from its sign mask alone -- exact
@@ -455,11 +471,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     uint32_t ql = 0, qflushed = 0;      // wave-uniform: entries staged / already in global memory
     uint32_t nbl = 0, nbflushed = 0;    // the same for batch records
     const uint32_t w = b * 4u + wave;
-#ifdef CX_S3_STAMPS
-    unsigned long long* stamp = nullptr;   // the buffer belongs to the vertex stage in this build
-#else
     unsigned long long* stamp = P.stamps ? P.stamps + (size_t)w * 4u : nullptr;
-#endif
     if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     const cx_tile tile = cx_tile_of(P, T, b, wave);
     const uint32_t k0 = tile.k0, j0 = tile.j0, ib = tile.ib, nrows = tile.nrows;
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
 
 // ---- S2: exclusive scan of the per-wave totals (one workgroup of 16 waves; coalesced loads of
 // CX_SC chunks of 1024 waves at a time), output offsets per wave, the flat batch list, the counters.
-#define CX_SC 4
+#define CX_SC 12
 // inclusive prefix sum over the wave with DPP row shifts / broadcasts (no LDS crossbar round trips)
 __device__ __forceinline__ uint32_t cx_wave_incl_scan(uint32_t x, uint32_t lane) {
     (void)lane;
@@ -770,19 +782,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_vertices(const cx_params P, con
         const uint32_t* __restrict__ q = P.queue + D.qofs;
         cx_run run;
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
-#ifdef CX_S3_STAMPS
-        unsigned long long tloc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const unsigned long long tb__ = __builtin_amdgcn_s_memtime();
-        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, tloc);
-        if (P.stamps && lane == 0) {
-            unsigned long long* dst = P.stamps + ((size_t)(blockIdx.x * 4u + wave)) * 8u;
-            for (int k = 0; k < 7; k++) dst[k] += tloc[k];
-            dst[5] += __builtin_amdgcn_s_memtime() - tb__;   // whole batch
-            dst[7] += 1;                                      // batches
-        }
-#else
         if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri);
-#endif
         else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave]);
         if (fn >= nbatches) break;
         f = fn;
