@@ -4,7 +4,7 @@
 // A cell OWNS the 7 lattice edges q -> q+d, d = 4di+2dj+dk in 1..7, and (when all 8 corners are
 // inside the array) the 6 Kuhn tetrahedra of its voxel.  Vertex id of an edge = (lin(q) << 3) | d.
 //
-// Staged pipeline (rows of n2 % 4 == 0 samples, 16-byte aligned grid) -- no atomics, no barriers:
+// Staged pipeline (any grid with n2 >= 4) -- no atomics, no barriers:
 //   S1  cx_k_stream            one pass over the samples: sign bits packed per lane, active cells (sign
 //                              change among the 8 corners) appended to a per-wave queue in global memory
 //                              as packed entries; the queue is cut into batches of >= CX_BATCH_MIN cells
@@ -15,7 +15,7 @@
 //                              cell records.
 //   K2  cx_k_emit_triangles    one lane per cell record: expands the tetrahedra into index triples, looking
 //                              vertex indices up in the per-cell table.
-// Any other shape: cx_k_classify_generic (one lane per cell, LDS queue, one reservation atomic per
+// Rows shorter than 4 samples, or on request (CX_KERNEL_GENERIC): cx_k_classify_generic (one lane per cell, LDS queue, one reservation atomic per
 // workgroup and counter -- same-address atomics saturate near 88/us on MI355X) followed by K2.
 #include <cstdlib>
 
@@ -460,6 +460,10 @@ __device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task&
 // second wait for the store's round trip (measured: +45 % kernel time with one store per active step).
 #define CX_SQ 1024u     // queue entries a wave stages (one step adds at most 1024)
 #define CX_SBR 32u      // batch records a wave stages
+// ALIGNED: n2 % 4 == 0 and a 16-byte aligned grid (rows start on 16-byte boundaries, every lane holds 4 samples
+// of one row).  Otherwise the 16-byte loads are only 4-byte aligned and the lane that holds the end of a row
+// loads the row's last 4 samples and shifts them into place, repeating the last one (a clamped corner).
+template <bool ALIGNED>
 __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
@@ -517,15 +521,18 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     };
     if (nrows != 0u && p < ib) {
         const uint32_t kofs = k0 + 4u * lane;
-        const bool lane_valid = kofs < P.n2;                      // n2 % 4 == 0
-        const uint32_t kofs_c = lane_valid ? kofs : (P.n2 - 4u);
+        const bool lane_valid = kofs < P.n2;
+        const uint32_t nvalid = lane_valid ? min(4u, P.n2 - kofs) : 0u;   // samples of the row this lane holds (ALIGNED: 4 or 0)
+        const uint32_t kofs_c = (nvalid == 4u) ? kofs : (P.n2 - 4u);      // other lanes (re-)read the row's last 4 samples
+        const uint32_t kshift = kofs - kofs_c;                            // ... and shift them into place (1..3; garbage for lanes off the row)
         const uint32_t last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
         const bool halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
         // cells whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
         uint32_t mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
+        if (!ALIGNED) mr &= cx_rowmask(CX_RJ, 1u) * ((1u << nvalid) - 1u);   // cells that exist in this lane
         if (!lane_valid) mr = 0;   // lanes right of the array hold re-read samples: they own no cells
         uint32_t mk = mr;
-        if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << 3);       // m == 3 at the array edge
+        if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << (nvalid - 1u));   // the last sample of the row has no k+1
         uint32_t mj = 0;
         for (uint32_t r = 0; r < CX_RJ; r++)
             if (j0 + r + 1u < P.n1) mj |= 0xFu << (CX_ROWBITS * r);
@@ -552,7 +559,14 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
             uint32_t own = 0, halo = 0;
 #pragma unroll
             for (int r = 0; r <= CX_RJ; r++) {
-                const float dx = R.v[r].x - P.vcmp, dy = R.v[r].y - P.vcmp, dz = R.v[r].z - P.vcmp, dw = R.v[r].w - P.vcmp;
+                float vx = R.v[r].x, vy = R.v[r].y, vz = R.v[r].z;
+                const float vw = R.v[r].w;
+                if (!ALIGNED) {   // lane at the end of the row: samples kofs.. of (n2-4 .. n2-1), the last one repeated
+                    vx = (kshift == 1u) ? vy : ((kshift == 2u) ? vz : ((kshift == 3u) ? vw : vx));
+                    vy = (kshift == 0u) ? vy : ((kshift == 1u) ? vz : vw);
+                    vz = (kshift == 0u) ? vz : vw;
+                }
+                const float dx = vx - P.vcmp, dy = vy - P.vcmp, dz = vz - P.vcmp, dw = vw - P.vcmp;
                 const float dh = R.hv[r] - P.vcmp;
                 own |= (__float_as_uint(dx) >> 31) << (CX_ROWBITS * r + 0);
                 own |= (__float_as_uint(dy) >> 31) << (CX_ROWBITS * r + 1);
@@ -1017,7 +1031,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, co
 
 // ---- launchers --------------------------------------------------------------------------------------
 bool cx_fast_classify_supported(const cx_params& P) {
-    return (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
+    return P.n2 >= 4u && ((reinterpret_cast<uintptr_t>(P.grid) & 3u) == 0u);   // a lane loads 4 samples of one row
 }
 
 cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
@@ -1043,7 +1057,9 @@ cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
 }
 
 void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
-    hipLaunchKernelGGL(cx_k_stream, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
+    const bool aligned = (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
+    if (aligned) hipLaunchKernelGGL(cx_k_stream<true>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
+    else hipLaunchKernelGGL(cx_k_stream<false>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
 }
 
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {

@@ -89,6 +89,27 @@ def test_random_fields_ragged_shapes(ctx, shape, seed):
         check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310, 1)
 
 
+@pytest.mark.parametrize("shape,seed", [((6, 5, 4), 11), ((6, 5, 5), 12), ((6, 5, 6), 13), ((6, 5, 7), 14), ((9, 6, 257), 15),
+                                        ((5, 9, 258), 16), ((4, 5, 259), 17), ((3, 18, 513), 18), ((20, 20, 255), 19)])
+def test_rows_not_multiple_of_four(ctx, shape, seed):
+    """rows whose length is not a multiple of 4 (16-byte loads only 4-byte aligned, the lane at the end of a row
+    shifts its samples into place), one to three k-segments"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal(shape).astype(np.float32)
+    check_against_oracle(ctx, A, 0.1, _ffi.CX_DIAG_CPYTHON310, 1)
+    check_against_oracle(ctx, A, 0.1, _ffi.CX_DIAG_CANONICAL, 0)
+
+
+@pytest.mark.parametrize("shape,seed", [((5, 7, 9), 21), ((17, 16, 65), 22), ((33, 31, 64), 23), ((20, 20, 255), 24)])
+def test_generic_kernel_on_request(ctx, shape, seed):
+    """the shape-agnostic classify kernel (rows shorter than 4 samples need it; CX_KERNEL_GENERIC forces it)"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal(shape).astype(np.float32)
+    check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_GENERIC, 1)
+
+
 def test_empty_and_full(ctx):
     from contourist_amd import _ffi
     A = np.ones((8, 8, 8), dtype=np.float32)
