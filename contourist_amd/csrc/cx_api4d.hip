@@ -20,7 +20,7 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz};
+    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits};
     for (void* p : all)
         if (p) (void)hipFree(p);
     delete S;
@@ -158,7 +158,24 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
             }
         }
         P.hash_xyz = S->hash_xyz;
+        P.nw3 = (P.n3 + 31u) / 32u;
+        P.nrows = P.n0 * P.n1 * P.n2;
+        P.div_w = cx_fdiv_make(P.nw3);
+        P.div_r2 = cx_fdiv_make(P.n1 * P.n2);
+        P.div_r1 = cx_fdiv_make(P.n2);
+        {
+            const size_t need = (size_t)P.nrows * P.nw3 + 64u;
+            if (S->signbits_cap < need) {
+                CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (S->signbits) (void)hipFree(S->signbits);
+                S->signbits = nullptr; S->signbits_cap = 0;
+                CX4_HIP(ctx, hipMalloc(&S->signbits, need * sizeof(uint32_t)));
+                S->signbits_cap = need;
+            }
+            P.signbits = S->signbits;
+        }
         CX4_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
+        cx_launch_signbits4d(P, ctx->stream);
         cx_launch_classify4d(P, ctx->stream);
         cx_launch_emit_tets(P, ctx->stream);
         CX4_HIP(ctx, hipGetLastError());

@@ -21,6 +21,16 @@
 #include "cx_tables4d.h"
 
 __device__ constexpr uint8_t CX_PC[24][5] = CX_PENT_CORNERS_INIT;
+// inclusive prefix sum over the wave (DPP row shifts / broadcasts)
+__device__ __forceinline__ uint32_t cx_wave_incl_scan4(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
 #define CX_PENT_MASK(n) (uint32_t)((1u << CX_PC[n][0]) | (1u << CX_PC[n][1]) | (1u << CX_PC[n][2]) | (1u << CX_PC[n][3]) | (1u << CX_PC[n][4]))
 
 __device__ __forceinline__ void cx_unravel4(const cx_params4& P, uint32_t lin, uint32_t q[4]) {
@@ -142,7 +152,7 @@ __device__ __forceinline__ cx_cell4 cx_classify_cell4(const cx_params4& P, const
     return R;
 }
 
-#define CX4_QCAP 1024u
+#define CX4_QCAP 2048u   // one step of the classify kernel adds at most 64 x 32 cells
 
 struct cx_run4 {
     uint32_t v, t, c, b;
@@ -214,7 +224,38 @@ __device__ __forceinline__ void cx_process_queue4(const cx_params4& P, const uin
     }
 }
 
-__global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const uint32_t cells_per_block) {
+// ---- sign bitmap: one pass over the samples at streaming speed.  A wave takes 8 consecutive chunks of
+// 64 samples of a row (8 loads in flight); a chunk's 64 comparison results are one ballot = 2 words.
+__global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const uint32_t nchunk, const uint32_t nchunks_total) {
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c0 = wave * 8u;
+    if (c0 >= nchunks_total) return;
+    const float* __restrict__ A = P.grid;
+    float f[8];
+    bool ok[8];
+    uint32_t row[8], ch[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) {
+        const uint32_t c = min(c0 + u, nchunks_total - 1u);
+        row[u] = c / nchunk;
+        ch[u] = c - row[u] * nchunk;
+        const uint32_t l = ch[u] * 64u + lane;
+        ok[u] = l < P.n3;
+        f[u] = ok[u] ? A[(size_t)row[u] * P.n3 + l] : 0.0f;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) {
+        const uint64_t m = __ballot(ok[u] && f[u] < P.vcmp);
+        if (c0 + u < nchunks_total && lane < 2u && 2u * ch[u] + lane < P.nw3)
+            P.signbits[(size_t)row[u] * P.nw3 + 2u * ch[u] + lane] = lane ? (uint32_t)(m >> 32) : (uint32_t)m;
+    }
+}
+
+// ---- classify: phase A finds the active cells (sign change among the 16 clamped corners) from the sign
+// bitmap, 32 cells per lane with word-wide OR / AND over the 8 rows of a hyper-voxel and over (l, l+1);
+// phase B re-reads the corners of the queued cells only (a fraction of a percent of the grid).
+__global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const uint32_t items_per_block) {
     __shared__ uint32_t s_queue[4][CX4_QCAP];
     __shared__ uint32_t s_tot[4][4];
     __shared__ uint32_t s_base[4];
@@ -222,26 +263,53 @@ __global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* qq = s_queue[wave];
     uint32_t qn = 0;
-    uint32_t gbase = blockIdx.x * cells_per_block + wave * 64u;
-    const uint32_t gend = min(blockIdx.x * cells_per_block + cells_per_block, P.nsamples);
+    const uint32_t nitems = P.nrows * P.nw3;   // one item = one bitmap word = 32 cells of one row
+    uint32_t gbase = blockIdx.x * items_per_block + wave * 64u;
+    const uint32_t gend = min(blockIdx.x * items_per_block + items_per_block, nitems);
     bool streaming = gbase < gend;
+    const uint32_t* __restrict__ W = P.signbits;
+    const uint32_t s2 = P.nw3, s1 = P.n2 * P.nw3, s0 = P.n1 * P.n2 * P.nw3;
     for (;;) {
-        while (streaming && qn + 64u <= CX4_QCAP) {
-            const uint32_t lin = gbase + lane;
-            const bool in = lin < gend;
-            const uint32_t linc = in ? lin : (P.nsamples - 1u);
-            uint32_t q[4];
-            cx_unravel4(P, linc, q);
-            float f[16];
-            const uint32_t vm = cx_load_corners4(P, linc, q, f);
-            uint32_t sm = 0;
+        while (streaming) {
+            const uint32_t idx = gbase + lane;
+            const bool in = idx < gend;
+            const uint32_t ic = in ? idx : (nitems - 1u);
+            const uint32_t row = cx_div(ic, P.div_w);
+            const uint32_t lw = ic - row * P.nw3;
+            const uint32_t i = cx_div(row, P.div_r2);
+            const uint32_t r = row - i * (P.n1 * P.n2);
+            const uint32_t j = cx_div(r, P.div_r1);
+            const uint32_t k = r - j * P.n2;
+            const uint32_t o0 = (i + 1u < P.n0) ? s0 : 0u, o1 = (j + 1u < P.n1) ? s1 : 0u, o2 = (k + 1u < P.n2) ? s2 : 0u;
+            const bool more = lw + 1u < P.nw3;   // the row goes on in the next word
+            // bit positions of this word that are lattice points, and the one whose l+1 does not exist
+            const uint32_t left = P.n3 - lw * 32u;
+            const uint32_t valid = (left >= 32u) ? 0xFFFFFFFFu : ((1u << left) - 1u);
+            const uint32_t edge = (left <= 32u) ? (1u << (left - 1u)) : 0u;
+            uint32_t any = 0, all = 0xFFFFFFFFu;
 #pragma unroll
-            for (int c = 0; c < 16; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
-            const uint32_t smv = sm & vm;
-            const bool active = in && smv != 0u && smv != vm;
-            const uint64_t act = __ballot(active);
-            if (active) qq[qn + cx_mbcnt(act)] = lin;
-            qn += (uint32_t)__popcll(act);
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t at = ic + ((c & 4u) ? o0 : 0u) + ((c & 2u) ? o1 : 0u) + ((c & 1u) ? o2 : 0u);
+                const uint32_t w = W[at];
+                const uint32_t nx = more ? W[at + 1u] : 0u;
+                uint32_t sh = (w >> 1) | (nx << 31);          // the samples at l+1
+                sh = (sh & ~edge) | (w & edge);               // clamped at the end of the row
+                any |= w | sh;
+                all &= w & sh;
+            }
+            uint32_t act = in ? (any & ~all & valid) : 0u;
+            const uint32_t cnt = __popc(act);
+            const uint32_t incl = cx_wave_incl_scan4(cnt);
+            const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+            if (qn + tot > CX4_QCAP) break;                   // wave-uniform: emit what is queued, then redo this step
+            uint32_t pos = qn + incl - cnt;
+            const uint32_t lin0 = row * P.n3 + lw * 32u;
+            while (act) {
+                const uint32_t bit = __ffs(act) - 1u;
+                act &= act - 1u;
+                qq[pos++] = lin0 + bit;
+            }
+            qn += tot;
             gbase += 256u;
             streaming = gbase < gend;
         }
@@ -432,12 +500,19 @@ const uint64_t* cx_pent_lut_device() {
     return (const uint64_t*)p;
 }
 
+void cx_launch_signbits4d(const cx_params4& P, hipStream_t s) {
+    const uint32_t nchunk = (P.n3 + 63u) / 64u;
+    const uint32_t total = P.nrows * nchunk;
+    const uint32_t waves = (total + 7u) / 8u;
+    hipLaunchKernelGGL(cx_k_signbits4, dim3((waves + 3u) / 4u), dim3(256), 0, s, P, nchunk, total);
+}
 void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
-    uint32_t cpb = (P.nsamples + 3071u) / 3072u;
-    cpb = (cpb + 255u) & ~255u;
-    if (cpb < 4096u) cpb = 4096u;
-    const uint32_t blocks = (P.nsamples + cpb - 1u) / cpb;
-    hipLaunchKernelGGL(cx_k_classify4d, dim3(blocks), dim3(256), 0, s, P, cpb);
+    const uint32_t nitems = P.nrows * P.nw3;
+    uint32_t ipb = (nitems + 3071u) / 3072u;
+    ipb = (ipb + 255u) & ~255u;
+    if (ipb < 256u) ipb = 256u;
+    const uint32_t blocks = (nitems + ipb - 1u) / ipb;
+    hipLaunchKernelGGL(cx_k_classify4d, dim3(blocks), dim3(256), 0, s, P, ipb);
 }
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s) {
     const uint32_t blocks = (P.ccap + 255u) / 256u;

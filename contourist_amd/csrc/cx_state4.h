@@ -19,7 +19,13 @@ struct cx_params4 {
     uint32_t* counters;
     const uint64_t* hash_xyz;
     const uint64_t* lut;
+    // sign bitmap: bit l%32 of word [row(i,j,k)][l/32] <=> sample < isovalue
+    uint32_t* signbits;
+    uint32_t nw3;              // words per row
+    uint32_t nrows;            // n0*n1*n2
+    cx_fdiv div_w, div_r2, div_r1;   // / nw3, / (n1*n2), / n2
 };
+void cx_launch_signbits4d(const cx_params4& P, hipStream_t s);
 void cx_launch_classify4d(const cx_params4& P, hipStream_t s);
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s);
 void cx_launch_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, const uint32_t org[4], hipStream_t s);
@@ -39,6 +45,8 @@ struct cx_state4 {
     uint32_t vcap = 0, ccap = 0, tcap = 0;
     uint64_t* hash_xyz = nullptr;
     size_t hash_cap = 0;
+    uint32_t* signbits = nullptr;
+    size_t signbits_cap = 0;
     int64_t hash_key[7] = {-1, -1, -1, -1, -1, -1, -1};
     int64_t origin[4] = {0, 0, 0, 0};
     bool extracted = false;
