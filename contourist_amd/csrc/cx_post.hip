@@ -92,6 +92,27 @@ __device__ __forceinline__ void cxp_max32(uint32_t* addr, uint32_t v) {
     if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
     atomicMax(addr, v);
 }
+// the same for a whole wave: when all its lanes share one key (component) they reduce among themselves and issue
+// ONE atomic; a wave that straddles components falls back to one call per lane.  (With values that grow along
+// the array -- vertices ordered by x -- the plain read alone does not help: every caller raises the maximum.)
+// All lanes of the wave must call it; `active` masks the idle ones.
+__device__ __forceinline__ void cxp_wave_max64(u64* table, uint32_t key, u64 v, bool active) {
+    const uint64_t act = __ballot(active);
+    if (act == 0ULL) return;
+    const uint32_t k = (uint32_t)__shfl((int)key, __ffsll((long long)act) - 1);
+    if (__ballot(active && key != k) != 0ULL) {   // wave-uniform
+        if (active) cxp_max64(&table[key], v);
+        return;
+    }
+    u64 m = active ? v : 0ULL;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), o);
+        const u64 other = ((u64)hi << 32) | lo;
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63u) == 0u) cxp_max64(&table[k], m);
+}
 
 // union-find over 32-bit ids; parent word = (parity << 32) | parent id.  Root = smallest priority.
 __device__ __forceinline__ uint32_t cxp_find(const u64* parent, uint32_t x, uint32_t& parity) {
@@ -472,12 +493,15 @@ __global__ void cxp_k_edges(const int32_t* tri, uint32_t nt, u64* ekeys, u64* ev
 // per component (root triangle): largest x over its vertices
 __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    const uint32_t root = (uint32_t)parent[t];
+    const bool have = t < nt;
+    uint32_t root = 0;
     u64 m = 0;
+    if (have) {
+        root = (uint32_t)parent[t];
 #pragma unroll
-    for (int s = 0; s < 3; s++) m = max(m, cxp_orderable(pts[(size_t)tri[(size_t)t * 3 + s] * 3]));
-    cxp_max64(&cmaxx[root], m);
+        for (int s = 0; s < 3; s++) m = max(m, cxp_orderable(pts[(size_t)tri[(size_t)t * 3 + s] * 3]));
+    }
+    cxp_wave_max64(cmaxx, root, m, have);
 }
 // among the vertices at that x: the one with the largest index (surface_geometry.py:79 max((x, index)))
 __global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, uint32_t* cmaxv) {
