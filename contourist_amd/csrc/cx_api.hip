@@ -254,7 +254,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             CX_HIP(ctx, hipMalloc(&ctx->brec, nbrec * sizeof(cx_brec)));
             ctx->brec_cap = nbrec;
         }
-        // batches: at most one short batch per streaming wave plus one per CX_BATCH_MIN (128) queued cells; queued
+        // batches: at most one short batch per streaming wave plus one per CX_BATCH_MIN (>= 128) queued cells; queued
         // cells = cell records + array-boundary cells without vertices.  Sized from the cell capacity, so a
         // surface that fits the cell capacity fits here (cx_counts_get reports CX_ERR_CAPACITY otherwise).
         const size_t boundary = (size_t)(ctx->n0 * ctx->n1 + ctx->n0 * ctx->n2 + ctx->n1 * ctx->n2);

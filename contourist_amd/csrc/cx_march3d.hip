@@ -35,7 +35,7 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #define CX_RJ 4             // cell rows per wave in the stream kernel (a workgroup covers 4*CX_RJ rows)
 #endif
 #ifndef CX_BATCH_MIN
-#define CX_BATCH_MIN 128u   // a streaming wave closes a batch once it holds this many cells
+#define CX_BATCH_MIN 512u   // a streaming wave closes a batch once it holds this many cells (128..1024 measured: 512 best)
 #endif
 
 // ---- per-cell path ------------------------------------------------------------------------------
