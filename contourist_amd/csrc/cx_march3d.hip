@@ -992,7 +992,9 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
             vi[sidx] = (int32_t)(pr.x + __popc(pr.y & ((1u << (cd >> 3)) - 1u)));
         }
         if (ok && !(P.flags & CX_DBG_NO_TRIS)) {
-            int32_t* out = P.tris + ((size_t)L.tfirst[wave][cell] + j) * 3u;
+            // 32-bit wrap-around on purpose: tfirst = first - rank may be "negative" when the wave's cells come from
+            // different reservations (generic path); the sum is the triangle index again
+            int32_t* out = P.tris + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 3u;
             out[0] = vi[0]; out[1] = vi[1]; out[2] = vi[2];
         }
     }

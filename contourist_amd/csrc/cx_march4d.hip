@@ -391,12 +391,23 @@ __device__ __forceinline__ void py_slots3(const uint64_t h[3], int m, uint32_t s
 }
 
 // =================================================================================================
-// K2: one lane per record -> tetrahedra
+// K2: tetrahedra.  Phase 0, one lane per cell record: table entries of the 15 owner corners and the
+// corner hashes go to LDS.  Then, for 4 groups of 6 pentatopes: phase 1 (per cell) decides pattern and
+// set-order permutation of each pentatope and writes one slot word per tetrahedron; phase 2, one lane
+// per TETRAHEDRON, reads the 4 (owner corner, direction) references from the table and stores 16
+// bytes next to its neighbours' (the first version stored 4 bytes per lane and cell: 64 cache lines
+// per store instruction).
 // =================================================================================================
+struct cx_tet_lds {
+    uint32_t vf[4][16][64];
+    uint16_t em[4][16][64];
+    uint64_t h[4][16][64];
+    uint16_t slot[4][18 * 64];     // per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9
+    uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
+    uint32_t tfirst[4][64];        // first tetrahedron of the cell in this group minus its rank in the wave
+};
 __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
-    __shared__ uint32_t s_vf[4][16][64];
-    __shared__ uint16_t s_em[4][16][64];
-    __shared__ uint64_t s_h[4][16][64];
+    __shared__ cx_tet_lds L;
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;
     const uint32_t lane = cx_lane_id();
@@ -433,8 +444,8 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
             vf = (uint32_t)e;
             em = (uint32_t)(e >> 32);
         }
-        s_vf[wave][c][lane] = vf;
-        s_em[wave][c][lane] = (uint16_t)em;
+        L.vf[wave][c][lane] = vf;
+        L.em[wave][c][lane] = (uint16_t)em;
     }
     // corner hashes (absolute lattice coordinates) for the set-order emulation
     if (emulate) {
@@ -442,52 +453,83 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
             const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
             const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
             const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
-            s_h[wave][c][lane] = py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
+            L.h[wave][c][lane] = py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
         }
     }
-    int32_t* out = P.tets + (size_t)c4.z * 4u;
-    for (int n = 0; n < 24; n++) {
-        if (!real_voxel || ((pskip >> n) & 1u)) continue;
-        const uint32_t pat = cx_pent_pattern(sm, n);
-        const uint32_t nlow = __popc(pat);
-        if (nlow == 0u || nlow == 5u) continue;
-        uint32_t perm_id = 0;
-        if (emulate && (nlow == 2u || nlow == 3u)) {
-            // least = the 2-set, most = the 3-set, each in insertion (path) order
-            const bool low_is_two = (nlow == 2u);
-            uint64_t h2[3], h3[3];
-            int n2 = 0, n3 = 0;
-            for (int m = 0; m < 5; m++) {
-                const uint64_t hm = s_h[wave][CX_PC[n][m]][lane];
-                const bool is_low = (pat >> m) & 1u;
-                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                else { if (n3 < 3) h3[n3] = hm; n3++; }
+    uint32_t done = 0;   // tetrahedra of this cell already written
+    for (int g = 0; g < 4; g++) {
+        // ---- phase 1: slot words of the group's tetrahedra
+        uint32_t cnt = 0;
+        uint32_t pats[6], perms[6], nts[6];
+        for (int pn = 0; pn < 6; pn++) {
+            const int n = g * 6 + pn;
+            pats[pn] = 0; perms[pn] = 0; nts[pn] = 0;
+            if (!real_voxel || ((pskip >> n) & 1u)) continue;
+            const uint32_t pat = cx_pent_pattern(sm, n);
+            const uint32_t nlow = __popc(pat);
+            if (nlow == 0u || nlow == 5u) continue;
+            uint32_t perm_id = 0;
+            if (emulate && (nlow == 2u || nlow == 3u)) {
+                // least = the 2-set, most = the 3-set, each in insertion (path) order
+                const bool low_is_two = (nlow == 2u);
+                uint64_t h2[3], h3[3];
+                int n2 = 0, n3 = 0;
+                for (int m = 0; m < 5; m++) {
+                    const uint64_t hm = L.h[wave][CX_PC[n][m]][lane];
+                    const bool is_low = (pat >> m) & 1u;
+                    if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                    else { if (n3 < 3) h3[n3] = hm; n3++; }
+                }
+                uint32_t s2[3], s3[3];
+                py_slots3(h2, 2, s2);
+                py_slots3(h3, 3, s3);
+                const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
+                // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
+                uint32_t o0 = 0, o1 = 1, o2 = 2;
+                if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
+                if (s3[o1] > s3[o2]) { const uint32_t t = o1; o1 = o2; o2 = t; }
+                if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
+                const uint32_t p3 = o0 * 2u + ((o1 > o2) ? 1u : 0u);   // (0,1,2)=0 (0,2,1)=1 (1,0,2)=2 (1,2,0)=3 (2,0,1)=4 (2,1,0)=5
+                perm_id = (p3 << 1) | swapped;
             }
-            uint32_t s2[3], s3[3];
-            py_slots3(h2, 2, s2);
-            py_slots3(h3, 3, s3);
-            const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
-            // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
-            uint32_t o0 = 0, o1 = 1, o2 = 2;
-            if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
-            if (s3[o1] > s3[o2]) { const uint32_t t = o1; o1 = o2; o2 = t; }
-            if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
-            const uint32_t p3 = o0 * 2u + ((o1 > o2) ? 1u : 0u);   // (0,1,2)=0 (0,2,1)=1 (1,0,2)=2 (1,2,0)=3 (2,0,1)=4 (2,1,0)=5
-            perm_id = (p3 << 1) | swapped;
+            pats[pn] = pat; perms[pn] = perm_id;
+            nts[pn] = (nlow == 2u || nlow == 3u) ? 3u : 1u;
+            cnt += nts[pn];
         }
-        const uint64_t* e = P.lut + (((size_t)n * 32u + pat) * 12u + perm_id) * 2u;
-        const uint64_t w0 = e[0], w1 = e[1];
-        const uint32_t nt = (uint32_t)(w1 >> 32) & 3u;
-        for (uint32_t k = 0; k < nt; k++) {
-            const uint32_t word = (k == 0) ? (uint32_t)w0 : ((k == 1) ? (uint32_t)(w0 >> 32) : (uint32_t)w1);
+        const uint32_t incl = cx_wave_incl_scan4(cnt);
+        const uint32_t ttot = (uint32_t)__shfl((int)incl, 63);
+        uint32_t pos = incl - cnt;
+        L.tfirst[wave][lane] = c4.z + done - pos;   // tetrahedron j of the wave's group goes to tfirst[cell] + j
+        for (int pn = 0; pn < 6; pn++) {
+            L.pinfo[wave][pn][lane] = (uint16_t)(pats[pn] | (perms[pn] << 5));
+            for (uint32_t k = 0; k < nts[pn]; k++) L.slot[wave][pos++] = (uint16_t)(lane | ((uint32_t)pn << 6) | (k << 9));
+        }
+        done += cnt;
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: one lane per tetrahedron
+        for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
+            const uint32_t j = j0 + lane;
+            const bool ok = j < ttot;
+            const uint32_t w = L.slot[wave][ok ? j : 0u];
+            const uint32_t cell = w & 63u, pn = (w >> 6) & 7u, k = (w >> 9) & 3u;
+            const uint32_t pi = L.pinfo[wave][pn][cell];
+            const uint32_t n = (uint32_t)g * 6u + pn;
+            const uint64_t* e = P.lut + (((size_t)n * 32u + (pi & 31u)) * 12u + (pi >> 5)) * 2u;
+            const uint64_t wsel = (k == 2u) ? e[1] : e[0];
+            const uint32_t word = (k == 1u) ? (uint32_t)(wsel >> 32) : (uint32_t)wsel;
+            int4 t4;
+            int32_t* tv = reinterpret_cast<int32_t*>(&t4);
 #pragma unroll
-            for (uint32_t s = 0; s < 4; s++) {
-                const uint32_t ref = (word >> (8u * s)) & 0xFFu;
+            for (uint32_t s_ = 0; s_ < 4; s_++) {
+                const uint32_t ref = (word >> (8u * s_)) & 0xFFu;
                 const uint32_t c1 = ref >> 4, d = ref & 15u;
-                const uint32_t vf = s_vf[wave][c1][lane], em = s_em[wave][c1][lane];
-                *out++ = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
+                const uint32_t vf = L.vf[wave][c1][cell], em = L.em[wave][c1][cell];
+                tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
             }
+            // 32-bit wrap-around on purpose (tfirst = first - rank can be "negative" across reservations)
+            if (ok) *reinterpret_cast<int4*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u) = t4;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

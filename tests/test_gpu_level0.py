@@ -110,6 +110,17 @@ def test_generic_kernel_on_request(ctx, shape, seed):
     check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_GENERIC, 1)
 
 
+def test_generic_kernel_many_reservations(ctx):
+    """a grid large enough that the generic kernel's workgroups reserve output ranges in arbitrary order:
+    the triangle kernel then meets waves whose cells belong to different reservations"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(31)
+    A = rng.standard_normal((72, 70, 68)).astype(np.float32)
+    ctx.reserve(400000, 1200000, 2400000)
+    for rep in range(3):
+        check_against_oracle(ctx, A, 0.8, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_GENERIC, 1)
+
+
 def test_empty_and_full(ctx):
     from contourist_amd import _ffi
     A = np.ones((8, 8, 8), dtype=np.float32)
