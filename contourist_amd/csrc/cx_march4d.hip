@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const 
         ch[u] = c - row[u] * nchunk;
         const uint32_t l = ch[u] * 64u + lane;
         ok[u] = l < P.n3;
-        f[u] = ok[u] ? A[(size_t)row[u] * P.n3 + l] : 0.0f;
+        f[u] = A[(size_t)row[u] * P.n3 + min(l, P.n3 - 1u)];   // unconditional: all 8 loads in flight
     }
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) {

@@ -45,6 +45,20 @@ post = ctx.postprocess4d(100)
 torch.cuda.synchronize()
 dp = time.perf_counter() - t0
 n = A.numel()
+# CPU baseline: the oracle's C restatement (1 thread) on a slab of the same field
+cpu = None
+try:
+    from oracle import level0_4d
+    planes = min(12, shape[0])
+    lo = (shape[0] - planes) // 2     # a slab through the middle, where the surface is
+    host = A[lo:lo + planes].contiguous().cpu().numpy()
+    t0 = time.perf_counter()
+    O = level0_4d.march4d(host, v, diag_mode=1)
+    tc = time.perf_counter() - t0
+    cpu = {"value": host.size / tc / 1e6, "unit": "Mhypervoxels/s", "cores": 1, "kind": "port",
+           "sample": "planes %d:%d of the field (%d samples, %d tetrahedra) in %.1f s, oracle/march4d_oracle.c single thread" % (lo, lo + planes, host.size, len(O["tets"]), tc)}
+except Exception as e:   # the oracle is test infrastructure; the bench line stands without it
+    cpu = {"error": str(e)}
 print(json.dumps({"workload": "%dx%dx%dx%d fp32, two moving blobs + noise, v=%g" % (shape + (v,)), "counts": c, "post": post,
                   "level0_ms": dt * 1e3, "Mhypervoxels_per_s": n / dt / 1e6, "hbm_frac_input_bytes": 4 * n / dt / 8e12,
-                  "postprocess_ms": dp * 1e3}))
+                  "postprocess_ms": dp * 1e3, "cpu_baseline": cpu}))
