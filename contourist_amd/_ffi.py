@@ -22,7 +22,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -40,6 +40,24 @@ class HipLibraryMissing(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must not hold two HIP runtimes.  A PyTorch-ROCm wheel ships its own libamdhip64.so and names it
+    without the version, so the dynamic loader does not recognise ROCm's libamdhip64.so.7 (loaded for this
+    library) as the same thing: torch.cuda then finds "no HIP GPUs".  If such a wheel is installed, load ITS
+    runtime first -- this library's NEEDED libamdhip64.so.7 binds to it by soname -- whether or not torch gets
+    imported later.  Without torch the ROCm copy on the library's RUNPATH is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass   # best effort: the library itself still loads (against ROCm's runtime)
+
+
 def load():
     """load (once) and type the shared library; raises HipLibraryMissing loudly if absent."""
     global _lib
@@ -49,6 +67,7 @@ def load():
         raise HipLibraryMissing(
             "%s not found: build it with `python -m contourist_amd.build` (hipcc --offload-arch=gfx950). "
             "contourist_amd has no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, u32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_double
     L.cx_version.restype = ctypes.c_char_p
@@ -71,6 +90,8 @@ def load():
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_postprocess3d": [vp, u32, vp],
         "cx_postprocess3d_ex": [vp, u32, dbl, vp],
+        "cx_select_seeded3d": [vp, vp, i64, vp, vp],
+        "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
         "cx_debug_stamps": [vp, i64, vp],
@@ -179,6 +200,22 @@ class Context(object):
         self._check(self.lib.cx_level0_download(self.handle, verts.ctypes.data, tris.ctypes.data))
         keys = verts[:, 3].copy().view(np.uint32)
         return verts[:, :3].copy(), keys, tris
+
+    def set_reference_corner(self, corner=(0, 0, 0)):
+        self._check(self.lib.cx_set_reference_corner(self.handle, *[int(c) for c in corner]))
+
+    def select_seeded(self, endpoints, voxel_range=None):
+        """restrict the next post-passes to the components reached from `endpoints` (n x 2 x 3 lattice points);
+        voxel_range = (lo[3], hi[3]) in_range box of the growth (default: the whole array);
+        -> dict(seed_voxels, groups_kept, triangles_kept)"""
+        ep = np.ascontiguousarray(np.asarray(endpoints, dtype=np.int64).reshape(-1, 6), dtype=np.int32)
+        out = np.zeros(4, dtype=np.int64)
+        box = None
+        if voxel_range is not None:
+            box = np.ascontiguousarray(np.asarray(voxel_range, dtype=np.int64).reshape(6), dtype=np.int32)
+        self._check(self.lib.cx_select_seeded3d(self.handle, ep.ctypes.data, int(len(ep)),
+                                                box.ctypes.data if box is not None else None, out.ctypes.data))
+        return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), triangles_kept=int(out[2]))
 
     def postprocess3d(self, flags=0, smooth=0.0):
         out = np.zeros(8, dtype=np.int64)

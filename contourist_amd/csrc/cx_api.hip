@@ -66,6 +66,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->wsum) (void)hipFree(ctx->wsum);
     if (ctx->wbase) (void)hipFree(ctx->wbase);
+    if (ctx->tri_keep) (void)hipFree(ctx->tri_keep);
     if (ctx->brec) (void)hipFree(ctx->brec);
     if (ctx->flat) (void)hipFree(ctx->flat);
     if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
@@ -141,6 +142,13 @@ extern "C" int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t
 extern "C" int cx_set_origin(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2) {
     if (!ctx || o0 < 0 || o1 < 0 || o2 < 0 || o0 > 0x7FFFFFFFLL || o1 > 0x7FFFFFFFLL || o2 > 0x7FFFFFFFLL) return CX_ERR_INVALID;
     ctx->origin[0] = o0; ctx->origin[1] = o1; ctx->origin[2] = o2;
+    return CX_OK;
+}
+
+extern "C" int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2) {
+    if (!ctx || c0 < 0 || c1 < 0 || c2 < 0) return CX_ERR_INVALID;
+    ctx->corner_ref[0] = c0; ctx->corner_ref[1] = c1; ctx->corner_ref[2] = c2;
+    ctx->post_valid = false;
     return CX_OK;
 }
 
@@ -249,7 +257,8 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         const size_t nbrec = nw * T.bcap;
         if (ctx->brec_cap < nbrec) {
             CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->brec) (void)hipFree(ctx->brec);
+            if (ctx->tri_keep) (void)hipFree(ctx->tri_keep);
+    if (ctx->brec) (void)hipFree(ctx->brec);
             ctx->brec = nullptr; ctx->brec_cap = 0;
             CX_HIP(ctx, hipMalloc(&ctx->brec, nbrec * sizeof(cx_brec)));
             ctx->brec_cap = nbrec;
@@ -297,6 +306,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     CX_HIP(ctx, hipGetLastError());
     ctx->extracted = true;
     ctx->post_valid = false;
+    ctx->keep_valid = false;
     return CX_OK;
 }
 

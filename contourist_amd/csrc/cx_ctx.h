@@ -33,6 +33,7 @@ struct cx_ctx {
     size_t hash_xy_cap = 0;
     int64_t hash_xy_n0 = 0, hash_xy_n1 = 0, hash_xy_o0 = -1, hash_xy_o1 = -1;
     int64_t origin[3] = {0, 0, 0};
+    int64_t corner_ref[3] = {0, 0, 0};   // > 0: the reference's corner for the Level-1 scales (cx_set_reference_corner)
     int64_t origin4[4] = {0, 0, 0, 0};
     cx_state4* s4 = nullptr;
     // Level-0 outputs
@@ -45,6 +46,10 @@ struct cx_ctx {
     bool extracted = false;
     cx_counts counts = {0, 0, 0, 0};
     cx_params last;
+    // seeded selection (cx_select_seeded3d): triangle mask followed by vertex mask, valid until the next extraction
+    uint8_t* tri_keep = nullptr;
+    size_t keep_cap = 0;
+    bool keep_valid = false;
     // Level-1
     cx_post_state* post = nullptr;
     bool post_valid = false;

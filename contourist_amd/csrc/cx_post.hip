@@ -258,9 +258,10 @@ struct cxp_weld_params {
 
 // weld: bucket -> vertex with the smallest priority
 __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint32_t nv, cxp_weld_params W, u64* tkeys, u64* tvals,
-                                  u64 mask) {
+                                  u64 mask, const uint8_t* vkeep) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
+    if (vkeep && !vkeep[v]) return;   // seeded selection: vertices of dropped components do not exist
     const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
     const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
     const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
@@ -274,9 +275,10 @@ __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint3
     atomicMin(&tvals[slot], ((u64)prio[v] << 32) | (u64)v);
 }
 __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_params W, const u64* tkeys, const u64* tvals, u64 mask,
-                                  uint32_t* rep) {
+                                  uint32_t* rep, const uint8_t* vkeep) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
+    if (vkeep && !vkeep[v]) { rep[v] = v; return; }
     const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
     const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
     const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
@@ -765,19 +767,29 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
         hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
                            P.value, ctx->verts, nv, pts, prio);
         CXP_HIP(ctx, hipMemcpyAsync(tri, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        CXP_HIP(ctx, hipMemsetAsync(alive, 1, nt, st));
+        const uint8_t* vkeep = nullptr;
+        if (ctx->keep_valid) {   // cx_select_seeded3d: only the triangles (and vertices) of the selected components exist
+            CXP_HIP(ctx, hipMemcpyAsync(alive, ctx->tri_keep, nt, hipMemcpyDeviceToDevice, st));
+            vkeep = ctx->tri_keep + nt;
+        } else {
+            CXP_HIP(ctx, hipMemsetAsync(alive, 1, nt, st));
+        }
         hipLaunchKernelGGL(cxp_k_tri_prio, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, prio, nt, tprio3);
         // ---- weld (tetrahedral.py:190-215): expander = int(10000 / corner)
         cxp_weld_params W;
-        const double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
+        // the reference's `corner` (voxels per axis); a sample array with a margin around the reference's grid
+        // carries the reference's own corner in ctx->corner_ref (cx_set_reference_corner)
+        double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
+        for (int a = 0; a < 3; a++)
+            if (ctx->corner_ref[a] > 0) corner[a] = (double)ctx->corner_ref[a];
         for (int a = 0; a < 3; a++) W.ex[a] = std::trunc((10000 * 1.0) / corner[a]);
         const u64 wsz = cxp_table_size(nv);
         if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->tvals, wsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)wsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, CXP_EMPTY);
-        hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1);
-        hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep);
+        hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, vkeep);
+        hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep, vkeep);
         hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr);
         const u64 tsz = cxp_table_size(nt);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);

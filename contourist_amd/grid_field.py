@@ -78,6 +78,7 @@ class FunctionGrid(object):
         self.grid_dimensions = np.array(shape, dtype=int) - 1
         assert np.all(self.grid_dimensions >= 1)
         self._dense = samples if _is_torch(samples) else np.ascontiguousarray(samples, dtype=np.float32)
+        self.array_backed = True      # f cannot be evaluated outside the samples
         dense = self._dense
 
         def lookup(*xyz):
@@ -162,10 +163,10 @@ class FunctionGrid(object):
         return (maxf, minf, result)
 
     # ---- dense samples for the device path -----------------------------------------------------
-    def _evaluate(self, shape):
-        """f over index tuples of `shape` -> float64 array.  Tries one broadcast call
+    def _evaluate(self, shape, first=0):
+        """f over index tuples first .. first+shape-1 -> float64 array.  Tries one broadcast call
         f(X, Y, Z) first; falls back to one Python call per sample."""
-        axes = [self.mins[a] + self.delta[a] * np.arange(shape[a], dtype=float) for a in range(self.dimension)]
+        axes = [self.mins[a] + self.delta[a] * (np.arange(shape[a], dtype=float) + first) for a in range(self.dimension)]
         mesh = np.meshgrid(*axes, indexing="ij")
         try:
             out = np.asarray(self.f(*mesh), dtype=float)
@@ -182,8 +183,14 @@ class FunctionGrid(object):
             out[idx] = self.f(*[axes[a][idx[a]] for a in range(self.dimension)])
         return out
 
-    def dense_samples(self):
-        """fp32 samples at grid vertices 0..grid_dimensions inclusive (numpy array or CUDA/HIP tensor)."""
+    def dense_samples(self, margin=0):
+        """fp32 samples at grid vertices 0..grid_dimensions inclusive (numpy array or CUDA/HIP tensor).
+        margin > 0 (callable f only): vertices -margin .. grid_dimensions+margin, the lattice the reference reaches
+        when a seed voxel lies on the rim of the grid (tetrahedral.py:396-441 does not range-check seed voxels)."""
+        if margin:
+            assert not getattr(self, "array_backed", False), "a sample array cannot be evaluated outside itself"
+            shape = tuple(int(n) + 1 + 2 * margin for n in self.grid_dimensions)
+            return np.ascontiguousarray(self._evaluate(shape, first=-margin), dtype=np.float32)
         if self._dense is None:
             shape = tuple(int(n) + 1 for n in self.grid_dimensions)
             self._dense = np.ascontiguousarray(self._evaluate(shape), dtype=np.float32)

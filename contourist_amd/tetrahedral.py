@@ -49,7 +49,7 @@ class GridContour3d(object):
     """
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True,
-                 callback=None, device=None, diagonal="cpython310", context=None):
+                 callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None):
         self.corner = np.array(corner, dtype=int)
         assert self.corner.shape == (3,), "dimension must be 3"
         if segment_endpoints is not None:
@@ -62,6 +62,7 @@ class GridContour3d(object):
         self.dimension = 3
         self.linear_interpolate = True
         self.end_points = segment_endpoints
+        self.voxel_range = voxel_range    # in_range box of the seeded growth (lo, hi); None = the whole array
         self.value = float(value)
         self.callback = callback
         self.flatten = False
@@ -117,6 +118,15 @@ class GridContour3d(object):
             assert self.smooth > 0 and self.smooth <= 1
         ctx = self.context()
         if self._post is None:
+            # explicit end points restrict the result to the components the reference's breadth-first search
+            # reaches from them (tetrahedral.py:396-463); None = every component (exhaustive search_for_endpoints)
+            if self.end_points is not None and len(self.end_points):
+                self.seeded = ctx.select_seeded(self.end_points, self.voxel_range)
+            if self.voxel_range is not None:   # the array has a margin: Level-1 scales of the reference's own grid
+                lo, hi = self.voxel_range
+                ctx.set_reference_corner([int(h) - int(l) for l, h in zip(lo, hi)])
+            else:
+                ctx.set_reference_corner((0, 0, 0))
             self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0)
         pts, tris = ctx.download_level1(self._post)
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
@@ -216,8 +226,21 @@ class Delta3DContour(object):
         self.grid_endpoints = grid_endpoints
         if self.flatten:
             raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
-        result = GridContour3d(tuple(int(n) for n in grid.grid_dimensions), grid.dense_samples(), self.value,
-                               grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device)
+        gd = np.array([int(n) for n in grid.grid_dimensions])
+        self._grid_shift = 0
+        if grid_endpoints and not getattr(grid, "array_backed", False):
+            # explicit end points on a callable field: the reference does not range-check its seed voxels and
+            # evaluates f one lattice step outside the grid (tetrahedral.py:396-441); sample that rim too and
+            # keep the breadth-first growth inside the reference's grid
+            m = 1
+            shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
+            result = GridContour3d(tuple(gd + 2 * m), grid.dense_samples(margin=m), self.value, shifted,
+                                   linear_interpolate=self.linear_interpolate, device=self.device,
+                                   voxel_range=((m, m, m), tuple(gd + m)))
+            self._grid_shift = m
+        else:
+            result = GridContour3d(tuple(gd), grid.dense_samples(), self.value,
+                                   grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device)
         result.flatten = self.flatten
         result.smooth = self.smooth
         return result
@@ -233,6 +256,8 @@ class Delta3DContour(object):
 
     def get_points_and_triangles(self):
         (grid_points, triangles) = self.contour_maker.get_points_and_triangles()
+        if len(grid_points) and getattr(self, "_grid_shift", 0):
+            grid_points = grid_points - float(self._grid_shift)
         points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
         return (points, triangles)
 

@@ -102,6 +102,22 @@ int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts);
 /* same with GridContour.smooth_interpolations(smooth) (tetrahedral.py:329-351, 547-550) between the weld and
  * the tiny collapse; 0 < smooth <= 1, smooth == 0 disables it */
 int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts);
+/* Seeded selection.  Replaces GridContour.find_initial_voxels / expand_voxels (tetrahedral.py:396-463): the
+ * reference only enumerates the surface voxels it reaches breadth-first (26 neighbours) from its end point
+ * pairs; the dense march finds every surface voxel, and this call restricts the NEXT cx_postprocess3d* calls
+ * (until the next extraction) to the triangles of the voxel groups reached from the given pairs.
+ * endpoints_ijk: n x 6 int32 lattice points (i0,j0,k0, i1,j1,k1) whose samples straddle the isovalue; they are
+ * bisected and mapped to seed voxels exactly as the reference does.  out_counts (4 x int64): [0] seed voxels,
+ * [1] voxel groups kept, [2] triangles kept, [3] rejected pairs (the reference asserts on those; CX_ERR_INVALID).
+ * range_lo_hi: NULL, or 6 int32 (lo[3], hi[3]) = the reference's in_range box (tetrahedral.py:465-469) when the
+ * sample array carries a margin around the reference's grid (the reference evaluates its callable outside the
+ * grid for seed voxels on the rim; growth stays inside the box).
+ * Not calling it keeps every component, as the reference's exhaustive search_for_endpoints() does. */
+/* The Level-1 scales (weld buckets int(10000/corner), tiny-simplex extent 1/corner) use corner = n-1 per axis.
+ * When the sample array carries a margin around the reference's grid, hand over the reference's own corner
+ * (voxels per axis); 0 restores the default. */
+int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2);
+int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 

@@ -83,6 +83,25 @@ def test_two_dots_reference_golden():
     assert expected <= got
 
 
+def test_two_dots_seeded_selection_is_the_reference_test_exactly():
+    """contourist/test/test_tetrahedral.py:13-37 with its end points: the seeded search (find_initial_voxels +
+    expand_voxels, restated in oracle/seeds.py) keeps exactly the 8 triangles the reference's test asserts"""
+    from oracle import seeds
+    G = load("two_dots")
+    A, v = G["A"], float(G["value"])
+    O = level0.march3d(A, v, diag_mode=1)
+    keys = level0.edge_keys_from_pairs(O["pairs"], A.shape)
+    # the test's end points (-8,-8,-8) -> (-8,-8,8) are lattice points (0,0,0) -> (0,0,8) of the reference's grid =
+    # (1,1,1) -> (1,1,9) of the golden array, which carries one lattice step of margin (indices -1..9)
+    mask, surface = seeds.select(A, v, [[(1, 1, 1), (1, 1, 9)]], keys, O["tris"], lo=(1, 1, 1), hi=(9, 9, 9))
+    world = O["xyz"] * G["delta"] + G["mins"]
+    ipts = np.trunc(world).astype(int)
+    got = set(frozenset(tuple(ipts[i]) for i in t) for t in O["tris"][mask])
+    expected = set(frozenset(tuple(p) for p in tri) for tri in G["expected_int_triangles"].reshape(-1, 3, 3))
+    assert got == expected and len(got) == 8
+    assert surface == {(0, 0, 1), (1, 1, 1)}      # voxel (-1,-1,0) (not range-checked seed) and voxel (0,0,0)
+
+
 def test_set_order_emulation_matches_this_cpython():
     """tuple hash + 8-slot set order; checked against the running interpreter
     (only meaningful on CPython 3.8+ / 64-bit, which is what produced the goldens)."""
