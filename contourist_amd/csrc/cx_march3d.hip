@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
                     q[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
                 }
                 ql += tot;
+#ifndef CX_S1_NO_COUNT   // timing experiments only
                 // counts of this lane's 16 cells, all at once on the packed sign words: corner
                 // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
                 // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
@@ -638,6 +639,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
                 CX_TET_COUNT(b6, b4) CX_TET_COUNT(b4, b5) CX_TET_COUNT(b5, b1)
 #undef CX_TET_COUNT
                 acc.t += nt;
+#endif
                 qn += tot;
                 if (qn - qstart >= CX_BATCH_MIN) close_batch();
             }

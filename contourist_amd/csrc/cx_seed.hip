@@ -179,11 +179,59 @@ __global__ void cxs_k_seeds(cxs_grid G, const int32_t* ep, uint32_t n, unsigned 
 }
 // flag[] = groups reached; seedkeep[] = seed voxels themselves (a seed voxel outside the in_range box is kept and
 // grows one step into the box, as the reference's first expand_voxels round does)
+// many end point pairs (coarse crossing search, skip > 1): one thread per pair, no shared `visited` set -- each end
+// point yields its own voxel or its first border neighbour.  (The reference's shared set only changes which of
+// several adjacent candidate voxels gets picked when pairs collide.)  Slots 2s, 2s+1; 0xFFFFFFFF = none.
+__global__ void cxs_k_seeds_parallel(cxs_grid G, const int32_t* ep, uint32_t n, uint32_t* seeds, uint32_t* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    seeds[2 * s] = seeds[2 * s + 1] = 0xFFFFFFFFu;
+    int lowp[3] = {ep[s * 6 + 0], ep[s * 6 + 1], ep[s * 6 + 2]}, highp[3] = {ep[s * 6 + 3], ep[s * 6 + 4], ep[s * 6 + 5]};
+    for (int a = 0; a < 3; a++) {
+        const int lim = (int)(a == 0 ? G.n0 : (a == 1 ? G.n1 : G.n2));
+        if (lowp[a] < 0 || highp[a] < 0 || lowp[a] >= lim || highp[a] >= lim) { atomicAdd(&out[1], 1u); return; }
+    }
+    double lowv = cxs_f(G, lowp), highv = cxs_f(G, highp);
+    if (lowv > G.value || highv < G.value) {
+        for (int a = 0; a < 3; a++) { const int t = lowp[a]; lowp[a] = highp[a]; highp[a] = t; }
+        const double t = lowv; lowv = highv; highv = t;
+    }
+    if (!(lowv <= G.value && highv >= G.value)) { atomicAdd(&out[1], 1u); return; }
+    while (abs(lowp[0] - highp[0]) > 1 || abs(lowp[1] - highp[1]) > 1 || abs(lowp[2] - highp[2]) > 1) {
+        int mid[3];
+        for (int a = 0; a < 3; a++) {
+            const int sum = lowp[a] + highp[a];
+            mid[a] = (sum >= 0) ? sum / 2 : -((-sum + 1) / 2);
+        }
+        if (cxs_f(G, mid) < G.value) { for (int a = 0; a < 3; a++) lowp[a] = mid[a]; }
+        else { for (int a = 0; a < 3; a++) highp[a] = mid[a]; }
+    }
+    for (int which = 0; which < 2; which++) {
+        const int* p = which ? highp : lowp;
+        bool inside;
+        if (cxs_border_voxel(G, p[0], p[1], p[2], inside)) {
+            seeds[2 * s + which] = ((uint32_t)p[0] * G.n1 + (uint32_t)p[1]) * G.n2 + (uint32_t)p[2];
+            continue;
+        }
+        bool found = false;
+        for (int di = -1; di <= 1 && !found; di++)
+            for (int dj = -1; dj <= 1 && !found; dj++)
+                for (int dk = -1; dk <= 1 && !found; dk++) {
+                    if (di == 0 && dj == 0 && dk == 0) continue;
+                    if (cxs_border_voxel(G, p[0] + di, p[1] + dj, p[2] + dk, inside)) {
+                        seeds[2 * s + which] = ((uint32_t)(p[0] + di) * G.n1 + (uint32_t)(p[1] + dj)) * G.n2 + (uint32_t)(p[2] + dk);
+                        found = true;
+                    }
+                }
+    }
+    if (s == 0) out[0] = 2u * n;   // slots to look at
+}
 __global__ void cxs_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint32_t* seeds,
                            const uint32_t* nseeds, uint8_t* flag, uint8_t* seedkeep, cxs_grid G) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseeds[0]) return;
     const uint32_t lin = seeds[s];
+    if (lin == 0xFFFFFFFFu) return;
     const uint32_t plane = G.n1 * G.n2;
     const int i = (int)(lin / plane), j = (int)((lin % plane) / G.n2), k = (int)(lin % G.n2);
     const uint32_t r = cxs_lookup(cells, ncells, vmap, lin);
@@ -251,7 +299,7 @@ extern "C" int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int
     int32_t* ep = nullptr;
     unsigned long long* visited = nullptr;
     unsigned long long vsize = 1024;
-    while (vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
+    while (n <= 1024 && vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
     int rc = CX_OK;
     uint32_t host_out[4] = {0, 0, 0, 0};
     do {
@@ -274,7 +322,10 @@ extern "C" int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int
             hipLaunchKernelGGL(cxs_k_map, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent);
             hipLaunchKernelGGL(cxs_k_union, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
-            hipLaunchKernelGGL(cxs_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
+            if (n <= 1024)   // sequential, with the reference's shared visited set
+                hipLaunchKernelGGL(cxs_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
+            else
+                hipLaunchKernelGGL(cxs_k_seeds_parallel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, G, ep, (uint32_t)n, seeds, out);
             hipLaunchKernelGGL(cxs_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
             hipLaunchKernelGGL(cxs_k_keep, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, parent, flag, flag + ncells + 64, tri_keep, ctx->tris, vkeep, out, G);
         }

@@ -221,14 +221,14 @@ class Delta3DContour(object):
                         return (start_grid, end_grid)
         return None
 
-    def get_contour_maker(self, grid_endpoints):
+    def get_contour_maker(self, grid_endpoints, rim=True):
         grid = self.grid
         self.grid_endpoints = grid_endpoints
         if self.flatten:
             raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
         gd = np.array([int(n) for n in grid.grid_dimensions])
         self._grid_shift = 0
-        if grid_endpoints and not getattr(grid, "array_backed", False):
+        if grid_endpoints and rim and not getattr(grid, "array_backed", False):
             # explicit end points on a callable field: the reference does not range-check its seed voxels and
             # evaluates f one lattice step outside the grid (tetrahedral.py:396-441); sample that rim too and
             # keep the breadth-first growth inside the reference's grid
@@ -246,12 +246,22 @@ class Delta3DContour(object):
         return result
 
     def search_for_endpoints(self, skip=1):
-        """Reference: exhaustive crossing search + new contour maker (tetrahedral.py:74-81).
-        Here: run the device march (which contains the crossing search); `grid_endpoints` is then
-        derived from the crossing edges the march found.  `skip` only thins that list."""
+        """Reference: crossing search over every skip-th lattice point + new contour maker (tetrahedral.py:74-81,
+        grid_field.py:64-84).  skip == 1 (the canonical call): the device march contains the exhaustive search and
+        every component is returned; `grid_endpoints` is derived lazily from the crossing edges it found.
+        skip > 1: the coarse search runs on the dense samples, its segments seed the reference's breadth-first
+        growth (cx_select_seeded3d), so components the coarse lattice misses stay out, as in the reference."""
+        self._skip = skip
+        if skip > 1:
+            (maxf, minf, segments) = self.grid.find_contour_crossing_grid_segments(self.value, skip)
+            self.grid_values = (minf, maxf)
+            # coarse segments lie inside the grid: no rim of extra samples needed (rim=False)
+            self.contour_maker = self.get_contour_maker(segments if len(segments) else None, rim=False)
+            self.contour_maker.march()
+            self.grid_endpoints = segments
+            return
         self.contour_maker = self.get_contour_maker(None)
         self.contour_maker.march()
-        self._skip = skip
         self.grid_endpoints = _LazyEndpoints(self.contour_maker, skip)
 
     def get_points_and_triangles(self):

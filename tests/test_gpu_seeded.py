@@ -101,3 +101,54 @@ def test_bad_endpoints_are_rejected():
             ctx.select_seeded([[(0, 0, 0), (0, 0, 1)]])          # both outside the sphere: do not straddle the isovalue
     finally:
         ctx.close()
+
+
+def test_search_for_endpoints_with_skip():
+    """skip > 1: the coarse crossing search seeds the growth; a component that the coarse lattice misses is not
+    returned (the reference's sparsity mode, grid_field.py:64-84 + tetrahedral.py:396-463), a large one is."""
+    from contourist_amd import tetrahedral
+    n = 48
+    ax = np.arange(n, dtype=np.float64)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    big = np.sqrt((X - 16.3) ** 2 + (Y - 16.1) ** 2 + (Z - 16.2) ** 2) - 9.0       # sphere of radius 9
+    small = np.sqrt((X - 38.5) ** 2 + (Y - 38.5) ** 2 + (Z - 38.5) ** 2) - 1.2     # sphere of radius 1.2 between coarse points
+    A = np.minimum(big, small).astype(np.float32)
+    full = tetrahedral.TriangulatedIsosurfaces([0] * 3, None, [1] * 3, A, 0.0, [])
+    full.search_for_endpoints()
+    p_all, t_all = full.get_points_and_triangles()
+    coarse = tetrahedral.TriangulatedIsosurfaces([0] * 3, None, [1] * 3, A, 0.0, [])
+    coarse.search_for_endpoints(skip=8)
+    p_big, t_big = coarse.get_points_and_triangles()
+    assert 0 < len(t_big) < len(t_all)
+    assert np.all(np.linalg.norm(np.asarray(p_big) - np.array([16.3, 16.1, 16.2]), axis=1) < 10.5)   # only the big sphere
+    near_small = np.linalg.norm(np.asarray(p_all) - 38.5, axis=1) < 3
+    assert near_small.any()                                                            # the exhaustive search has both
+    # closed surface: Euler characteristic 2
+    assert len(p_big) - len(t_big) // 2 == 2
+
+
+def test_many_seeds_take_the_parallel_path():
+    """more than 1024 end point pairs: one thread per pair; same selection as the oracle on a field where
+    every candidate voxel of a pair belongs to one component"""
+    from oracle import level0, seeds
+    G = np.load(os.path.join(GOLDEN_DIR, "blobs27.npz"))
+    A, v = G["A"], float(G["value"])
+    ctx, counts, xyz, keys, tris = level0_on_device(A, v)
+    try:
+        O = level0.march3d(A, v, diag_mode=1)
+        ko = level0.edge_keys_from_pairs(O["pairs"], A.shape)
+        lin, d = keys >> 3, keys & 7
+        n1n2 = A.shape[1] * A.shape[2]
+        q = np.stack([lin // n1n2, (lin // A.shape[2]) % A.shape[1], lin % A.shape[2]], axis=1)
+        dv = np.stack([(d >> 2) & 1, (d >> 1) & 1, d & 1], axis=1)
+        # all crossing edges of the component that contains vertex 0, repeated to exceed 1024 pairs
+        mask0, surf = seeds.select(A, v, [[tuple(q[0]), tuple(q[0] + dv[0])]], ko, O["tris"])
+        vox = seeds.triangle_voxels(ko, O["tris"], A.shape)
+        comp_vertices = np.unique(np.vectorize({int(k): n for n, k in enumerate(keys)}.get)(ko[np.unique(O["tris"][mask0])]))
+        eps = [[tuple(int(x) for x in q[p]), tuple(int(x) for x in q[p] + dv[p])] for p in comp_vertices]
+        while len(eps) <= 1024:
+            eps = eps + eps
+        got = ctx.select_seeded(eps)
+        assert got["triangles_kept"] == int(mask0.sum())
+    finally:
+        ctx.close()
