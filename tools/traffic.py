@@ -13,7 +13,7 @@ for name in ("fetch", "write"):
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in acc.items():
-            kk = k.split("(")[0].strip()
+            kk = k.split("(")[0].replace("void ", "").split("<")[0].strip()
             if kk.startswith("cx_k_"):
                 vals[kk][c] = sum(v[1:]) / max(len(v) - 1, 1)
 for kk, d in vals.items():
