@@ -127,11 +127,36 @@ __device__ __forceinline__ uint32_t cxp_find(const u64* parent, uint32_t x, uint
     parity = par;
     return x;
 }
+// find with path halving (parity kept consistent: the word of x becomes (parity to its grandparent, grandparent)).
+// fresh == false reads through the CU's L1: every triangle of a component walks to the same few roots, and
+// L2-coherent loads of one address from the whole chip serialise in a single L2 channel (measured: 9 ms for
+// 67 M edges, independent of the edge table).  Stale words are harmless -- links only ever point from a larger
+// to a smaller id, so a stale parent is still an ancestor -- except for liveness: after a failed CAS the retry
+// reads fresh.
+__device__ __forceinline__ uint32_t cxp_find_halving(u64* parent, uint32_t x, uint32_t& parity, bool fresh) {
+    uint32_t par = 0;
+    for (;;) {
+        const u64 w = fresh ? __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[x];
+        const uint32_t p = (uint32_t)w;
+        if (p == x) break;
+        const u64 wp = fresh ? __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[p];
+        const uint32_t g = (uint32_t)wp;
+        // halve the path with a PLAIN store when it is still what was read (a lost race only loses the shortcut;
+        // the word stays a valid relation either way).  No atomic: device-scope atomics are executed at the memory
+        // side of the fabric, 64 bytes of write traffic each, ~21 G/s for the whole chip -- the edge kernel's bound.
+        if (g != p && parent[x] == w) parent[x] = ((((w >> 32) ^ (wp >> 32)) & 1ULL) << 32) | (u64)g;
+        par ^= (uint32_t)(w >> 32) & 1u;
+        x = p;
+    }
+    parity = par;
+    return x;
+}
 // link the sets of a and b; rel = parity between a and b (0: same winding class)
 __device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uint32_t a, uint32_t b, uint32_t rel) {
+    bool fresh = false;
     for (;;) {
         uint32_t pa, pb;
-        uint32_t ra = cxp_find(parent, a, pa), rb = cxp_find(parent, b, pb);
+        uint32_t ra = cxp_find_halving(parent, a, pa, fresh), rb = cxp_find_halving(parent, b, pb, fresh);
         if (ra == rb) return;
         const uint32_t ka = prio ? prio[ra] : ra, kb = prio ? prio[rb] : rb;
         const bool a_wins = (ka < kb) || (ka == kb && ra < rb);
@@ -139,6 +164,7 @@ __device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uin
         const u64 expect = (u64)lose;                                  // still a root, parity 0
         const u64 desired = ((u64)((pa ^ pb ^ rel) & 1u) << 32) | (u64)win;
         if (atomicCAS(&parent[lose], expect, desired) == expect) return;
+        fresh = true;
     }
 }
 
@@ -469,7 +495,17 @@ __device__ __forceinline__ uint32_t cxp_edge_dir(const int32_t* tri, uint32_t t,
     const uint32_t a = tri[(size_t)t * 3], b = tri[(size_t)t * 3 + 1], c = tri[(size_t)t * 3 + 2];
     return ((a == lo && b == hi) || (b == lo && c == hi) || (c == lo && a == hi)) ? 1u : 0u;
 }
-__global__ void cxp_k_edges(const int32_t* tri, uint32_t nt, u64* ekeys, u64* evals, u64 mask, u64* parent) {
+// edge table: slot s = (key at tab[2s], first triangle at tab[2s+1]) -- one cache line per probe.
+// Slots are placed by the SMALLER vertex id (lo * mult + a few bits of the larger one): vertex ids follow the
+// order of the march, so the triangles of a wave probe neighbouring lines instead of random ones.
+// Device-scope atomics are executed at the memory side of the fabric (64 bytes of write traffic each, ~21 G/s for
+// the whole chip: PMC TCC_ATOMIC / WRITE_SIZE), so they are what this stage is bound by: ONE read-modify-write per
+// edge visit claims the key, the claimant publishes its triangle with a plain store (kernel 1); after the kernel
+// boundary every other visitor finds the slot again with plain loads and links itself to the claimant (kernel 2).
+__device__ __forceinline__ u64 cxp_edge_slot(uint32_t lo, uint32_t hi, u64 mask, u64 mult) {
+    return ((u64)lo * mult + (cxp_mix((u64)hi) % mult)) & mask;
+}
+__global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64 mask, u64 mult) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
@@ -478,15 +514,28 @@ __global__ void cxp_k_edges(const int32_t* tri, uint32_t nt, u64* ekeys, u64* ev
         const uint32_t p = v[e], q = v[(e + 1) % 3];
         const uint32_t lo = min(p, q), hi = max(p, q);
         const u64 key = ((u64)lo << 32) | (u64)hi;
-        u64 slot = cxp_mix(key) & mask;
+        u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         for (;;) {
-            const u64 cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
-            if (cur == CXP_EMPTY || cur == key) break;
+            const u64 cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
+            if (cur == CXP_EMPTY) { tab[2 * slot + 1] = (u64)t; break; }
+            if (cur == key) break;
             slot = (slot + 1) & mask;
         }
-        const u64 first = atomicCAS(&evals[slot], CXP_EMPTY, (u64)t);
-        if (first != CXP_EMPTY && (uint32_t)first != t) {
-            const uint32_t o = (uint32_t)first;
+    }
+}
+__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const uint32_t lo = min(p, q), hi = max(p, q);
+        const u64 key = ((u64)lo << 32) | (u64)hi;
+        u64 slot = cxp_edge_slot(lo, hi, mask, mult);
+        while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
+        const uint32_t o = (uint32_t)tab[2 * slot + 1];
+        if (o != t) {
             const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;
             cxp_union(parent, nullptr, t, o, same_dir);   // same direction = inconsistent winding = parity 1
         }
@@ -570,6 +619,14 @@ static inline u64 cxp_table_size(size_t n) {
     while (s < 2 * (u64)n + 16) s <<= 1;
     return s;
 }
+// edge tables: n = 3 * triangles is an upper bound that only an open mesh without shared edges reaches; a closed
+// mesh has half as many distinct edges.  5/4 of the bound keeps the worst case below a load of 0.8 and the usual
+// case near 0.25-0.4 with half the footprint (the table is touched at random: footprint is what costs)
+static inline u64 cxp_edge_table_size(size_t n) {
+    u64 s = 1024;
+    while (s < (5 * (u64)n) / 4 + 16) s <<= 1;
+    return s;
+}
 
 static int cxp_scan(cx_ctx* ctx, cx_post_state* S, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev) {
     const uint32_t nb = cxp_blocks(n, CXP_SCAN_BLOCK);
@@ -648,22 +705,21 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     uint32_t ncomp = 0;
     if (do_orient && nt2) {
         // ---- orientation: edge table + parity union-find over triangles
-        const u64 esz = cxp_table_size((size_t)nt2 * 3);
-        if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
-        if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
+        const u64 esz = cxp_edge_table_size((size_t)nt2 * 3);
+        if ((rc = cxp_reserve(ctx, S->tkeys, 2 * esz * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->parent, (size_t)nt2 * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t))))) return rc;
-        u64* ekeys = (u64*)S->tkeys.p;
-        u64* evals = (u64*)S->tvals.p;
+        u64* etab = (u64*)S->tkeys.p;
         u64* parent = (u64*)S->parent.p;
         u64* cmaxx = (u64*)S->comp.p;
         u64* cbest = cmaxx + nt2;
         uint32_t* cmaxv = (uint32_t*)(cbest + nt2);
         uint32_t* cstart = cmaxv + nt2;
-        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
-        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, evals, (size_t)esz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
-        hipLaunchKernelGGL(cxp_k_edges, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, ekeys, evals, esz - 1, parent);
+        const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
+        hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
+        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
