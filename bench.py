@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--rotate", type=int, default=0, help="number of distinct grids cycled (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the shape-agnostic classify kernel")
+    ap.add_argument("--strong", action="store_true",
+                    help="ONE size^3 volume split into N slabs (SURVEY config 3) instead of one size^3 slab per GPU")
     return ap.parse_args()
 
 
@@ -81,25 +83,31 @@ def main():
     n = args.size
     nrot = args.rotate or (1 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
 
-    # every rank owns `n` planes (+1 halo plane from its upper neighbour, except the last rank)
+    # weak scaling (default): every rank owns `n` planes of its own field; strong scaling: the ranks own the
+    # axis-0 slabs of ONE n^3 field.  Either way +1 halo plane from the upper neighbour, except on the last rank.
     has_upper = distributed and rank + 1 < world
+    i0, i1 = cxdist.slab_bounds(n, world, rank) if args.strong else (0, n)
+    n_own = i1 - i0
     slabs = []
     for r in range(nrot):
-        own = synthetic.smooth_noise_torch((n, n, n), 1235 + 97 * rank + r, args.passes, dev)
-        buf = torch.empty((n + (1 if has_upper else 0), n, n), dtype=torch.float32, device=dev)
-        buf[:n] = own
+        if args.strong:
+            own = synthetic.smooth_noise_torch((n, n, n), 1235 + r, args.passes, dev)[i0:i1]
+        else:
+            own = synthetic.smooth_noise_torch((n, n, n), 1235 + 97 * rank + r, args.passes, dev)
+        buf = torch.empty((n_own + (1 if has_upper else 0), n, n), dtype=torch.float32, device=dev)
+        buf[:n_own] = own
         del own
         slabs.append(buf)
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
     ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
-    ctx.set_origin(rank * n, 0, 0)
+    ctx.set_origin(i0 if args.strong else rank * n, 0, 0)
     flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
 
     def halo_exchange(buf):
         """lower plane of rank r+1 -> halo plane of rank r (RCCL send/recv over xGMI)"""
-        cxdist.exchange_halo(buf, n, rank, world, dist)
+        cxdist.exchange_halo(buf, n_own, rank, world, dist)
 
     def step(i):
         buf = slabs[i % nrot]
@@ -139,7 +147,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples_per_rank = n ** 3
+    samples_per_rank = n_own * n * n
+    total_samples = n ** 3 if args.strong else world * n ** 3
     if rank == 0:
         nt = max(timing["n"], 1)
         k1_ms = timing["classify_ms"] / nt
@@ -171,21 +180,22 @@ def main():
                 traffic = None
         out = {
             "metric": "Mvoxels/s isosurface extraction on 512^3 fp32 grid" if n == 512 else "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % n,
-            "value": world * samples_per_rank * args.steps / elapsed / 1e6,
+            "value": total_samples * args.steps / elapsed / 1e6,
             "unit": "Mvoxels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%dx%d fp32 smooth-noise slab per GPU ([1,2,1]/4 x %d passes, closed interior), isovalue %g, marching tetrahedra Level-0 (classify+interpolate+emit indexed mesh)"
-                            % (n, n, n, args.passes, args.value),
-                "partition": "axis-0 slabs, 1-plane halo over RCCL" if distributed else "single GPU",
+                "workload": "%dx%dx%d fp32 smooth-noise %s ([1,2,1]/4 x %d passes, closed interior), isovalue %g, marching tetrahedra Level-0 (classify+interpolate+emit indexed mesh)"
+                            % (n, n, n, "volume split over the GPUs" if args.strong else "slab per GPU", args.passes, args.value),
+                "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if args.strong else
+                              "one slab per GPU (axis 0), 1-plane halo over RCCL") if distributed else "single GPU",
                 "active_voxel_fraction": final["n_border_voxels"] / float((n - 1) ** 3),
                 "vertices": final["n_vertices"], "triangles": final["n_triangles"],
                 "grids_rotated": nrot,
