@@ -169,8 +169,8 @@ int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32
 int cx_timing_enable(cx_ctx* ctx, int on);
 int cx_timing_read(cx_ctx* ctx, double ms[8], int* n);
 
-/* diagnostic builds only: per-wave s_memtime stamps of the classify kernel (4 per wave: start, end of
- * streaming, after the reservation, end).  words > 0 allocates, host != NULL copies out, 0/NULL frees. */
+/* diagnostics: per-wave s_memtime stamps of the stream kernel (4 words per wave: [0] start, [1] end; [2..3]
+ * unused).  words > 0 allocates, host != NULL copies out, 0/NULL frees. */
 int cx_debug_stamps(cx_ctx* ctx, int64_t words, unsigned long long* host);
 
 /* library build info: "gfx950;<git describe or date>" */

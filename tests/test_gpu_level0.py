@@ -121,6 +121,16 @@ def test_generic_kernel_many_reservations(ctx):
         check_against_oracle(ctx, A, 0.8, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_GENERIC, 1)
 
 
+def test_long_tasks_flush_queue_and_batch_records(ctx, monkeypatch):
+    """a dense surface with very long streaming tasks (CX_TASKS tuning knob): every wave queues ~65 k cells,
+    so the LDS-staged queue entries AND the LDS-staged batch records are flushed many times per task"""
+    from contourist_amd import _ffi
+    monkeypatch.setenv("CX_TASKS", "2")
+    rng = np.random.RandomState(41)
+    A = rng.standard_normal((128, 32, 256)).astype(np.float32)
+    check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+
+
 def test_empty_and_full(ctx):
     from contourist_amd import _ffi
     A = np.ones((8, 8, 8), dtype=np.float32)
