@@ -287,7 +287,9 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
                 if (!ev->e[n]) CX_HIP(ctx, hipEventCreate(&ev->e[n]));
         }
     }
-    CX_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
+    // the generic kernel accumulates into the counters; the staged pipeline's scan kernel writes all of them
+    if (!staged || (flags & CX_DBG_PHASE_A_ONLY))
+        CX_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[0], ctx->stream));
     if (staged) {
         cx_launch_stream(P, T, ctx->stream);
