@@ -226,7 +226,8 @@ __device__ __forceinline__ void cx_process_queue4(const cx_params4& P, const uin
 
 // ---- sign bitmap: one pass over the samples at streaming speed.  A wave takes 8 consecutive chunks of
 // 64 samples of a row (8 loads in flight); a chunk's 64 comparison results are one ballot = 2 words.
-__global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const uint32_t nchunk, const uint32_t nchunks_total) {
+__global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const uint32_t nchunk, const cx_fdiv div_chunk,
+                                                      const uint32_t nchunks_total) {
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t c0 = wave * 8u;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const 
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) {
         const uint32_t c = min(c0 + u, nchunks_total - 1u);
-        row[u] = c / nchunk;
+        row[u] = (nchunk == 1u) ? c : cx_div(c, div_chunk);   // no 8 integer divisions per wave (they were 2/3 of its instructions)
         ch[u] = c - row[u] * nchunk;
         const uint32_t l = ch[u] * 64u + lane;
         ok[u] = l < P.n3;
@@ -412,13 +413,14 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x + wave * 64u >= ncells) return;
+    const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
+    // waves walk the record array grid-stride: a workgroup holds 69 KB of LDS, so launching one per 256 records of
+    // CAPACITY (262 k mostly idle waves on config 4) kept the chip busy with empty workgroups
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx - lane < ncells; idx += gridDim.x * blockDim.x) {
     const bool have = idx < ncells;
     uint4 c4 = make_uint4(0, 0, 0, 0);
     if (have) c4 = P.cells[idx];
     const uint32_t lin = c4.x, sm = c4.y & 0xFFFFu;
-    const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
     uint32_t q[4];
     cx_unravel4(P, lin, q);
     const bool real_voxel = have && q[0] + 1 < P.n0 && q[1] + 1 < P.n1 && q[2] + 1 < P.n2 && q[3] + 1 < P.n3;
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
@@ -546,7 +549,7 @@ void cx_launch_signbits4d(const cx_params4& P, hipStream_t s) {
     const uint32_t nchunk = (P.n3 + 63u) / 64u;
     const uint32_t total = P.nrows * nchunk;
     const uint32_t waves = (total + 7u) / 8u;
-    hipLaunchKernelGGL(cx_k_signbits4, dim3((waves + 3u) / 4u), dim3(256), 0, s, P, nchunk, total);
+    hipLaunchKernelGGL(cx_k_signbits4, dim3((waves + 3u) / 4u), dim3(256), 0, s, P, nchunk, cx_fdiv_make(nchunk), total);
 }
 void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
     const uint32_t nitems = P.nrows * P.nw3;
@@ -557,7 +560,8 @@ void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
     hipLaunchKernelGGL(cx_k_classify4d, dim3(blocks), dim3(256), 0, s, P, ipb);
 }
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s) {
-    const uint32_t blocks = (P.ccap + 255u) / 256u;
+    uint32_t blocks = (P.ccap + 255u) / 256u;
+    if (blocks > 256u * 4u) blocks = 256u * 4u;   // grid-stride: a few workgroups per CU
     hipLaunchKernelGGL(cx_k_emit_tets, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P);
 }
 void cx_launch_hash_xyz(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t n2, const uint32_t org[4], hipStream_t s) {

@@ -158,3 +158,15 @@ def test_capacity_growth(ctx):
     rng = np.random.RandomState(3)
     A = rng.standard_normal((48, 48, 48)).astype(np.float32)    # ~all voxels active: exceeds default buffers
     check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+
+
+def test_context_reuse_across_shapes_and_kernels(ctx):
+    """one context, grids of different shapes and both classify paths in turn: buffers are regrown or reused,
+    results stay exact"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(51)
+    seq = [((24, 20, 36), 0), ((9, 40, 12), _ffi.CX_KERNEL_GENERIC), ((40, 33, 65), 0), ((6, 6, 6), 0),
+           ((24, 20, 36), _ffi.CX_KERNEL_GENERIC), ((50, 12, 260), 0), ((9, 40, 12), 0)]
+    for shape, extra in seq:
+        A = rng.standard_normal(shape).astype(np.float32)
+        check_against_oracle(ctx, A, 0.4, _ffi.CX_DIAG_CPYTHON310 | extra, 1)
