@@ -776,7 +776,10 @@ __global__ __launch_bounds__(256) void cx_k_list_batches(const cx_params P, cons
 }
 
 // ---- S3: vertex records, per-cell table entries and cell records; one wave per batch, grid-stride
-__global__ __launch_bounds__(256) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
+#ifndef CX_S3_MIN_WAVES
+#define CX_S3_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
     __shared__ float4 s_vstage[4][CX_VSTAGE];
     __shared__ uint8_t s_ntri[256];
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
@@ -1004,7 +1007,10 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
 }
 
 // one lane per cell record; waves walk the record array grid-stride (the record count lives on the device)
-__global__ __launch_bounds__(256) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
+#ifndef CX_K2_MIN_WAVES
+#define CX_K2_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
     __shared__ cx_tri_lds L;
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
