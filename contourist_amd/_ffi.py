@@ -23,7 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
 
@@ -104,6 +104,8 @@ def load():
         "cx_level1_4d_download": [vp, vp, vp],
         "cx_morph_triangles": [vp, vp],
         "cx_morph_download": [vp, vp, vp, vp],
+        "cx_morph_eval": [vp, dbl, vp],
+        "cx_morph_eval_download": [vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }
@@ -285,6 +287,18 @@ class Context(object):
         tris = np.empty((int(out[2]), 3), dtype=np.int32)
         self._check(self.lib.cx_morph_download(self.handle, pts.ctypes.data, segs.ctypes.data, tris.ctypes.data))
         return pts, segs, tris, int(out[4])
+
+    def morph_eval(self, t, download=True):
+        """surface at time t from the last morph_triangles() -> (points (P,3) float64, triangles (Q,3) int32)
+        or, with download=False, just the counts (the mesh stays on the device)"""
+        out = np.zeros(2, dtype=np.int64)
+        self._check(self.lib.cx_morph_eval(self.handle, float(t), out.ctypes.data))
+        if not download:
+            return int(out[0]), int(out[1])
+        pts = np.empty((int(out[0]), 3), dtype=np.float64)
+        tris = np.empty((int(out[1]), 3), dtype=np.int32)
+        self._check(self.lib.cx_morph_eval_download(self.handle, pts.ctypes.data, tris.ctypes.data))
+        return pts, tris
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

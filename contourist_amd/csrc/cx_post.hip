@@ -46,6 +46,7 @@ struct cx_post_state {
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
+    int64_t me_points = 0, me_tris = 0;   // last cx_morph_eval
 };
 
 static int cxp_reserve(cx_ctx* ctx, cxp_dev& d, size_t bytes) {
@@ -1410,6 +1411,89 @@ extern "C" int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segm
         CXP_HIP(ctx, hipMemcpyAsync(segments, S->msegs.p, (size_t)S->ms_out * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (triangles && S->mt_out)
         CXP_HIP(ctx, hipMemcpyAsync(triangles, S->mtris.p, (size_t)S->mt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+// ---- B6: the surface at time t from the morph triangles (misc/morph_triangles.js:26-140; MorphTriangles.triangles_at):
+// a triangle is visible while t lies inside the intervals of all three of its segments; its corners are the
+// points of its segments at t (linear interpolation, low t -> high t).  Points and triangles are compacted in index
+// order (the order numpy.unique / boolean indexing give on the host).
+__device__ __forceinline__ bool cxp_seg_inside(const double* P4, const int32_t* segs, uint32_t s, double t) {
+    const double lo = P4[(size_t)segs[(size_t)s * 2] * 4 + 3], hi = P4[(size_t)segs[(size_t)s * 2 + 1] * 4 + 3];
+    return lo <= t && t <= hi;
+}
+__global__ void cxp_k_morph_visible(const double* P4, const int32_t* segs, const int32_t* tris, uint32_t nt, double t,
+                                    uint32_t* tflag, uint32_t* sused) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nt) return;
+    const uint32_t s0 = tris[(size_t)q * 3], s1 = tris[(size_t)q * 3 + 1], s2 = tris[(size_t)q * 3 + 2];
+    const bool vis = cxp_seg_inside(P4, segs, s0, t) && cxp_seg_inside(P4, segs, s1, t) && cxp_seg_inside(P4, segs, s2, t);
+    tflag[q] = vis ? 1u : 0u;
+    if (vis) { sused[s0] = 1u; sused[s1] = 1u; sused[s2] = 1u; }
+}
+__global__ void cxp_k_morph_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint32_t* sused,
+                                   const uint32_t* snew, double* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns || !sused[s]) return;
+    const double* a = P4 + (size_t)segs[(size_t)s * 2] * 4;
+    const double* b = P4 + (size_t)segs[(size_t)s * 2 + 1] * 4;
+    const double lo = a[3], hi = b[3];
+    const double lam = (hi > lo) ? (t - lo) / (hi - lo) : 0.0;
+    double* o = out + (size_t)snew[s] * 3;
+    o[0] = a[0] + lam * (b[0] - a[0]); o[1] = a[1] + lam * (b[1] - a[1]); o[2] = a[2] + lam * (b[2] - a[2]);
+}
+__global__ void cxp_k_morph_tris(const int32_t* tris, uint32_t nt, const uint32_t* tflag, const uint32_t* tnew, const uint32_t* snew,
+                                 int32_t* out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nt || !tflag[q]) return;
+    int32_t* o = out + (size_t)tnew[q] * 3;
+    o[0] = (int32_t)snew[tris[(size_t)q * 3]]; o[1] = (int32_t)snew[tris[(size_t)q * 3 + 1]]; o[2] = (int32_t)snew[tris[(size_t)q * 3 + 2]];
+}
+extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    cx_post_state* S = ctx->post;
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t ns = (uint32_t)S->ms_out, nt = (uint32_t)S->mt_out;
+    S->me_points = 0; S->me_tris = 0;
+    if (out_counts) { out_counts[0] = 0; out_counts[1] = 0; }
+    if (!ns || !nt) return CX_OK;
+    int rc;
+    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(ns + nt + 32) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + nt + 32) * sizeof(uint32_t)))) return rc;
+    uint32_t* sused = (uint32_t*)S->flags.p;
+    uint32_t* tflag = sused + ns + 8;
+    uint32_t* snew = (uint32_t*)S->scan.p;
+    uint32_t* tnew = snew + ns + 8;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    const double* P4 = (const double*)S->pts.p;
+    const int32_t* segs = (const int32_t*)S->msegs.p;
+    const int32_t* tris = (const int32_t*)S->mtris.p;
+    CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(cxp_k_morph_visible, dim3(cxp_blocks(nt)), dim3(256), 0, st, P4, segs, tris, nt, t, tflag, sused);
+    if ((rc = cxp_scan(ctx, S, sused, snew, ns, misc + 8))) return rc;
+    if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 9))) return rc;
+    uint32_t tot[2] = {0, 0};
+    CXP_HIP(ctx, hipMemcpyAsync(tot, misc + 8, sizeof(tot), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(tot[0] + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(tot[1] + 1) * 3 * sizeof(int32_t)))) return rc;
+    if (tot[0]) hipLaunchKernelGGL(cxp_k_morph_points, dim3(cxp_blocks(ns)), dim3(256), 0, st, P4, segs, ns, t, sused, snew, (double*)S->pts_out.p);
+    if (tot[1]) hipLaunchKernelGGL(cxp_k_morph_tris, dim3(cxp_blocks(nt)), dim3(256), 0, st, tris, nt, tflag, tnew, snew, (int32_t*)S->tri_out.p);
+    CXP_HIP(ctx, hipGetLastError());
+    S->me_points = tot[0]; S->me_tris = tot[1];
+    if (out_counts) { out_counts[0] = tot[0]; out_counts[1] = tot[1]; }
+    return CX_OK;
+}
+extern "C" int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    cx_post_state* S = ctx->post;
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    if (points_xyz && S->me_points)
+        CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->me_points * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (triangles && S->me_tris)
+        CXP_HIP(ctx, hipMemcpyAsync(triangles, S->tri_out.p, (size_t)S->me_tris * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CX_OK;
 }

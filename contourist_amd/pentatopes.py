@@ -111,6 +111,15 @@ class GridContour4D(object):
         return morph_geometry.MorphTriangles(pts, segs, tris)
 
 
+    def triangles_at(self, t, download=True):
+        """surface at grid time t, evaluated on the device from the morph triangles of collect_morph_triangles()
+        (misc/morph_triangles.js:26-140; same result as MorphTriangles.triangles_at on the host).
+        -> (points (P,3) float64 grid coordinates, triangles (Q,3) int32), or the two counts with download=False"""
+        if getattr(self, "n_components", None) is None:
+            self.collect_morph_triangles()
+        return self.context().morph_eval(t, download)
+
+
 class Delta4DContour(tetrahedral.Delta3DContour):
     "world-coordinate facade (pentatopes.py:42-68)"
 

@@ -159,6 +159,12 @@ int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* tets);
  * (segment indices). */
 int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts);
 int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32_t* triangles);
+/* The surface at time t from the morph triangles of the last cx_morph_triangles: the consumer-side evaluation of
+ * misc/morph_triangles.js:26-140 (a triangle is visible while t is inside the intervals of all three of its
+ * segments; corners = points of the segments at t).  out_counts (2 x int64): [0] points, [1] triangles.
+ * Download: points np*3 doubles, triangles nt*3 int32 (indices into those points, original triangle order). */
+int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts);
+int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.

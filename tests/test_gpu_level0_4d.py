@@ -123,3 +123,23 @@ def test_morph_triangles_device(name):
     tmid = 0.5 * (MT.min_value + MT.max_value) + 0.013
     pts, tris = MT.triangles_at(tmid)
     assert len(tris) > 0 and tris.max() < len(pts)
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")))
+def test_per_t_surfaces_on_device_equal_host_evaluation(name):
+    """B6: the surface at time t from the morph triangles -- device kernel vs MorphTriangles.triangles_at (numpy)"""
+    from contourist_amd import pentatopes
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    maker = pentatopes.GridContour4D(tuple(np.array(A.shape) - 1), A, v)
+    maker.find_tetrahedra()
+    MT = maker.collect_morph_triangles()
+    n_nonempty = 0
+    for t in np.linspace(MT.min_value, MT.max_value, 9):
+        ph, th = MT.triangles_at(float(t))
+        pd, td = maker.triangles_at(float(t))
+        assert len(ph) == len(pd) and len(th) == len(td)
+        assert np.array_equal(th, td)
+        assert np.allclose(ph, pd, rtol=0, atol=1e-12)
+        n_nonempty += len(td) > 0
+    assert n_nonempty >= 3

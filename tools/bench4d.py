@@ -44,6 +44,18 @@ t0 = time.perf_counter()
 post = ctx.postprocess4d(100)
 torch.cuda.synchronize()
 dp = time.perf_counter() - t0
+# morph triangles (B4/B5) and the per-t surfaces (B6) at n3 times: "per-t isosurface stream"
+t0 = time.perf_counter()
+mt = ctx.morph_triangles()
+torch.cuda.synchronize()
+dm = time.perf_counter() - t0
+ts = [float(x) for x in torch.linspace(float(mt[0][:, 3].min()), float(mt[0][:, 3].max()), shape[3])] if len(mt[0]) else []
+ntris_t = 0
+t0 = time.perf_counter()
+for tt in ts:
+    ntris_t += ctx.morph_eval(tt, download=False)[1]
+torch.cuda.synchronize()
+de = time.perf_counter() - t0
 n = A.numel()
 # CPU baseline: the oracle's C restatement (1 thread) on a slab of the same field
 cpu = None
@@ -61,4 +73,7 @@ except Exception as e:   # the oracle is test infrastructure; the bench line sta
     cpu = {"error": str(e)}
 print(json.dumps({"workload": "%dx%dx%dx%d fp32, two moving blobs + noise, v=%g" % (shape + (v,)), "counts": c, "post": post,
                   "level0_ms": dt * 1e3, "Mhypervoxels_per_s": n / dt / 1e6, "hbm_frac_input_bytes": 4 * n / dt / 8e12,
-                  "postprocess_ms": dp * 1e3, "cpu_baseline": cpu}))
+                  "postprocess_ms": dp * 1e3, "morph_triangles_ms": dm * 1e3, "morph_triangles": int(len(mt[2])),
+                  "per_t_surfaces": {"times": len(ts), "triangles": int(ntris_t), "ms": de * 1e3,
+                                     "Mtriangles_per_s": ntris_t / de / 1e6 if de > 0 else 0.0},
+                  "cpu_baseline": cpu}))
