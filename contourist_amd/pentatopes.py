@@ -139,6 +139,16 @@ class Delta4DContour(tetrahedral.Delta3DContour):
         grid_morph_triangles = contour_maker.collect_morph_triangles()
         return grid_morph_triangles.from_grid_coordinates(self.grid)
 
+    def triangles_at(self, t):
+        """surface at WORLD time t (device evaluation of the morph triangles, misc/morph_triangles.js:26-140):
+        (points (P,3) world coordinates, triangles (Q,3) int32)"""
+        grid = self.grid
+        tg = (float(t) - float(grid.mins[-1])) / float(grid.delta[-1])
+        pts, tris = self.contour_maker.triangles_at(tg)
+        if len(pts):
+            pts = pts * np.asarray(grid.delta[:3], dtype=float) + np.asarray(grid.mins[:3], dtype=float)
+        return pts, tris
+
     def to_json(self):
         "pentatopes.py:85-89"
         morph_triangles = self.collect_morph_triangles()
