@@ -510,7 +510,6 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
-#pragma unroll
     for (int e = 0; e < 3; e++) {
         const uint32_t p = v[e], q = v[(e + 1) % 3];
         const uint32_t lo = min(p, q), hi = max(p, q);
