@@ -516,7 +516,10 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
         const u64 key = ((u64)lo << 32) | (u64)hi;
         u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         for (;;) {
-            const u64 cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
+            // plain read first: the second visitor of an edge usually finds the key already there and needs no
+            // read-modify-write (a stale EMPTY only costs the CAS it would have done anyway)
+            u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
             if (cur == CXP_EMPTY) { tab[2 * slot + 1] = (u64)t; break; }
             if (cur == key) break;
             slot = (slot + 1) & mask;
