@@ -82,6 +82,9 @@ def main():
             dist.init_process_group(backend)
     n = args.size
     nrot = args.rotate or (1 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
+    overlap_halo = distributed and os.environ.get("BENCH_SYNC_HALO", "0") != "1"
+    if overlap_halo:
+        nrot = max(nrot, 2)      # the halo of the next volume is exchanged while the current one is extracted
 
     # weak scaling (default): every rank owns `n` planes of its own field; strong scaling: the ranks own the
     # axis-0 slabs of ONE n^3 field.  Either way +1 halo plane from the upper neighbour, except on the last rank.
@@ -109,9 +112,18 @@ def main():
         """lower plane of rank r+1 -> halo plane of rank r (RCCL send/recv over xGMI)"""
         cxdist.exchange_halo(buf, n_own, rank, world, dist)
 
+    pending = {}
+
     def step(i):
         buf = slabs[i % nrot]
-        if distributed:
+        if overlap_halo:
+            # one process per GPU; the only exchange of the path is the 1-plane halo.  The exchange for volume i+1
+            # (another buffer) is posted before volume i is extracted and runs on RCCL's stream meanwhile.
+            if i not in pending:
+                pending[i] = cxdist.HaloExchange(buf, n_own, rank, world, dist)
+            pending.pop(i).finish()
+            pending[i + 1] = cxdist.HaloExchange(slabs[(i + 1) % nrot], n_own, rank, world, dist)
+        elif distributed:
             halo_exchange(buf)
         ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
         ctx.extract3d_async(args.value, flags)
@@ -136,6 +148,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    for h in pending.values():        # the exchange posted for the volume after the last one
+        h.finish()
+    pending.clear()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -196,6 +211,7 @@ def main():
                             % (n, n, n, "volume split over the GPUs" if args.strong else "slab per GPU", args.passes, args.value),
                 "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if args.strong else
                               "one slab per GPU (axis 0), 1-plane halo over RCCL") if distributed else "single GPU",
+                "halo_exchange": ("overlapped with the previous volume's extraction" if overlap_halo else "in line") if distributed else None,
                 "active_voxel_fraction": final["n_border_voxels"] / float((n - 1) ** 3),
                 "vertices": final["n_vertices"], "triangles": final["n_triangles"],
                 "grids_rotated": nrot,

@@ -44,6 +44,42 @@ def exchange_halo(local, n_own, rank, world, dist=None):
         local[n_own].copy_(recv)
 
 
+class HaloExchange(object):
+    """a halo exchange in flight: start() posts the send / receive, finish() makes the current stream (and, for
+    host-staged gloo, the host) wait for it.  Lets the exchange for the NEXT volume run while the current one
+    is being extracted."""
+
+    def __init__(self, local, n_own, rank, world, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.local, self.n_own, self.works, self.staged_recv = local, n_own, [], None
+        if world == 1:
+            return
+        staged = local.is_cuda and dist.get_backend() == "gloo"      # gloo moves host memory: stage the plane
+        send = local[0].contiguous()
+        recv = local[n_own] if rank + 1 < world else None
+        if staged:
+            send = send.cpu()
+            recv = recv.cpu() if recv is not None else None
+            self.staged_recv = recv
+        ops = []
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, send, rank - 1))
+        if rank + 1 < world:
+            ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
+        self._keep = (send, recv)
+        if ops:
+            self.works = dist.batch_isend_irecv(ops)
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.staged_recv is not None:
+            self.local[self.n_own].copy_(self.staged_recv)
+            self.staged_recv = None
+
+
 def hip_extract(device=0, diagonal_flags=1):
     "default local extractor: the HIP Level-0 march. returns f(local_array_or_tensor, value, origin) -> (xyz, keys, tris)"
     from . import _ffi
