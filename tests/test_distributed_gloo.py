@@ -74,3 +74,43 @@ def test_slab_bounds_cover():
             b = [cd.slab_bounds(n0, world, r) for r in range(world)]
             assert b[0][0] == 0 and b[-1][1] == n0
             assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+
+
+def overlap_worker(rank, world, port, outdir):
+    """two volumes in rotation: the halo of volume i+1 is exchanged (HaloExchange.start) while volume i is in use"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n_own, has_upper = 4, rank + 1 < world
+    vols = []
+    for r in range(2):
+        buf = torch.full((n_own + (1 if has_upper else 0), 3, 5), -1.0)
+        buf[:n_own] = torch.arange(n_own * 15, dtype=torch.float32).reshape(n_own, 3, 5) + 1000.0 * rank + 100000.0 * r
+        vols.append(buf)
+    pending = {}
+    ok = True
+    for i in range(6):
+        buf = vols[i % 2]
+        if i not in pending:
+            pending[i] = cd.HaloExchange(buf, n_own, rank, world, dist)
+        pending.pop(i).finish()
+        pending[i + 1] = cd.HaloExchange(vols[(i + 1) % 2], n_own, rank, world, dist)
+        if has_upper:     # the halo plane is the upper neighbour's first plane of the same volume
+            want = torch.arange(15, dtype=torch.float32).reshape(3, 5) + 1000.0 * (rank + 1) + 100000.0 * (i % 2)
+            ok = ok and bool(torch.equal(buf[n_own], want))
+    for h in pending.values():
+        h.finish()
+    with open(os.path.join(outdir, "ok%d" % rank), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_halo_exchange(tmp_path):
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(overlap_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert open(os.path.join(str(tmp_path), "ok%d" % rank)).read() == "1"
