@@ -142,6 +142,25 @@ __device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t
 // the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
 // entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
 // one coalesced 16-byte store) -- no divergent per-direction loop.
+// Vertex records and triangles are not read again by the pipeline: nontemporal stores keep them from sitting dirty
+// in L2 / Infinity Cache until the NEXT extraction's stream kernel has to push them out (measured: stream kernel
+// 0.148 -> 0.129 ms inside the pipeline, whole extraction -5 %).  Table entries and cell records are read by the
+// triangle kernel right away and stay ordinary stores.  -DCX_NT_VERTS=0 / -DCX_NT_TRIS=0 for A/B.
+#ifndef CX_NT_VERTS
+#define CX_NT_VERTS 1
+#endif
+#ifndef CX_NT_TRIS
+#define CX_NT_TRIS 1
+#endif
+#ifndef CX_NT_GRID
+#define CX_NT_GRID 0
+#endif
+typedef float cx_v4f __attribute__((ext_vector_type(4)));
+#if CX_NT_VERTS
+#define CX_STORE_VERT(ptr, val) __builtin_nontemporal_store(cx_v4f{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4f*>(ptr))
+#else
+#define CX_STORE_VERT(ptr, val) (*(ptr) = (val))
+#endif
 // one round of 64 queued cells, as the vertex stage carries it from its front half (decode, prefix
 // sums, slot table, sample loads issued) to its back half (interpolation, stores)
 struct cx_vround {
@@ -254,7 +273,7 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
 #pragma unroll
             for (uint32_t r = 0; r < CX_VR; r++) {
                 const uint32_t o = 64u * r + lane;
-                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[Ra.base.v + o] = rec4[r];
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec4[r]);
             }
             const uint32_t* slot = slot2 + par * 448u;
             for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
@@ -266,7 +285,7 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
                 const float f0 = A[lin2];
                 const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
                 const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
-                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) P.verts[Ra.base.v + o] = r4;
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], r4);
             }
             if (Ra.emask && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[Ra.lin] = ((uint64_t)Ra.emask << 32) | (uint64_t)(Ra.base.v + Ra.vpre);
         }
@@ -549,7 +568,14 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
             for (int r = 0; r <= CX_RJ; r++) {
                 const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
                 const uint32_t rowofs = (pc * P.n1 + jr) * P.n2;
+#if CX_NT_GRID   // A/B: streaming loads of the grid (do not keep it in L2 / Infinity Cache)
+                {
+                    const cx_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const cx_v4f*>(A + rowofs + kofs_c));
+                    R.v[r] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                }
+#else
                 R.v[r] = *reinterpret_cast<const float4*>(A + rowofs + kofs_c);      // lanes right of the array re-read its last 4 samples
+#endif
                 R.hv[r] = A[rowofs + (halo_in ? k0 + 256u : 0u)];                    // wave-uniform address
             }
         };
@@ -1000,12 +1026,29 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
             // 32-bit wrap-around on purpose: tfirst = first - rank may be "negative" when the wave's cells come from
             // different reservations (generic path); the sum is the triangle index again
             int32_t* out = P.tris + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 3u;
+#if CX_NT_TRIS
+            typedef int32_t cx_v3i __attribute__((ext_vector_type(3)));
+            __builtin_nontemporal_store(cx_v3i{vi[0], vi[1], vi[2]}, reinterpret_cast<cx_v3i*>(out));
+#else
             out[0] = vi[0]; out[1] = vi[1]; out[2] = vi[2];
+#endif
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef CX_NT_RECS
+#define CX_NT_RECS 1     // the cell records are read once: nontemporal loads (A/B: ~1.5 %, within noise)
+#endif
+__device__ __forceinline__ uint4 cx_load_record(const uint4* p) {
+#if CX_NT_RECS
+    typedef uint32_t cx_v4u __attribute__((ext_vector_type(4)));
+    const cx_v4u v = __builtin_nontemporal_load(reinterpret_cast<const cx_v4u*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 // one lane per cell record; waves walk the record array grid-stride (the record count lives on the device)
 #ifndef CX_K2_MIN_WAVES
 #define CX_K2_MIN_WAVES 1
@@ -1023,13 +1066,13 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 zero = make_uint4(0, 0, 0, 0);
     cx_tri_in Ia, Ib;
-    cx_tri_fetch(P, hash_xy, (idx < ncells) ? P.cells[idx] : zero, Ia);
-    uint4 rec_b = (idx + stride < ncells) ? P.cells[idx + stride] : zero;
+    cx_tri_fetch(P, hash_xy, (idx < ncells) ? cx_load_record(P.cells + idx) : zero, Ia);
+    uint4 rec_b = (idx + stride < ncells) ? cx_load_record(P.cells + idx + stride) : zero;
     cx_tri_pin(Ia, rec_b);          // nothing is in flight when the loop is entered
     while (idx - lane < ncells) {   // wave-uniform
         const uint32_t nidx = idx + stride;
         cx_tri_fetch(P, hash_xy, rec_b, Ib);                                    // loads of the next record ...
-        uint4 rec_c = (nidx + stride < ncells) ? P.cells[nidx + stride] : zero;   // ... and the record after it
+        uint4 rec_c = (nidx + stride < ncells) ? cx_load_record(P.cells + nidx + stride) : zero;   // ... and the record after it
         const uint32_t ttot = cx_tri_phase1(P, L, lane, wave, Ia);
         cx_tri_pin(Ib, rec_c);                                                  // ... are back before the stores go out
         cx_tri_phase2(P, L, lane, wave, ttot);

@@ -529,7 +529,11 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
                 tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
             }
             // 32-bit wrap-around on purpose (tfirst = first - rank can be "negative" across reservations)
-            if (ok) *reinterpret_cast<int4*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u) = t4;
+            if (ok) {   // not read again by the pipeline: nontemporal (see cx_march3d.hip)
+                typedef int32_t cx_v4i __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(cx_v4i{t4.x, t4.y, t4.z, t4.w},
+                                            reinterpret_cast<cx_v4i*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u));
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }

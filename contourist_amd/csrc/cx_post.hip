@@ -128,36 +128,14 @@ __device__ __forceinline__ uint32_t cxp_find(const u64* parent, uint32_t x, uint
     parity = par;
     return x;
 }
-// find with path halving (parity kept consistent: the word of x becomes (parity to its grandparent, grandparent)).
-// fresh == false reads through the CU's L1: every triangle of a component walks to the same few roots, and
-// L2-coherent loads of one address from the whole chip serialise in a single L2 channel (measured: 9 ms for
-// 67 M edges, independent of the edge table).  Stale words are harmless -- links only ever point from a larger
-// to a smaller id, so a stale parent is still an ancestor -- except for liveness: after a failed CAS the retry
-// reads fresh.
-__device__ __forceinline__ uint32_t cxp_find_halving(u64* parent, uint32_t x, uint32_t& parity, bool fresh) {
-    uint32_t par = 0;
-    for (;;) {
-        const u64 w = fresh ? __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[x];
-        const uint32_t p = (uint32_t)w;
-        if (p == x) break;
-        const u64 wp = fresh ? __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[p];
-        const uint32_t g = (uint32_t)wp;
-        // halve the path with a PLAIN store when it is still what was read (a lost race only loses the shortcut;
-        // the word stays a valid relation either way).  No atomic: device-scope atomics are executed at the memory
-        // side of the fabric, 64 bytes of write traffic each, ~21 G/s for the whole chip -- the edge kernel's bound.
-        if (g != p && parent[x] == w) parent[x] = ((((w >> 32) ^ (wp >> 32)) & 1ULL) << 32) | (u64)g;
-        par ^= (uint32_t)(w >> 32) & 1u;
-        x = p;
-    }
-    parity = par;
-    return x;
-}
-// link the sets of a and b; rel = parity between a and b (0: same winding class)
+// link the sets of a and b; rel = parity between a and b (0: same winding class).
+// Every access to the parent words is a device-scope atomic (loads included): the L2s of the 8 XCDs are not
+// coherent with each other inside a kernel, and a version with plain loads and plain path-halving stores showed a
+// rare wrong winding of one component (stale lines mixing with memory-side compare-and-swaps).
 __device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uint32_t a, uint32_t b, uint32_t rel) {
-    bool fresh = false;
     for (;;) {
         uint32_t pa, pb;
-        uint32_t ra = cxp_find_halving(parent, a, pa, fresh), rb = cxp_find_halving(parent, b, pb, fresh);
+        uint32_t ra = cxp_find(parent, a, pa), rb = cxp_find(parent, b, pb);
         if (ra == rb) return;
         const uint32_t ka = prio ? prio[ra] : ra, kb = prio ? prio[rb] : rb;
         const bool a_wins = (ka < kb) || (ka == kb && ra < rb);
@@ -165,7 +143,6 @@ __device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uin
         const u64 expect = (u64)lose;                                  // still a root, parity 0
         const u64 desired = ((u64)((pa ^ pb ^ rel) & 1u) << 32) | (u64)win;
         if (atomicCAS(&parent[lose], expect, desired) == expect) return;
-        fresh = true;
     }
 }
 
@@ -520,7 +497,7 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
             // read-modify-write (a stale EMPTY only costs the CAS it would have done anyway)
             u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
-            if (cur == CXP_EMPTY) { tab[2 * slot + 1] = (u64)t; break; }
+            if (cur == CXP_EMPTY) { __hip_atomic_store(&tab[2 * slot + 1], (u64)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             if (cur == key) break;
             slot = (slot + 1) & mask;
         }
