@@ -24,13 +24,24 @@ SYMBOLS = [
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
+CX2_ALL_CHAINS = 1
+CX2_NO_DEDUPE = 2
+CX2_SEARCH_SEEDS = 4
 
 
 class CxCounts(ctypes.Structure):
     _fields_ = [("n_cells", ctypes.c_int64), ("n_vertices", ctypes.c_int64),
                 ("n_triangles", ctypes.c_int64), ("n_border_voxels", ctypes.c_int64)]
+
+
+class CxCounts2D(ctypes.Structure):
+    _fields_ = [("n_points", ctypes.c_uint32), ("n_chains", ctypes.c_uint32), ("n_pairs", ctypes.c_uint32), ("n_levels", ctypes.c_uint32)]
+
+
+CHAIN2D_DTYPE = np.dtype([("level", np.int32), ("closed", np.int32), ("first", np.uint32), ("count", np.uint32)])
 
 
 class HipLibraryMissing(RuntimeError):
@@ -106,6 +117,8 @@ def load():
         "cx_morph_download": [vp, vp, vp, vp],
         "cx_morph_eval": [vp, dbl, vp],
         "cx_morph_eval_download": [vp, vp, vp],
+        "cx_contour2d_extract": [vp, vp, ctypes.c_int, i64, i64, vp, ctypes.c_int32, vp, i64, u32, vp, ctypes.POINTER(CxCounts2D)],
+        "cx_contour2d_download": [vp, vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
     }
@@ -299,6 +312,32 @@ class Context(object):
         tris = np.empty((int(out[1]), 3), dtype=np.int32)
         self._check(self.lib.cx_morph_eval_download(self.handle, pts.ctypes.data, tris.ctypes.data))
         return pts, tris
+
+    def contour2d(self, samples, values, seeds=None, flags=0, mins_delta=None, device_ptr=None, shape=None):
+        """polylines of a 2-D sample array at every isovalue of `values` (ascending, distinct)
+        -> (points (P,2) float64, keys (P,) int64, chains (C,) CHAIN2D_DTYPE, n_pairs).
+        samples: fp32 numpy array (n, m), or None with device_ptr + shape for samples already in HBM.
+        seeds: (S,4) int32 rows (i, j, role, level index), or None for the reference's grid search."""
+        vals = np.ascontiguousarray(values, dtype=np.float64)
+        if device_ptr is None:
+            arr = np.ascontiguousarray(samples, dtype=np.float32)
+            assert arr.ndim == 2
+            n, m = arr.shape
+            ptr, on_device = arr.ctypes.data, 0
+        else:
+            n, m = (int(x) for x in shape)
+            ptr, on_device = int(device_ptr), 1
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int32).reshape(-1, 4)
+        md = None if mins_delta is None else np.ascontiguousarray(mins_delta, dtype=np.float64).reshape(4)
+        c = CxCounts2D()
+        self._check(self.lib.cx_contour2d_extract(self.handle, ptr, on_device, n, m, vals.ctypes.data, len(vals),
+                                                  None if sd is None or len(sd) == 0 else sd.ctypes.data, 0 if sd is None else len(sd),
+                                                  int(flags), None if md is None else md.ctypes.data, ctypes.byref(c)))
+        pts = np.empty((c.n_points, 2), dtype=np.float64)
+        keys = np.empty((c.n_points,), dtype=np.int64)
+        chains = np.empty((c.n_chains,), dtype=CHAIN2D_DTYPE)
+        self._check(self.lib.cx_contour2d_download(self.handle, pts.ctypes.data, keys.ctypes.data, chains.ctypes.data))
+        return pts, keys, chains, int(c.n_pairs)
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

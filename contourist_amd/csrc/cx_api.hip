@@ -60,6 +60,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     (void)hipDeviceSynchronize();
     cx_post_free(ctx);
     cx_state4_free(ctx);
+    cx_state2_free(ctx);
     free_outputs(ctx);
     if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
     if (ctx->celltab) (void)hipFree(ctx->celltab);

@@ -6,6 +6,7 @@
 
 struct cx_post_state;  // Level-1 buffers (cx_post.hip)
 struct cx_state4;       // 4-D march state (cx_api4d.hip)
+struct cx_state2;       // 2-D contour lines (cx_contour2d.hip)
 
 struct cx_ctx {
     int device = 0;
@@ -36,6 +37,7 @@ struct cx_ctx {
     int64_t corner_ref[3] = {0, 0, 0};   // > 0: the reference's corner for the Level-1 scales (cx_set_reference_corner)
     int64_t origin4[4] = {0, 0, 0, 0};
     cx_state4* s4 = nullptr;
+    cx_state2* s2 = nullptr;
     // Level-0 outputs
     float4* verts = nullptr;
     uint4* cells = nullptr;
@@ -64,5 +66,8 @@ struct cx_ctx {
 
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);
+int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev);
 // cx_api4d.hip
 void cx_state4_free(cx_ctx* ctx);
+// cx_contour2d.hip
+void cx_state2_free(cx_ctx* ctx);

@@ -619,6 +619,15 @@ static int cxp_scan(cx_ctx* ctx, cx_post_state* S, const uint32_t* in, uint32_t*
     return CX_OK;
 }
 
+// exclusive scan for the other translation units (cx_contour2d.hip); sums_tmp holds n/1024 + 2 words
+int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev) {
+    const uint32_t nb = cxp_blocks(n, CXP_SCAN_BLOCK);
+    hipLaunchKernelGGL(cxp_k_scan_blocks, dim3(nb ? nb : 1), dim3(256), 0, ctx->stream, in, out, sums_tmp, n);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums_tmp, nb, total_dev);
+    if (n) hipLaunchKernelGGL(cxp_k_scan_add, dim3(cxp_blocks(n)), dim3(256), 0, ctx->stream, out, sums_tmp, n);
+    return CX_OK;
+}
+
 static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_dev) {
     for (int it = 0; it < 64; it++) {
         CXP_HIP(ctx, hipMemsetAsync(changed_dev, 0, sizeof(uint32_t), ctx->stream));

@@ -166,6 +166,40 @@ int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32
 int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts);
 int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
 
+/* ---- 2-D contour lines at several isovalues ------------------------------------------------------
+ * Replaces triangulated.Grid2DContour (search_grid :198-212, find_initial_contour_pairs :299-320,
+ * expand_contour_pairs :322-331, get_contour_sequences :226-297; triangulated.py) for one sample array and ALL
+ * isovalues of multiple_2d_contour.Multiple2DContourGrid.get_contours_dictionary (multiple_2d_contour.py:17-30,
+ * level lookup by bisection as in classify_endpoint_values :48-59) in one pass over the samples.
+ * samples: fp32 A[n][m] (host pointer, or device pointer when on_device != 0; array axes (0,1) are the reference's
+ * (x,y)); values: ascending, distinct.  A sample equal to an isovalue counts as high.
+ * seeds: nseeds x (i, j, role, level index) int32 -- the polylines grown from the pairs around lattice point (i,j)
+ * as their low (role 0) or high (role 1) end are kept, exactly the reference's seeded growth; nseeds == 0: the seeds
+ * of the reference's own grid search (every crossing axis edge that starts at i < n-1, j < m-1).
+ * mins_delta: {min_x, min_y, delta_x, delta_y} for FunctionGrid.from_grid_coordinates (grid_field.py:89-93), or NULL
+ * for grid coordinates.
+ * Output (cx_contour2d_download): points n_points x 2 float64, polyline by polyline; keys n_points int64 =
+ * ((3*(i*m+j) + d) << 16) | level index for the crossing of the lattice edge from (i,j) in direction d (0: (1,0),
+ * 1: (0,1), 2: (1,1)); chains: one cx_chain2d per polyline, ordered by their first crossing's id. */
+#define CX2_ALL_CHAINS 1u   /* keep every polyline (no seeded growth) */
+#define CX2_NO_DEDUPE 2u    /* keep points that are np.allclose to their predecessor (triangulated.py:268) */
+#define CX2_SEARCH_SEEDS 4u /* with explicit seeds: add the seeds of the grid search too (multiple_2d_contour.py:39-41) */
+typedef struct {
+    uint32_t n_points;   /* points in the polylines returned */
+    uint32_t n_chains;   /* polylines returned */
+    uint32_t n_pairs;    /* crossings found on the whole lattice, all levels */
+    uint32_t n_levels;
+} cx_counts2d;
+typedef struct {
+    int32_t level;       /* index into values */
+    int32_t closed;      /* the `closed` flag of get_contour_sequences */
+    uint32_t first;      /* first point */
+    uint32_t count;      /* number of points */
+} cx_chain2d;
+int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_device, int64_t n, int64_t m, const double* values, int32_t nvalues,
+                         const int32_t* seeds, int64_t nseeds, uint32_t flags, const double* mins_delta, cx_counts2d* out);
+int cx_contour2d_download(cx_ctx* ctx, double* points_xy, int64_t* keys, cx_chain2d* chains);
+
 /* ---- measurement ----------------------------------------------------------------------------------
  * When enabled, every extract records HIP events around its kernels on the context's stream.
  * cx_timing_read synchronises and returns the summed milliseconds since the last reset:
