@@ -13,7 +13,7 @@
 // Here: a sample equal to the isovalue counts as high only (f < z is low, as in the 3-D march), so every crossed
 // triangle holds exactly one segment and every pair has at most two neighbours.  Segments are directed with the low
 // side on the left, which gives every crossing one successor and one predecessor; polylines are then ranked with
-// pointer jumping.  No atomics on the data path except the two lock-free union-finds (growth groups, chains).
+// pointer jumping (no atomics); the growth groups of the seeded search are a lock-free union-find over whole polylines.
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -40,7 +40,7 @@ struct c2_buf {
     size_t cap = 0;
 };
 struct cx_state2 {
-    c2_buf grid, values, cnt, base, sums, pts, keys, succ, pred, parent, cparent, mark, head, cyc, ptr[2], dist[2], len, hflag, cidx,
+    c2_buf grid, values, cnt, base, sums, pts, keys, succ, pred, parent, mark, rmark, rep, rank, cyc, jst[2], len, hflag, cidx,
         chead, clen, coff, opts, okeys, ochain, keep, fidx, fpts, fkeys, chains, scal, seeds;
     cx_counts2d counts = {0, 0, 0, 0};
     bool valid = false;
@@ -64,8 +64,8 @@ static int c2_reserve(cx_ctx* ctx, c2_buf& b, size_t bytes) {
 void cx_state2_free(cx_ctx* ctx) {
     if (!ctx->s2) return;
     cx_state2* S = ctx->s2;
-    c2_buf* all[] = {&S->grid, &S->values, &S->cnt, &S->base, &S->sums, &S->pts, &S->keys, &S->succ, &S->pred, &S->parent, &S->cparent,
-                     &S->mark, &S->head, &S->cyc, &S->ptr[0], &S->ptr[1], &S->dist[0], &S->dist[1], &S->len, &S->hflag, &S->cidx, &S->chead,
+    c2_buf* all[] = {&S->grid, &S->values, &S->cnt, &S->base, &S->sums, &S->pts, &S->keys, &S->succ, &S->pred, &S->parent,
+                     &S->mark, &S->rmark, &S->rep, &S->rank, &S->cyc, &S->jst[0], &S->jst[1], &S->len, &S->hflag, &S->cidx, &S->chead,
                      &S->clen, &S->coff, &S->opts, &S->okeys, &S->ochain, &S->keep, &S->fidx, &S->fpts, &S->fkeys, &S->chains, &S->scal,
                      &S->seeds};
     for (c2_buf* b : all)
@@ -81,6 +81,16 @@ struct c2_grid {
     uint32_t nvalues;
     const uint32_t* base;   // exclusive scan of the crossings per lattice edge, edge = 3*(i*m+j) + d
 };
+// the sorted isovalues are searched several times per crossing: kernels copy them to LDS first (up to C2_SV of them;
+// longer lists are searched in global memory)
+#define C2_SV 1024
+#define C2_STAGE_VALUES(G)                                                              \
+    __shared__ double c2_sv[C2_SV];                                                     \
+    if ((G).nvalues <= C2_SV) {                                                         \
+        for (uint32_t k__ = threadIdx.x; k__ < (G).nvalues; k__ += blockDim.x) c2_sv[k__] = (G).values[k__]; \
+        __syncthreads();                                                                \
+        (G).values = c2_sv;                                                             \
+    }
 // the three forward lattice edges of a point: d 0: (1,0), 1: (0,1), 2: (1,1)
 __device__ __forceinline__ bool c2_edge_valid(const c2_grid& G, uint32_t i, uint32_t j, int d) {
     return (d == 1 || i + 1 < G.n) && (d == 0 || j + 1 < G.m);
@@ -115,17 +125,24 @@ __device__ __forceinline__ uint32_t c2_id_of(const c2_grid& G, int ai, int aj, d
     return G.base[e] + (lvl - c2_upper(G, fmin(fa, fb)));
 }
 
-__global__ void c2_k_count(c2_grid G, uint32_t* cnt) {
+// *tie is set when a sample on a searched axis edge equals one of the isovalues (the seed search then needs the
+// per-sample pass c2_k_seed_ties)
+__global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie) {
+    C2_STAGE_VALUES(G)
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= G.n * G.m) return;
     const uint32_t i = lin / G.m, j = lin - i * G.m;
     const double f0 = c2_f(G, i, j);
+    const uint32_t u0 = c2_upper(G, f0);
+    if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
     for (int d = 0; d < 3; d++) {
         uint32_t c = 0;
         if (c2_edge_valid(G, i, j, d)) {
-            uint32_t s, e;
-            c2_levels(G, f0, c2_f(G, i + (d != 1), j + (d != 0)), s, e);
-            c = e - s;
+            const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
+            if (f0 != f1) {
+                const uint32_t u1 = c2_upper(G, f1);
+                c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
+            }
         }
         cnt[3u * lin + d] = c;
     }
@@ -158,51 +175,64 @@ __device__ __forceinline__ void c2_link(const c2_grid& G, const int vi[3], const
         pred[id] = c2_id_of(G, vi[s], vj[s], f[s], vi[tail_other], vj[tail_other], f[tail_other], lvl);
 }
 
-__global__ void c2_k_emit(c2_grid G, double2* pts, c2_u64* keys, uint32_t* succ, uint32_t* pred, uint32_t* parent, uint32_t* cparent) {
-    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= G.n * G.m) return;
+// A block looks at C2_EPB lattice edges, queues the crossed ones (about one in ten on smooth fields) in LDS and then
+// works through the queue with all of its lanes, one edge per lane
+#define C2_EPT 8u
+#define C2_EPB (256u * C2_EPT)
+__global__ __launch_bounds__(256) void c2_k_emit(c2_grid G, const uint32_t* cnt, double2* pts, c2_u64* keys, uint32_t* succ, uint32_t* pred) {
+    __shared__ uint32_t s_q[C2_EPB];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0u;
+    C2_STAGE_VALUES(G)
+    __syncthreads();
+    const uint32_t nedges = 3u * G.n * G.m, e0 = blockIdx.x * C2_EPB;
+    for (uint32_t k = 0; k < C2_EPT; k++) {
+        const uint32_t e = e0 + k * 256u + threadIdx.x;
+        if (e < nedges && cnt[e] != 0u) s_q[atomicAdd(&s_n, 1u)] = e;   // the order in the queue does not matter: ids come from base[]
+    }
+    __syncthreads();
+    const uint32_t nq = s_n;
+    for (uint32_t q = threadIdx.x; q < nq; q += 256u) {
+    const uint32_t eidx = s_q[q];
+    const uint32_t lin = eidx / 3u;
+    const int d = (int)(eidx - 3u * lin);
     const int i = (int)(lin / G.m), j = (int)(lin - (uint32_t)i * G.m);
     const double f0 = c2_f(G, i, j);
-    for (int d = 0; d < 3; d++) {
-        if (!c2_edge_valid(G, i, j, d)) continue;
-        const int bi = i + (d != 1), bj = j + (d != 0);
-        const double f1 = c2_f(G, bi, bj);
-        uint32_t s, e;
-        c2_levels(G, f0, f1, s, e);
-        if (s == e) continue;
-        const uint32_t id0 = G.base[3u * lin + d];
-        // oriented pair (triangulated.py:339-353)
-        const bool first_low = f0 < f1;
-        const double flow = first_low ? f0 : f1, fhigh = first_low ? f1 : f0;
-        const double li = first_low ? i : bi, lj = first_low ? j : bj, hi = first_low ? bi : i, hj = first_low ? bj : j;
-        const double den = 1.0 * (fhigh - flow);
-        // the two triangles of the edge, corners counter-clockwise in (i, j)
-        int t1i[3], t1j[3], t2i[3], t2j[3], a1, b1, a2, b2;
-        bool has1, has2;
-        if (d == 0) {
-            has1 = j + 1 < (int)G.m;  t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j; t1i[2] = i + 1; t1j[2] = j + 1; a1 = 0; b1 = 1;
-            has2 = j >= 1;            t2i[0] = i; t2j[0] = j - 1; t2i[1] = i + 1; t2j[1] = j; t2i[2] = i; t2j[2] = j; a2 = 2; b2 = 1;
-        } else if (d == 1) {
-            has1 = i + 1 < (int)G.n;  t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j + 1; t1i[2] = i; t1j[2] = j + 1; a1 = 0; b1 = 2;
-            has2 = i >= 1;            t2i[0] = i - 1; t2j[0] = j; t2i[1] = i; t2j[1] = j; t2i[2] = i; t2j[2] = j + 1; a2 = 1; b2 = 2;
-        } else {
-            has1 = true;              t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j; t1i[2] = i + 1; t1j[2] = j + 1; a1 = 0; b1 = 2;
-            has2 = true;              t2i[0] = i; t2j[0] = j; t2i[1] = i + 1; t2j[1] = j + 1; t2i[2] = i; t2j[2] = j + 1; a2 = 0; b2 = 1;
-        }
-        for (uint32_t lvl = s; lvl < e; lvl++) {
-            const uint32_t id = id0 + (lvl - s);
-            const double z = G.values[lvl];
-            double ratio = 0.5;
-            if (!(fabs(den) <= 1e-8)) ratio = (z - flow) / den;
-            pts[id] = make_double2(li + ratio * (hi - li), lj + ratio * (hj - lj));
-            keys[id] = ((c2_u64)(3u * lin + (uint32_t)d) << 16) | (c2_u64)lvl;
-            succ[id] = C2_NIL;
-            pred[id] = C2_NIL;
-            parent[id] = id;
-            cparent[id] = id;
-            if (has1) c2_link(G, t1i, t1j, a1, b1, lvl, z, id, succ, pred);
-            if (has2) c2_link(G, t2i, t2j, a2, b2, lvl, z, id, succ, pred);
-        }
+    const int bi = i + (d != 1), bj = j + (d != 0);
+    const double f1 = c2_f(G, bi, bj);
+    uint32_t s, e;
+    c2_levels(G, f0, f1, s, e);
+    const uint32_t id0 = G.base[eidx];
+    // oriented pair (triangulated.py:339-353)
+    const bool first_low = f0 < f1;
+    const double flow = first_low ? f0 : f1, fhigh = first_low ? f1 : f0;
+    const double li = first_low ? i : bi, lj = first_low ? j : bj, hi = first_low ? bi : i, hj = first_low ? bj : j;
+    const double den = 1.0 * (fhigh - flow);
+    // the two triangles of the edge, corners counter-clockwise in (i, j)
+    int t1i[3], t1j[3], t2i[3], t2j[3], a1, b1, a2, b2;
+    bool has1, has2;
+    if (d == 0) {
+        has1 = j + 1 < (int)G.m;  t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j; t1i[2] = i + 1; t1j[2] = j + 1; a1 = 0; b1 = 1;
+        has2 = j >= 1;            t2i[0] = i; t2j[0] = j - 1; t2i[1] = i + 1; t2j[1] = j; t2i[2] = i; t2j[2] = j; a2 = 2; b2 = 1;
+    } else if (d == 1) {
+        has1 = i + 1 < (int)G.n;  t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j + 1; t1i[2] = i; t1j[2] = j + 1; a1 = 0; b1 = 2;
+        has2 = i >= 1;            t2i[0] = i - 1; t2j[0] = j; t2i[1] = i; t2j[1] = j; t2i[2] = i; t2j[2] = j + 1; a2 = 1; b2 = 2;
+    } else {
+        has1 = true;              t1i[0] = i; t1j[0] = j; t1i[1] = i + 1; t1j[1] = j; t1i[2] = i + 1; t1j[2] = j + 1; a1 = 0; b1 = 2;
+        has2 = true;              t2i[0] = i; t2j[0] = j; t2i[1] = i + 1; t2j[1] = j + 1; t2i[2] = i; t2j[2] = j + 1; a2 = 0; b2 = 1;
+    }
+    for (uint32_t lvl = s; lvl < e; lvl++) {
+        const uint32_t id = id0 + (lvl - s);
+        const double z = G.values[lvl];
+        double ratio = 0.5;
+        if (!(fabs(den) <= 1e-8)) ratio = (z - flow) / den;
+        pts[id] = make_double2(li + ratio * (hi - li), lj + ratio * (hj - lj));
+        keys[id] = ((c2_u64)eidx << 16) | (c2_u64)lvl;
+        succ[id] = C2_NIL;
+        pred[id] = C2_NIL;
+        if (has1) c2_link(G, t1i, t1j, a1, b1, lvl, z, id, succ, pred);
+        if (has2) c2_link(G, t2i, t2j, a2, b2, lvl, z, id, succ, pred);
+    }
     }
 }
 
@@ -225,14 +255,6 @@ __device__ __forceinline__ void c2_union(uint32_t* parent, uint32_t a, uint32_t 
         if (atomicCAS(&parent[lose], lose, win) == lose) return;
     }
 }
-__global__ void c2_k_flatten(uint32_t* parent, uint32_t n) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) {
-        const uint32_t root = c2_find(parent, r);
-        __hip_atomic_store(&parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 __device__ __constant__ int c2_off_i[6] = {0, 1, 1, 0, -1, -1};   // adjacent_offsets (triangulated.py:10-12)
 __device__ __constant__ int c2_off_j[6] = {1, 1, 0, -1, -1, 0};
 // the first pair around point (i,j) in the given role at level lvl (role 0: the point is the low end), or C2_NIL
@@ -258,8 +280,13 @@ __device__ __forceinline__ void c2_decode(const c2_grid& G, c2_u64 key, int& i, 
     bi = i + (d != 1u);
     bj = j + (d != 0u);
 }
-// pairs that share an end point in the same role belong to one growth group (expand_contour_pairs :322-331)
-__global__ void c2_k_group(c2_grid G, const c2_u64* keys, uint32_t nv, uint32_t* parent) {
+// Growth groups (expand_contour_pairs :322-331): pairs that share an end point in the same role grow together.  The
+// pairs of one chain already do; what is left is to unite CHAINS that pass the same lattice point in the same role
+// (a saddle), which is rare: the union-find runs over chain representatives and most threads do no atomic at all.
+// search != 0: the pair also is a seed of the exhaustive search (search_grid :198-212: a crossed axis edge from (i,j)
+// with i < n-1, j < m-1) -- a strictly crossed edge lies in the growth group of both of its end points.
+__global__ void c2_k_group(c2_grid G, const c2_u64* keys, const uint32_t* rep, uint32_t nv, int search, uint32_t* parent, uint32_t* mark) {
+    C2_STAGE_VALUES(G)
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
     int i, j, bi, bj;
@@ -268,8 +295,16 @@ __global__ void c2_k_group(c2_grid G, const c2_u64* keys, uint32_t nv, uint32_t*
     const bool first_low = c2_f(G, i, j) < G.values[lvl];
     const uint32_t ra = c2_first_around(G, i, j, first_low ? 0 : 1, lvl);
     const uint32_t rb = c2_first_around(G, bi, bj, first_low ? 1 : 0, lvl);
-    if (ra != C2_NIL && ra != id) c2_union(parent, id, ra);
-    if (rb != C2_NIL && rb != id) c2_union(parent, id, rb);
+    const uint32_t me = rep[id];
+    if (ra != C2_NIL && ra != id) {
+        const uint32_t o = rep[ra];
+        if (o != me) c2_union(parent, me, o);
+    }
+    if (rb != C2_NIL && rb != id) {
+        const uint32_t o = rep[rb];
+        if (o != me) c2_union(parent, me, o);
+    }
+    if (search && !((bi != i) && (bj != j)) && i + 1 < (int)G.n && j + 1 < (int)G.m) mark[me] = 1u;
 }
 // first index with values[idx] >= x
 __device__ __forceinline__ uint32_t c2_lower(const c2_grid& G, double x) {
@@ -280,17 +315,19 @@ __device__ __forceinline__ uint32_t c2_lower(const c2_grid& G, double x) {
     }
     return lo;
 }
-// marks the growth groups of the pairs around a seed point.  role 0: the reference took the point as the low end of
+// marks the chain of the first pair around a seed point.  role 0: the reference took the point as the low end of
 // its seed (f <= z); a point equal to z is a high point here, so its pairs are looked up in that role
-__device__ __forceinline__ void c2_mark_seed(const c2_grid& G, int i, int j, int role, uint32_t lvl, uint32_t* parent, uint32_t* mark) {
+__device__ __forceinline__ void c2_mark_seed(const c2_grid& G, int i, int j, int role, uint32_t lvl, const uint32_t* rep, uint32_t* mark) {
     if (i < 0 || j < 0 || i >= (int)G.n || j >= (int)G.m) return;
     if (role == 0 && c2_f(G, i, j) == G.values[lvl]) role = 1;
     const uint32_t r = c2_first_around(G, i, j, role, lvl);
-    if (r != C2_NIL) mark[c2_find(parent, r)] = 1u;
+    if (r != C2_NIL) mark[rep[r]] = 1u;
 }
-// seeds of the exhaustive search (search_grid :198-212): the axis edges from (i,j), i < n-1, j < m-1, with
-// f(low) <= z <= f(high); both end points seed (find_initial_contour_pairs :316-317)
-__global__ void c2_k_seed_search(c2_grid G, uint32_t* parent, uint32_t* mark) {
+// an axis edge whose lower sample EQUALS the isovalue is no pair here but a seed of the reference's search
+// (f(low) <= z <= f(high)): its end points seed in the role they have under the build's rule (run only when
+// c2_k_count saw such a sample)
+__global__ void c2_k_seed_ties(c2_grid G, const uint32_t* rep, uint32_t* mark) {
+    C2_STAGE_VALUES(G)
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= G.n * G.m) return;
     const int i = (int)(lin / G.m), j = (int)(lin - (uint32_t)i * G.m);
@@ -300,91 +337,103 @@ __global__ void c2_k_seed_search(c2_grid G, uint32_t* parent, uint32_t* mark) {
         const int bi = i + (d == 0), bj = j + (d == 1);
         const double f1 = c2_f(G, bi, bj);
         const bool fwd = f0 <= f1;
-        const uint32_t s = c2_lower(G, fmin(f0, f1)), e = c2_upper(G, fmax(f0, f1));
+        const double lo = fmin(f0, f1);
+        const uint32_t s = c2_lower(G, lo), e = c2_upper(G, lo);   // the levels equal to the lower sample
         for (uint32_t lvl = s; lvl < e; lvl++) {
-            c2_mark_seed(G, fwd ? i : bi, fwd ? j : bj, 0, lvl, parent, mark);
-            c2_mark_seed(G, fwd ? bi : i, fwd ? bj : j, 1, lvl, parent, mark);
+            c2_mark_seed(G, fwd ? i : bi, fwd ? j : bj, 0, lvl, rep, mark);
+            c2_mark_seed(G, fwd ? bi : i, fwd ? bj : j, 1, lvl, rep, mark);
         }
     }
 }
 // explicit seeds: (i, j, role, level index) -- the pairs around the point in that role (find_initial_contour_pairs :316-317)
-__global__ void c2_k_seed_points(c2_grid G, const int32_t* seeds, uint32_t nseeds, uint32_t* parent, uint32_t* mark) {
+__global__ void c2_k_seed_points(c2_grid G, const int32_t* seeds, uint32_t nseeds, const uint32_t* rep, uint32_t* mark) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseeds) return;
     const int32_t* q = seeds + 4 * (size_t)s;
     if (q[3] < 0 || q[3] >= (int)G.nvalues || (q[2] != 0 && q[2] != 1)) return;
-    c2_mark_seed(G, q[0], q[1], q[2], (uint32_t)q[3], parent, mark);
+    c2_mark_seed(G, q[0], q[1], q[2], (uint32_t)q[3], rep, mark);
+}
+// a seeded chain seeds its whole growth group
+__global__ void c2_k_mark_roots(const uint32_t* rep, const uint32_t* mark, uint32_t nv, uint32_t* parent, uint32_t* rmark) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nv || rep[id] != id || !mark[id]) return;
+    rmark[c2_find(parent, id)] = 1u;
 }
 
 // ---- chains ----------------------------------------------------------------------------------------------
-__global__ void c2_k_chain_union(const uint32_t* succ, uint32_t nv, uint32_t* cparent) {
+// Pointer jumping along the predecessor links, all chains at once, no atomics.  State of element i after k rounds:
+//   x = ptr   the element reached after y steps back from i (an open chain's head points to itself)
+//   y = hop   number of steps to ptr; the window of i is the y elements i, pred(i), ... in front of ptr
+//   z = mn    smallest label in the window; label = 0 for the head of an open chain, id + 1 otherwise
+//   w = off   steps from i back to the nearest element with that label
+// Merging the window of i with the window of ptr doubles it.  Open chain: done when the window holds the head
+// (mn == 0): off is the distance to the head.  Closed chain: when i and ptr report the same mn their windows overlap,
+// i.e. together they cover the whole cycle: mn is the smallest id of the cycle and off the distance back to it, which
+// is the rank of i when the cycle is opened in front of its smallest id.
+__global__ void c2_k_jump_init(const uint32_t* pred, uint32_t nv, uint4* st) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
+    const uint32_t p = pred[id];
+    st[id] = (p == C2_NIL) ? make_uint4(id, 0u, 0u, 0u) : make_uint4(p, 1u, id + 1u, 0u);
+}
+__global__ void c2_k_jump(const uint4* in, uint4* out, uint32_t nv, uint32_t* changed) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nv) return;
+    const uint4 a = in[id];
+    if (a.x == id) {   // a head, or a cycle whose length divides hop: final
+        out[id] = a;
+        return;
+    }
+    const uint4 b = in[a.x];
+    uint4 r;
+    r.x = b.x;
+    r.y = a.y + b.y;
+    if (b.z < a.z) {
+        r.z = b.z;
+        r.w = a.y + b.w;
+    } else {
+        r.z = a.z;
+        r.w = a.w;
+    }
+    out[id] = r;
+    if (!(r.z == 0u || a.z == b.z)) *changed = 1u;
+}
+// rep = first element of the chain (head, or smallest id of a cycle), rank = position in the chain, len[rep], cyc[rep]
+__global__ void c2_k_chain_finish(const uint4* st, const uint32_t* succ, uint32_t nv, uint32_t* rep, uint32_t* rank, uint32_t* len, uint32_t* cyc,
+                                  uint32_t* parent) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nv) return;
+    const uint4 a = st[id];
+    const uint32_t r = (a.z == 0u) ? a.x : a.z - 1u;
+    rep[id] = r;
+    rank[id] = a.w;
+    if (r == id) cyc[id] = (a.z != 0u) ? 1u : 0u;
+    parent[id] = id;
     const uint32_t s = succ[id];
-    if (s != C2_NIL) c2_union(cparent, id, s);
-}
-__global__ void c2_k_heads(const uint32_t* pred, const uint32_t* cparent, uint32_t nv, uint32_t* head) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    if (pred[id] == C2_NIL) head[cparent[id]] = id;   // an open chain has exactly one such element
-}
-// closed chains are opened in front of their smallest id (the root of the union-find)
-__global__ void c2_k_cut(uint32_t* succ, uint32_t* pred, const uint32_t* cparent, uint32_t nv, uint32_t* head, uint32_t* cyc) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    cyc[id] = 0u;
-    if (cparent[id] != id || head[id] != C2_NIL) return;
-    head[id] = id;
-    cyc[id] = 1u;
-    const uint32_t p = pred[id];
-    if (p != C2_NIL) succ[p] = C2_NIL;
-    pred[id] = C2_NIL;
-}
-__global__ void c2_k_rank_init(const uint32_t* pred, uint32_t nv, uint32_t* ptr, uint32_t* dist) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    const uint32_t p = pred[id];
-    ptr[id] = (p == C2_NIL) ? id : p;
-    dist[id] = (p == C2_NIL) ? 0u : 1u;
-}
-__global__ void c2_k_rank_jump(const uint32_t* ptr, const uint32_t* dist, uint32_t nv, uint32_t* ptr2, uint32_t* dist2, uint32_t* changed) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    const uint32_t p = ptr[id], pp = ptr[p];
-    ptr2[id] = pp;
-    dist2[id] = dist[id] + dist[p];   // dist[p] is 0 once p is the head of its chain
-    if (pp != p) *changed = 1u;
-}
-__global__ void c2_k_lengths(const uint32_t* succ, const uint32_t* cparent, const uint32_t* dist, uint32_t nv, uint32_t* len) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    if (succ[id] == C2_NIL) len[cparent[id]] = dist[id] + 1u;
+    if (s == C2_NIL || s == r) len[r] = a.w + 1u;   // the last element of the chain
 }
 // hflag[id] = 1 for the head of a chain that is kept
-__global__ void c2_k_head_flags(const uint32_t* cparent, const uint32_t* head, uint32_t* parent, const uint32_t* mark, int all, uint32_t nv,
-                                uint32_t* hflag) {
+__global__ void c2_k_head_flags(const uint32_t* rep, uint32_t* parent, const uint32_t* mark, int all, uint32_t nv, uint32_t* hflag) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
     uint32_t f = 0;
-    if (head[cparent[id]] == id) f = all ? 1u : (mark[c2_find(parent, id)] ? 1u : 0u);
+    if (rep[id] == id) f = all ? 1u : (mark[c2_find(parent, id)] ? 1u : 0u);
     hflag[id] = f;
 }
-__global__ void c2_k_chain_table(const uint32_t* hflag, const uint32_t* cidx, const uint32_t* cparent, const uint32_t* len, uint32_t nv,
-                                 uint32_t* chead, uint32_t* clen) {
+__global__ void c2_k_chain_table(const uint32_t* hflag, const uint32_t* cidx, const uint32_t* len, uint32_t nv, uint32_t* chead, uint32_t* clen) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv || !hflag[id]) return;
     const uint32_t c = cidx[id];
     chead[c] = id;
-    clen[c] = len[cparent[id]];
+    clen[c] = len[id];
 }
-__global__ void c2_k_place(const double2* pts, const c2_u64* keys, const uint32_t* cparent, const uint32_t* head, const uint32_t* hflag,
-                           const uint32_t* cidx, const uint32_t* coff, const uint32_t* dist, uint32_t nv, double2* opts, c2_u64* okeys,
-                           uint32_t* ochain) {
+__global__ void c2_k_place(const double2* pts, const c2_u64* keys, const uint32_t* rep, const uint32_t* hflag, const uint32_t* cidx,
+                           const uint32_t* coff, const uint32_t* rank, uint32_t nv, double2* opts, c2_u64* okeys, uint32_t* ochain) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
-    const uint32_t h = head[cparent[id]];
+    const uint32_t h = rep[id];
     if (!hflag[h]) return;
-    const uint32_t c = cidx[h], pos = coff[c] + dist[id];
+    const uint32_t c = cidx[h], pos = coff[c] + rank[id];
     opts[pos] = pts[id];
     okeys[pos] = keys[id];
     ochain[pos] = c;
@@ -463,16 +512,19 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     if (mins_delta) memcpy(scal_host, mins_delta, sizeof(scal_host));
     if ((rc = c2_reserve(ctx, S->scal, 64))) return rc;
     C2_HIP(ctx, hipMemcpyAsync(S->scal.p, scal_host, sizeof(scal_host), hipMemcpyHostToDevice, st));
-    uint32_t* scratch = (uint32_t*)((char*)S->scal.p + 32);   // [0] scan total, [1] changed flag
+    uint32_t* scratch = (uint32_t*)((char*)S->scal.p + 32);   // [0] scan total, [1] changed flag, [2] tie flag
+    C2_HIP(ctx, hipMemsetAsync(scratch, 0, 16, st));
     const size_t E = 3 * N;
     if ((rc = c2_reserve(ctx, S->cnt, E * 4)) || (rc = c2_reserve(ctx, S->base, (E + 1) * 4)) || (rc = c2_reserve(ctx, S->sums, (E / 1024 + 4) * 4)))
         return rc;
     c2_grid G{A, (uint32_t)n, (uint32_t)m, (const double*)S->values.p, (uint32_t)nvalues, (const uint32_t*)S->base.p};
-    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p);
+    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p, scratch + 2);
     cx_scan_u32(ctx, (const uint32_t*)S->cnt.p, (uint32_t*)S->base.p, (uint32_t)E, (uint32_t*)S->sums.p, scratch);
-    uint32_t nv = 0;
-    C2_HIP(ctx, hipMemcpyAsync(&nv, scratch, 4, hipMemcpyDeviceToHost, st));
+    uint32_t head3[3] = {0, 0, 0};
+    C2_HIP(ctx, hipMemcpyAsync(head3, scratch, 12, hipMemcpyDeviceToHost, st));
     C2_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t nv = head3[0];
+    const bool ties = head3[2] != 0;
     S->counts = cx_counts2d{0, 0, nv, (uint32_t)nvalues};
     if (nv == 0) {
         S->valid = true;
@@ -484,8 +536,8 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
         return CX_ERR_UNSUPPORTED;
     }
     const size_t V = nv;
-    c2_buf* u32s[] = {&S->succ, &S->pred, &S->parent, &S->cparent, &S->mark, &S->head, &S->cyc, &S->ptr[0], &S->ptr[1], &S->dist[0], &S->dist[1],
-                      &S->len, &S->hflag, &S->cidx, &S->ochain, &S->keep, &S->fidx};
+    c2_buf* u32s[] = {&S->succ, &S->pred, &S->parent, &S->mark, &S->rmark, &S->rep, &S->rank, &S->cyc, &S->len, &S->hflag, &S->cidx, &S->ochain, &S->keep,
+                      &S->fidx};
     for (c2_buf* b : u32s)
         if ((rc = c2_reserve(ctx, *b, (V + 1) * 4))) return rc;
     if ((rc = c2_reserve(ctx, S->pts, V * 16)) || (rc = c2_reserve(ctx, S->keys, V * 8)) || (rc = c2_reserve(ctx, S->opts, V * 16)) ||
@@ -494,49 +546,46 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     if (S->sums.cap < (V / 1024 + 4) * 4 && (rc = c2_reserve(ctx, S->sums, (V / 1024 + 4) * 4))) return rc;
     double2* pts = (double2*)S->pts.p;
     c2_u64* keys = (c2_u64*)S->keys.p;
-    uint32_t *succ = (uint32_t*)S->succ.p, *pred = (uint32_t*)S->pred.p, *parent = (uint32_t*)S->parent.p, *cparent = (uint32_t*)S->cparent.p;
-    uint32_t *mark = (uint32_t*)S->mark.p, *head = (uint32_t*)S->head.p, *cyc = (uint32_t*)S->cyc.p, *len = (uint32_t*)S->len.p;
+    uint32_t *succ = (uint32_t*)S->succ.p, *pred = (uint32_t*)S->pred.p, *parent = (uint32_t*)S->parent.p, *rep = (uint32_t*)S->rep.p;
+    uint32_t *mark = (uint32_t*)S->mark.p, *rmark = (uint32_t*)S->rmark.p, *rank = (uint32_t*)S->rank.p, *cyc = (uint32_t*)S->cyc.p, *len = (uint32_t*)S->len.p;
     uint32_t *hflag = (uint32_t*)S->hflag.p, *cidx = (uint32_t*)S->cidx.p;
     const uint32_t gb = c2_blocks(V);
-    hipLaunchKernelGGL(c2_k_emit, dim3(c2_blocks(N)), dim3(256), 0, st, G, pts, keys, succ, pred, parent, cparent);
-    // growth groups and seeds
+    hipLaunchKernelGGL(c2_k_emit, dim3((uint32_t)((E + C2_EPB - 1) / C2_EPB)), dim3(256), 0, st, G, (const uint32_t*)S->cnt.p, pts, keys, succ, pred);
     const int all = (flags & CX2_ALL_CHAINS) ? 1 : 0;
-    if (!all) {
-        C2_HIP(ctx, hipMemsetAsync(mark, 0, V * 4, st));
-        hipLaunchKernelGGL(c2_k_group, dim3(gb), dim3(256), 0, st, G, keys, nv, parent);
-        if (nseeds > 0) {
-            if ((rc = c2_reserve(ctx, S->seeds, (size_t)nseeds * 16))) return rc;
-            C2_HIP(ctx, hipMemcpyAsync(S->seeds.p, seeds, (size_t)nseeds * 16, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(c2_k_seed_points, dim3(c2_blocks((size_t)nseeds)), dim3(256), 0, st, G, (const int32_t*)S->seeds.p, (uint32_t)nseeds,
-                               parent, mark);
-        }
-        if (nseeds <= 0 || (flags & CX2_SEARCH_SEEDS)) hipLaunchKernelGGL(c2_k_seed_search, dim3(c2_blocks(N)), dim3(256), 0, st, G, parent, mark);
-    }
-    // chains: identity, heads, cuts, ranks
-    hipLaunchKernelGGL(c2_k_chain_union, dim3(gb), dim3(256), 0, st, succ, nv, cparent);
-    hipLaunchKernelGGL(c2_k_flatten, dim3(gb), dim3(256), 0, st, cparent, nv);
-    C2_HIP(ctx, hipMemsetAsync(head, 0xFF, V * 4, st));
-    hipLaunchKernelGGL(c2_k_heads, dim3(gb), dim3(256), 0, st, pred, cparent, nv, head);
-    hipLaunchKernelGGL(c2_k_cut, dim3(gb), dim3(256), 0, st, succ, pred, cparent, nv, head, cyc);
+    // chains: first element, rank, length
+    if ((rc = c2_reserve(ctx, S->jst[0], V * 16)) || (rc = c2_reserve(ctx, S->jst[1], V * 16))) return rc;
     int cur = 0;
-    hipLaunchKernelGGL(c2_k_rank_init, dim3(gb), dim3(256), 0, st, pred, nv, (uint32_t*)S->ptr[0].p, (uint32_t*)S->dist[0].p);
+    hipLaunchKernelGGL(c2_k_jump_init, dim3(gb), dim3(256), 0, st, pred, nv, (uint4*)S->jst[0].p);
     for (int round = 0;; round++) {
-        if (round >= 34) {
+        if (round >= 40) {
             ctx->err = "cx_contour2d_extract: chain ranking did not converge";
             return CX_ERR_HIP;
         }
         C2_HIP(ctx, hipMemsetAsync(scratch + 1, 0, 4, st));
-        hipLaunchKernelGGL(c2_k_rank_jump, dim3(gb), dim3(256), 0, st, (const uint32_t*)S->ptr[cur].p, (const uint32_t*)S->dist[cur].p, nv,
-                           (uint32_t*)S->ptr[1 - cur].p, (uint32_t*)S->dist[1 - cur].p, scratch + 1);
+        hipLaunchKernelGGL(c2_k_jump, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[cur].p, (uint4*)S->jst[1 - cur].p, nv, scratch + 1);
         cur = 1 - cur;
         uint32_t changed = 0;
         C2_HIP(ctx, hipMemcpyAsync(&changed, scratch + 1, 4, hipMemcpyDeviceToHost, st));
         C2_HIP(ctx, hipStreamSynchronize(st));
         if (!changed) break;
     }
-    const uint32_t* dist = (const uint32_t*)S->dist[cur].p;
-    hipLaunchKernelGGL(c2_k_lengths, dim3(gb), dim3(256), 0, st, succ, cparent, dist, nv, len);
-    hipLaunchKernelGGL(c2_k_head_flags, dim3(gb), dim3(256), 0, st, cparent, head, parent, mark, all, nv, hflag);
+    hipLaunchKernelGGL(c2_k_chain_finish, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[cur].p, succ, nv, rep, rank, len, cyc, parent);
+    // growth groups of chains and their seeds
+    if (!all) {
+        const bool search = nseeds <= 0 || (flags & CX2_SEARCH_SEEDS);
+        C2_HIP(ctx, hipMemsetAsync(mark, 0, V * 4, st));
+        C2_HIP(ctx, hipMemsetAsync(rmark, 0, V * 4, st));
+        hipLaunchKernelGGL(c2_k_group, dim3(gb), dim3(256), 0, st, G, keys, rep, nv, search ? 1 : 0, parent, mark);
+        if (search && ties) hipLaunchKernelGGL(c2_k_seed_ties, dim3(c2_blocks(N)), dim3(256), 0, st, G, rep, mark);
+        if (nseeds > 0) {
+            if ((rc = c2_reserve(ctx, S->seeds, (size_t)nseeds * 16))) return rc;
+            C2_HIP(ctx, hipMemcpyAsync(S->seeds.p, seeds, (size_t)nseeds * 16, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(c2_k_seed_points, dim3(c2_blocks((size_t)nseeds)), dim3(256), 0, st, G, (const int32_t*)S->seeds.p, (uint32_t)nseeds,
+                               rep, mark);
+        }
+        hipLaunchKernelGGL(c2_k_mark_roots, dim3(gb), dim3(256), 0, st, rep, mark, nv, parent, rmark);
+    }
+    hipLaunchKernelGGL(c2_k_head_flags, dim3(gb), dim3(256), 0, st, rep, parent, rmark, all, nv, hflag);
     cx_scan_u32(ctx, hflag, cidx, nv, (uint32_t*)S->sums.p, scratch);
     uint32_t nchains = 0;
     C2_HIP(ctx, hipMemcpyAsync(&nchains, scratch, 4, hipMemcpyDeviceToHost, st));
@@ -550,7 +599,7 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
         (rc = c2_reserve(ctx, S->coff, ((size_t)nchains + 1) * 4)) || (rc = c2_reserve(ctx, S->chains, (size_t)nchains * sizeof(cx_chain2d))))
         return rc;
     uint32_t *chead = (uint32_t*)S->chead.p, *clen = (uint32_t*)S->clen.p, *coff = (uint32_t*)S->coff.p;
-    hipLaunchKernelGGL(c2_k_chain_table, dim3(gb), dim3(256), 0, st, hflag, cidx, cparent, len, nv, chead, clen);
+    hipLaunchKernelGGL(c2_k_chain_table, dim3(gb), dim3(256), 0, st, hflag, cidx, len, nv, chead, clen);
     cx_scan_u32(ctx, clen, coff, nchains, (uint32_t*)S->sums.p, scratch);
     uint32_t nsel = 0;
     C2_HIP(ctx, hipMemcpyAsync(&nsel, scratch, 4, hipMemcpyDeviceToHost, st));
@@ -562,7 +611,7 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     double2* opts = (double2*)S->opts.p;
     c2_u64* okeys = (c2_u64*)S->okeys.p;
     uint32_t *ochain = (uint32_t*)S->ochain.p, *keep = (uint32_t*)S->keep.p, *fidx = (uint32_t*)S->fidx.p;
-    hipLaunchKernelGGL(c2_k_place, dim3(gb), dim3(256), 0, st, pts, keys, cparent, head, hflag, cidx, coff, dist, nv, opts, okeys, ochain);
+    hipLaunchKernelGGL(c2_k_place, dim3(gb), dim3(256), 0, st, pts, keys, rep, hflag, cidx, coff, rank, nv, opts, okeys, ochain);
     hipLaunchKernelGGL(c2_k_keep, dim3(c2_blocks(nsel)), dim3(256), 0, st, opts, ochain, coff, nsel, (flags & CX2_NO_DEDUPE) ? 0 : 1, keep);
     cx_scan_u32(ctx, keep, fidx, nsel, (uint32_t*)S->sums.p, scratch);
     uint32_t nfinal = 0;

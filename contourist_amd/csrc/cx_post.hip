@@ -194,13 +194,20 @@ __global__ __launch_bounds__(256) void cxp_k_scan_blocks(const uint32_t* in, uin
     }
     if (threadIdx.x == 255) sums[blockIdx.x] = s[255];
 }
+// one workgroup turns the block sums into exclusive offsets: 16 consecutive sums per thread, 16384 per pass
+#define CXP_SUMS_PER_THREAD 16u
 __global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total) {
     __shared__ uint32_t s[1024];
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nb; base += 1024u) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < nb) ? sums[i] : 0u;
-        s[threadIdx.x] = v;
+    for (uint32_t base = 0; base < nb; base += 1024u * CXP_SUMS_PER_THREAD) {
+        const uint32_t i0 = base + threadIdx.x * CXP_SUMS_PER_THREAD;
+        uint32_t v[CXP_SUMS_PER_THREAD], t = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < CXP_SUMS_PER_THREAD; k++) {
+            v[k] = (i0 + k < nb) ? sums[i0 + k] : 0u;
+            t += v[k];
+        }
+        s[threadIdx.x] = t;
         __syncthreads();
         for (uint32_t o = 1; o < 1024; o <<= 1) {
             const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
@@ -208,10 +215,15 @@ __global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t
             s[threadIdx.x] += x;
             __syncthreads();
         }
-        if (i < nb) sums[i] = carry + s[threadIdx.x] - v;
-        const uint32_t blocktot = s[1023];
+        uint32_t run = carry + s[threadIdx.x] - t;
+#pragma unroll
+        for (uint32_t k = 0; k < CXP_SUMS_PER_THREAD; k++) {
+            if (i0 + k < nb) sums[i0 + k] = run;
+            run += v[k];
+        }
+        const uint32_t passtot = s[1023];
         __syncthreads();
-        carry += blocktot;
+        carry += passtot;
     }
     if (threadIdx.x == 0) *total = carry;
 }
