@@ -6,7 +6,7 @@ Same constructors, attributes and return types; the lattice walk itself (search_
 expand_contour_pairs, get_contour_sequences) runs on the GPU in one pass (csrc/cx_contour2d.hip through
 _ffi.Context.contour2d).  There is no CPU fallback: without the HIP library the constructors raise.
 
-Differences from the reference, all about its set-iteration-order artefacts (DESIGN.md section 10):
+Differences from the reference, all about its set-iteration-order artefacts (DESIGN.md section 9):
   * a sample exactly equal to the isovalue counts as high only; the reference gives such a point both roles and
     resolves the resulting branches in set order,
   * a point is dropped when it is np.allclose to its predecessor on the polyline; the reference compares with the
