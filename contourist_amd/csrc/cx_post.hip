@@ -272,7 +272,11 @@ struct cxp_weld_params {
     double ex[3];
 };
 
-// weld: bucket -> vertex with the smallest priority
+// weld: bucket -> vertex with the LARGEST priority (= largest edge key).  The members of a bucket are crossings on the
+// upward edges of one lattice point (truncation puts everything in [V, V + 1/expander)^3 together), so the largest key
+// is the most diagonal edge -- the one the reference's "last inserted wins" (tetrahedral.py:198-203) picks most often,
+// because an edge shared by fewer voxels is first met later (probe on the corner = 511 fixture: 56 of 112 buckets
+// agree, against 15 of 112 for the smallest key; tiny-collapse counts then fall inside the reference's own band)
 __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint32_t nv, cxp_weld_params W, u64* tkeys, u64* tvals,
                                   u64 mask, const uint8_t* vkeep) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +292,7 @@ __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint3
         if (cur == CXP_EMPTY || cur == key) break;
         slot = (slot + 1) & mask;
     }
-    atomicMin(&tvals[slot], ((u64)prio[v] << 32) | (u64)v);
+    atomicMax(&tvals[slot], ((u64)prio[v] << 32) | (u64)v);
 }
 __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_params W, const u64* tkeys, const u64* tvals, u64 mask,
                                   uint32_t* rep, const uint8_t* vkeep) {
@@ -844,7 +848,7 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
         if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->tvals, wsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)wsz, CXP_EMPTY);
-        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, (u64)0);
         hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, vkeep);
         hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep, vkeep);
         hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr);

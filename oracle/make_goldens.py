@@ -260,9 +260,77 @@ def make_two_dots(outdir=GOLDEN_DIR):
     print("two_dots: %d triangles" % len(got))
 
 
+COARSE = dict(corner=511, center=(201.25, 310.5, 255.75), radius2=144.0,
+              end_points=[[[201, 310, 255], [201, 310, 275]]])
+
+
+def coarse_field(i, j, k):
+    "fp32 sample of the coarse-regime fixture at lattice point (i, j, k); works on scalars and on arrays"
+    cx, cy, cz = COARSE["center"]
+    return np.float32((i - cx) ** 2 + (j - cy) ** 2 + (k - cz) ** 2)
+
+
+def make_coarse(outdir=GOLDEN_DIR):
+    """Grid3DContour(511, 511, 511, f, v, end points) on a sphere of radius 12 (tetrahedral.py:104-107): the COARSE
+    regime of the post-passes -- weld bucket 1/int(10000/511) = 1/19 voxel, tiny threshold 0.05 voxel.
+    Only the surface neighbourhood is ever evaluated by the reference; the fixture stores the parameters of the field,
+    the Level-0 snapshot, the triangle counts after every stage for 5 voxel orders and the native Level-1 mesh."""
+    grid_field, surface_geometry, tetrahedral, triangulated = reference_modules()
+    c = COARSE["corner"]
+
+    def f(x, y, z):
+        return float(coarse_field(float(x), float(y), float(z)))
+    runs = []
+    for order, seed in (("native", 0), ("sorted", 0), ("reversed", 0), ("shuffled", 1), ("shuffled", 2)):
+        t0 = time.time()
+        cm = tetrahedral.Grid3DContour(c, c, c, f, COARSE["radius2"], [[tuple(a), tuple(b)] for a, b in COARSE["end_points"]])
+        cm.find_initial_voxels()
+        while cm.new_surface_voxels:
+            cm.expand_voxels()
+        voxels = list(cm.surface_voxels)
+        if order == "sorted":
+            voxels = sorted(voxels)
+        elif order == "reversed":
+            voxels = sorted(voxels, reverse=True)
+        elif order == "shuffled":
+            voxels = sorted(voxels)
+            random.Random(seed).shuffle(voxels)
+        for triple in voxels:
+            cm.enumerate_voxel_triangles(triple)
+        out = {}
+        if order == "native":
+            pair_list = list(cm.interpolated_contour_pairs.keys())
+            pair_index = {p: n for n, p in enumerate(pair_list)}
+            out["l0_pairs"] = np.array([list(p[0]) + list(p[1]) for p in pair_list], dtype=np.int32).reshape(-1, 6)
+            out["l0_xyz"] = np.array([cm.interpolated_contour_pairs[p] for p in pair_list], dtype=np.float64).reshape(-1, 3)
+            out["l0_tris"] = np.array([[pair_index[p] for p in s] for s in cm.simplex_sets], dtype=np.int64).reshape(-1, 3)
+        n0 = len(cm.simplex_sets)
+        cm.quantize_interpolations()
+        n1 = len(cm.simplex_sets)
+        cm.remove_tiny_simplices()
+        n2 = len(cm.simplex_sets)
+        geometry = cm.extract_surface_geometry(True)
+        out["l1_grid_points"] = np.array(geometry.vertices, dtype=np.float64).reshape(-1, 3)
+        out["l1_triangles"] = np.array(geometry.oriented_triangles, dtype=np.int64).reshape(-1, 3)
+        out["counts"] = (n0, n1, n2, len(out["l1_triangles"]))
+        runs.append(out)
+        print("coarse %-9s emitted %d  weld %d  tiny %d  final %d  (%.1fs)" % ((order,) + out["counts"] + (time.time() - t0,)))
+    base = runs[0]
+    stage = np.array([r["counts"] for r in runs], dtype=np.int64)
+    np.savez_compressed(os.path.join(outdir, "coarse_sphere_r12_corner511.npz"),
+                        corner=np.int64(c), center=np.array(COARSE["center"]), value=np.float64(COARSE["radius2"]),
+                        end_points=np.array(COARSE["end_points"], dtype=np.int32),
+                        l0_pairs=base["l0_pairs"], l0_xyz=base["l0_xyz"], l0_tris=base["l0_tris"],
+                        l1_grid_points=base["l1_grid_points"], l1_triangles=base["l1_triangles"],
+                        stage_counts=stage)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:]
     F = fields()
+    if names == ["coarse"]:
+        make_coarse()
+        sys.exit(0)
     if not names or "two_dots" in names:
         make_two_dots()
     for name, spec in F.items():

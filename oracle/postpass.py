@@ -64,7 +64,9 @@ def _tri_priority(keys, tri):
 
 def weld(keys, xyz, tris, corner):
     """A6.  keys (V,) edge keys, xyz (V,3) grid coords, tris (T,3) vertex indices.
-    Canonical representative of a bucket = member with the smallest edge key.
+    Canonical representative of a bucket = member with the LARGEST edge key (the members of a bucket are crossings
+    on the upward edges of one lattice point; the largest key is the most diagonal edge, which is what the reference's
+    order-dependent "last inserted wins" (:198-203) picks most often: fixture coarse_sphere_r12_corner511).
     returns (rep (V,) vertex index of each vertex's representative, tris' (T',3))
     Triangles whose three representatives are not distinct are dropped (:209-211); triangles that
     become the same vertex SET are merged (set semantics :206-211) -- canonical survivor = the one
@@ -73,7 +75,7 @@ def weld(keys, xyz, tris, corner):
     q = weld_buckets(xyz, corner)
     rep = np.arange(len(keys), dtype=np.int64)
     best = {}
-    for v in np.argsort(keys, kind="stable"):
+    for v in np.argsort(-keys, kind="stable"):
         b = (int(q[v, 0]), int(q[v, 1]), int(q[v, 2]))
         if b not in best:
             best[b] = int(v)

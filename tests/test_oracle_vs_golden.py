@@ -126,3 +126,22 @@ def test_set_order_emulation_matches_this_cpython():
         for p in pts:
             s.add(p)
         assert [pts[i] for i in np.argsort(slots)] == list(s)
+
+
+def test_coarse_regime_oracle_vs_reference():
+    """corner = 511 (weld buckets of 1/19 voxel): the oracle's post-pass reproduces the reference's weld exactly; its
+    canonical tiny collapse lands inside the reference's own order-variation band, its clean-up at most 0.5 % below"""
+    import os
+    from oracle import level0, postpass
+    G = np.load(os.path.join(GOLDEN_DIR, "coarse_sphere_r12_corner511.npz"))
+    c = int(G["corner"])
+    corner = np.array([c] * 3)
+    assert int(postpass.expander_for(corner)[0]) == 19
+    keys = level0.edge_keys_from_pairs(G["l0_pairs"], (c + 1,) * 3)
+    L1 = postpass.level1_from_level0(keys, G["l0_xyz"], G["l0_tris"], corner)
+    sc = G["stage_counts"]
+    assert len(G["l0_tris"]) == sc[0, 0] and len(set(sc[:, 0].tolist())) == 1
+    assert L1["n_after_weld"] == sc[0, 1] and len(set(sc[:, 1].tolist())) == 1
+    assert sc[:, 2].min() <= L1["n_after_tiny"] <= sc[:, 2].max()
+    assert sc[:, 3].min() * 0.995 <= len(L1["triangles"]) <= sc[:, 3].max()
+    assert len(set(sc[:, 3].tolist())) > 1      # the reference itself does not agree with itself here
