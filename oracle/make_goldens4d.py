@@ -72,6 +72,13 @@ def fields4d():
     # two blobs that merge over time
     C = np.minimum((X - 3.7) ** 2 + (Y - 4.6) ** 2 + (Z - 4.8) ** 2, (X - 6.4) ** 2 + (Y - 5.4) ** 2 + (Z - 5.1) ** 2) - 0.45 * T
     F["merge_11x11x11x9"] = dict(A=close4(C, 60.0).astype(np.float32), value=1.2)
+    # the reference's own demo field (pentatopes.py:528-551 `test0`: period-3 pattern of spheres morphing into bars,
+    # value 2.0, with samples exactly equal to the value), on a lattice large enough to close its rim
+    g = np.arange(13, dtype=np.float64)
+    X, Y, Z, T = np.meshgrid(g % 3, g % 3, g % 3, np.arange(9, dtype=np.float64), indexing="ij")
+    p1, p2 = 0.5 * (8 - T), 0.5 * T
+    D = p1 * np.sqrt(X * X + Y * Y + Z * Z) + p2 * np.minimum(np.sqrt(X * X + Y * Y), np.sqrt(X * X + Z * Z))
+    F["test0_style_13x13x13x9"] = dict(A=close4(D, 60.0).astype(np.float32), value=2.0)
     return F
 
 
