@@ -127,25 +127,35 @@ __device__ __forceinline__ uint32_t c2_id_of(const c2_grid& G, int ai, int aj, d
 
 // *tie is set when a sample on a searched axis edge equals one of the isovalues (the seed search then needs the
 // per-sample pass c2_k_seed_ties)
-__global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie) {
+__global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie, unsigned long long* total64) {
     C2_STAGE_VALUES(G)
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == 0) s_total = 0u;
+    __syncthreads();
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= G.n * G.m) return;
-    const uint32_t i = lin / G.m, j = lin - i * G.m;
-    const double f0 = c2_f(G, i, j);
-    const uint32_t u0 = c2_upper(G, f0);
-    if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
-    for (int d = 0; d < 3; d++) {
-        uint32_t c = 0;
-        if (c2_edge_valid(G, i, j, d)) {
-            const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
-            if (f0 != f1) {
-                const uint32_t u1 = c2_upper(G, f1);
-                c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
+    if (lin < G.n * G.m) {
+        const uint32_t i = lin / G.m, j = lin - i * G.m;
+        const double f0 = c2_f(G, i, j);
+        const uint32_t u0 = c2_upper(G, f0);
+        if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
+        uint32_t mine = 0;
+        for (int d = 0; d < 3; d++) {
+            uint32_t c = 0;
+            if (c2_edge_valid(G, i, j, d)) {
+                const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
+                if (f0 != f1) {
+                    const uint32_t u1 = c2_upper(G, f1);
+                    c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
+                }
             }
+            cnt[3u * lin + d] = c;
+            mine += c;
         }
-        cnt[3u * lin + d] = c;
+        if (mine) atomicAdd(&s_total, mine);
     }
+    __syncthreads();
+    // the 32-bit scan cannot see an overflow: the grand total is also kept in 64 bits (one atomic per block)
+    if (threadIdx.x == 0 && s_total) atomicAdd(total64, (unsigned long long)s_total);
 }
 
 // the segment of level z inside the counter-clockwise triangle (v0, v1, v2): links crossing `id`, which lies on the
@@ -512,28 +522,29 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     if (mins_delta) memcpy(scal_host, mins_delta, sizeof(scal_host));
     if ((rc = c2_reserve(ctx, S->scal, 64))) return rc;
     C2_HIP(ctx, hipMemcpyAsync(S->scal.p, scal_host, sizeof(scal_host), hipMemcpyHostToDevice, st));
-    uint32_t* scratch = (uint32_t*)((char*)S->scal.p + 32);   // [0] scan total, [1] changed flag, [2] tie flag
-    C2_HIP(ctx, hipMemsetAsync(scratch, 0, 16, st));
+    uint32_t* scratch = (uint32_t*)((char*)S->scal.p + 32);   // [0] scan total, [1] changed flag, [2] tie flag, [4..5] 64-bit total
+    C2_HIP(ctx, hipMemsetAsync(scratch, 0, 24, st));
     const size_t E = 3 * N;
     if ((rc = c2_reserve(ctx, S->cnt, E * 4)) || (rc = c2_reserve(ctx, S->base, (E + 1) * 4)) || (rc = c2_reserve(ctx, S->sums, (E / 1024 + 4) * 4)))
         return rc;
     c2_grid G{A, (uint32_t)n, (uint32_t)m, (const double*)S->values.p, (uint32_t)nvalues, (const uint32_t*)S->base.p};
-    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p, scratch + 2);
+    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p, scratch + 2, (unsigned long long*)(scratch + 4));
     cx_scan_u32(ctx, (const uint32_t*)S->cnt.p, (uint32_t*)S->base.p, (uint32_t)E, (uint32_t*)S->sums.p, scratch);
-    uint32_t head3[3] = {0, 0, 0};
-    C2_HIP(ctx, hipMemcpyAsync(head3, scratch, 12, hipMemcpyDeviceToHost, st));
+    uint32_t head6[6] = {0, 0, 0, 0, 0, 0};
+    C2_HIP(ctx, hipMemcpyAsync(head6, scratch, 24, hipMemcpyDeviceToHost, st));
     C2_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t nv = head3[0];
-    const bool ties = head3[2] != 0;
+    const uint32_t nv = head6[0];
+    const bool ties = head6[2] != 0;
+    const unsigned long long total64 = ((unsigned long long)head6[5] << 32) | head6[4];
+    if (total64 >= 0x7FFFFFFFull) {
+        ctx->err = "cx_contour2d_extract: " + std::to_string(total64) + " crossings (more than 2^31): contour fewer levels per call";
+        return CX_ERR_UNSUPPORTED;
+    }
     S->counts = cx_counts2d{0, 0, nv, (uint32_t)nvalues};
     if (nv == 0) {
         S->valid = true;
         if (out) *out = S->counts;
         return CX_OK;
-    }
-    if (nv >= 0x7FFFFFFFu) {
-        ctx->err = "cx_contour2d_extract: more than 2^31 crossings";
-        return CX_ERR_UNSUPPORTED;
     }
     const size_t V = nv;
     c2_buf* u32s[] = {&S->succ, &S->pred, &S->parent, &S->mark, &S->rmark, &S->rep, &S->rank, &S->cyc, &S->len, &S->hflag, &S->cidx, &S->ochain, &S->keep,

@@ -198,6 +198,20 @@ def test_empty_and_invalid_inputs():
     B[9, 9] = np.inf
     pts, keys, chains, npairs = ctx.contour2d(B, [0.0], None, _ffi.CX2_ALL_CHAINS)
     assert npairs > 0 and int(chains["count"].sum()) == len(pts)
+    # more than 2^31 crossings in one call are refused (counted in 64 bits), not wrapped
+    W = np.random.RandomState(3).standard_normal((2048, 2048)).astype(np.float32)
+    with pytest.raises(_ffi.CxError) as e:
+        ctx.contour2d(W, np.linspace(-3.0, 3.0, 1000))
+    assert e.value.code == -6 and "crossings" in str(e.value)
+    # ... and more levels than the LDS copy holds are searched in global memory, same result
+    many = np.linspace(-2.0, 2.0, 1500)
+    few = many[700:710]
+    a = ctx.contour2d(A, many, None, _ffi.CX2_ALL_CHAINS)
+    b = ctx.contour2d(A, few, None, _ffi.CX2_ALL_CHAINS)
+    sel = np.isin(a[2]["level"], np.arange(700, 710))
+    assert sel.sum() == len(b[2]) and np.array_equal(a[2]["count"][sel], b[2]["count"])
+    pa = np.concatenate([a[0][c["first"]:c["first"] + c["count"]] for c in a[2][sel]]) if sel.any() else np.zeros((0, 2))
+    assert np.array_equal(pa, b[0])
     # seeds outside the lattice or on the wrong side are ignored
     seeds = np.array([[-1, 0, 0, 0], [16, 3, 1, 0], [2, 2, 0, 5], [2, 2, 7, 0]], dtype=np.int32)
     pts, keys, chains, _ = ctx.contour2d(A, [0.0], seeds)
