@@ -42,7 +42,7 @@ struct cxp_dev {
 };
 
 struct cx_post_state {
-    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc, links;
+    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
@@ -63,7 +63,7 @@ void cx_post_free(cx_ctx* ctx) {
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->links};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -513,29 +513,16 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
             // read-modify-write (a stale EMPTY only costs the CAS it would have done anyway)
             u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
-            // value word: low half = the claimant, high half = another triangle on the edge (all ones: none yet)
-            uint32_t* val = reinterpret_cast<uint32_t*>(&tab[2 * slot + 1]);
-            if (cur == CXP_EMPTY) { __hip_atomic_store(&val[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            if (cur == key) { __hip_atomic_store(&val[1], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (cur == CXP_EMPTY) { __hip_atomic_store(&tab[2 * slot + 1], (u64)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (cur == key) break;
             slot = (slot + 1) & mask;
         }
     }
 }
-// Linking in three steps, so that almost no union needs an atomic (the union-find is bound by device-scope atomics,
-// and a plain find walks long chains):
-//   A  every triangle looks up its (up to) three neighbours and points ITSELF at the smallest one below it, with the
-//      parity of their relative winding -- a forest by construction (pointers go down), written without atomics;
-//      it also notes, for the edges it did not claim, the claimant and the parity (links[]);
-//   B  pointer jumping flattens the forest (cxp_flatten);
-//   C  every noted edge whose two triangles ended up under different roots is united with the atomic union-find:
-//      with triangles in march order nearly every triangle has a smaller neighbour, so only the few hundred
-//      thousand edges that close a sheet on itself get here.
-#define CXP_NOLINK 0xFFFFFFFFu
-__global__ void cxp_k_edges_neighbours(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent, uint32_t* links) {
+__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
-    uint32_t best = t, best_par = 0;
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const uint32_t p = v[e], q = v[(e + 1) % 3];
@@ -543,40 +530,11 @@ __global__ void cxp_k_edges_neighbours(const int32_t* tri, uint32_t nt, const u6
         const u64 key = ((u64)lo << 32) | (u64)hi;
         u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
-        const u64 val = tab[2 * slot + 1];
-        const uint32_t first = (uint32_t)val, other = (uint32_t)(val >> 32);
-        const uint32_t nb = (first != t) ? first : other;        // the claimant sees one of the others, everybody else the claimant
-        uint32_t link = CXP_NOLINK;
-        if (nb != CXP_NOLINK && nb != t) {
-            const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, nb, lo, hi)) ? 1u : 0u;   // same direction = parity 1
-            if (first != t) link = first | (same_dir << 31);
-            if (nb < best) { best = nb; best_par = same_dir; }
+        const uint32_t o = (uint32_t)tab[2 * slot + 1];
+        if (o != t) {
+            const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;
+            cxp_union(parent, nullptr, t, o, same_dir);   // same direction = inconsistent winding = parity 1
         }
-        links[(size_t)t * 3 + e] = link;
-    }
-    parent[t] = ((u64)best_par << 32) | (u64)best;
-}
-__global__ void cxp_k_edges_unite(uint32_t nt, const uint32_t* links, u64* parent) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = t < nt;
-    const u64 wt = have ? parent[t] : 0ULL;     // flattened by step B: (parity to the root, root)
-    const uint32_t mine = (uint32_t)wt;
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        uint32_t other = mine, rel = 0;
-        if (have) {
-            const uint32_t link = links[(size_t)t * 3 + e];
-            if (link != CXP_NOLINK) {
-                const u64 wo = parent[link & 0x7FFFFFFFu];
-                other = (uint32_t)wo;
-                rel = ((uint32_t)(wt >> 32) ^ (uint32_t)(wo >> 32) ^ (link >> 31)) & 1u;   // parity between the two ROOTS
-            }
-        }
-        // equal roots prove one tree.  Otherwise unite the two roots (the finds then start at the top); neighbouring
-        // lanes usually sit on the same pair of trees: a lane repeats its predecessor's pair only once per wave
-        const uint32_t prev_mine = (uint32_t)__shfl_up((int)mine, 1), prev_other = (uint32_t)__shfl_up((int)other, 1);
-        const bool repeat = (threadIdx.x & 63u) != 0u && prev_mine == mine && prev_other == other;
-        if (other != mine && !repeat) cxp_union(parent, nullptr, mine, other, rel);
     }
 }
 // per component (root triangle): largest x over its vertices
@@ -763,13 +721,10 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         uint32_t* cmaxv = (uint32_t*)(cbest + nt2);
         uint32_t* cstart = cmaxv + nt2;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
+        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-        if ((rc = cxp_reserve(ctx, S->links, (size_t)nt2 * 3 * sizeof(uint32_t)))) return rc;
-        uint32_t* links = (uint32_t*)S->links.p;
-        hipLaunchKernelGGL(cxp_k_edges_neighbours, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, links);
-        if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
-        hipLaunchKernelGGL(cxp_k_edges_unite, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, links, parent);
+        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
