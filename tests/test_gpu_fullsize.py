@@ -74,3 +74,60 @@ def test_more_than_2_29_samples_is_refused():
             ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
     finally:
         ctx.close()
+
+
+def edge_consistency(tris):
+    """(manifold edges, manifold edges whose two triangles run along them in the SAME direction).
+    A consistently wound surface has none of the latter (surface_geometry.py:110-138)."""
+    t = np.asarray(tris, dtype=np.int64)
+    a = np.concatenate([t[:, 0], t[:, 1], t[:, 2]])
+    b = np.concatenate([t[:, 1], t[:, 2], t[:, 0]])
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    fwd = (a == lo).astype(np.int64)
+    key = lo * (t.max() + 1) + hi
+    order = np.argsort(key, kind="stable")
+    key, fwd = key[order], fwd[order]
+    start = np.concatenate([[True], key[1:] != key[:-1]])
+    idx = np.nonzero(start)[0]
+    count = np.diff(np.concatenate([idx, [len(key)]]))
+    two = idx[count == 2]
+    same = int(np.sum(fwd[two] == fwd[two + 1]))
+    return len(two), same, int(np.sum(count != 2))
+
+
+def test_level1_orientation_at_full_size():
+    """Level 1 on a 512^3 grid (weld buckets of 1/19 voxel): a thick spherical shell, i.e. two concentric spheres whose
+    Level-0 windings are opposite (low is between them).  Every manifold edge is run in opposite directions by its two
+    triangles, and the reference's rule (normal_x > 0 at the vertex with the largest x,
+    surface_geometry.py:79-103) makes BOTH enclose a positive volume."""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi
+    dev = torch.device("cuda", 0)
+    shape = (512, 512, 512)
+    r2 = sphere_field(shape, (250.25, 260.5, 255.75), torch, dev)
+    A = ((r2 - 200.0 ** 2) * (r2 - 110.0 ** 2) * 1e-4).contiguous()
+    del r2
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid(A.data_ptr(), shape, keepalive=A)
+        ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
+        post = ctx.postprocess3d(0)
+        pts, tris = ctx.download_level1(post)
+        # (more than 2 components: patches that hang on an edge shared by 3+ triangles -- the weld pinches sheets
+        # together -- are linked through one pair of that edge's triangles only and may end up on their own)
+        assert post["n_components"] >= 2 and post["n_triangles"] == len(tris) > 500000
+        manifold, same, other = edge_consistency(tris)
+        assert manifold > 0.99 * 1.5 * len(tris) and other < 0.001 * manifold and same <= 1e-4 * manifold
+        # signed volume of each sphere (split by the distance from the centre): outward normals on both
+        rr = np.linalg.norm(pts[tris].mean(axis=1) - np.array([250.25, 260.5, 255.75]), axis=1)
+        vols = []
+        for part in (rr < 155.0, rr >= 155.0):
+            p = pts[tris[part]]
+            vols.append(np.einsum("ij,ij->i", p[:, 0], np.cross(p[:, 1], p[:, 2])).sum() / 6.0)
+        assert abs(vols[0] / (4.0 / 3.0 * np.pi * 110.0 ** 3) - 1.0) < 0.01 and abs(vols[1] / (4.0 / 3.0 * np.pi * 200.0 ** 3) - 1.0) < 0.01
+        again = ctx.postprocess3d(0)
+        assert again == post
+    finally:
+        ctx.close()
+        del A
+        torch.cuda.empty_cache()
