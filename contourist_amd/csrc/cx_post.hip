@@ -513,10 +513,8 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
             // read-modify-write (a stale EMPTY only costs the CAS it would have done anyway)
             u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
-            // value word: low half = the claimant, high half = ONE of the other triangles on the edge (the last to write)
-            uint32_t* val = reinterpret_cast<uint32_t*>(&tab[2 * slot + 1]);
-            if (cur == CXP_EMPTY) { __hip_atomic_store(&val[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            if (cur == key) { __hip_atomic_store(&val[1], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (cur == CXP_EMPTY) { __hip_atomic_store(&tab[2 * slot + 1], (u64)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (cur == key) break;
             slot = (slot + 1) & mask;
         }
     }
@@ -532,12 +530,8 @@ __global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab
         const u64 key = ((u64)lo << 32) | (u64)hi;
         u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
-        // one link per edge: the claimant and the triangle recorded next to it.  An edge with three or more triangles
-        // (sheets pinched together by the weld) cannot have all of them pairwise opposite; linking every visitor to
-        // the claimant would feed the union-find contradictory parities, and whichever loses flips a whole subtree
-        const u64 val = tab[2 * slot + 1];
-        const uint32_t o = (uint32_t)val;
-        if (o != t && (uint32_t)(val >> 32) == t) {
+        const uint32_t o = (uint32_t)tab[2 * slot + 1];
+        if (o != t) {
             const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;
             cxp_union(parent, nullptr, t, o, same_dir);   // same direction = inconsistent winding = parity 1
         }

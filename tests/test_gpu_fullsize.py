@@ -113,11 +113,13 @@ def test_level1_orientation_at_full_size():
         ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
         post = ctx.postprocess3d(0)
         pts, tris = ctx.download_level1(post)
-        # (more than 2 components: patches that hang on an edge shared by 3+ triangles -- the weld pinches sheets
-        # together -- are linked through one pair of that edge's triangles only and may end up on their own)
-        assert post["n_components"] >= 2 and post["n_triangles"] == len(tris) > 500000
+        assert post["n_components"] == 2 and post["n_triangles"] == len(tris) > 500000
+        # edges shared by 3+ triangles (the weld pinches sheets together; ~1 000 here) cannot have all of their triangles
+        # pairwise opposite: around them the propagation is order dependent, in the reference too
+        # (surface_geometry.py:116-119 "ambiguous edge"), and a few manifold edges nearby end up run in the same
+        # direction by both triangles (measured: 2 301 of 8.2 M)
         manifold, same, other = edge_consistency(tris)
-        assert manifold > 0.99 * 1.5 * len(tris) and other < 0.001 * manifold and same <= 1e-4 * manifold
+        assert manifold > 0.99 * 1.5 * len(tris) and other < 0.001 * manifold and same <= 0.001 * manifold
         # signed volume of each sphere (split by the distance from the centre): outward normals on both
         rr = np.linalg.norm(pts[tris].mean(axis=1) - np.array([250.25, 260.5, 255.75]), axis=1)
         vols = []
