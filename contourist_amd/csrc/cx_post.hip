@@ -42,7 +42,7 @@ struct cxp_dev {
 };
 
 struct cx_post_state {
-    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
+    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc, late;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
@@ -63,7 +63,7 @@ void cx_post_free(cx_ctx* ctx) {
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->late};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -519,7 +519,19 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
         }
     }
 }
-__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent) {
+// mode 2 (windings given by the caller, cx_surface_geometry): every visitor of an edge is united with the claimant
+// with the parity of their relative winding, as the reference propagates it (surface_geometry.py:110-138).
+// mode 0 (meshes of the march, which winds every triangle from low to high): two triangles that run along a shared
+// edge in the same direction only occur where the weld has pinched sheets together along an edge shared by 3+
+// triangles -- exactly the links that contradict each other (such an edge cannot have all of its triangles pairwise
+// opposite).  United in one racing kernel, a contradictory union won somewhere and flipped a whole subtree: up to 4 %
+// of the area of a 512^3 spherical shell came out wound the wrong way, differently from run to run.  So the links
+// that need no flip are united here and the others are queued (late[], *nlate) for cxp_k_edges_link_late (mode 1: a
+// second pass instead, if the queue overflows): a late link connects what it touches -- a patch that hangs on that
+// edge alone still joins the component, as in the reference's traversal -- but never flips: both sides keep the
+// march's winding and the component is then turned as a whole by the max-x rule.
+__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent, int mode, u64* late,
+                                 uint32_t late_cap, uint32_t* nlate) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
@@ -531,11 +543,23 @@ __global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab
         u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
         const uint32_t o = (uint32_t)tab[2 * slot + 1];
-        if (o != t) {
-            const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;
-            cxp_union(parent, nullptr, t, o, same_dir);   // same direction = inconsistent winding = parity 1
+        if (o == t) continue;
+        const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;   // same direction = parity 1
+        if (mode == 2) {
+            cxp_union(parent, nullptr, t, o, same_dir);
+        } else if (mode == 0 && same_dir) {
+            const uint32_t k = atomicAdd(nlate, 1u);
+            if (k < late_cap) late[k] = ((u64)o << 32) | (u64)t;
+        } else if ((mode == 0) == (same_dir == 0u)) {
+            cxp_union(parent, nullptr, t, o, 0u);
         }
     }
+}
+__global__ void cxp_k_edges_link_late(const u64* late, uint32_t n, u64* parent) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 w = late[i];
+    cxp_union(parent, nullptr, (uint32_t)w, (uint32_t)(w >> 32), 0u);
 }
 // per component (root triangle): largest x over its vertices
 __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
@@ -660,7 +684,7 @@ static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_d
 // Shared tail: clean (optional) + compaction + orientation (optional) on S->pts (nv x 3 doubles),
 // S->tri (nt x 3), S->alive.  prio = vertex priorities.  Results in S->pts_out / S->tri_out.
 static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, bool do_clean, bool do_orient,
-                            uint32_t* tprio3, int64_t* out_counts) {
+                            uint32_t* tprio3, int64_t* out_counts, bool coherent) {
     int rc;
     double* pts = (double*)S->pts.p;
     uint32_t* prio = (uint32_t*)S->prio.p;
@@ -724,7 +748,21 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent);
+        const uint32_t late_cap = nt2 / 8 + 1024;
+        if ((rc = cxp_reserve(ctx, S->late, (size_t)late_cap * sizeof(u64)))) return rc;
+        CXP_HIP(ctx, hipMemsetAsync(misc + 20, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 0 : 2,
+                           (u64*)S->late.p, late_cap, misc + 20);
+        uint32_t nlate = 0;
+        if (coherent) {
+            CXP_HIP(ctx, hipMemcpyAsync(&nlate, misc + 20, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CXP_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if (nlate > late_cap)
+            hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, 1, (u64*)S->late.p,
+                               late_cap, misc + 20);
+        else if (nlate)
+            hipLaunchKernelGGL(cxp_k_edges_link_late, dim3(cxp_blocks(nlate)), dim3(256), 0, st, (const u64*)S->late.p, nlate, parent);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
@@ -887,7 +925,7 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
         CXP_HIP(ctx, hipStreamSynchronize(st));
         counts[2] = h[0]; counts[3] = h[1];
     }
-    if ((rc = cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts))) return rc;
+    if ((rc = cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, true))) return rc;   // the march winds every triangle low -> high
     ctx->post_valid = true;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
     return CX_OK;
@@ -936,7 +974,7 @@ extern "C" int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv_
                            (const u64*)nullptr);
     }
     int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if ((rc = cxp_clean_orient(ctx, S, nv, nt, mode != 0, mode != 2, tprio3, counts))) return rc;
+    if ((rc = cxp_clean_orient(ctx, S, nv, nt, mode != 0, mode != 2, tprio3, counts, false))) return rc;   // caller's windings: arbitrary
     if (S->nv_out) CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->nv_out * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (S->nt_out) CXP_HIP(ctx, hipMemcpyAsync(tris, S->tri_out.p, (size_t)S->nt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     CXP_HIP(ctx, hipStreamSynchronize(st));

@@ -115,11 +115,10 @@ def test_level1_orientation_at_full_size():
         pts, tris = ctx.download_level1(post)
         assert post["n_components"] == 2 and post["n_triangles"] == len(tris) > 500000
         # edges shared by 3+ triangles (the weld pinches sheets together; ~1 000 here) cannot have all of their triangles
-        # pairwise opposite: around them the propagation is order dependent, in the reference too
-        # (surface_geometry.py:116-119 "ambiguous edge"), and a few manifold edges nearby end up run in the same
-        # direction by both triangles (measured: 2 300 .. 13 000 of 8.2 M, it varies from run to run)
+        # pairwise opposite; the linking never flips across them (cx_post.hip, cxp_k_edges_link), so every MANIFOLD edge
+        # stays consistently wound
         manifold, same, other = edge_consistency(tris)
-        assert manifold > 0.99 * 1.5 * len(tris) and other < 0.001 * manifold and same <= 0.005 * manifold
+        assert manifold > 0.99 * 1.5 * len(tris) and other < 0.001 * manifold and same <= 1e-5 * manifold
         # signed volume of each sphere (split by the distance from the centre): outward normals on both
         rr = np.linalg.norm(pts[tris].mean(axis=1) - np.array([250.25, 260.5, 255.75]), axis=1)
         vols = []
