@@ -23,3 +23,16 @@ for n in (64, 128, 256, 512):
         t = np.asarray(tris, dtype=np.int64)
         print(n, "flags", flags, post, "manifold", m, "same-direction", same, "non-2 edges", other, flush=True)
     ctx.close()
+
+# the bench field (smooth noise, closed interior) at 256^3 and 384^3
+from contourist_amd import synthetic
+for n in (256, 384):
+    A = synthetic.smooth_noise_torch((n,) * 3, 1235, 1400, dev)
+    ctx = _ffi.Context(0)
+    ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+    ctx.extract3d(0.0, 1)
+    post = ctx.postprocess3d(0)
+    pts, tris = ctx.download_level1(post)
+    m, same, other = edge_consistency(tris)
+    print("noise", n, post, "manifold", m, "same-direction", same, "non-2 edges", other, flush=True)
+    ctx.close()
