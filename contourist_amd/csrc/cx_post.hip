@@ -1189,8 +1189,10 @@ __device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32
     double tv[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) v[s] = (uint32_t)tets[(size_t)t * 4 + s];
-    // (a,b,c,d) = vertices in ascending priority (sorting network)
-#define CXP_CSWAP(x, y) if (prio[v[x]] > prio[v[y]]) { const uint32_t tmp = v[x]; v[x] = v[y]; v[y] = tmp; }
+    // (a,b,c,d) = vertices in ascending priority (sorting network); the stored order is positively oriented
+    // (cxp_k_tets_orient), tsign = orientation of (a,b,c,d)
+    double tsign = 1.0;
+#define CXP_CSWAP(x, y) if (prio[v[x]] > prio[v[y]]) { const uint32_t tmp = v[x]; v[x] = v[y]; v[y] = tmp; tsign = -tsign; }
     CXP_CSWAP(0, 1) CXP_CSWAP(2, 3) CXP_CSWAP(0, 2) CXP_CSWAP(1, 3) CXP_CSWAP(1, 2)
 #undef CXP_CSWAP
 #pragma unroll
@@ -1206,6 +1208,7 @@ __device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32
         const double mid = 0.5 * (ts[g + 1] + ts[g]);
         u64 sp[6];
         bool zero[6];
+        double px[6], py[6], pz[6];   // the slice points in the tetrahedron's own affine frame: a = 0, b = e1, c = e2, d = e3
         int m = 0;
 #pragma unroll
         for (int e = 0; e < 6; e++) {
@@ -1214,10 +1217,25 @@ __device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32
             if (mid + 1e-5 < v1 || mid - 1e-5 > v2) continue;      // morph_geometry.py:218
             sp[m] = ((u64)v[PI[e]] << 32) | (u64)v[PJ[e]];
             zero[m] = fabs(tv[PI[e]] - tv[PJ[e]]) <= t_eps;        // pentatopes.py:341-345
+            const double den = tv[PJ[e]] - tv[PI[e]];
+            const double lam = (den != 0.0) ? fmin(1.0, fmax(0.0, (mid - tv[PI[e]]) / den)) : 0.5;
+            const double ix = (PI[e] == 1) ? 1.0 : 0.0, iy = (PI[e] == 2) ? 1.0 : 0.0, iz = (PI[e] == 3) ? 1.0 : 0.0;
+            const double jx = (PJ[e] == 1) ? 1.0 : 0.0, jy = (PJ[e] == 2) ? 1.0 : 0.0, jz = (PJ[e] == 3) ? 1.0 : 0.0;
+            px[m] = ix + lam * (jx - ix); py[m] = iy + lam * (jy - iy); pz[m] = iz + lam * (jz - iz);
             m++;
         }
+        // winding: all tetrahedra are oriented alike with respect to the field gradient, so the slice triangle whose
+        // normal (inside the tetrahedron) points towards later times is wound alike everywhere -- a rule on the
+        // order of the vertex times only, which bin_times and the tiny collapse do not disturb
+        const double wx = tv[1] - tv[0], wy = tv[2] - tv[0], wz = tv[3] - tv[0];
+        auto wound = [&](int i0, int i1, int i2) {
+            const double ax = px[i1] - px[i0], ay = py[i1] - py[i0], az = pz[i1] - pz[i0];
+            const double bx = px[i2] - px[i0], by = py[i2] - py[i0], bz = pz[i2] - pz[i0];
+            const double det = (ay * bz - az * by) * wx + (az * bx - ax * bz) * wy + (ax * by - ay * bx) * wz;
+            if (det * tsign >= 0.0) emit(sp[i0], sp[i1], sp[i2]); else emit(sp[i0], sp[i2], sp[i1]);
+        };
         if (m == 3) {
-            if (!(zero[0] || zero[1] || zero[2])) { emit(sp[0], sp[1], sp[2]); n++; }
+            if (!(zero[0] || zero[1] || zero[2])) { wound(0, 1, 2); n++; }
         } else if (m == 4) {                                       // morph_geometry.py:176-186
             int p2 = -1;
             for (int e = 1; e < 4; e++) {
@@ -1226,13 +1244,99 @@ __device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32
             }
             for (int e = 1; e < 4; e++) {
                 if (e == p2 || p2 < 0) continue;
-                if (!(zero[0] || zero[p2] || zero[e])) { emit(sp[0], sp[p2], sp[e]); n++; }
+                if (!(zero[0] || zero[p2] || zero[e])) { wound(0, p2, e); n++; }
             }
         }
     }
     return n;
 }
 
+// Every tetrahedron of the 4-D march lies in the level set of the linear interpolant of ONE pentatope (Kuhn simplex
+// of its hypercube, pentatopes.py:15-26).  Its four indices are put in the order that makes
+// det[p1-p0, p2-p0, p3-p0, gradient] positive, with the points as the march interpolated them (before bin_times) and
+// the gradient of that interpolant: along the axis added at step i of the pentatope's lattice path it is the
+// difference of the two consecutive corner samples; the pentatope is the one whose path adds the axes in the order of
+// decreasing fractional coordinate of the tetrahedron's centroid.
+struct cxp_grid4 {
+    const float* A;
+    int n[4];
+    double value;
+};
+__device__ __forceinline__ void cxp_crossing4(const cxp_grid4& G, uint32_t key, double x[4]) {
+    const uint32_t lin = key >> 4, d = key & 15u;
+    const uint32_t s3 = (uint32_t)G.n[3], s2 = s3 * (uint32_t)G.n[2], s1 = s2 * (uint32_t)G.n[1];
+    uint32_t q[4];
+    q[0] = lin / s1;
+    uint32_t r = lin - q[0] * s1;
+    q[1] = r / s2;
+    r -= q[1] * s2;
+    q[2] = r / s3;
+    q[3] = r - q[2] * s3;
+    const uint32_t lin2 = lin + ((d & 8u) ? s1 : 0u) + ((d & 4u) ? s2 : 0u) + ((d & 2u) ? s3 : 0u) + (d & 1u);
+    const double f0 = (double)G.A[lin], f1 = (double)G.A[lin2];
+    const bool owner_low = !(f0 > f1);
+    const double flow = owner_low ? f0 : f1, fhigh = owner_low ? f1 : f0;
+    double ratio = 0.5;
+    const double den = 1.0 * (fhigh - flow);
+    if (!(fabs(den) <= 1e-8)) ratio = (G.value - flow) / den;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const double db = (double)((d >> (3 - a)) & 1u);
+        const double low = owner_low ? (double)q[a] : (double)q[a] + db, high = owner_low ? (double)q[a] + db : (double)q[a];
+        x[a] = low + ratio * (high - low);
+    }
+}
+__global__ void cxp_k_tets_orient(int32_t* tets, uint32_t nt, const uint32_t* keys, cxp_grid4 G) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    double p[4][4], c[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        cxp_crossing4(G, keys[(uint32_t)tets[(size_t)t * 4 + k]], p[k]);
+#pragma unroll
+        for (int a = 0; a < 4; a++) c[a] += 0.25 * p[k][a];
+    }
+    int base[4], ord[4] = {0, 1, 2, 3};
+    double frac[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        int i0 = (int)floor(c[a]);
+        i0 = max(0, min(i0, G.n[a] - 2));
+        base[a] = i0;
+        frac[a] = c[a] - (double)i0;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+#pragma unroll
+        for (int j = i; j > 0; j--)
+            if (frac[ord[j]] > frac[ord[j - 1]]) { const int x = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = x; }
+    int q[4] = {base[0], base[1], base[2], base[3]};
+    const size_t s3 = (size_t)G.n[3], s2 = s3 * (size_t)G.n[2], s1 = s2 * (size_t)G.n[1];
+    double prev = (double)G.A[q[0] * s1 + q[1] * s2 + q[2] * s3 + q[3]], g[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        q[ord[i]] += 1;
+        const double cur = (double)G.A[q[0] * s1 + q[1] * s2 + q[2] * s3 + q[3]];
+        g[ord[i]] = cur - prev;
+        prev = cur;
+    }
+    // det of the rows (p1-p0, p2-p0, p3-p0, g), expanded along the last row
+    double m[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) m[k][a] = p[k + 1][a] - p[0][a];
+    auto det3 = [&](int a, int b, int cc) {
+        return m[0][a] * (m[1][b] * m[2][cc] - m[1][cc] * m[2][b]) - m[0][b] * (m[1][a] * m[2][cc] - m[1][cc] * m[2][a]) +
+               m[0][cc] * (m[1][a] * m[2][b] - m[1][b] * m[2][a]);
+    };
+    const double det = -g[0] * det3(1, 2, 3) + g[1] * det3(0, 2, 3) - g[2] * det3(0, 1, 3) + g[3] * det3(0, 1, 2);
+    if (det < 0.0) {
+        const int32_t x = tets[(size_t)t * 4 + 2];
+        tets[(size_t)t * 4 + 2] = tets[(size_t)t * 4 + 3];
+        tets[(size_t)t * 4 + 3] = x;
+    }
+}
 __global__ void cxp_k_morph_count(const int32_t* tets, uint32_t nt, const double* pts, const uint32_t* prio, const u64* mm, uint32_t* counts) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -1331,8 +1435,7 @@ __global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u
             if (o >= t) continue;                                  // each unordered pair once
             const double l2 = fmax(lo, ttime[(size_t)o * 2]), h2 = fmin(hi, ttime[(size_t)o * 2 + 1]);
             if (!(l2 < h2)) continue;
-            const uint32_t same_dir = (cxp_edge_dir(tri, t, elo, ehi) == cxp_edge_dir(tri, o, elo, ehi)) ? 1u : 0u;
-            cxp_union(parent, nullptr, t, o, same_dir);
+            cxp_union(parent, nullptr, t, o, 0u);   // connectivity only: the slices are wound alike (cxp_morph_slices)
         }
     }
 }
@@ -1361,6 +1464,11 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
         if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
         uint32_t* cnt = (uint32_t*)S->flags.p;
         uint32_t* off = (uint32_t*)S->scan.p;
+        cxp_grid4 G4;
+        G4.A = G->grid;
+        for (int k = 0; k < 4; k++) G4.n[k] = (int)G->n[k];
+        G4.value = G->value;
+        hipLaunchKernelGGL(cxp_k_tets_orient, dim3(cxp_blocks(nt)), dim3(256), 0, st, (int32_t*)S->tri_out.p, nt, prio, G4);
         hipLaunchKernelGGL(cxp_k_morph_count, dim3(cxp_blocks(nt)), dim3(256), 0, st, tets, nt, pts, prio, mm, cnt);
         if ((rc = cxp_scan(ctx, S, cnt, off, nt, misc + 1))) return rc;
         uint32_t ntri = 0;
