@@ -612,20 +612,27 @@ __global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* p
     if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
     if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) cxp_max32(&cstart[root], t);
 }
-// final winding: triangle parity relative to the root, and the root's flip so that the start triangle gets dotx > 0
-__global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, uint32_t* ncomp) {
+// the root's flip, so that the start triangle gets dotx > 0 (surface_geometry.py:99-103).  Decided in its own kernel,
+// BEFORE any triangle is rewritten: cxp_k_orient reverses triangles in place, and reading the start triangle there
+// raced with the thread that reverses it (a component came out partly wound one way and partly the other, rarely)
+__global__ void cxp_k_comp_decide(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, u64* cflip) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const u64 w = parent[t];
+    const uint32_t root = (uint32_t)w;
+    if (cstart[root] != t) return;
+    const uint32_t spar = (uint32_t)(w >> 32) & 1u;
+    cflip[root] = (u64)((((cxp_dotx(tri, t, pts) < 0.0) ? 1u : 0u) ^ spar) & 1u);   // in the root's frame
+}
+// final winding: triangle parity relative to the root, and the root's flip
+__global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const u64* parent, const u64* cflip, uint32_t* ncomp) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const u64 w = parent[t];
     const uint32_t root = (uint32_t)w, par = (uint32_t)(w >> 32) & 1u;
     if (root == t) atomicAdd(ncomp, 1u);
-    const uint32_t s = cstart[root];
-    const uint32_t spar = (uint32_t)(parent[s] >> 32) & 1u;
-    const uint32_t flip_root = ((cxp_dotx(tri, s, pts) < 0.0) ? 1u : 0u) ^ spar;   // in the root's frame
-    if ((par ^ flip_root) & 1u) {
-        const int32_t b = tri[(size_t)t * 3 + 1];
+    if ((par ^ (uint32_t)cflip[root]) & 1u) {
         // reversed(orientation): (a,b,c) -> (c,b,a)
-        tri[(size_t)t * 3 + 1] = b;
         const int32_t a = tri[(size_t)t * 3];
         tri[(size_t)t * 3] = tri[(size_t)t * 3 + 2];
         tri[(size_t)t * 3 + 2] = a;
@@ -770,7 +777,8 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv);
         hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest);
         hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart);
-        hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, misc + 3);
+        hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, cbest);
+        hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cbest, misc + 3);
         CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -1533,7 +1541,8 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv);
             hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest);
             hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart);
-            hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, misc + 3);
+            hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest);
+            hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, parent, cbest, misc + 3);
             uint32_t ncomp = 0;
             CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             CXP_HIP(ctx, hipStreamSynchronize(st));

@@ -146,3 +146,35 @@ def test_per_t_surfaces_on_device_equal_host_evaluation(name):
         assert np.allclose(ph, pd, rtol=0, atol=1e-12)
         n_nonempty += len(td) > 0
     assert n_nonempty >= 3
+
+
+def test_time_slices_are_consistently_wound_at_size():
+    """64 x 64 x 64 x 32 (two moving blobs): every time slice of the morph triangles is a surface whose manifold edges
+    are run in opposite directions by their two triangles (the reference's orient_triangles aims at exactly that,
+    surface_geometry.py:110-138) -- none may be run in the same direction"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi
+    from test_gpu_fullsize import edge_consistency
+    dev = torch.device("cuda", 0)
+    shape = (64, 64, 64, 32)
+    ax = [torch.arange(n, device=dev, dtype=torch.float32) / (n - 1) for n in shape]
+    X, Y, Z, T = torch.meshgrid(*ax, indexing="ij")
+    A = torch.exp(-(((X - 0.30 - 0.35 * T) ** 2 + (Y - 0.35 - 0.2 * T) ** 2 + (Z - 0.5) ** 2) / (2 * 0.12 ** 2))) + \
+        torch.exp(-(((X - 0.70 + 0.30 * T) ** 2 + (Y - 0.65 + 0.2 * T) ** 2 + (Z - 0.45 - 0.1 * T) ** 2) / (2 * 0.10 ** 2)))
+    for axis in range(4):
+        for idx in (0, 1, -1, -2):
+            A.select(axis, idx).fill_(0.0)
+    A = A.contiguous()
+    ctx = _ffi.Context(0)
+    try:
+        ctx.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(100)
+        mt = ctx.morph_triangles()
+        tmin, tmax = float(mt[0][:, 3].min()), float(mt[0][:, 3].max())
+        for frac in (0.13, 0.37, 0.52, 0.81):
+            pts, tris = ctx.morph_eval(tmin + frac * (tmax - tmin))
+            manifold, same, other = edge_consistency(tris)
+            assert len(tris) > 10000 and manifold > 1.3 * len(tris) and same == 0
+    finally:
+        ctx.close()
