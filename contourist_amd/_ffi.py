@@ -22,7 +22,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -101,6 +101,8 @@ def load():
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_postprocess3d": [vp, u32, vp],
         "cx_postprocess3d_ex": [vp, u32, dbl, vp],
+        "cx_level0_points_f64": [vp, vp],
+        "cx_postprocess3d_mesh": [vp, vp, i64, vp, i64, vp, u32, dbl, vp],
         "cx_select_seeded3d": [vp, vp, i64, vp, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
@@ -235,6 +237,24 @@ class Context(object):
     def postprocess3d(self, flags=0, smooth=0.0):
         out = np.zeros(8, dtype=np.int64)
         self._check(self.lib.cx_postprocess3d_ex(self.handle, int(flags), float(smooth or 0.0), out.ctypes.data))
+        return dict(n_vertices=int(out[0]), n_triangles=int(out[1]), n_after_weld=int(out[2]),
+                    n_after_tiny=int(out[3]), n_components=int(out[4]))
+
+    def level0_points_f64(self, counts):
+        "float64 coordinates of the Level-0 vertices as the reference interpolates them, in download_level0 order"
+        pts = np.empty((int(counts["n_vertices"]), 3), dtype=np.float64)
+        self._check(self.lib.cx_level0_points_f64(self.handle, pts.ctypes.data))
+        return pts
+
+    def postprocess3d_mesh(self, points, triangles, corner, flags=0, smooth=0.0):
+        """Level 1 of an assembled Level-0 mesh (vertices in ascending global edge-id order, float64 grid coordinates of
+        the whole volume, triangles as indices) -> the same dict as postprocess3d; fetch with download_level1"""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        c3 = np.ascontiguousarray(corner, dtype=np.int64).reshape(3)
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cx_postprocess3d_mesh(self.handle, pts.ctypes.data, len(pts), tris.ctypes.data, len(tris), c3.ctypes.data,
+                                                   int(flags), float(smooth or 0.0), out.ctypes.data))
         return dict(n_vertices=int(out[0]), n_triangles=int(out[1]), n_after_weld=int(out[2]),
                     n_after_tiny=int(out[3]), n_components=int(out[4]))
 

@@ -234,8 +234,11 @@ __global__ void cxp_k_scan_add(uint32_t* out, const uint32_t* sums, uint32_t n) 
 
 // ---- step kernels -------------------------------------------------------------------------------------
 // float64 vertex coordinates exactly as the reference computes them (tetrahedral.py:471-487)
+struct cxp_origin3 {
+    double o[3];   // lattice coordinates of sample (0,0,0) in the whole volume (cx_set_origin), or zeros
+};
 __global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, cx_fdiv dplane, cx_fdiv drow,
-                                   double value, const float4* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio) {
+                                   double value, const float4* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio, cxp_origin3 org) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     const uint32_t key = __float_as_uint(verts[v].w);
@@ -252,7 +255,7 @@ __global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uin
     double ratio = 0.5;
     const double den = 1.0 * (fhigh - flow);
     if (!(fabs(den) <= 1e-8)) ratio = (value - flow) / den;
-    const double q[3] = {(double)i, (double)j, (double)k};
+    const double q[3] = {(double)i + org.o[0], (double)j + org.o[1], (double)k + org.o[2]};   // integers: exact
     const uint32_t db[3] = {(d >> 2) & 1u, (d >> 1) & 1u, d & 1u};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -843,17 +846,9 @@ extern "C" int cx_postprocess3d(cx_ctx* ctx, uint32_t flags, int64_t* out_counts
     return cx_postprocess3d_ex(ctx, flags, 0.0, out_counts);
 }
 
-extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {
-    if (!ctx) return CX_ERR_INVALID;
-    if (!ctx->extracted) { ctx->err = "cx_postprocess3d: no valid extraction"; return CX_ERR_STATE; }
-    CXP_HIP(ctx, hipSetDevice(ctx->device));
-    cx_post_state* S;
-    int rc = cxp_state(ctx, &S);
-    if (rc) return rc;
-    const uint32_t nv = (uint32_t)ctx->counts.n_vertices, nt = (uint32_t)ctx->counts.n_triangles;
-    const bool do_clean = !(flags & 1u);
-    hipStream_t st = ctx->stream;
-    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// buffers of the 3-D post-pass for nv vertices and nt triangles
+static int cxp_reserve3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt) {
+    int rc;
     if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv + 1) * 3 * sizeof(double)))) return rc;
     if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = cxp_reserve(ctx, S->rep, (size_t)(nv + 1) * (sizeof(uint32_t) + 1)))) return rc;
@@ -861,6 +856,13 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     if ((rc = cxp_reserve(ctx, S->alive, (size_t)nt + 16))) return rc;
     if ((rc = cxp_reserve(ctx, S->parent, (size_t)(nv + 1) * sizeof(u64)))) return rc;
     if ((rc = cxp_reserve(ctx, S->parent2, (size_t)(nv + 1) * sizeof(u64)))) return rc;
+    return CX_OK;
+}
+// weld -> (smooth) -> tiny collapse -> clean -> orient on S->pts / S->prio / S->tri / S->alive (A6..A10)
+static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, const double corner[3], const uint8_t* vkeep, bool do_clean,
+                     double smooth, bool coherent, int64_t* counts) {
+    int rc;
+    hipStream_t st = ctx->stream;
     double* pts = (double*)S->pts.p;
     uint32_t* prio = (uint32_t*)S->prio.p;
     uint32_t* rep = (uint32_t*)S->rep.p;
@@ -870,25 +872,9 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     uint8_t* alive = (uint8_t*)S->alive.p;
     uint32_t* misc = (uint32_t*)S->misc.p;
     if (nv && nt) {
-        const cx_params& P = ctx->last;
-        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
-                           P.value, ctx->verts, nv, pts, prio);
-        CXP_HIP(ctx, hipMemcpyAsync(tri, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        const uint8_t* vkeep = nullptr;
-        if (ctx->keep_valid) {   // cx_select_seeded3d: only the triangles (and vertices) of the selected components exist
-            CXP_HIP(ctx, hipMemcpyAsync(alive, ctx->tri_keep, nt, hipMemcpyDeviceToDevice, st));
-            vkeep = ctx->tri_keep + nt;
-        } else {
-            CXP_HIP(ctx, hipMemsetAsync(alive, 1, nt, st));
-        }
         hipLaunchKernelGGL(cxp_k_tri_prio, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, prio, nt, tprio3);
         // ---- weld (tetrahedral.py:190-215): expander = int(10000 / corner)
         cxp_weld_params W;
-        // the reference's `corner` (voxels per axis); a sample array with a margin around the reference's grid
-        // carries the reference's own corner in ctx->corner_ref (cx_set_reference_corner)
-        double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
-        for (int a = 0; a < 3; a++)
-            if (ctx->corner_ref[a] > 0) corner[a] = (double)ctx->corner_ref[a];
         for (int a = 0; a < 3; a++) W.ex[a] = std::trunc((10000 * 1.0) / corner[a]);
         const u64 wsz = cxp_table_size(nv);
         if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
@@ -933,7 +919,94 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
         CXP_HIP(ctx, hipStreamSynchronize(st));
         counts[2] = h[0]; counts[3] = h[1];
     }
-    if ((rc = cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, true))) return rc;   // the march winds every triangle low -> high
+    return cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, coherent);
+}
+
+extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) { ctx->err = "cx_postprocess3d: no valid extraction"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)ctx->counts.n_vertices, nt = (uint32_t)ctx->counts.n_triangles;
+    hipStream_t st = ctx->stream;
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;
+    const cx_params& P = ctx->last;
+    const uint8_t* vkeep = nullptr;
+    if (nv && nt) {
+        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
+                           P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, cxp_origin3{{0.0, 0.0, 0.0}});
+        CXP_HIP(ctx, hipMemcpyAsync(S->tri.p, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (ctx->keep_valid) {   // cx_select_seeded3d: only the triangles (and vertices) of the selected components exist
+            CXP_HIP(ctx, hipMemcpyAsync(S->alive.p, ctx->tri_keep, nt, hipMemcpyDeviceToDevice, st));
+            vkeep = ctx->tri_keep + nt;
+        } else {
+            CXP_HIP(ctx, hipMemsetAsync(S->alive.p, 1, nt, st));
+        }
+    }
+    // the reference's `corner` (voxels per axis); a sample array with a margin around the reference's grid
+    // carries the reference's own corner in ctx->corner_ref (cx_set_reference_corner)
+    double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
+    for (int a = 0; a < 3; a++)
+        if (ctx->corner_ref[a] > 0) corner[a] = (double)ctx->corner_ref[a];
+    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, vkeep, !(flags & 1u), smooth, true, counts))) return rc;   // the march winds every triangle low -> high
+    ctx->post_valid = true;
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    return CX_OK;
+}
+
+// float64 coordinates of the Level-0 vertices exactly as the reference interpolates them (tetrahedral.py:471-487) in the
+// grid coordinates of the whole volume (the origin of cx_set_origin is added to the lattice points BEFORE the
+// interpolation, so a slab yields bit for bit what the whole volume would), in the order of cx_level0_download -- what cx_postprocess3d works on, for callers that assemble the meshes of several slabs
+extern "C" int cx_level0_points_f64(cx_ctx* ctx, double* points_xyz) {
+    if (!ctx || !points_xyz) return CX_ERR_INVALID;
+    if (!ctx->extracted) { ctx->err = "cx_level0_points_f64: no valid extraction"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)ctx->counts.n_vertices;
+    if (!nv) return CX_OK;
+    if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
+    const cx_params& P = ctx->last;
+    const cxp_origin3 org{{(double)ctx->origin[0], (double)ctx->origin[1], (double)ctx->origin[2]}};
+    hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, ctx->stream, P.grid, P.n1, P.n2, P.div_plane, P.div_row, P.value,
+                       ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
+    CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts.p, (size_t)nv * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->post_valid = false;   // the post-pass buffers no longer hold a Level-1 mesh
+    return CX_OK;
+}
+
+// Level 1 of a Level-0 mesh handed over by the caller, e.g. assembled from the slabs of several GPUs: vertices in
+// ASCENDING EDGE-ID ORDER (their index is their priority) with the coordinates of cx_level0_points_f64 in the grid
+// coordinates of the whole volume, triangles as indices wound as the march wound them.
+extern "C" int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv64, const int32_t* tris, int64_t nt64, const int64_t* corner3,
+                                     uint32_t flags, double smooth, int64_t* out_counts) {
+    if (!ctx || !corner3 || nv64 < 0 || nt64 < 0 || (nv64 && !points_xyz) || (nt64 && !tris)) return CX_ERR_INVALID;
+    if (nv64 >= 0x7FFFFFFFLL || nt64 >= 0x7FFFFFFFLL || corner3[0] < 1 || corner3[1] < 1 || corner3[2] < 1) {
+        ctx->err = "cx_postprocess3d_mesh: corner >= 1 per axis and fewer than 2^31 vertices / triangles";
+        return CX_ERR_INVALID;
+    }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)nv64, nt = (uint32_t)nt64;
+    hipStream_t st = ctx->stream;
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;
+    if (nv && nt) {
+        CXP_HIP(ctx, hipMemcpyAsync(S->pts.p, points_xyz, (size_t)nv * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+        CXP_HIP(ctx, hipMemcpyAsync(S->tri.p, tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        CXP_HIP(ctx, hipMemsetAsync(S->alive.p, 1, nt, st));
+        hipLaunchKernelGGL(cxp_k_iota_prio, dim3(cxp_blocks(nv)), dim3(256), 0, st, (uint32_t*)S->prio.p, nv);
+    }
+    const double corner[3] = {(double)corner3[0], (double)corner3[1], (double)corner3[2]};
+    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, nullptr, !(flags & 1u), smooth, !(flags & 4u), counts))) return rc;
     ctx->post_valid = true;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
     return CX_OK;

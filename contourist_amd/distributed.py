@@ -80,10 +80,12 @@ class HaloExchange(object):
             self.staged_recv = None
 
 
-def hip_extract(device=0, diagonal_flags=1):
-    "default local extractor: the HIP Level-0 march. returns f(local_array_or_tensor, value, origin) -> (xyz, keys, tris)"
+def hip_extract(device=0, diagonal_flags=1, float64_points=False, context=None):
+    """default local extractor: the HIP Level-0 march. returns f(local_array_or_tensor, value, origin) -> (xyz, keys, tris).
+    float64_points: xyz are the float64 coordinates the reference interpolates (what the Level-1 post-pass works on)
+    instead of the march's fp32 ones.  run.context is the context used."""
     from . import _ffi
-    ctx = _ffi.Context(device)
+    ctx = context or _ffi.Context(device)
 
     def run(local, value, origin=(0, 0, 0)):
         ctx.set_origin(*origin)
@@ -92,11 +94,16 @@ def hip_extract(device=0, diagonal_flags=1):
         else:
             ctx.upload_grid(local)
         counts = ctx.extract3d(value, diagonal_flags)
-        return ctx.download_level0(counts)
+        xyz, keys, tris = ctx.download_level0(counts)
+        if float64_points:
+            xyz = ctx.level0_points_f64(counts)
+        return xyz, keys, tris
+    run.context = ctx
+    run.global_points = bool(float64_points)   # level0_points_f64 already adds the origin (exactly, before interpolating)
     return run
 
 
-def local_to_global(xyz, keys, tris, local_shape, i0, n_own, has_halo):
+def local_to_global(xyz, keys, tris, local_shape, i0, n_own, has_halo, xyz_is_global=False):
     """Level-0 mesh of one slab -> global ids.
     returns (gkeys (V',) int64 of the vertices this rank OWNS, gxyz (V',3), tri_gkeys (T,3) int64)"""
     n1, n2 = int(local_shape[1]), int(local_shape[2])
@@ -105,7 +112,8 @@ def local_to_global(xyz, keys, tris, local_shape, i0, n_own, has_halo):
     gkeys = keys + offset
     tri_gkeys = gkeys[np.asarray(tris, dtype=np.int64)] if len(tris) else np.zeros((0, 3), dtype=np.int64)
     gxyz = np.asarray(xyz, dtype=np.float64).copy()
-    gxyz[:, 0] += i0
+    if not xyz_is_global:
+        gxyz[:, 0] += i0
     if has_halo:
         owner_plane = (keys >> 3) // (n1 * n2)           # local plane of the owning lattice point
         own = owner_plane < n_own
@@ -146,7 +154,7 @@ def extract_slabs(own_planes, value, rank, world, extract_fn, global_shape, dist
     exchange_halo(local, n_own, rank, world, dist)
     arg = local if local.is_cuda else local.numpy()
     xyz, keys, tris = extract_fn(arg, value, (i0, 0, 0))
-    part = local_to_global(xyz, keys, tris, tuple(local.shape), i0, n_own, has_halo)
+    part = local_to_global(xyz, keys, tris, tuple(local.shape), i0, n_own, has_halo, getattr(extract_fn, "global_points", False))
     if not gather:
         return part
     if world == 1:
@@ -156,3 +164,21 @@ def extract_slabs(own_planes, value, rank, world, extract_fn, global_shape, dist
     if rank == 0:
         return assemble(gathered)
     return None
+
+
+def level1_slabs(own_planes, value, rank, world, global_shape, device=0, clean=True, smooth=None, dist=None):
+    """Level 1 (weld, tiny collapse, clean, orient: tetrahedral.py:190-215, 353-375, surface_geometry.py:14-140) of a
+    volume that is spread over the ranks in slabs along axis 0: every rank marches its slab on its GPU, the Level-0
+    meshes are gathered on rank 0 (vertices with the float64 coordinates the reference interpolates, global edge ids)
+    and post-processed there as ONE mesh -- components, weld buckets and the max-x orientation rule see the whole
+    surface.  Rank 0 returns (grid_points (V,3) float64, triangles (T,3) int32, counts), the others None."""
+    fn = hip_extract(device, float64_points=True)
+    mesh = extract_slabs(own_planes, value, rank, world, fn, global_shape, dist=dist, gather=True)
+    if rank != 0:
+        return None
+    keys, xyz, tris = mesh
+    ctx = fn.context
+    corner = [int(n) - 1 for n in global_shape]
+    post = ctx.postprocess3d_mesh(xyz, tris, corner, 0 if clean else 1, smooth or 0.0)
+    pts, t1 = ctx.download_level1(post)
+    return pts, t1, post

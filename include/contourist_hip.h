@@ -118,6 +118,18 @@ int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out
  * (voxels per axis); 0 restores the default. */
 int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2);
 int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
+/* Level 1 of a mesh assembled by the caller -- the way several GPUs share one volume: every rank marches its slab
+ * (cx_extract3d), takes the float64 coordinates the reference would have interpolated (cx_level0_points_f64: nv*3
+ * doubles in the order of cx_level0_download, in the grid coordinates of the whole volume = lattice point + origin of
+ * cx_set_origin; tetrahedral.py:471-487) and its triangles, the owner of the result
+ * concatenates them in ASCENDING GLOBAL EDGE-ID ORDER (ids are global by formula; the index of a vertex is then its
+ * priority in the canonical choices) and runs the same weld / tiny collapse / clean / orient on them:
+ * corner = voxels per axis of the WHOLE volume, coordinates in its grid coordinates, triangles wound as the march
+ * wound them (flags bit 2 set: windings are arbitrary, propagate them like cx_surface_geometry); flags bit 0 as in
+ * cx_postprocess3d.  Results through cx_level1_download. */
+int cx_level0_points_f64(cx_ctx* ctx, double* points_xyz);
+int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv, const int32_t* tris, int64_t nt, const int64_t* corner3,
+                          uint32_t flags, double smooth, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 

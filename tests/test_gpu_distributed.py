@@ -82,3 +82,77 @@ def test_two_ranks_gloo_hip(tmp_path):
     out = level0.canonical_level0(got["keys"], got["xyz"], got["tris"])
     assert np.array_equal(ref[0], out[0]) and np.array_equal(ref[2], out[2])
     assert np.allclose(ref[1], out[1], rtol=1e-6, atol=1e-6)
+
+
+def same_level1(A, pts0, tris0, pts1, tris1):
+    """two Level-1 meshes are the same surface: the same multiset of float64 points, and the same oriented triangles
+    written as triples of weld-bucket ids (the vertex numbering differs: march order on a single GPU, edge-id order
+    for an assembled mesh)"""
+    from oracle import postpass
+    corner = np.array(A.shape) - 1
+
+    def rows(P):
+        return P[np.lexsort((P[:, 2], P[:, 1], P[:, 0]))]
+    assert pts0.shape == pts1.shape and np.array_equal(rows(pts0), rows(pts1))
+    a = postpass.canonical_level1(pts0, tris0, corner)
+    b = postpass.canonical_level1(pts1, tris1, corner)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def whole_level1(A, value):
+    from contourist_amd import _ffi
+    ctx = _ffi.Context(0)
+    ctx.upload_grid(A)
+    ctx.extract3d(value, 1)
+    post = ctx.postprocess3d(0)
+    pts, tris = ctx.download_level1(post)
+    return pts, tris, post
+
+
+def test_level1_of_slabs_in_one_process():
+    """Level 1 of a mesh assembled from three slabs == Level 1 of the undivided volume, bit for bit: same counts
+    after every stage, same float64 points, same oriented triangles"""
+    from contourist_amd import distributed as cd
+    A = field()
+    pts0, tris0, post0 = whole_level1(A, 0.2)
+    run = cd.hip_extract(0, float64_points=True)
+    parts = []
+    world = 3
+    for rank in range(world):
+        i0, i1 = cd.slab_bounds(A.shape[0], world, rank)
+        has_halo = rank + 1 < world
+        local = np.ascontiguousarray(A[i0:i1 + (1 if has_halo else 0)])
+        xyz, keys, tris = run(local, 0.2, (i0, 0, 0))
+        assert xyz.dtype == np.float64
+        parts.append(cd.local_to_global(xyz, keys, tris, local.shape, i0, i1 - i0, has_halo, xyz_is_global=True))
+    keys, xyz, tris = cd.assemble(parts)
+    post = run.context.postprocess3d_mesh(xyz, tris, [n - 1 for n in A.shape])
+    pts1, tris1 = run.context.download_level1(post)
+    assert post == post0
+    same_level1(A, pts0, tris0, pts1, tris1)
+
+
+def _worker_level1(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    A = field()
+    i0, i1 = cd.slab_bounds(A.shape[0], world, rank)
+    res = cd.level1_slabs(A[i0:i1], 0.2, rank, world, A.shape, device=0, dist=dist)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "l1.npz"), pts=res[0], tris=res[1], counts=np.array([res[2][k] for k in sorted(res[2])]))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level1_two_ranks_gloo_hip(tmp_path):
+    import torch.multiprocessing as mp
+    A = field()
+    pts0, tris0, post0 = whole_level1(A, 0.2)
+    mp.spawn(_worker_level1, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "l1.npz"))
+    assert got["counts"].tolist() == [post0[k] for k in sorted(post0)]
+    same_level1(A, pts0, tris0, got["pts"], got["tris"])
