@@ -42,7 +42,7 @@ struct cxp_dev {
 };
 
 struct cx_post_state {
-    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc, late;
+    cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
@@ -63,7 +63,7 @@ void cx_post_free(cx_ctx* ctx) {
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->late};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -522,19 +522,17 @@ __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64
         }
     }
 }
-// mode 2 (windings given by the caller, cx_surface_geometry): every visitor of an edge is united with the claimant
-// with the parity of their relative winding, as the reference propagates it (surface_geometry.py:110-138).
-// mode 0 (meshes of the march, which winds every triangle from low to high): two triangles that run along a shared
-// edge in the same direction only occur where the weld has pinched sheets together along an edge shared by 3+
+// coherent == 0 (windings given by the caller, cx_surface_geometry): every visitor of an edge is united with the
+// claimant with the parity of their relative winding, as the reference propagates it (surface_geometry.py:110-138).
+// coherent != 0 (meshes of the march, which winds every triangle from low to high): two triangles that run along a
+// shared edge in the same direction only occur where the weld has pinched sheets together along an edge shared by 3+
 // triangles -- exactly the links that contradict each other (such an edge cannot have all of its triangles pairwise
-// opposite).  United in one racing kernel, a contradictory union won somewhere and flipped a whole subtree: up to 4 %
-// of the area of a 512^3 spherical shell came out wound the wrong way, differently from run to run.  So the links
-// that need no flip are united here and the others are queued (late[], *nlate) for cxp_k_edges_link_late (mode 1: a
-// second pass instead, if the queue overflows): a late link connects what it touches -- a patch that hangs on that
-// edge alone still joins the component, as in the reference's traversal -- but never flips: both sides keep the
-// march's winding and the component is then turned as a whole by the max-x rule.
-__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent, int mode, u64* late,
-                                 uint32_t late_cap, uint32_t* nlate) {
+// opposite).  United with their parities in one racing kernel, a contradictory union won somewhere and flipped a
+// whole subtree: up to 4 % of the area of a 512^3 spherical shell came out wound the wrong way, differently from run
+// to run.  So on these meshes a link only connects and never flips (parity 0; the neighbour's winding is not even
+// read): both sides keep the march's winding -- a patch that hangs on a pinched edge still joins the component, as in
+// the reference's traversal -- and the component is then turned as a whole by the max-x rule.
+__global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent, int coherent) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
@@ -547,22 +545,10 @@ __global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab
         while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
         const uint32_t o = (uint32_t)tab[2 * slot + 1];
         if (o == t) continue;
-        const uint32_t same_dir = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;   // same direction = parity 1
-        if (mode == 2) {
-            cxp_union(parent, nullptr, t, o, same_dir);
-        } else if (mode == 0 && same_dir) {
-            const uint32_t k = atomicAdd(nlate, 1u);
-            if (k < late_cap) late[k] = ((u64)o << 32) | (u64)t;
-        } else if ((mode == 0) == (same_dir == 0u)) {
-            cxp_union(parent, nullptr, t, o, 0u);
-        }
+        uint32_t rel = 0;
+        if (!coherent) rel = (cxp_edge_dir(tri, t, lo, hi) == cxp_edge_dir(tri, o, lo, hi)) ? 1u : 0u;   // same direction = parity 1
+        cxp_union(parent, nullptr, t, o, rel);
     }
-}
-__global__ void cxp_k_edges_link_late(const u64* late, uint32_t n, u64* parent) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 w = late[i];
-    cxp_union(parent, nullptr, (uint32_t)w, (uint32_t)(w >> 32), 0u);
 }
 // per component (root triangle): largest x over its vertices
 __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
@@ -758,21 +744,7 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-        const uint32_t late_cap = nt2 / 8 + 1024;
-        if ((rc = cxp_reserve(ctx, S->late, (size_t)late_cap * sizeof(u64)))) return rc;
-        CXP_HIP(ctx, hipMemsetAsync(misc + 20, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 0 : 2,
-                           (u64*)S->late.p, late_cap, misc + 20);
-        uint32_t nlate = 0;
-        if (coherent) {
-            CXP_HIP(ctx, hipMemcpyAsync(&nlate, misc + 20, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            CXP_HIP(ctx, hipStreamSynchronize(st));
-        }
-        if (nlate > late_cap)
-            hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, 1, (u64*)S->late.p,
-                               late_cap, misc + 20);
-        else if (nlate)
-            hipLaunchKernelGGL(cxp_k_edges_link_late, dim3(cxp_blocks(nlate)), dim3(256), 0, st, (const u64*)S->late.p, nlate, parent);
+        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
