@@ -40,7 +40,7 @@ struct c2_buf {
     size_t cap = 0;
 };
 struct cx_state2 {
-    c2_buf grid, values, cnt, base, sums, pts, keys, succ, pred, parent, mark, rmark, rep, rank, cyc, jst[2], len, hflag, cidx,
+    c2_buf grid, values, cnt, base, sums, pts, keys, succ, pred, parent, mark, rmark, rep, rank, cyc, jst[2], alist, len, hflag, cidx,
         chead, clen, coff, opts, okeys, ochain, keep, fidx, fpts, fkeys, chains, scal, seeds;
     cx_counts2d counts = {0, 0, 0, 0};
     bool valid = false;
@@ -65,7 +65,7 @@ void cx_state2_free(cx_ctx* ctx) {
     if (!ctx->s2) return;
     cx_state2* S = ctx->s2;
     c2_buf* all[] = {&S->grid, &S->values, &S->cnt, &S->base, &S->sums, &S->pts, &S->keys, &S->succ, &S->pred, &S->parent,
-                     &S->mark, &S->rmark, &S->rep, &S->rank, &S->cyc, &S->jst[0], &S->jst[1], &S->len, &S->hflag, &S->cidx, &S->chead,
+                     &S->mark, &S->rmark, &S->rep, &S->rank, &S->cyc, &S->jst[0], &S->jst[1], &S->alist, &S->len, &S->hflag, &S->cidx, &S->chead,
                      &S->clen, &S->coff, &S->opts, &S->okeys, &S->ochain, &S->keep, &S->fidx, &S->fpts, &S->fkeys, &S->chains, &S->scal,
                      &S->seeds};
     for (c2_buf* b : all)
@@ -127,35 +127,25 @@ __device__ __forceinline__ uint32_t c2_id_of(const c2_grid& G, int ai, int aj, d
 
 // *tie is set when a sample on a searched axis edge equals one of the isovalues (the seed search then needs the
 // per-sample pass c2_k_seed_ties)
-__global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie, unsigned long long* total64) {
+__global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie) {
     C2_STAGE_VALUES(G)
-    __shared__ uint32_t s_total;
-    if (threadIdx.x == 0) s_total = 0u;
-    __syncthreads();
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin < G.n * G.m) {
-        const uint32_t i = lin / G.m, j = lin - i * G.m;
-        const double f0 = c2_f(G, i, j);
-        const uint32_t u0 = c2_upper(G, f0);
-        if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
-        uint32_t mine = 0;
-        for (int d = 0; d < 3; d++) {
-            uint32_t c = 0;
-            if (c2_edge_valid(G, i, j, d)) {
-                const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
-                if (f0 != f1) {
-                    const uint32_t u1 = c2_upper(G, f1);
-                    c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
-                }
+    if (lin >= G.n * G.m) return;
+    const uint32_t i = lin / G.m, j = lin - i * G.m;
+    const double f0 = c2_f(G, i, j);
+    const uint32_t u0 = c2_upper(G, f0);
+    if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
+    for (int d = 0; d < 3; d++) {
+        uint32_t c = 0;
+        if (c2_edge_valid(G, i, j, d)) {
+            const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
+            if (f0 != f1) {
+                const uint32_t u1 = c2_upper(G, f1);
+                c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
             }
-            cnt[3u * lin + d] = c;
-            mine += c;
         }
-        if (mine) atomicAdd(&s_total, mine);
+        cnt[3u * lin + d] = c;
     }
-    __syncthreads();
-    // the 32-bit scan cannot see an overflow: the grand total is also kept in 64 bits (one atomic per block)
-    if (threadIdx.x == 0 && s_total) atomicAdd(total64, (unsigned long long)s_total);
 }
 
 // the segment of level z inside the counter-clockwise triangle (v0, v1, v2): links crossing `id`, which lies on the
@@ -386,18 +376,27 @@ __global__ void c2_k_jump_init(const uint32_t* pred, uint32_t nv, uint4* st) {
     const uint32_t p = pred[id];
     st[id] = (p == C2_NIL) ? make_uint4(id, 0u, 0u, 0u) : make_uint4(p, 1u, id + 1u, 0u);
 }
-__global__ void c2_k_jump(const uint4* in, uint4* out, uint32_t nv, uint32_t* changed) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nv) return;
-    const uint4 a = in[id];
+// Bit 31 of hop marks an element whose state is final; it is copied from then on.  Most polylines are short and
+// the rounds are paid by the longest: after C2_FULL_ROUNDS rounds over all elements the unfinished ones are listed
+// (c2_k_jump_flags + scan + c2_k_jump_list) and the remaining rounds run over that list only.  Elements outside the
+// list hold the same final state in both buffers (one full round is run after the round the list is taken from).
+#define C2_FIN 0x80000000u
+#define C2_FULL_ROUNDS 7
+__device__ __forceinline__ void c2_jump_one(const uint4* in, uint4* out, uint32_t id, uint32_t* changed) {
+    uint4 a = in[id];
+    if (a.y & C2_FIN) {
+        out[id] = a;
+        return;
+    }
     if (a.x == id) {   // a head, or a cycle whose length divides hop: final
+        a.y |= C2_FIN;
         out[id] = a;
         return;
     }
     const uint4 b = in[a.x];
     uint4 r;
     r.x = b.x;
-    r.y = a.y + b.y;
+    r.y = a.y + (b.y & ~C2_FIN);
     if (b.z < a.z) {
         r.z = b.z;
         r.w = a.y + b.w;
@@ -405,15 +404,31 @@ __global__ void c2_k_jump(const uint4* in, uint4* out, uint32_t nv, uint32_t* ch
         r.z = a.z;
         r.w = a.w;
     }
+    if (r.z == 0u || a.z == b.z) r.y |= C2_FIN; else *changed = 1u;
     out[id] = r;
-    if (!(r.z == 0u || a.z == b.z)) *changed = 1u;
+}
+__global__ void c2_k_jump(const uint4* in, uint4* out, uint32_t nv, uint32_t* changed) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < nv) c2_jump_one(in, out, id, changed);
+}
+__global__ void c2_k_jump_listed(const uint4* in, uint4* out, const uint32_t* list, uint32_t n, uint32_t* changed) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) c2_jump_one(in, out, list[k], changed);
+}
+__global__ void c2_k_jump_flags(const uint4* st, uint32_t nv, uint32_t* flag) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < nv) flag[id] = (st[id].y & C2_FIN) ? 0u : 1u;
+}
+__global__ void c2_k_jump_list(const uint32_t* flag, const uint32_t* pos, uint32_t nv, uint32_t* list) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < nv && flag[id]) list[pos[id]] = id;
 }
 // rep = first element of the chain (head, or smallest id of a cycle), rank = position in the chain, len[rep], cyc[rep]
 __global__ void c2_k_chain_finish(const uint4* st, const uint32_t* succ, uint32_t nv, uint32_t* rep, uint32_t* rank, uint32_t* len, uint32_t* cyc,
                                   uint32_t* parent) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
-    const uint4 a = st[id];
+    const uint4 a = st[id];   // (hop is not needed any more)
     const uint32_t r = (a.z == 0u) ? a.x : a.z - 1u;
     rep[id] = r;
     rank[id] = a.w;
@@ -528,16 +543,17 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     if ((rc = c2_reserve(ctx, S->cnt, E * 4)) || (rc = c2_reserve(ctx, S->base, (E + 1) * 4)) || (rc = c2_reserve(ctx, S->sums, (E / 1024 + 4) * 4)))
         return rc;
     c2_grid G{A, (uint32_t)n, (uint32_t)m, (const double*)S->values.p, (uint32_t)nvalues, (const uint32_t*)S->base.p};
-    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p, scratch + 2, (unsigned long long*)(scratch + 4));
-    cx_scan_u32(ctx, (const uint32_t*)S->cnt.p, (uint32_t*)S->base.p, (uint32_t)E, (uint32_t*)S->sums.p, scratch);
+    hipLaunchKernelGGL(c2_k_count, dim3(c2_blocks(N)), dim3(256), 0, st, G, (uint32_t*)S->cnt.p, scratch + 2);
+    // (the scan also returns the total in 64 bits: a 32-bit total cannot show an overflow)
+    cx_scan_u32(ctx, (const uint32_t*)S->cnt.p, (uint32_t*)S->base.p, (uint32_t)E, (uint32_t*)S->sums.p, scratch, (unsigned long long*)(scratch + 4));
     uint32_t head6[6] = {0, 0, 0, 0, 0, 0};
     C2_HIP(ctx, hipMemcpyAsync(head6, scratch, 24, hipMemcpyDeviceToHost, st));
     C2_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t nv = head6[0];
     const bool ties = head6[2] != 0;
     const unsigned long long total64 = ((unsigned long long)head6[5] << 32) | head6[4];
-    if (total64 >= 0x7FFFFFFFull) {
-        ctx->err = "cx_contour2d_extract: " + std::to_string(total64) + " crossings (more than 2^31): contour fewer levels per call";
+    if (total64 >= 0x20000000ull) {   // ids, and three times the longest chain, must stay below 2^31
+        ctx->err = "cx_contour2d_extract: " + std::to_string(total64) + " crossings (more than 2^29): contour fewer levels per call";
         return CX_ERR_UNSUPPORTED;
     }
     S->counts = cx_counts2d{0, 0, nv, (uint32_t)nvalues};
@@ -567,18 +583,36 @@ extern "C" int cx_contour2d_extract(cx_ctx* ctx, const float* samples, int on_de
     if ((rc = c2_reserve(ctx, S->jst[0], V * 16)) || (rc = c2_reserve(ctx, S->jst[1], V * 16))) return rc;
     int cur = 0;
     hipLaunchKernelGGL(c2_k_jump_init, dim3(gb), dim3(256), 0, st, pred, nv, (uint4*)S->jst[0].p);
+    uint32_t nlist = 0;           // 0: rounds over all elements
+    const uint32_t* list = nullptr;
     for (int round = 0;; round++) {
-        if (round >= 40) {
+        if (round >= 48) {
             ctx->err = "cx_contour2d_extract: chain ranking did not converge";
             return CX_ERR_HIP;
         }
         C2_HIP(ctx, hipMemsetAsync(scratch + 1, 0, 4, st));
-        hipLaunchKernelGGL(c2_k_jump, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[cur].p, (uint4*)S->jst[1 - cur].p, nv, scratch + 1);
+        if (nlist)
+            hipLaunchKernelGGL(c2_k_jump_listed, dim3(c2_blocks(nlist)), dim3(256), 0, st, (const uint4*)S->jst[cur].p, (uint4*)S->jst[1 - cur].p, list,
+                               nlist, scratch + 1);
+        else
+            hipLaunchKernelGGL(c2_k_jump, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[cur].p, (uint4*)S->jst[1 - cur].p, nv, scratch + 1);
         cur = 1 - cur;
         uint32_t changed = 0;
         C2_HIP(ctx, hipMemcpyAsync(&changed, scratch + 1, 4, hipMemcpyDeviceToHost, st));
         C2_HIP(ctx, hipStreamSynchronize(st));
         if (!changed) break;
+        if (round == C2_FULL_ROUNDS && nv > (1u << 20)) {
+            // the list of elements that were unfinished BEFORE this round (buffer 1 - cur): whatever finished earlier has
+            // just been copied, i.e. is the same in both buffers, and can be left alone from now on
+            if ((rc = c2_reserve(ctx, S->alist, V * 4))) return rc;
+            hipLaunchKernelGGL(c2_k_jump_flags, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[1 - cur].p, nv, hflag);
+            cx_scan_u32(ctx, hflag, cidx, nv, (uint32_t*)S->sums.p, scratch);
+            hipLaunchKernelGGL(c2_k_jump_list, dim3(gb), dim3(256), 0, st, hflag, cidx, nv, (uint32_t*)S->alist.p);
+            C2_HIP(ctx, hipMemcpyAsync(&nlist, scratch, 4, hipMemcpyDeviceToHost, st));
+            C2_HIP(ctx, hipStreamSynchronize(st));
+            list = (const uint32_t*)S->alist.p;
+            if (nlist == 0) break;   // (cannot happen while `changed` is set; defensive)
+        }
     }
     hipLaunchKernelGGL(c2_k_chain_finish, dim3(gb), dim3(256), 0, st, (const uint4*)S->jst[cur].p, succ, nv, rep, rank, len, cyc, parent);
     // growth groups of chains and their seeds

@@ -66,7 +66,8 @@ struct cx_ctx {
 
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);
-int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev);
+int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev,
+                unsigned long long* total64_dev = nullptr);   // total64: the total without the wrap at 2^32
 // cx_api4d.hip
 void cx_state4_free(cx_ctx* ctx);
 // cx_contour2d.hip

@@ -196,9 +196,10 @@ __global__ __launch_bounds__(256) void cxp_k_scan_blocks(const uint32_t* in, uin
 }
 // one workgroup turns the block sums into exclusive offsets: 16 consecutive sums per thread, 16384 per pass
 #define CXP_SUMS_PER_THREAD 16u
-__global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total) {
+__global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total, unsigned long long* total64) {
     __shared__ uint32_t s[1024];
     uint32_t carry = 0;
+    unsigned long long wide = 0;   // the same total without the wrap at 2^32 (each pass adds less than 2^32)
     for (uint32_t base = 0; base < nb; base += 1024u * CXP_SUMS_PER_THREAD) {
         const uint32_t i0 = base + threadIdx.x * CXP_SUMS_PER_THREAD;
         uint32_t v[CXP_SUMS_PER_THREAD], t = 0;
@@ -224,8 +225,12 @@ __global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t
         const uint32_t passtot = s[1023];
         __syncthreads();
         carry += passtot;
+        wide += (unsigned long long)passtot;
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        if (total64) *total64 = wide;
+    }
 }
 __global__ void cxp_k_scan_add(uint32_t* out, const uint32_t* sums, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,16 +655,16 @@ static int cxp_scan(cx_ctx* ctx, cx_post_state* S, const uint32_t* in, uint32_t*
     if (rc) return rc;
     uint32_t* sums = (uint32_t*)S->blocksums.p;
     hipLaunchKernelGGL(cxp_k_scan_blocks, dim3(nb ? nb : 1), dim3(256), 0, ctx->stream, in, out, sums, n);
-    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, total_dev);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, total_dev, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(cxp_k_scan_add, dim3(cxp_blocks(n)), dim3(256), 0, ctx->stream, out, sums, n);
     return CX_OK;
 }
 
 // exclusive scan for the other translation units (cx_contour2d.hip); sums_tmp holds n/1024 + 2 words
-int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev) {
+int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev, unsigned long long* total64_dev) {
     const uint32_t nb = cxp_blocks(n, CXP_SCAN_BLOCK);
     hipLaunchKernelGGL(cxp_k_scan_blocks, dim3(nb ? nb : 1), dim3(256), 0, ctx->stream, in, out, sums_tmp, n);
-    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums_tmp, nb, total_dev);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums_tmp, nb, total_dev, total64_dev);
     if (n) hipLaunchKernelGGL(cxp_k_scan_add, dim3(cxp_blocks(n)), dim3(256), 0, ctx->stream, out, sums_tmp, n);
     return CX_OK;
 }

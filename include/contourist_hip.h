@@ -188,6 +188,8 @@ int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
  * seeds: nseeds x (i, j, role, level index) int32 -- the polylines grown from the pairs around lattice point (i,j)
  * as their low (role 0) or high (role 1) end are kept, exactly the reference's seeded growth; nseeds == 0: the seeds
  * of the reference's own grid search (every crossing axis edge that starts at i < n-1, j < m-1).
+ * Limits: n*m <= 2^30 samples, at most 65535 values, fewer than 2^29 crossings (all levels together) per call
+ * (CX_ERR_UNSUPPORTED otherwise: contour fewer levels per call).
  * mins_delta: {min_x, min_y, delta_x, delta_y} for FunctionGrid.from_grid_coordinates (grid_field.py:89-93), or NULL
  * for grid coordinates.
  * Output (cx_contour2d_download): points n_points x 2 float64, polyline by polyline; keys n_points int64 =

@@ -198,7 +198,7 @@ def test_empty_and_invalid_inputs():
     B[9, 9] = np.inf
     pts, keys, chains, npairs = ctx.contour2d(B, [0.0], None, _ffi.CX2_ALL_CHAINS)
     assert npairs > 0 and int(chains["count"].sum()) == len(pts)
-    # more than 2^31 crossings in one call are refused (counted in 64 bits), not wrapped
+    # more than 2^29 crossings in one call are refused (the 32-bit scan would wrap at 2^32: the total is also counted in 64 bits)
     W = np.random.RandomState(3).standard_normal((2048, 2048)).astype(np.float32)
     with pytest.raises(_ffi.CxError) as e:
         ctx.contour2d(W, np.linspace(-3.0, 3.0, 1000))
