@@ -269,3 +269,24 @@ def test_large_field_many_levels_properties():
     # the same job with the duplicate drop and the grid-search seeds loses nothing but near-duplicate points (np.allclose scales with the coordinate: 0.03 lattice units at 3000)
     pts2, keys2, chains2, _ = ctx.contour2d(None, values, None, 0, device_ptr=t.data_ptr(), shape=(n, m))
     assert len(chains) - 1 <= len(chains2) <= len(chains) and len(pts2) <= len(pts) and len(pts2) > 0.95 * len(pts)
+
+
+def test_reference_demo_and_level_classes():
+    """the reference's own svg demo (triangulated.py:56-61) and the two classes that choose their own levels
+    (multiple_2d_contour.py:84-108) run through the mirrored API"""
+    import math
+    from contourist_amd import triangulated, multiple_2d_contour
+    from oracle import contour2d as o2
+    svg = triangulated.svg_demo()
+    assert svg.count("<path") == 3 and "viewBox" in svg          # the reference finds 3 open contours on this grid
+
+    def f(x, y):
+        return x * x + y * (y + 1) * (y - 1) - math.sin(2 * y * y + 4 * x)
+    for cls, n in ((multiple_2d_contour.Linear2DContour, 5), (multiple_2d_contour.Percentile2DContour, 4)):
+        M = cls(-1, -1, 1, 1, 0.05, 0.05, f, breakpoints=n)
+        d = M.get_contours_dictionary()
+        assert sorted(d) == sorted(set(float(v) for v in M.values))
+        nn, mm, A = triangulated.grid_lattice(M.grid)
+        for v in d:
+            want = [(c, p * M.grid.delta + M.grid.mins) for c, p, _ in o2.contours(A, float(v), None, "build")]
+            assert o2.canonical(d[v]) == o2.canonical(want), "level %r" % v
