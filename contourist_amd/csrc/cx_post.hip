@@ -973,6 +973,8 @@ extern "C" int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int6
     int rc = cxp_state(ctx, &S);
     if (rc) return rc;
     const uint32_t nv = (uint32_t)nv64, nt = (uint32_t)nt64;
+    for (int64_t n = 0; n < nt64 * 3; n++)   // a bad index would be a fault on the device
+        if (tris[n] < 0 || tris[n] >= nv64) { ctx->err = "cx_postprocess3d_mesh: triangle index out of range"; return CX_ERR_INVALID; }
     hipStream_t st = ctx->stream;
     int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;

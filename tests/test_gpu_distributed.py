@@ -156,3 +156,17 @@ def test_level1_two_ranks_gloo_hip(tmp_path):
     got = np.load(os.path.join(str(tmp_path), "l1.npz"))
     assert got["counts"].tolist() == [post0[k] for k in sorted(post0)]
     same_level1(A, pts0, tris0, got["pts"], got["tris"])
+
+
+def test_postprocess_mesh_rejects_bad_indices():
+    from contourist_amd import _ffi
+    ctx = _ffi.Context(0)
+    pts = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    with pytest.raises(_ffi.CxError):
+        ctx.postprocess3d_mesh(pts, [[0, 1, 3]], [4, 4, 4])
+    with pytest.raises(_ffi.CxError):
+        ctx.postprocess3d_mesh(pts, [[0, 1, 2]], [4, 0, 4])
+    post = ctx.postprocess3d_mesh(pts, [[0, 1, 2]], [4, 4, 4])
+    assert post["n_triangles"] == 1 and post["n_vertices"] == 3
+    p1, t1 = ctx.download_level1(post)
+    assert sorted(t1[0].tolist()) == [0, 1, 2]
