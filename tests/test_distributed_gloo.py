@@ -114,3 +114,62 @@ def test_overlapped_halo_exchange(tmp_path):
     mp.spawn(overlap_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):
         assert open(os.path.join(str(tmp_path), "ok%d" % rank)).read() == "1"
+
+
+def oracle_extract_global(local, value, origin=(0, 0, 0)):
+    """like oracle_extract, but with the float64 points in the coordinates of the WHOLE volume, interpolated from
+    the global lattice points (what cx_level0_points_f64 returns on the device): bit for bit what the undivided
+    volume yields"""
+    from oracle import level0
+    O = level0.march3d(local, value, diag_mode=1, origin=origin)
+    keys = level0.edge_keys_from_pairs(O["pairs"], local.shape)
+    low, high = O["pairs"][:, :3].astype(np.int64), O["pairs"][:, 3:].astype(np.int64)
+    flow = local[tuple(low.T)].astype(np.float64)
+    fhigh = local[tuple(high.T)].astype(np.float64)
+    den = 1.0 * (fhigh - flow)
+    ratio = np.where(np.abs(den) <= 1e-8, 0.5, (value - flow) / np.where(den == 0, 1.0, den))
+    org = np.array(origin, dtype=np.float64)
+    xyz = (low + org) + ratio[:, None] * ((high + org) - (low + org))
+    return xyz, keys, O["tris"]
+
+
+oracle_extract_global.global_points = True
+
+
+def worker_level1(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    A = field()
+    i0, i1 = cd.slab_bounds(A.shape[0], world, rank)
+    res = cd.extract_slabs(A[i0:i1], 0.1, rank, world, oracle_extract_global, A.shape, dist=dist)
+    if rank == 0:
+        keys, xyz, tris = res
+        np.savez(os.path.join(outdir, "l1in.npz"), keys=keys, xyz=xyz, tris=tris)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level1_input_of_slabs_is_the_undivided_volume(tmp_path):
+    """world_size 2 over gloo: the mesh rank 0 hands to the Level-1 post-pass (distributed.level1_slabs) -- vertices
+    in ascending global edge-id order, float64 points, triangles -- is bit for bit the Level-0 mesh of the undivided
+    volume, so the post-pass (here the oracle's) gives the same Level-1 mesh"""
+    import torch.multiprocessing as mp
+    from oracle import level0, postpass
+    mp.spawn(worker_level1, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "l1in.npz"))
+    A = field()
+    xyz, keys, tris = oracle_extract_global(A, 0.1)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got["keys"], keys[order]) and np.all(np.diff(got["keys"]) > 0)
+    assert np.array_equal(got["xyz"], xyz[order])                       # exactly, not just close
+    ref = level0.canonical_level0(keys, xyz, tris)
+    out = level0.canonical_level0(got["keys"], got["xyz"], got["tris"])
+    assert np.array_equal(ref[2], out[2])
+    corner = np.array(A.shape) - 1
+    a = postpass.level1_from_level0(keys, xyz, tris, corner)
+    b = postpass.level1_from_level0(got["keys"], got["xyz"], got["tris"], corner)
+    assert a["n_after_weld"] == b["n_after_weld"] and a["n_after_tiny"] == b["n_after_tiny"]
+    assert np.array_equal(postpass.canonical_level1(a["grid_points"], a["triangles"], corner),
+                          postpass.canonical_level1(b["grid_points"], b["triangles"], corner))
