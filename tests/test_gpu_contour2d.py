@@ -290,3 +290,40 @@ def test_reference_demo_and_level_classes():
         for v in d:
             want = [(c, p * M.grid.delta + M.grid.mins) for c, p, _ in o2.contours(A, float(v), None, "build")]
             assert o2.canonical(d[v]) == o2.canonical(want), "level %r" % v
+
+
+def test_random_fields_levels_and_seeds_equal_oracle():
+    """60 random cases: shapes 2..40, rough to smooth, some quantised (many samples equal to a level), 1..5 levels,
+    a third of them with explicit end points: polylines == oracle, pair for pair"""
+    from contourist_amd import _ffi
+    from oracle import contour2d as o2
+    ctx = _ffi.Context(0)
+    rng = np.random.RandomState(2024)
+    for case in range(60):
+        n, m = int(rng.randint(2, 41)), int(rng.randint(2, 41))
+        A = smooth2((n, m), 3000 + case, int(rng.randint(0, 4))) if n * m > 4 else rng.standard_normal((n, m)).astype(np.float32)
+        if rng.rand() < 0.3:
+            A = (np.round(A * 4) / 4).astype(np.float32)
+        raw = rng.uniform(-1.2, 1.2, size=int(rng.randint(1, 6)))
+        values = sorted(set((np.round(raw * 4) / 4).tolist())) if rng.rand() < 0.5 else sorted(set(np.round(raw, 3).tolist()))
+        values = [float(v) for v in values]
+        seeded = rng.rand() < 0.33
+        for k, v in enumerate(values):
+            L = o2.Lattice(A, v, "build")
+            eps = None
+            if seeded:
+                cand = L.search_grid()
+                if not cand:
+                    continue
+                pick = rng.choice(len(cand), size=min(len(cand), 1 + int(rng.randint(0, 3))), replace=False)
+                eps = [cand[int(p)] for p in pick]
+            want = o2.contours(A, v, eps, "build", dedupe=False)
+            seeds = None
+            if eps is not None:
+                rows = []
+                for (a, b) in eps:
+                    lo, hi = L.seed_points(a, b)
+                    rows += [(lo[0], lo[1], 0, 0), (hi[0], hi[1], 1, 0)]
+                seeds = np.array(rows, dtype=np.int32)
+            got, _ = device_chains(A, [v], seeds, _ffi.CX2_NO_DEDUPE, ctx=ctx)
+            assert o2.canonical_keys(got[0]) == o2.canonical_keys(want), "case %d shape %s level %r seeded %s" % (case, A.shape, v, seeded)
