@@ -370,18 +370,41 @@ __global__ void c2_k_mark_roots(const uint32_t* rep, const uint32_t* mark, uint3
 // (mn == 0): off is the distance to the head.  Closed chain: when i and ptr report the same mn their windows overlap,
 // i.e. together they cover the whole cycle: mn is the smallest id of the cycle and off the distance back to it, which
 // is the rank of i when the cycle is opened in front of its smallest id.
+// The first C2_WALK steps are walked one by one (the predecessors of a crossing are its neighbours in memory, and
+// three rounds over all elements cost more than eight short dependent loads): the state starts with a window of up to
+// C2_WALK elements instead of one.
+#define C2_WALK 8
+#define C2_FIN 0x80000000u
 __global__ void c2_k_jump_init(const uint32_t* pred, uint32_t nv, uint4* st) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nv) return;
-    const uint32_t p = pred[id];
-    st[id] = (p == C2_NIL) ? make_uint4(id, 0u, 0u, 0u) : make_uint4(p, 1u, id + 1u, 0u);
+    uint32_t p = pred[id];
+    if (p == C2_NIL) {   // the head of an open chain: label 0, final
+        st[id] = make_uint4(id, C2_FIN, 0u, 0u);
+        return;
+    }
+    uint32_t hop = 1, mn = id + 1u, off = 0;   // window {id}, ptr = p
+    bool fin = false;
+    for (int k = 1; k < C2_WALK; k++) {
+        if (p == id) { fin = true; break; }            // a short cycle: the window is the whole cycle
+        const uint32_t q = pred[p];
+        if (q == C2_NIL) {                             // p is the head: take it in and stop there
+            mn = 0u;
+            off = hop;
+            fin = true;
+            break;
+        }
+        if (p + 1u < mn) { mn = p + 1u; off = hop; }   // p joins the window
+        hop++;
+        p = q;
+    }
+    st[id] = make_uint4(p, hop | (fin ? C2_FIN : 0u), mn, off);
 }
 // Bit 31 of hop marks an element whose state is final; it is copied from then on.  Most polylines are short and
 // the rounds are paid by the longest: after C2_FULL_ROUNDS rounds over all elements the unfinished ones are listed
 // (c2_k_jump_flags + scan + c2_k_jump_list) and the remaining rounds run over that list only.  Elements outside the
 // list hold the same final state in both buffers (one full round is run after the round the list is taken from).
-#define C2_FIN 0x80000000u
-#define C2_FULL_ROUNDS 7
+#define C2_FULL_ROUNDS 4
 __device__ __forceinline__ void c2_jump_one(const uint4* in, uint4* out, uint32_t id, uint32_t* changed) {
     uint4 a = in[id];
     if (a.y & C2_FIN) {
