@@ -50,7 +50,12 @@ def unpack_edge_ids4(keys, shape):
 
 
 class GridContour4D(object):
-    "device-backed counterpart of GridContour4D (pentatopes.py:92-444), grid coordinates"
+    """device-backed counterpart of GridContour4D (pentatopes.py:92-444), grid coordinates.
+
+    segment_endpoints: kept in `end_points` for inspection but NOT used to restrict the result -- the dense march
+    returns every component of the 4-D level set, i.e. what the reference returns after search_for_endpoints();
+    with explicit end points the reference only grows from them (80-neighbour growth, pentatopes.py:127-160) and
+    returns the components it reaches, a subset.  (The 3-D path does implement that restriction: cx_select_seeded3d.)"""
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
                  device=None, diagonal="cpython310", context=None):
