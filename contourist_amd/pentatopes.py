@@ -54,7 +54,7 @@ class GridContour4D(object):
 
     segment_endpoints: kept in `end_points` for inspection but NOT used to restrict the result -- the dense march
     returns every component of the 4-D level set, i.e. what the reference returns after search_for_endpoints();
-    with explicit end points the reference only grows from them (80-neighbour growth, pentatopes.py:127-160) and
+    with explicit end points the reference only grows from them (80-neighbour growth: tetrahedral.py:396-463 with OFFSETS4D, pentatopes.py:32-39) and
     returns the components it reaches, a subset.  (The 3-D path does implement that restriction: cx_select_seeded3d.)"""
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
