@@ -23,7 +23,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -112,6 +112,7 @@ def load():
         "cx_grid4d_adopt_device": [vp, vp, i64, i64, i64, i64],
         "cx_set_origin4d": [vp, i64, i64, i64, i64],
         "cx_extract4d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
+        "cx_select_seeded4d": [vp, vp, i64, vp],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
         "cx_level1_4d_download": [vp, vp, vp],
@@ -290,6 +291,14 @@ class Context(object):
         c = CxCounts()
         self._check(self.lib.cx_extract4d(self.handle, float(value), int(flags), ctypes.byref(c)))
         return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
+
+    def select_seeded4d(self, endpoints):
+        """restrict the 4-D post-pass to the components the reference's seeded search reaches from the lattice end
+        point pairs [(i0,j0,k0,l0), (i1,j1,k1,l1)] -> dict(seed_voxels, groups_kept, tetrahedra_kept)"""
+        ep = np.ascontiguousarray(np.asarray(endpoints, dtype=np.int64).reshape(-1, 8), dtype=np.int32)
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.cx_select_seeded4d(self.handle, ep.ctypes.data, int(len(ep)), out.ctypes.data))
+        return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), tetrahedra_kept=int(out[2]))
 
     def download_level0_4d(self, counts):
         "-> (xyzt (V,4) float32, edge ids (V,) uint32, tetrahedra (T,4) int32)"

@@ -20,7 +20,7 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits};
+    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep};
     for (void* p : all)
         if (p) (void)hipFree(p);
     delete S;
@@ -46,6 +46,7 @@ static int set_dims4(cx_ctx* ctx, cx_state4* S, int64_t n0, int64_t n1, int64_t 
     }
     S->n[0] = n0; S->n[1] = n1; S->n[2] = n2; S->n[3] = n3;
     S->extracted = false;
+    S->keep_valid = false;
     return CX_OK;
 }
 
@@ -191,6 +192,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         if (c.n_cells <= S->ccap && c.n_vertices <= S->vcap && c.n_triangles <= S->tcap) {
             S->extracted = true;
             S->post_valid = false;
+            S->keep_valid = false;
             S->value = value;
             return CX_OK;
         }

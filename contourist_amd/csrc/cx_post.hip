@@ -1087,6 +1087,10 @@ __global__ void cxp_k_vertices4_f64(const float* __restrict__ A, uint32_t n1, ui
     prio[v] = key;
 }
 
+__global__ void cxp_k_and_mask(uint8_t* alive, const uint8_t* keep, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && !keep[t]) alive[t] = 0;
+}
 __global__ void cxp_k_drop_instant(const int32_t* tets, uint8_t* alive, uint32_t nt, const double* pts, double eps) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -1174,6 +1178,8 @@ extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts)
         hipLaunchKernelGGL(cxp_k_vertices4_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, G->grid, n1, n2, n3, cx_fdiv_make(n1 * n2 * n3),
                            cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio);
         hipLaunchKernelGGL(cxp_k_drop_instant, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1e-7);
+        // cx_select_seeded4d: only the tetrahedra of the selected components exist
+        if (G->keep_valid) hipLaunchKernelGGL(cxp_k_and_mask, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, (const uint8_t*)G->tet_keep, nt);
         CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 4);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent, nv);

@@ -1,0 +1,297 @@
+// cx_seed4.hip -- seeded selection of level-set components for the 4-D march (C ABI: cx_select_seeded4d).
+//
+// The 4-D contour maker of the reference inherits its search from the 3-D one (contourist/tetrahedral.py) and runs it
+// with the 80 neighbour offsets of pentatopes.py:32-39:
+//   find_initial_voxels  tetrahedral.py:396-441  each end point pair is bisected until adjacent; for both points: the
+//                                                point's own hyper-voxel if it is a border voxel, else the first border
+//                                                voxel among its 80 neighbours (OFFSETS4D order); shared `visited` set
+//   expand_voxels        :443-463                breadth-first over the 80 neighbours, border voxels inside the grid only
+//   border_voxel         :383-394                min <= value <= max over the 16 corners and not np.allclose(value, corners)
+// Here, as in cx_seed.hip: the dense march has produced every hyper-voxel with a sign change (cell records); they are
+// grouped by 80-connectivity with a lock-free union-find, the groups that contain a seed voxel are kept and the
+// tetrahedra of all other hyper-voxels are masked out for cx_postprocess4d.  A tetrahedron belongs to the hyper-voxel
+// whose corner 0 is the componentwise minimum of the owners of its four edges (every tetrahedron touches all five
+// corners of its pentatope, every pentatope contains corner 0 of its hypercube).
+// Deviations: hyper-voxels whose corners only touch the isovalue (no strict sign change) do not bridge groups; seed
+// points whose hyper-voxel is not inside the array are skipped.
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "cx_state4.h"
+
+#define CXS4_HIP(ctx, call)                                                                      \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return (e__ == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;                      \
+        }                                                                                        \
+    } while (0)
+
+#define CXS4_NONE 0xFFFFFFFFu
+
+struct cxs4_grid {
+    const float* A;
+    uint32_t n[4];
+    double value;
+};
+__device__ __forceinline__ uint32_t cxs4_lin(const cxs4_grid& G, const int p[4]) {
+    return (((uint32_t)p[0] * G.n[1] + (uint32_t)p[1]) * G.n[2] + (uint32_t)p[2]) * G.n[3] + (uint32_t)p[3];
+}
+__device__ __forceinline__ void cxs4_unravel(const cxs4_grid& G, uint32_t lin, int p[4]) {
+    p[3] = (int)(lin % G.n[3]); lin /= G.n[3];
+    p[2] = (int)(lin % G.n[2]); lin /= G.n[2];
+    p[1] = (int)(lin % G.n[1]);
+    p[0] = (int)(lin / G.n[1]);
+}
+__device__ __forceinline__ bool cxs4_voxel_inside(const cxs4_grid& G, const int p[4]) {
+    for (int a = 0; a < 4; a++)
+        if (p[a] < 0 || p[a] + 1 >= (int)G.n[a]) return false;
+    return true;
+}
+// a record of a real hyper-voxel with a strict sign change among its 16 corners
+__device__ __forceinline__ bool cxs4_is_voxel_record(const cxs4_grid& G, const uint4& c) {
+    const uint32_t sm = c.y & 0xFFFFu;
+    if (sm == 0u || sm == 0xFFFFu) return false;
+    int p[4];
+    cxs4_unravel(G, c.x, p);
+    return cxs4_voxel_inside(G, p);
+}
+__device__ __forceinline__ uint32_t cxs4_find(uint32_t* parent, uint32_t x) {
+    for (;;) {
+        const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        const uint32_t g = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != p) atomicCAS(&parent[x], p, g);   // path halving
+        x = p;
+    }
+}
+__device__ __forceinline__ void cxs4_union(uint32_t* parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = cxs4_find(parent, a);
+        b = cxs4_find(parent, b);
+        if (a == b) return;
+        const uint32_t win = min(a, b), lose = max(a, b);
+        if (atomicCAS(&parent[lose], lose, win) == lose) return;
+    }
+}
+
+__global__ void cxs4_k_map(const uint4* cells, uint32_t ncells, uint32_t* vmap, uint32_t* parent, cxs4_grid G) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ncells) return;
+    parent[r] = r;
+    const uint4 c = cells[r];
+    if (cxs4_is_voxel_record(G, c)) vmap[c.x] = r;
+}
+// record index of the hyper-voxel at p, or CXS4_NONE (the map is not cleared: entries validate themselves)
+__device__ __forceinline__ uint32_t cxs4_lookup(const cxs4_grid& G, const uint4* cells, uint32_t ncells, const uint32_t* vmap, const int p[4]) {
+    if (!cxs4_voxel_inside(G, p)) return CXS4_NONE;
+    const uint32_t lin = cxs4_lin(G, p);
+    const uint32_t r = vmap[lin];
+    if (r >= ncells) return CXS4_NONE;
+    const uint4 c = cells[r];
+    return (c.x == lin && cxs4_is_voxel_record(G, c)) ? r : CXS4_NONE;
+}
+__global__ void cxs4_k_union(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs4_grid G) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ncells) return;
+    const uint4 c = cells[r];
+    if (!cxs4_is_voxel_record(G, c)) return;
+    int p[4];
+    cxs4_unravel(G, c.x, p);
+    // the 40 "forward" neighbours (the other 40 are reached from the other side)
+    for (int code = 41; code < 81; code++) {   // offsets in lexicographic order, (0,0,0,0) is code 40
+        int o[4], x = code;
+        o[3] = x % 3 - 1; x /= 3;
+        o[2] = x % 3 - 1; x /= 3;
+        o[1] = x % 3 - 1; x /= 3;
+        o[0] = x - 1;
+        const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
+        const uint32_t other = cxs4_lookup(G, cells, ncells, vmap, q);
+        if (other != CXS4_NONE) cxs4_union(parent, r, other);
+    }
+}
+__global__ void cxs4_k_flatten(uint32_t* parent, uint32_t n) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) parent[r] = cxs4_find(parent, r);
+}
+
+__device__ bool cxs4_border_voxel(const cxs4_grid& G, const int p[4]) {
+    if (!cxs4_voxel_inside(G, p)) return false;
+    double lo = 1e300, hi = -1e300;
+    bool allclose = true;
+    for (int c = 0; c < 16; c++) {
+        const int q[4] = {p[0] + ((c >> 3) & 1), p[1] + ((c >> 2) & 1), p[2] + ((c >> 1) & 1), p[3] + (c & 1)};
+        const double f = (double)G.A[cxs4_lin(G, q)];
+        lo = fmin(lo, f); hi = fmax(hi, f);
+        if (!(fabs(G.value - f) <= 1e-8 + 1e-5 * fabs(f))) allclose = false;
+    }
+    if (allclose) return false;
+    return lo <= G.value && hi >= G.value;
+}
+__device__ bool cxs4_visit(unsigned long long* table, unsigned long long mask, const int p[4]) {   // true: newly added
+    const unsigned long long key = ((unsigned long long)(p[0] + 4) << 48) | ((unsigned long long)(p[1] + 4) << 32) |
+                                   ((unsigned long long)(p[2] + 4) << 16) | (unsigned long long)(p[3] + 4);
+    unsigned long long h = (key * 0x9E3779B97F4A7C15ULL) >> 20;
+    for (;;) {
+        const unsigned long long cur = table[h & mask];
+        if (cur == key + 1ULL) return false;
+        if (cur == 0ULL) { table[h & mask] = key + 1ULL; return true; }
+        h++;
+    }
+}
+// seeds, sequentially, as the reference runs them (one thread; end point lists are short).
+// out[0] = number of seed voxels, out[1] = end point pairs that do not straddle the isovalue or lie outside the grid
+__global__ void cxs4_k_seeds(cxs4_grid G, const int32_t* ep, uint32_t n, unsigned long long* visited, unsigned long long vmask,
+                             uint32_t* seeds, uint32_t* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t ns = 0, bad = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        int lowp[4], highp[4];
+        bool okp = true;
+        for (int a = 0; a < 4; a++) {
+            lowp[a] = ep[s * 8 + a];
+            highp[a] = ep[s * 8 + 4 + a];
+            if (lowp[a] < 0 || highp[a] < 0 || lowp[a] >= (int)G.n[a] || highp[a] >= (int)G.n[a]) okp = false;
+        }
+        if (!okp) { bad++; continue; }
+        double lowv = (double)G.A[cxs4_lin(G, lowp)], highv = (double)G.A[cxs4_lin(G, highp)];
+        if (lowv > G.value || highv < G.value) {
+            for (int a = 0; a < 4; a++) { const int t = lowp[a]; lowp[a] = highp[a]; highp[a] = t; }
+            const double t = lowv; lowv = highv; highv = t;
+        }
+        if (!(lowv <= G.value && highv >= G.value)) { bad++; continue; }   // the reference asserts here (:412-414)
+        for (;;) {
+            bool far = false;
+            for (int a = 0; a < 4; a++) far = far || abs(lowp[a] - highp[a]) > 1;
+            if (!far) break;
+            int mid[4];
+            for (int a = 0; a < 4; a++) mid[a] = (lowp[a] + highp[a]) / 2;   // both non-negative: Python floor division
+            if ((double)G.A[cxs4_lin(G, mid)] < G.value) { for (int a = 0; a < 4; a++) lowp[a] = mid[a]; }
+            else { for (int a = 0; a < 4; a++) highp[a] = mid[a]; }
+        }
+        for (int which = 0; which < 2; which++) {
+            const int* p = which ? highp : lowp;
+            if (!cxs4_visit(visited, vmask, p)) continue;
+            if (cxs4_border_voxel(G, p)) { seeds[ns++] = cxs4_lin(G, p); continue; }
+            bool found = false;
+            for (int code = 0; code < 81 && !found; code++) {
+                if (code == 40) continue;
+                int o[4], x = code;
+                o[3] = x % 3 - 1; x /= 3;
+                o[2] = x % 3 - 1; x /= 3;
+                o[1] = x % 3 - 1; x /= 3;
+                o[0] = x - 1;
+                const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
+                bool neg = false;
+                for (int a = 0; a < 4; a++) neg = neg || q[a] < 0 || q[a] >= (int)G.n[a];
+                if (neg) continue;   // not inside the array: cannot be a border voxel here, and not worth a table entry
+                if (!cxs4_visit(visited, vmask, q)) continue;
+                if (cxs4_border_voxel(G, q)) { seeds[ns++] = cxs4_lin(G, q); found = true; }
+            }
+        }
+    }
+    out[0] = ns;
+    out[1] = bad;
+}
+__global__ void cxs4_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint32_t* seeds,
+                            const uint32_t* nseeds, uint8_t* flag, cxs4_grid G) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseeds[0]) return;
+    int p[4];
+    cxs4_unravel(G, seeds[s], p);
+    const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, p);
+    if (r != CXS4_NONE) flag[parent[r]] = 1;   // (a border voxel without a strict sign change has no tetrahedra and does not grow here)
+}
+// keep[t] = 1 for the tetrahedra of the hyper-voxels in flagged groups; out[2] groups kept, out[3] tetrahedra kept
+__global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint8_t* flag,
+                            const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    int b[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+    for (int k = 0; k < 4; k++) {
+        int p[4];
+        cxs4_unravel(G, vkeys[(uint32_t)tets[(size_t)t * 4 + k]] >> 4, p);
+        for (int a = 0; a < 4; a++) b[a] = min(b[a], p[a]);
+    }
+    const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, b);
+    const uint8_t k = (r != CXS4_NONE && flag[parent[r]] != 0) ? 1 : 0;
+    keep[t] = k;
+    if (k) atomicAdd(&out[3], 1u);
+}
+__global__ void cxs4_k_count_groups(const uint32_t* parent, uint32_t ncells, const uint8_t* flag, uint32_t* out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < ncells && parent[r] == r && flag[r]) atomicAdd(&out[2], 1u);
+}
+
+extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, int64_t* out_counts) {
+    if (!ctx || (n > 0 && !endpoints_ijkl) || n < 0) return CX_ERR_INVALID;
+    cx_state4* S4 = ctx->s4;
+    if (!S4 || !S4->extracted) { ctx->err = "cx_select_seeded4d: no valid 4-D extraction"; return CX_ERR_STATE; }
+    CXS4_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t ncells = (uint32_t)S4->counts.n_cells, nt = (uint32_t)S4->counts.n_triangles;
+    cxs4_grid G;
+    G.A = S4->grid;
+    size_t nsamples = 1;
+    for (int a = 0; a < 4; a++) { G.n[a] = (uint32_t)S4->n[a]; nsamples *= (size_t)S4->n[a]; }
+    G.value = S4->value;
+    if (S4->keep_cap < (size_t)nt + 64) {
+        if (S4->tet_keep) (void)hipFree(S4->tet_keep);
+        S4->tet_keep = nullptr; S4->keep_cap = 0;
+        CXS4_HIP(ctx, hipMalloc(&S4->tet_keep, (size_t)nt + 64));
+        S4->keep_cap = (size_t)nt + 64;
+    }
+    S4->keep_valid = false;
+    uint32_t *vmap = nullptr, *parent = nullptr, *seeds = nullptr, *out = nullptr;
+    uint8_t* flag = nullptr;
+    int32_t* ep = nullptr;
+    unsigned long long* visited = nullptr;
+    unsigned long long vsize = 1024;
+    while (vsize < (unsigned long long)n * 164ULL * 4ULL) vsize <<= 1;
+    int rc = CX_OK;
+    uint32_t host_out[4] = {0, 0, 0, 0};
+    do {
+        hipError_t e;
+#define CXS4_TRY(call) if ((e = (call)) != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP; break; }
+        CXS4_TRY(hipMalloc(&vmap, (nsamples + 64) * sizeof(uint32_t)));
+        CXS4_TRY(hipMalloc(&parent, ((size_t)ncells + 64) * sizeof(uint32_t)));
+        CXS4_TRY(hipMalloc(&flag, (size_t)ncells + 64));
+        CXS4_TRY(hipMalloc(&seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t)));
+        CXS4_TRY(hipMalloc(&out, 16 * sizeof(uint32_t)));
+        CXS4_TRY(hipMalloc(&ep, ((size_t)n * 8 + 8) * sizeof(int32_t)));
+        CXS4_TRY(hipMalloc(&visited, vsize * sizeof(unsigned long long)));
+        CXS4_TRY(hipMemsetAsync(flag, 0, (size_t)ncells + 64, st));
+        CXS4_TRY(hipMemsetAsync(out, 0, 16 * sizeof(uint32_t), st));
+        CXS4_TRY(hipMemsetAsync(visited, 0, vsize * sizeof(unsigned long long), st));
+        CXS4_TRY(hipMemsetAsync(S4->tet_keep, 0, (size_t)nt + 64, st));
+        if (n) CXS4_TRY(hipMemcpyAsync(ep, endpoints_ijkl, (size_t)n * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (ncells && nt) {
+            const uint32_t blocks = (ncells + 255u) / 256u;
+            hipLaunchKernelGGL(cxs4_k_map, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
+            hipLaunchKernelGGL(cxs4_k_union, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
+            hipLaunchKernelGGL(cxs4_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
+            hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
+            hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, G);
+            hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, S4->tets, S4->vkeys, nt,
+                               S4->tet_keep, out, G);
+            hipLaunchKernelGGL(cxs4_k_count_groups, dim3(blocks), dim3(256), 0, st, parent, ncells, flag, out);
+        }
+        CXS4_TRY(hipGetLastError());
+        CXS4_TRY(hipMemcpyAsync(host_out, out, sizeof(host_out), hipMemcpyDeviceToHost, st));
+        CXS4_TRY(hipStreamSynchronize(st));
+#undef CXS4_TRY
+    } while (0);
+    void* scratch[] = {vmap, parent, flag, seeds, out, ep, visited};
+    for (void* p : scratch)
+        if (p) (void)hipFree(p);
+    if (rc) return rc;
+    if (out_counts) {
+        out_counts[0] = host_out[0]; out_counts[1] = host_out[2]; out_counts[2] = host_out[3]; out_counts[3] = host_out[1];
+    }
+    if (host_out[1]) { ctx->err = "cx_select_seeded4d: an end point pair does not straddle the isovalue (or lies outside the grid)"; return CX_ERR_INVALID; }
+    S4->keep_valid = true;
+    S4->post_valid = false;
+    return CX_OK;
+}

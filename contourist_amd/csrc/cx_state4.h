@@ -53,5 +53,9 @@ struct cx_state4 {
     bool post_valid = false;
     double value = 0.0;
     cx_counts counts = {0, 0, 0, 0};
+    // seeded selection (cx_select_seeded4d): mask over the Level-0 tetrahedra, valid until the next extraction
+    uint8_t* tet_keep = nullptr;
+    size_t keep_cap = 0;
+    bool keep_valid = false;
 };
 

@@ -52,10 +52,10 @@ def unpack_edge_ids4(keys, shape):
 class GridContour4D(object):
     """device-backed counterpart of GridContour4D (pentatopes.py:92-444), grid coordinates.
 
-    segment_endpoints: kept in `end_points` for inspection but NOT used to restrict the result -- the dense march
-    returns every component of the 4-D level set, i.e. what the reference returns after search_for_endpoints();
-    with explicit end points the reference only grows from them (80-neighbour growth: tetrahedral.py:396-463 with OFFSETS4D, pentatopes.py:32-39) and
-    returns the components it reaches, a subset.  (The 3-D path does implement that restriction: cx_select_seeded3d.)"""
+    segment_endpoints: lattice point pairs that straddle the value.  None or empty: every component of the 4-D level
+    set (what the reference returns after search_for_endpoints()); otherwise find_tetrahedra() keeps the components the
+    reference's search reaches from them (80-neighbour growth: tetrahedral.py:396-463 with OFFSETS4D,
+    pentatopes.py:32-39; on the device: cx_select_seeded4d).  march() always returns the whole Level-0 mesh."""
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
                  device=None, diagonal="cpython310", context=None):
@@ -99,6 +99,8 @@ class GridContour4D(object):
         coordinates, keys (V,) edge ids, tetrahedra (T,4) int32, counts)"""
         L = self.march()
         ctx = self.context()
+        if self.end_points is not None and len(self.end_points):
+            self.seeded = ctx.select_seeded4d(self.end_points)
         post = ctx.postprocess4d(nbins)
         pts, tets = ctx.download_level1_4d(post)
         self.post_counts = post

@@ -155,6 +155,13 @@ int cx_grid4d_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int
 int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2, int64_t n3);
 int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3);
 int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
+/* Seeded selection in 4-D, the counterpart of cx_select_seeded3d: GridContour4D(corner, function, value, endpoints)
+ * (pentatopes.py:92-100) grows from its end points with the methods it inherits (tetrahedral.py:396-463) over the 80
+ * neighbours of pentatopes.py:32-39.  endpoints_ijkl: n x 8 int32 lattice points (i0,j0,k0,l0, i1,j1,k1,l1) whose
+ * samples straddle the isovalue.  Call between cx_extract4d and cx_postprocess4d; restricts the post-pass (until the
+ * next extraction) to the tetrahedra of the hyper-voxel groups reached.  out_counts (4 x int64): [0] seed voxels,
+ * [1] groups kept, [2] tetrahedra kept, [3] rejected pairs (CX_ERR_INVALID). */
+int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, int64_t* out_counts);
 int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, int32_t* tets);
 /* GridContour4D.find_tetrahedra's post-steps on the device: bin_times(nbins) (pentatopes.py:162-169),
  * drop_instant_tetrahedra(1e-7) (:171-189), remove_tiny_simplices(1e-3) (tetrahedral.py:353-375).

@@ -72,6 +72,14 @@ def fields4d():
     # two blobs that merge over time
     C = np.minimum((X - 3.7) ** 2 + (Y - 4.6) ** 2 + (Z - 4.8) ** 2, (X - 6.4) ** 2 + (Y - 5.4) ** 2 + (Z - 5.1) ** 2) - 0.45 * T
     F["merge_11x11x11x9"] = dict(A=close4(C, 60.0).astype(np.float32), value=1.2)
+    # two blobs that never meet; explicit end points reach one of them (seeded growth, tetrahedral.py:396-463 with the
+    # 80 offsets of pentatopes.py:32-39)
+    g10 = np.arange(12, dtype=np.float64)
+    X2, Y2, Z2, T2 = np.meshgrid(g10, g10, g10, np.arange(7, dtype=np.float64), indexing="ij")
+    E = np.minimum((X2 - 3.2) ** 2 + (Y2 - 3.4) ** 2 + (Z2 - 3.1) ** 2 + 0.3 * (T2 - 3.0) ** 2,
+                   (X2 - 8.1) ** 2 + (Y2 - 7.9) ** 2 + (Z2 - 8.3) ** 2 + 0.3 * (T2 - 3.0) ** 2)
+    F["two_blobs_seeded_12x12x12x7"] = dict(A=close4(E, 60.0).astype(np.float32), value=2.6,
+                                            end_points=[[[3, 3, 3, 3], [3, 3, 6, 3]]])
     # the reference's own demo field (pentatopes.py:528-551 `test0`: period-3 pattern of spheres morphing into bars,
     # value 2.0, with samples exactly equal to the value), on a lattice large enough to close its rim
     g = np.arange(13, dtype=np.float64)
@@ -82,7 +90,7 @@ def fields4d():
     return F
 
 
-def run_reference4d(A, value):
+def run_reference4d(A, value, end_points=None):
     pentatopes = reference_modules4d()
     A = np.ascontiguousarray(A, dtype=np.float32)
     shape = A.shape
@@ -94,10 +102,14 @@ def run_reference4d(A, value):
             return float(outside)
         return float(A[idx])
     t0 = time.time()
-    M = pentatopes.MorphingIsoSurfaces([0.0] * 4, [n - 2 for n in shape], [1.0] * 4, f, float(value), [])
-    assert tuple(M.grid.grid_dimensions) == tuple(n - 1 for n in shape)
-    M.search_for_endpoints()
-    cm = M.contour_maker
+    if end_points is None:
+        M = pentatopes.MorphingIsoSurfaces([0.0] * 4, [n - 2 for n in shape], [1.0] * 4, f, float(value), [])
+        assert tuple(M.grid.grid_dimensions) == tuple(n - 1 for n in shape)
+        M.search_for_endpoints()
+        cm = M.contour_maker
+    else:
+        # the reference's own way of calling the 4-D march (test0, pentatopes.py:528-551): explicit end points
+        cm = pentatopes.GridContour4D([n - 1 for n in shape], f, float(value), [[list(a), list(b)] for a, b in end_points])
     cm.find_initial_voxels()
     while cm.new_surface_voxels:
         cm.expand_voxels()
@@ -139,7 +151,9 @@ if __name__ == "__main__":
     for name, spec in fields4d().items():
         if names and name not in names:
             continue
-        G = run_reference4d(spec["A"], spec["value"])
+        G = run_reference4d(spec["A"], spec["value"], spec.get("end_points"))
+        if "end_points" in spec:
+            G["end_points"] = np.array(spec["end_points"], dtype=np.int32)
         np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **G)
         print("%-22s shape=%s v=%g  hypervoxels %d  verts %d  tets %d | after drop %d after tiny %d | morph: %d segments %d triangles (%.1fs)" % (
             name, spec["A"].shape, spec["value"], len(G["surface_voxels"]), len(G["l0_pairs"]), len(G["l0_tets"]),

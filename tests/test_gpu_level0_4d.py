@@ -13,7 +13,8 @@ G4 = os.path.join(ROOT, "tests", "golden4d")
 
 
 def names():
-    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")) if os.path.isdir(G4) else []
+    # (fixtures named *seeded* were made with explicit end points: the reference reached a subset; own tests below)
+    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz") and "seeded" not in f) if os.path.isdir(G4) else []
 
 
 def check(A, v, diagonal, diag_mode):
@@ -128,7 +129,7 @@ def test_morph_triangles_device(name):
     assert len(tris) > 0 and tris.max() < len(pts)
 
 
-@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")))
+@pytest.mark.parametrize("name", names())
 def test_per_t_surfaces_on_device_equal_host_evaluation(name):
     """B6: the surface at time t from the morph triangles -- device kernel vs MorphTriangles.triangles_at (numpy)"""
     from contourist_amd import pentatopes
@@ -178,3 +179,35 @@ def test_time_slices_are_consistently_wound_at_size():
             assert len(tris) > 10000 and manifold > 1.3 * len(tris) and same == 0
     finally:
         ctx.close()
+
+
+def test_seeded_growth_4d():
+    """explicit end points in 4-D (cx_select_seeded4d): the device keeps exactly the tetrahedra the restated search keeps
+    and the mirrored GridContour4D(corner, samples, value, end points) returns what the real reference returned"""
+    from contourist_amd import _ffi, pentatopes
+    from oracle import level0_4d, seeds
+    G = np.load(os.path.join(G4, "two_blobs_seeded_12x12x12x7.npz"))
+    A, v, eps = G["A"], float(G["value"]), G["end_points"]
+    corner = np.array(A.shape) - 1
+    maker = pentatopes.GridContour4D(tuple(corner), A, v, [[tuple(a), tuple(b)] for a, b in eps.tolist()])
+    L = maker.march()
+    kh = L["keys"].astype(np.int64)
+    keep, surf = seeds.select4d(A, v, eps, kh, L["tetrahedra"].astype(np.int64))
+    R = maker.find_tetrahedra()
+    kh = R["keys"].astype(np.int64)      # find_tetrahedra marches again: the 4-D vertex numbering is per extraction
+    assert maker.seeded["tetrahedra_kept"] == int(keep.sum()) == len(G["l0_tets"]) and maker.seeded["groups_kept"] == 1
+    assert R["counts"]["n_after_drop"] == int(G["n_tets_after_drop"]) and R["counts"]["n_after_tiny"] == int(G["n_tets_after_tiny"])
+    kr = level0_4d.edge_keys4(G["l0_pairs"], A.shape)
+    MT = maker.collect_morph_triangles()
+    assert len(MT.triangle_segment_indices) == len(G["mt_triangles"]) and len(MT.segment_point_indices) == len(G["mt_segments"])
+    rk = level0_4d.edge_keys4(G["mt_point_pairs"], A.shape)
+    got_seg = set((int(kh[i]), int(kh[j])) for i, j in MT.segment_point_indices)
+    assert got_seg == set((int(rk[i]), int(rk[j])) for i, j in G["mt_segments"])
+    # end points on the other blob select the other component; both together everything
+    ctx = maker.context()
+    other = ctx.select_seeded4d([[(8, 8, 8, 3), (8, 8, 11, 3)]])
+    both = ctx.select_seeded4d([[(3, 3, 3, 3), (3, 3, 6, 3)], [(8, 8, 8, 3), (8, 8, 11, 3)]])
+    assert other["tetrahedra_kept"] == len(L["tetrahedra"]) - int(keep.sum()) and both["tetrahedra_kept"] == len(L["tetrahedra"])
+    assert both["groups_kept"] == 2
+    with pytest.raises(_ffi.CxError):
+        ctx.select_seeded4d([[(0, 0, 0, 0), (1, 0, 0, 0)]])       # both on the same side

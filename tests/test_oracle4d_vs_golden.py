@@ -13,7 +13,8 @@ G4 = os.path.join(ROOT, "tests", "golden4d")
 
 
 def names():
-    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz")) if os.path.isdir(G4) else []
+    # (fixtures named *seeded* were made with explicit end points: the reference reached a subset; own tests below)
+    return sorted(f[:-4] for f in os.listdir(G4) if f.endswith(".npz") and "seeded" not in f) if os.path.isdir(G4) else []
 
 
 @pytest.mark.parametrize("name", names())
@@ -75,3 +76,20 @@ def test_morph_triangles_b4_b5(name):
     ot, label, flags = postpass4d.orient_morph_triangles(M)
     common, agree = postpass4d.winding_agreement(rk, G["mt_segments"], G["mt_triangles"], M["keys"], M["segments"], ot)
     assert common > 0.7 * len(ot) and agree == common
+
+
+def test_seeded_growth_4d_vs_reference():
+    """GridContour4D(corner, f, value, end points) of the reference (its own calling convention, pentatopes.py:528-551):
+    the restated search (oracle/seeds.py, 80 neighbours) selects exactly the hyper-voxels and tetrahedra it reached"""
+    from oracle import seeds
+    G = np.load(os.path.join(G4, "two_blobs_seeded_12x12x12x7.npz"))
+    A, v = G["A"], float(G["value"])
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    keep, surf = seeds.select4d(A, v, G["end_points"], ko, O["tets"])
+    assert 0 < keep.sum() < len(keep)                                    # the other blob is left out
+    assert sorted(surf) == sorted(tuple(int(x) for x in q) for q in G["surface_voxels"])
+    kr = level0_4d.edge_keys4(G["l0_pairs"], A.shape)
+    want = np.sort(kr[G["l0_tets"]], axis=1)
+    got = np.sort(ko[O["tets"][keep]], axis=1)
+    assert np.array_equal(want[np.lexsort(want.T[::-1])], got[np.lexsort(got.T[::-1])])
