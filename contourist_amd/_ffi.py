@@ -22,7 +22,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -104,6 +104,7 @@ def load():
         "cx_level0_points_f64": [vp, vp],
         "cx_postprocess3d_mesh": [vp, vp, i64, vp, i64, vp, u32, dbl, vp],
         "cx_select_seeded3d": [vp, vp, i64, vp, vp],
+        "cx_select_seeded3d_ex": [vp, vp, i64, vp, u32, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
@@ -222,7 +223,7 @@ class Context(object):
     def set_reference_corner(self, corner=(0, 0, 0)):
         self._check(self.lib.cx_set_reference_corner(self.handle, *[int(c) for c in corner]))
 
-    def select_seeded(self, endpoints, voxel_range=None):
+    def select_seeded(self, endpoints, voxel_range=None, all_in_range=False):
         """restrict the next post-passes to the components reached from `endpoints` (n x 2 x 3 lattice points);
         voxel_range = (lo[3], hi[3]) in_range box of the growth (default: the whole array);
         -> dict(seed_voxels, groups_kept, triangles_kept)"""
@@ -231,8 +232,8 @@ class Context(object):
         box = None
         if voxel_range is not None:
             box = np.ascontiguousarray(np.asarray(voxel_range, dtype=np.int64).reshape(6), dtype=np.int32)
-        self._check(self.lib.cx_select_seeded3d(self.handle, ep.ctypes.data, int(len(ep)),
-                                                box.ctypes.data if box is not None else None, out.ctypes.data))
+        self._check(self.lib.cx_select_seeded3d_ex(self.handle, ep.ctypes.data, int(len(ep)),
+                                                   box.ctypes.data if box is not None else None, 1 if all_in_range else 0, out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), triangles_kept=int(out[2]))
 
     def postprocess3d(self, flags=0, smooth=0.0):

@@ -141,7 +141,10 @@ extern "C" int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t
 }
 
 extern "C" int cx_set_origin(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2) {
-    if (!ctx || o0 < 0 || o1 < 0 || o2 < 0 || o0 > 0x7FFFFFFFLL || o1 > 0x7FFFFFFFLL || o2 > 0x7FFFFFFFLL) return CX_ERR_INVALID;
+    // (negative: an array with a rim of samples around the reference's grid; the hash order of the diagonals and
+    // cx_level0_points_f64 use lattice point + origin)
+    const int64_t lim = 0x3FFFFFFFLL;
+    if (!ctx || o0 < -lim || o1 < -lim || o2 < -lim || o0 > lim || o1 > lim || o2 > lim) return CX_ERR_INVALID;
     ctx->origin[0] = o0; ctx->origin[1] = o1; ctx->origin[2] = o2;
     return CX_OK;
 }

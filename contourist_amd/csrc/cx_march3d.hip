@@ -847,6 +847,14 @@ __device__ __forceinline__ uint64_t py_round(uint64_t acc, uint32_t x) {
     acc = (acc << 31) | (acc >> 33);
     return acc * CX_PY_P1;
 }
+// the same round for a lattice coordinate that may be negative (an array with a rim of samples around the reference's
+// grid has its origin at -1): CPython hashes a small int to itself, except hash(-1) == -2
+__device__ __forceinline__ uint64_t py_round_signed(uint64_t acc, int32_t x) {
+    const uint64_t lane = (x == -1) ? ~1ULL : (uint64_t)(int64_t)x;
+    acc += lane * CX_PY_P2;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * CX_PY_P1;
+}
 __device__ __forceinline__ uint64_t py_finish3(uint64_t acc) {
     acc += 3ULL ^ (CX_PY_P5 ^ 3527539ULL);
     return (acc == ~0ULL) ? 1546275796ULL : acc;
@@ -855,7 +863,7 @@ __global__ void cx_k_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n0 * n1) return;
     const uint32_t i = idx / n1, j = idx - i * n1;
-    table[idx] = py_round(py_round(CX_PY_P5, i + org0), j + org1);
+    table[idx] = py_round_signed(py_round_signed(CX_PY_P5, (int32_t)i + (int32_t)org0), (int32_t)j + (int32_t)org1);
 }
 // does a 2-element set {first inserted h1, then h2} iterate h2 first?
 __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
@@ -965,10 +973,18 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
         const uint32_t need = cx_need_hash(sm, tetskip, ntri);
         if (__ballot(need != 0u) != 0ULL) {
             uint64_t h[8];
+            if ((int32_t)P.org2 >= 0) {
 #pragma unroll
-            for (uint32_t c = 0; c < 8; c++) {
-                h[c] = 0;
-                if ((need >> c) & 1u) h[c] = py_finish3(py_round(I.hxy[c >> 1], I.ck + (c & 1u) + P.org2));
+                for (uint32_t c = 0; c < 8; c++) {
+                    h[c] = 0;
+                    if ((need >> c) & 1u) h[c] = py_finish3(py_round(I.hxy[c >> 1], I.ck + (c & 1u) + P.org2));
+                }
+            } else {   // negative origin (wave-uniform, rare): signed lanes
+#pragma unroll
+                for (uint32_t c = 0; c < 8; c++) {
+                    h[c] = 0;
+                    if ((need >> c) & 1u) h[c] = py_finish3(py_round_signed(I.hxy[c >> 1], (int32_t)(I.ck + (c & 1u)) + (int32_t)P.org2));
+                }
             }
 #pragma unroll
             for (int t = 0; t < 6; t++) {

@@ -250,7 +250,7 @@ __global__ void cxs_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* 
             }
 }
 __global__ void cxs_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* parent, const uint8_t* flag, const uint8_t* seedkeep,
-                           uint8_t* tri_keep, const int32_t* tris, uint8_t* vkeep, uint32_t* out, cxs_grid G) {
+                           uint8_t* tri_keep, const int32_t* tris, uint8_t* vkeep, uint32_t* out, cxs_grid G, int all_in_range) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= ncells) return;
     const uint4 c = cells[r];
@@ -258,7 +258,7 @@ __global__ void cxs_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* 
     if (!ntri) return;
     const uint32_t plane = G.n1 * G.n2;
     const bool inr = cxs_in_range(G, (int)(c.x / plane), (int)((c.x % plane) / G.n2), (int)(c.x % G.n2));
-    const bool keep = (inr && flag[parent[r]] != 0) || seedkeep[r] != 0;
+    const bool keep = (inr && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0;
     if (keep && parent[r] == r) atomicAdd(&out[2], 1u);   // groups kept
     for (uint32_t t = 0; t < ntri; t++) {
         tri_keep[c.z + t] = keep ? 1 : 0;
@@ -269,8 +269,15 @@ __global__ void cxs_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* 
     if (keep) atomicAdd(&out[3], ntri);
 }
 
+extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
+                                     int64_t* out_counts);
 extern "C" int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts) {
+    return cx_select_seeded3d_ex(ctx, endpoints_ijk, n, range_lo_hi, 0u, out_counts);
+}
+extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
+                                     int64_t* out_counts) {
     if (!ctx || (n > 0 && !endpoints_ijk) || n < 0) return CX_ERR_INVALID;
+    const int all_in_range = (flags & CX_SEED_ALL_IN_RANGE) ? 1 : 0;
     if (!ctx->extracted) { ctx->err = "cx_select_seeded3d: no valid extraction"; return CX_ERR_STATE; }
     CXS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -299,7 +306,8 @@ extern "C" int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int
     int32_t* ep = nullptr;
     unsigned long long* visited = nullptr;
     unsigned long long vsize = 1024;
-    while (n <= 1024 && vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
+    const int64_t CXS_SEQUENTIAL_MAX = 65536;   // beyond: one thread per pair, no shared visited set
+    while (n <= CXS_SEQUENTIAL_MAX && vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
     int rc = CX_OK;
     uint32_t host_out[4] = {0, 0, 0, 0};
     do {
@@ -322,12 +330,12 @@ extern "C" int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int
             hipLaunchKernelGGL(cxs_k_map, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent);
             hipLaunchKernelGGL(cxs_k_union, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
-            if (n <= 1024)   // sequential, with the reference's shared visited set
+            if (n <= CXS_SEQUENTIAL_MAX)   // sequential, with the reference's shared visited set
                 hipLaunchKernelGGL(cxs_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
             else
                 hipLaunchKernelGGL(cxs_k_seeds_parallel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, G, ep, (uint32_t)n, seeds, out);
             hipLaunchKernelGGL(cxs_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
-            hipLaunchKernelGGL(cxs_k_keep, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, parent, flag, flag + ncells + 64, tri_keep, ctx->tris, vkeep, out, G);
+            hipLaunchKernelGGL(cxs_k_keep, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, parent, flag, flag + ncells + 64, tri_keep, ctx->tris, vkeep, out, G, all_in_range);
         }
         CXS_TRY(hipGetLastError());
         CXS_TRY(hipMemcpyAsync(host_out, out, sizeof(host_out), hipMemcpyDeviceToHost, st));

@@ -63,6 +63,8 @@ class GridContour3d(object):
         self.linear_interpolate = True
         self.end_points = segment_endpoints
         self.voxel_range = voxel_range    # in_range box of the seeded growth (lo, hi); None = the whole array
+        self.keep_in_range = False        # True: every voxel of the box is kept, the end points only add seed voxels outside it
+        self.origin = (0, 0, 0)           # lattice coordinates of sample (0,0,0) in the reference's grid (hash order of the diagonals)
         self.value = float(value)
         self.callback = callback
         self.flatten = False
@@ -97,6 +99,7 @@ class GridContour3d(object):
         "Level 0 on the device (idempotent). returns the counts dict."
         if self._counts is None or force:
             self._bind_grid()
+            self.context().set_origin(*self.origin)
             self._counts = self.context().extract3d(self.value, self.flags)
             self._post = None
         return self._counts
@@ -121,7 +124,7 @@ class GridContour3d(object):
             # explicit end points restrict the result to the components the reference's breadth-first search
             # reaches from them (tetrahedral.py:396-463); None = every component (exhaustive search_for_endpoints)
             if self.end_points is not None and len(self.end_points):
-                self.seeded = ctx.select_seeded(self.end_points, self.voxel_range)
+                self.seeded = ctx.select_seeded(self.end_points, self.voxel_range, self.keep_in_range)
             if self.voxel_range is not None:   # the array has a margin: Level-1 scales of the reference's own grid
                 lo, hi = self.voxel_range
                 ctx.set_reference_corner([int(h) - int(l) for l, h in zip(lo, hi)])
@@ -237,6 +240,7 @@ class Delta3DContour(object):
             result = GridContour3d(tuple(gd + 2 * m), grid.dense_samples(margin=m), self.value, shifted,
                                    linear_interpolate=self.linear_interpolate, device=self.device,
                                    voxel_range=((m, m, m), tuple(gd + m)))
+            result.origin = (-m, -m, -m)      # the CPython-order diagonals hash the reference's own lattice coordinates
             self._grid_shift = m
         else:
             result = GridContour3d(tuple(gd), grid.dense_samples(), self.value,
@@ -260,9 +264,53 @@ class Delta3DContour(object):
             self.contour_maker.march()
             self.grid_endpoints = segments
             return
-        self.contour_maker = self.get_contour_maker(None)
+        rim = None if getattr(self.grid, "array_backed", False) else self._rim_segments()
+        if rim is not None and len(rim):
+            # the surface reaches the rim of the grid: the reference starts from every crossing segment without
+            # range-checking the voxels it starts from (tetrahedral.py:396-441), so the voxels one step OUTSIDE the grid
+            # next to the crossing segments on the rim get triangles too.  One extra sample all around, every voxel of
+            # the grid kept, the rim segments as seeds
+            self.contour_maker = self.get_contour_maker(rim, rim=True)
+            self.contour_maker.keep_in_range = True
+        else:
+            self.contour_maker = self.get_contour_maker(None)
         self.contour_maker.march()
-        self.grid_endpoints = _LazyEndpoints(self.contour_maker, skip)
+        self.grid_endpoints = _LazyEndpoints(self.contour_maker, skip, getattr(self, "_grid_shift", 0), self.grid.grid_dimensions)
+
+    def _rim_segments(self, shell=2):
+        """the crossing lattice segments of find_contour_crossing_grid_segments (grid_field.py:64-84: from every lattice
+        point 0 <= p < grid_dimensions to its 7 forward neighbours, strict sign change) that lie within `shell` lattice
+        steps of the rim of the grid, IN THE REFERENCE'S ORDER (points in index order, last axis fastest; neighbours in
+        the order of surrounding_vertices :52-62, first axis fastest).  None if no segment touches the rim itself.
+        The order matters: the reference walks its end points one after the other with one shared `visited` set
+        (tetrahedral.py:396-441), and which voxel next to the rim a point picks depends on what was visited before."""
+        gd = np.array([int(n) for n in self.grid.grid_dimensions])
+        S = np.asarray(self.grid.dense_samples_host(), dtype=np.float64)     # vertices 0 .. gd inclusive
+        v = float(self.value)
+        base = S[:gd[0], :gd[1], :gd[2]]
+        near = np.zeros(tuple(gd), dtype=bool)        # lower end within the shell
+        for a in range(3):
+            sl = [slice(None)] * 3
+            sl[a] = slice(0, shell + 1)
+            near[tuple(sl)] = True
+            sl[a] = slice(max(gd[a] - 1 - shell, 0), gd[a])
+            near[tuple(sl)] = True
+        rows, touches = [], False
+        for index in range(1, 8):
+            o = np.array([index & 1, (index >> 1) & 1, (index >> 2) & 1])          # first axis fastest (:58-61)
+            nb = S[o[0]:o[0] + gd[0], o[1]:o[1] + gd[1], o[2]:o[2] + gd[2]]
+            hit = np.argwhere(((base - v) * (nb - v) < 0) & near)
+            if len(hit) == 0:
+                continue
+            upper = hit + o
+            touches = touches or bool(np.any(hit == 0) or np.any(upper == gd))
+            lin = (hit[:, 0] * gd[1] + hit[:, 1]) * gd[2] + hit[:, 2]
+            rows.append(np.concatenate([lin[:, None], np.full((len(hit), 1), index), hit, upper], axis=1))
+        if not rows or not touches:
+            return None
+        R = np.concatenate(rows, axis=0)
+        R = R[np.lexsort((R[:, 1], R[:, 0]))]
+        return [(r[2:5].astype(int), r[5:8].astype(int)) for r in R]
 
     def get_points_and_triangles(self):
         (grid_points, triangles) = self.contour_maker.get_points_and_triangles()
@@ -275,13 +323,18 @@ class Delta3DContour(object):
 class _LazyEndpoints(object):
     "sequence of (vertex0, vertex1) crossing lattice segments, materialised on first use"
 
-    def __init__(self, maker, skip):
+    def __init__(self, maker, skip, shift=0, grid_dimensions=None):
         self._maker, self._skip, self._list = maker, skip, None
+        self._shift, self._gd = int(shift), grid_dimensions
 
     def _get(self):
         if self._list is None:
             L = self._maker.level0()
             lo, hi = unpack_edge_ids(L["keys"], self._maker.shape)
+            if self._shift:      # the array carries a rim of extra samples: back to the grid's own lattice
+                lo, hi = lo - self._shift, hi - self._shift
+                inside = np.all(lo >= 0, axis=1) & np.all(lo < np.asarray(self._gd, dtype=int), axis=1)
+                lo, hi = lo[inside], hi[inside]
             if self._skip > 1:
                 keep = np.all(lo % self._skip == 0, axis=1)
                 lo, hi = lo[keep], hi[keep]

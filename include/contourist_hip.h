@@ -118,6 +118,13 @@ int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out
  * (voxels per axis); 0 restores the default. */
 int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2);
 int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
+/* flags CX_SEED_ALL_IN_RANGE: every voxel inside range_lo_hi is kept (the exhaustive search_for_endpoints() of the
+ * reference, tetrahedral.py:74-81) and the end points only add the seed voxels OUTSIDE it: the reference does not
+ * range-check the voxels it starts from (:396-441), so a surface that reaches the rim of the grid gets triangles in
+ * the voxels one step outside, next to the crossing lattice segments on the rim. */
+#define CX_SEED_ALL_IN_RANGE 1u
+int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
+                          int64_t* out_counts);
 /* Level 1 of a mesh assembled by the caller -- the way several GPUs share one volume: every rank marches its slab
  * (cx_extract3d), takes the float64 coordinates the reference would have interpolated (cx_level0_points_f64: nv*3
  * doubles in the order of cx_level0_download, in the grid coordinates of the whole volume = lattice point + origin of
