@@ -65,7 +65,9 @@ int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_
 /* the grid is a sub-block of a larger volume starting at lattice point (o0,o1,o2) (slab partitions).
  * Only CX_DIAG_CPYTHON310 depends on it: the reference's set order hashes ABSOLUTE lattice
  * coordinates (tetrahedral.py:567-575), so slabs must hash global coordinates to agree with the
- * undivided volume.  Edge ids stay local; the caller adds (o0*n1*n2 + ...) << 3. */
+ * undivided volume.  Edge ids stay local; the caller adds (o0*n1*n2 + ...) << 3.
+ * Negative origins are allowed (|o| < 2^30): an array that carries a rim of samples around the reference's grid starts
+ * at lattice point -1 (CPython's hash(-1) == -2 is reproduced).  cx_level0_points_f64 adds the origin as well. */
 int cx_set_origin(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2);
 
 /* optional: pre-size the output buffers (cells / vertices / triangles); 0 keeps the default. */
