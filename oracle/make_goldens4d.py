@@ -145,9 +145,48 @@ def run_reference4d(A, value, end_points=None):
     return out
 
 
+def test0_field(x, y, z, t):
+    "the field of the reference's own 4-D demo (pentatopes.py:528-551, `test0`), restated: works on scalars and arrays"
+    x, y, z = np.mod(x, 3), np.mod(y, 3), np.mod(z, 3)
+    p1, p2 = 0.5 * (8 - t), 0.5 * t
+    return p1 * np.sqrt(x * x + y * y + z * z) + p2 * np.minimum(np.sqrt(x * x + y * y), np.sqrt(x * x + z * z))
+
+
+TEST0_END_POINTS = [([0] * 4, [4] * 3 + [0]), ([3, 2, 1, 0], [3, 3, 3, 8])]
+
+
+def make_test0():
+    """the reference's own call: GridContour4D([8]*4, function, 2.0, endpoints) with a CALLABLE evaluated in float64
+    (two of its start voxels lie outside the grid).  Stores the Level-0 snapshot only (edges and tetrahedra)."""
+    import contextlib
+    import io
+    pentatopes = reference_modules4d()
+
+    def f(x, y, z, t):
+        return float(test0_field(float(x), float(y), float(z), float(t)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = pentatopes.GridContour4D([8] * 4, f, 2.0, [(list(a), list(b)) for a, b in TEST0_END_POINTS])
+        G.find_initial_voxels()
+        while G.new_surface_voxels:
+            G.expand_voxels()
+        for q in G.surface_voxels:
+            G.enumerate_voxel_tetrahedra(q)
+    pair_list = list(G.interpolated_contour_pairs.keys())
+    pair_index = {p: n for n, p in enumerate(pair_list)}
+    pairs = np.array([list(p[0]) + list(p[1]) for p in pair_list], dtype=np.int32).reshape(-1, 8)
+    tets = np.array([[pair_index[p] for p in s] for s in G.simplex_sets], dtype=np.int64).reshape(-1, 4)
+    sv = np.array(sorted(tuple(int(x) for x in v) for v in G.surface_voxels), dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "reference_test0_seeded.npz"), l0_pairs=pairs, l0_tets=tets, surface_voxels=sv,
+                        end_points=np.array(TEST0_END_POINTS, dtype=np.int32), value=np.float64(2.0))
+    print("reference_test0_seeded: %d hyper-voxels, %d vertices, %d tetrahedra" % (len(sv), len(pairs), len(tets)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     names = sys.argv[1:]
+    if names == ["test0"]:
+        make_test0()
+        sys.exit(0)
     for name, spec in fields4d().items():
         if names and name not in names:
             continue

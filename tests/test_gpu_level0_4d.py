@@ -211,3 +211,22 @@ def test_seeded_growth_4d():
     assert both["groups_kept"] == 2
     with pytest.raises(_ffi.CxError):
         ctx.select_seeded4d([[(0, 0, 0, 0), (1, 0, 0, 0)]])       # both on the same side
+
+
+def test_reference_test0_call_on_device():
+    """the reference's own 4-D demo call (pentatopes.py:528-551) through the mirrored class: the device keeps the 26 004
+    tetrahedra the reference has inside the grid (its other 96 sit in two start voxels outside the grid)"""
+    from contourist_amd import pentatopes
+    from oracle.make_goldens4d import test0_field, TEST0_END_POINTS
+    G = np.load(os.path.join(G4, "reference_test0_seeded.npz"))
+    g = np.arange(9, dtype=np.float64)
+    X, Y, Z, T = np.meshgrid(g, g, g, g, indexing="ij")
+    A = test0_field(X, Y, Z, T).astype(np.float32)
+    maker = pentatopes.GridContour4D((8, 8, 8, 8), A, 2.0, [(tuple(a), tuple(b)) for a, b in TEST0_END_POINTS])
+    R = maker.find_tetrahedra()
+    P = G["l0_pairs"]
+    inside = (P.min(axis=1) >= 0) & (P.max(axis=1) <= 8)
+    assert maker.seeded["tetrahedra_kept"] == int(inside[G["l0_tets"]].all(axis=1).sum()) == 26004
+    assert maker.seeded["groups_kept"] >= 1 and R["counts"]["n_after_tiny"] > 0
+    MT = maker.collect_morph_triangles()
+    assert len(MT.triangle_segment_indices) > 0

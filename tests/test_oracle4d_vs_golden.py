@@ -93,3 +93,32 @@ def test_seeded_growth_4d_vs_reference():
     want = np.sort(kr[G["l0_tets"]], axis=1)
     got = np.sort(ko[O["tets"][keep]], axis=1)
     assert np.array_equal(want[np.lexsort(want.T[::-1])], got[np.lexsort(got.T[::-1])])
+
+
+def test_reference_test0_call():
+    """the reference's own 4-D demo call (pentatopes.py:528-551: GridContour4D([8]*4, function, 2.0, endpoints), the
+    callable evaluated in float64, two start voxels outside the grid): on fp32 samples of the same field the restated
+    search reaches the same hyper-voxels inside the grid and the march gives the same tetrahedra there"""
+    from oracle import seeds
+    from oracle.make_goldens4d import test0_field
+    G = np.load(os.path.join(G4, "reference_test0_seeded.npz"))
+    g = np.arange(9, dtype=np.float64)
+    X, Y, Z, T = np.meshgrid(g, g, g, g, indexing="ij")
+    A = test0_field(X, Y, Z, T).astype(np.float32)
+    v = float(G["value"])
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    keep, surf = seeds.select4d(A, v, G["end_points"], ko, O["tets"])
+    ref_inside = set(tuple(int(x) for x in q) for q in G["surface_voxels"] if q.min() >= 0 and q.max() < 8)
+    assert len(G["surface_voxels"]) - len(ref_inside) == 2            # (0,0,0,-1) and (3,3,3,8): seeds outside the grid
+    assert surf == ref_inside
+    P = G["l0_pairs"]
+    inside = (P.min(axis=1) >= 0) & (P.max(axis=1) <= 8)
+    tets_inside = inside[G["l0_tets"]].all(axis=1)
+    kr = np.full(len(P), -1, dtype=np.int64)
+    kr[inside] = level0_4d.edge_keys4(P[inside], A.shape)
+    want = np.sort(kr[G["l0_tets"][tets_inside]], axis=1)
+    got = np.sort(ko[O["tets"][keep]], axis=1)
+    a = set(map(tuple, want.tolist()))
+    b = set(map(tuple, got.tolist()))
+    assert a == b and len(a) == 26004           # every tetrahedron inside the grid; the other 96 sit in the two outside voxels
