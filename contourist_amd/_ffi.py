@@ -22,7 +22,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -105,6 +105,7 @@ def load():
         "cx_postprocess3d_mesh": [vp, vp, i64, vp, i64, vp, u32, dbl, vp],
         "cx_select_seeded3d": [vp, vp, i64, vp, vp],
         "cx_select_seeded3d_ex": [vp, vp, i64, vp, u32, vp],
+        "cx_seeded_masks_download": [vp, vp, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
@@ -235,6 +236,13 @@ class Context(object):
         self._check(self.lib.cx_select_seeded3d_ex(self.handle, ep.ctypes.data, int(len(ep)),
                                                    box.ctypes.data if box is not None else None, 1 if all_in_range else 0, out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), triangles_kept=int(out[2]))
+
+    def seeded_masks(self, counts):
+        "(triangle mask, vertex mask) of the last select_seeded as bool arrays (all True without a selection)"
+        tk = np.empty(int(counts["n_triangles"]), dtype=np.uint8)
+        vk = np.empty(int(counts["n_vertices"]), dtype=np.uint8)
+        self._check(self.lib.cx_seeded_masks_download(self.handle, tk.ctypes.data, vk.ctypes.data))
+        return tk.astype(bool), vk.astype(bool)
 
     def postprocess3d(self, flags=0, smooth=0.0):
         out = np.zeros(8, dtype=np.int64)

@@ -354,3 +354,21 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     ctx->post_valid = false;
     return CX_OK;
 }
+
+// host copies of the masks of the last cx_select_seeded3d (all ones when there is no selection): for callers that take
+// the Level-0 mesh to the host before the post-pass (cx_postprocess3d_mesh)
+extern "C" int cx_seeded_masks_download(cx_ctx* ctx, uint8_t* tri_keep, uint8_t* vert_keep) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) { ctx->err = "cx_seeded_masks_download: no valid extraction"; return CX_ERR_STATE; }
+    CXS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nt = (size_t)ctx->counts.n_triangles, nv = (size_t)ctx->counts.n_vertices;
+    if (!ctx->keep_valid) {
+        if (tri_keep) memset(tri_keep, 1, nt);
+        if (vert_keep) memset(vert_keep, 1, nv);
+        return CX_OK;
+    }
+    if (tri_keep && nt) CXS_HIP(ctx, hipMemcpyAsync(tri_keep, ctx->tri_keep, nt, hipMemcpyDeviceToHost, ctx->stream));
+    if (vert_keep && nv) CXS_HIP(ctx, hipMemcpyAsync(vert_keep, ctx->tri_keep + nt, nv, hipMemcpyDeviceToHost, ctx->stream));
+    CXS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}

@@ -15,7 +15,7 @@ Differences a caller can observe (see DESIGN.md "Boundary"):
     index / iterate like the reference's list of arrays / sorted list of tuples.
   * the march is a dense scan: EVERY component of the isosurface inside the grid is returned,
     not only those reachable from the seed segments.
-  * linear_interpolate=False (re-evaluating f off-grid) and flatten=True (serial LP decimation)
+  * flatten=True (serial LP decimation)
     are not offered on the device path and raise NotImplementedError.
 """
 import itertools
@@ -49,18 +49,20 @@ class GridContour3d(object):
     """
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True,
-                 callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None):
+                 callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None, function=None):
         self.corner = np.array(corner, dtype=int)
         assert self.corner.shape == (3,), "dimension must be 3"
         if segment_endpoints is not None:
             for (p1, p2) in segment_endpoints:
                 assert len(p1) == 3
                 assert len(p2) == 3
-        if not linear_interpolate:
-            raise NotImplementedError("linear_interpolate=False needs f off the grid; the device march "
-                                      "interpolates linearly between dense samples")
+        if not linear_interpolate and function is None:
+            raise NotImplementedError("linear_interpolate=False re-evaluates the function between the lattice points "
+                                      "(tetrahedral.py:488-505): it needs the callable, a sample array is not enough")
         self.dimension = 3
-        self.linear_interpolate = True
+        self.linear_interpolate = bool(linear_interpolate)
+        self.function = function      # f(i, j, k) in the lattice coordinates of `samples` (linear_interpolate=False only)
+        self._f_broadcasts = None
         self.end_points = segment_endpoints
         self.voxel_range = voxel_range    # in_range box of the seeded growth (lo, hi); None = the whole array
         self.keep_in_range = False        # True: every voxel of the box is kept, the end points only add seed voxels outside it
@@ -130,9 +132,89 @@ class GridContour3d(object):
                 ctx.set_reference_corner([int(h) - int(l) for l, h in zip(lo, hi)])
             else:
                 ctx.set_reference_corner((0, 0, 0))
-            self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0)
+            if self.linear_interpolate:
+                self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0)
+            else:
+                self._post = self._postprocess_refined(ctx, clean)
         pts, tris = ctx.download_level1(self._post)
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
+
+    # -- linear_interpolate=False (tetrahedral.py:488-505) ------------------------------------------------------
+    def _feval(self, P):
+        "function at the rows of P (N,3), float64: one broadcast call if the function allows it, else one call per row"
+        P = np.asarray(P, dtype=np.float64).reshape(-1, 3)
+        if len(P) == 0:
+            return np.zeros(0)
+        if self._f_broadcasts is not False:
+            try:
+                out = np.asarray(self.function(P[:, 0], P[:, 1], P[:, 2]), dtype=np.float64)
+                if out.shape != (len(P),):
+                    self._f_broadcasts = False
+                elif self._f_broadcasts is None:     # first time: spot-check the broadcast result against scalar calls
+                    probe = [0, len(P) // 2, len(P) - 1]
+                    self._f_broadcasts = all(abs(out[k] - float(self.function(*P[k]))) <= 1e-12 * max(1.0, abs(out[k])) for k in probe)
+                if self._f_broadcasts:
+                    return out
+            except Exception:
+                self._f_broadcasts = False
+        return np.array([float(self.function(*row)) for row in P], dtype=np.float64)
+
+    def _refined_points(self, keys):
+        """the reference's float64 crossing points with its regula-falsi refinement: contour_pair_interpolation
+        (tetrahedral.py:471-512) with linear_interpolate == False, iterations = 5, for every crossing edge at once"""
+        z = self.value
+        lo, hi = unpack_edge_ids(keys, self.shape)
+        low_a, high_a = lo.astype(np.float64), hi.astype(np.float64)
+        flow, fhigh = self._feval(low_a), self._feval(high_a)
+        swap = flow > fhigh                                                  # :478-480
+        low_a[swap], high_a[swap] = hi[swap].astype(np.float64), lo[swap].astype(np.float64)
+        flow, fhigh = np.where(swap, fhigh, flow), np.where(swap, flow, fhigh)
+        crosses = (flow <= z) & (fhigh >= z)
+        den = 1.0 * (fhigh - flow)
+        flat = np.abs(den) <= 1e-8                                           # np.allclose(denominator, 0)
+        ratio = np.where(flat, 0.5, (z - flow) / np.where(flat, 1.0, den))
+        P = low_a + ratio[:, None] * (high_a - low_a)
+        P[~crosses] = low_a[~crosses]                                        # ":509 temporary hack": interpolated = low_a
+        active = crosses.copy()
+        fint = np.full(len(P), z, dtype=np.float64)
+        if active.any():
+            fint[active] = self._feval(P[active])
+        for _ in range(5):                                                   # iterations=5
+            close_f = np.abs(fint - z) <= 1e-8 + 1e-5 * abs(z)
+            close_p = np.all(np.abs(low_a - high_a) <= 1e-8 + 1e-5 * np.abs(high_a), axis=1)
+            active = active & ~close_f & ~close_p
+            if not active.any():
+                break
+            below = active & (fint < z)
+            above = active & ~(fint < z)
+            low_a[below], flow[below] = P[below], fint[below]
+            high_a[above], fhigh[above] = P[above], fint[above]
+            r = (z - flow[active]) * 1.0 / (fhigh[active] - flow[active])
+            P[active] = low_a[active] + r[:, None] * (high_a[active] - low_a[active])
+            fint[active] = self._feval(P[active])
+        return P
+
+    def _postprocess_refined(self, ctx, clean):
+        """Level 1 on refined points: the Level-0 mesh comes to the host, its points are replaced by the reference's
+        refined ones (the caller's function is Python), and the same device post-pass runs on the result"""
+        L = self.level0()
+        keys, tris = L["keys"].astype(np.int64), L["triangles"].astype(np.int64)
+        tkeep, vkeep = ctx.seeded_masks(L["counts"])
+        tris = tris[tkeep]
+        used = np.zeros(len(keys), dtype=bool)
+        used[tris.ravel()] = True
+        used &= vkeep | used
+        ids = np.nonzero(used)[0]
+        order = ids[np.argsort(keys[ids], kind="stable")]                    # ascending edge id: index == priority
+        renum = -np.ones(len(keys), dtype=np.int64)
+        renum[order] = np.arange(len(order))
+        pts = self._refined_points(keys[order])
+        if self.voxel_range is not None:
+            lo, hi = self.voxel_range
+            corner = [int(h) - int(l) for l, h in zip(lo, hi)]
+        else:
+            corner = [int(c) for c in self.corner]
+        return ctx.postprocess3d_mesh(pts, renum[tris], corner, 0 if clean else 1, self.smooth or 0.0)
 
     def get_points_and_triangles(self, clean=True):
         "(grid_points (V,3) float64, triangles (T,3) int32 sorted rows)  (tetrahedral.py:528-552)"
@@ -180,7 +262,8 @@ def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_
         samples = g.dense_samples()
     else:
         samples = function
-    return GridContour3d(corner, samples, value, segment_endpoints, linear_interpolate, callback, device)
+    return GridContour3d(corner, samples, value, segment_endpoints, linear_interpolate, callback, device,
+                         function=function if callable(function) else None)
 
 
 class Delta3DContour(object):
@@ -239,15 +322,29 @@ class Delta3DContour(object):
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
             result = GridContour3d(tuple(gd + 2 * m), grid.dense_samples(margin=m), self.value, shifted,
                                    linear_interpolate=self.linear_interpolate, device=self.device,
-                                   voxel_range=((m, m, m), tuple(gd + m)))
+                                   voxel_range=((m, m, m), tuple(gd + m)), function=self._lattice_function(m))
             result.origin = (-m, -m, -m)      # the CPython-order diagonals hash the reference's own lattice coordinates
             self._grid_shift = m
         else:
             result = GridContour3d(tuple(gd), grid.dense_samples(), self.value,
-                                   grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device)
+                                   grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device,
+                                   function=self._lattice_function(0))
         result.flatten = self.flatten
         result.smooth = self.smooth
         return result
+
+    def _lattice_function(self, shift):
+        """f over the lattice coordinates of the sample array (which may start `shift` steps before the grid): what
+        FunctionGrid.grid_function does (grid_field.py:95-118, world = grid * delta + mins), usable on arrays.
+        None for a grid made from a sample array."""
+        grid = self.grid
+        if getattr(grid, "array_backed", False):
+            return None
+        mins, delta, f = grid.mins, grid.delta, grid.f
+
+        def lattice_f(i, j, k):
+            return f((i - shift) * delta[0] + mins[0], (j - shift) * delta[1] + mins[1], (k - shift) * delta[2] + mins[2])
+        return lattice_f
 
     def search_for_endpoints(self, skip=1):
         """Reference: crossing search over every skip-th lattice point + new contour maker (tetrahedral.py:74-81,

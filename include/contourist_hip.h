@@ -127,6 +127,10 @@ int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, con
 #define CX_SEED_ALL_IN_RANGE 1u
 int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
                           int64_t* out_counts);
+/* the masks of the last selection on the host (n_triangles and n_vertices bytes; all ones without a selection): for
+ * callers that refine the Level-0 mesh on the host before cx_postprocess3d_mesh -- linear_interpolate=False
+ * re-evaluates the caller's function between the lattice points (tetrahedral.py:488-505) */
+int cx_seeded_masks_download(cx_ctx* ctx, uint8_t* tri_keep, uint8_t* vert_keep);
 /* Level 1 of a mesh assembled by the caller -- the way several GPUs share one volume: every rank marches its slab
  * (cx_extract3d), takes the float64 coordinates the reference would have interpolated (cx_level0_points_f64: nv*3
  * doubles in the order of cx_level0_download, in the grid coordinates of the whole volume = lattice point + origin of

@@ -33,6 +33,14 @@ def demos(tetrahedral):
     D["torus"] = lambda: tetrahedral.Grid3DContour(30, 30, 30, shift_torus, 5 / 3.0, [[(0, 0, 0), (20, 15, 15)]])
     D["wave"] = lambda: tetrahedral.Grid3DContour(40, 40, 40, lambda x, y, z: 1.1 + math.sin(((x - 20) ** 2 + (y - 20) ** 2) * 0.02) - z, 0,
                                                  [[(20, 20, 0), (20, 20, 20)]])
+    # linear_interpolate=False (the default of contour_doodle.implicit_surface, contour_doodle.py:13-21): the crossing
+    # points are refined by regula falsi on the callable (tetrahedral.py:488-505)
+    d = 3.0 / 32
+    D["sphere_nonlinear"] = lambda: tetrahedral.TriangulatedIsosurfaces([-1.5] * 3, [1.5 - d] * 3, [d] * 3, lambda x, y, z: x * x + y * y + z * z,
+                                                                        1.0, [], linear_interpolate=False)
+    D["quartic_nonlinear"] = lambda: tetrahedral.TriangulatedIsosurfaces([-1.2] * 3, [1.2] * 3, [0.15] * 3,
+                                                                         lambda x, y, z: x ** 4 + y ** 4 + z ** 4 - 0.6 * x * y, 0.5, [],
+                                                                         linear_interpolate=False)
     return D
 
 
@@ -42,7 +50,7 @@ def main():
     for name, make in demos(tetrahedral).items():
         t0 = time.time()
         obj = make()
-        if name == "centered":
+        if name == "centered" or name.endswith("_nonlinear"):
             obj.search_for_endpoints()      # (the stale 2-D assert of the shared ctor rules out passing its end points)
         pts, tris = obj.get_points_and_triangles()
         pts = np.array(pts, dtype=np.float64).reshape(-1, 3)

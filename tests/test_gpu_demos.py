@@ -26,16 +26,22 @@ def calls(tetrahedral):
     D["torus"] = (lambda: tetrahedral.Grid3DContour(30, 30, 30, shift_torus, 5 / 3.0, [[(0, 0, 0), (20, 15, 15)]]), 30)
     D["wave"] = (lambda: tetrahedral.Grid3DContour(40, 40, 40, lambda x, y, z: 1.1 + math.sin(((x - 20) ** 2 + (y - 20) ** 2) * 0.02) - z, 0,
                                                    [[(20, 20, 0), (20, 20, 20)]]), 40)
+    d = 3.0 / 32
+    D["sphere_nonlinear"] = (lambda: tetrahedral.TriangulatedIsosurfaces([-1.5] * 3, [1.5 - d] * 3, [d] * 3, lambda x, y, z: x * x + y * y + z * z,
+                                                                         1.0, [], linear_interpolate=False), None)
+    D["quartic_nonlinear"] = (lambda: tetrahedral.TriangulatedIsosurfaces([-1.2] * 3, [1.2] * 3, [0.15] * 3,
+                                                                          lambda x, y, z: x ** 4 + y ** 4 + z ** 4 - 0.6 * x * y, 0.5, [],
+                                                                          linear_interpolate=False), None)
     return D
 
 
-@pytest.mark.parametrize("name", ["centered", "sphere", "hyperbola", "torus", "wave"])
+@pytest.mark.parametrize("name", ["centered", "sphere", "hyperbola", "torus", "wave", "sphere_nonlinear", "quartic_nonlinear"])
 def test_reference_demo(name):
     from contourist_amd import tetrahedral
     G = np.load(os.path.join(GD, name + ".npz"))
     make, side = calls(tetrahedral)[name]
     obj = make()
-    if name == "centered":
+    if side is None:
         obj.search_for_endpoints()
         mins, delta = obj.grid.mins, obj.grid.delta
         corner = np.array(obj.grid.grid_dimensions)
@@ -57,3 +63,10 @@ def test_reference_demo(name):
     print(name, "reference", len(G["triangles"]), "device", len(tris), "matched", common)
     assert abs(len(tris) - len(G["triangles"])) <= 0.002 * len(G["triangles"]) + 1
     assert common >= 0.985 * len(G["triangles"])
+    if name.endswith("_nonlinear"):
+        # the refined points lie on the surface far more closely than linear interpolation would put them
+        fn = {"sphere_nonlinear": lambda p: (p ** 2).sum(axis=1) - 1.0,
+              "quartic_nonlinear": lambda p: (p ** 4).sum(axis=1) - 0.6 * p[:, 0] * p[:, 1] - 0.5}[name]
+        mine, theirs = np.abs(fn(pts)), np.abs(fn(G["points"]))
+        assert mine.max() <= theirs.max() * 1.001 + 1e-9 and abs(mine.mean() - theirs.mean()) <= 0.01 * theirs.mean() + 1e-9
+        assert mine.mean() < 5e-5                      # (linear interpolation alone leaves ~1e-3 on these fields)
