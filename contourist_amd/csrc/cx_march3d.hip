@@ -962,6 +962,9 @@ __device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
 }
 
 // phase 1 of one record per lane: LDS tables and slot words; returns the wave's triangle count
+// NEG_ORIGIN: the array starts at a negative lattice point (rim of extra samples): signed hash lanes.  A kernel of its
+// own, because the extra path costs the common one ~9 % when it is a run-time branch (registers, code size)
+template <bool NEG_ORIGIN>
 __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
     const uint32_t sm = I.rec.y & 0xFFu, tetskip = (I.rec.y >> 8) & 0x3Fu, ntri = (I.rec.y >> 16) & 0xFFu;
     L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
@@ -973,13 +976,13 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
         const uint32_t need = cx_need_hash(sm, tetskip, ntri);
         if (__ballot(need != 0u) != 0ULL) {
             uint64_t h[8];
-            if ((int32_t)P.org2 >= 0) {
+            if (!NEG_ORIGIN) {
 #pragma unroll
                 for (uint32_t c = 0; c < 8; c++) {
                     h[c] = 0;
                     if ((need >> c) & 1u) h[c] = py_finish3(py_round(I.hxy[c >> 1], I.ck + (c & 1u) + P.org2));
                 }
-            } else {   // negative origin (wave-uniform, rare): signed lanes
+            } else {   // signed lanes
 #pragma unroll
                 for (uint32_t c = 0; c < 8; c++) {
                     h[c] = 0;
@@ -1069,6 +1072,7 @@ __device__ __forceinline__ uint4 cx_load_record(const uint4* p) {
 #ifndef CX_K2_MIN_WAVES
 #define CX_K2_MIN_WAVES 1
 #endif
+template <bool NEG_ORIGIN>
 __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(const cx_params P, const uint64_t* __restrict__ hash_xy) {
     __shared__ cx_tri_lds L;
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
         const uint32_t nidx = idx + stride;
         cx_tri_fetch(P, hash_xy, rec_b, Ib);                                    // loads of the next record ...
         uint4 rec_c = (nidx + stride < ncells) ? cx_load_record(P.cells + nidx + stride) : zero;   // ... and the record after it
-        const uint32_t ttot = cx_tri_phase1(P, L, lane, wave, Ia);
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
         cx_tri_pin(Ib, rec_c);                                                  // ... are back before the stores go out
         cx_tri_phase2(P, L, lane, wave, ttot);
         Ia = Ib;
@@ -1165,7 +1169,8 @@ void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipSt
     if (const char* e = getenv("CX_TGRID")) g = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g;   // tuning knob
     const uint32_t most = (P.ccap + 255u) / 256u;
     if (g > most) g = most;
-    hipLaunchKernelGGL(cx_k_emit_triangles, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
+    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_triangles<true>, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
+    else hipLaunchKernelGGL(cx_k_emit_triangles<false>, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {
