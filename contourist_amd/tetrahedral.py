@@ -67,6 +67,7 @@ class GridContour3d(object):
         self.voxel_range = voxel_range    # in_range box of the seeded growth (lo, hi); None = the whole array
         self.keep_in_range = False        # True: every voxel of the box is kept, the end points only add seed voxels outside it
         self.origin = (0, 0, 0)           # lattice coordinates of sample (0,0,0) in the reference's grid (hash order of the diagonals)
+        self.grid_shift = 0               # the sample array starts this many lattice steps before the reference's grid
         self.value = float(value)
         self.callback = callback
         self.flatten = False
@@ -137,6 +138,8 @@ class GridContour3d(object):
             else:
                 self._post = self._postprocess_refined(ctx, clean)
         pts, tris = ctx.download_level1(self._post)
+        if self.grid_shift and len(pts):
+            pts = pts - float(self.grid_shift)          # back to the reference's own lattice coordinates
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
 
     # -- linear_interpolate=False (tetrahedral.py:488-505) ------------------------------------------------------
@@ -259,6 +262,17 @@ def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_
     if callable(function):
         g = grid_field.FunctionGrid([0, 0, 0], [c - 0.5 for c in corner], [1, 1, 1], function)
         assert tuple(g.grid_dimensions) == corner
+        if segment_endpoints is not None and len(segment_endpoints):
+            # explicit end points: the reference does not range-check the voxels it starts from and evaluates the function
+            # one lattice step outside the grid (tetrahedral.py:396-441): sample that rim too, grow inside the grid only
+            m = 1
+            shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in segment_endpoints]
+            maker = GridContour3d(tuple(c + 2 * m for c in corner), g.dense_samples(margin=m), value, shifted, linear_interpolate, callback,
+                                  device, voxel_range=((m, m, m), tuple(c + m for c in corner)),
+                                  function=lambda i, j, k: function(i - m, j - m, k - m))
+            maker.origin = (-m, -m, -m)
+            maker.grid_shift = m
+            return maker
         samples = g.dense_samples()
     else:
         samples = function
@@ -324,6 +338,7 @@ class Delta3DContour(object):
                                    linear_interpolate=self.linear_interpolate, device=self.device,
                                    voxel_range=((m, m, m), tuple(gd + m)), function=self._lattice_function(m))
             result.origin = (-m, -m, -m)      # the CPython-order diagonals hash the reference's own lattice coordinates
+            result.grid_shift = m
             self._grid_shift = m
         else:
             result = GridContour3d(tuple(gd), grid.dense_samples(), self.value,
@@ -410,9 +425,7 @@ class Delta3DContour(object):
         return [(r[2:5].astype(int), r[5:8].astype(int)) for r in R]
 
     def get_points_and_triangles(self):
-        (grid_points, triangles) = self.contour_maker.get_points_and_triangles()
-        if len(grid_points) and getattr(self, "_grid_shift", 0):
-            grid_points = grid_points - float(self._grid_shift)
+        (grid_points, triangles) = self.contour_maker.get_points_and_triangles()      # (the maker undoes its own shift)
         points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
         return (points, triangles)
 

@@ -33,6 +33,11 @@ def demos(tetrahedral):
     D["torus"] = lambda: tetrahedral.Grid3DContour(30, 30, 30, shift_torus, 5 / 3.0, [[(0, 0, 0), (20, 15, 15)]])
     D["wave"] = lambda: tetrahedral.Grid3DContour(40, 40, 40, lambda x, y, z: 1.1 + math.sin(((x - 20) ** 2 + (y - 20) ** 2) * 0.02) - z, 0,
                                                  [[(20, 20, 0), (20, 20, 20)]])
+    # the field of the reference's own unit test (test/test_tetrahedral.py:13-37) in lattice coordinates through
+    # Grid3DContour: the dot at the corner of the grid is reached from a start voxel OUTSIDE the grid
+    def dots(x, y, z):
+        return 1 if (x == y == z == 0 or x == y == z == 4) else -1
+    D["grid_two_dots"] = lambda: tetrahedral.Grid3DContour(8, 8, 8, dots, 0, [[(0, 0, 0), (0, 0, 8)]])
     # linear_interpolate=False (the default of contour_doodle.implicit_surface, contour_doodle.py:13-21): the crossing
     # points are refined by regula falsi on the callable (tetrahedral.py:488-505)
     d = 3.0 / 32

@@ -26,6 +26,9 @@ def calls(tetrahedral):
     D["torus"] = (lambda: tetrahedral.Grid3DContour(30, 30, 30, shift_torus, 5 / 3.0, [[(0, 0, 0), (20, 15, 15)]]), 30)
     D["wave"] = (lambda: tetrahedral.Grid3DContour(40, 40, 40, lambda x, y, z: 1.1 + math.sin(((x - 20) ** 2 + (y - 20) ** 2) * 0.02) - z, 0,
                                                    [[(20, 20, 0), (20, 20, 20)]]), 40)
+    def dots(x, y, z):
+        return 1 if (x == y == z == 0 or x == y == z == 4) else -1
+    D["grid_two_dots"] = (lambda: tetrahedral.Grid3DContour(8, 8, 8, dots, 0, [[(0, 0, 0), (0, 0, 8)]]), 8)
     d = 3.0 / 32
     D["sphere_nonlinear"] = (lambda: tetrahedral.TriangulatedIsosurfaces([-1.5] * 3, [1.5 - d] * 3, [d] * 3, lambda x, y, z: x * x + y * y + z * z,
                                                                          1.0, [], linear_interpolate=False), None)
@@ -35,7 +38,7 @@ def calls(tetrahedral):
     return D
 
 
-@pytest.mark.parametrize("name", ["centered", "sphere", "hyperbola", "torus", "wave", "sphere_nonlinear", "quartic_nonlinear"])
+@pytest.mark.parametrize("name", ["centered", "sphere", "hyperbola", "torus", "wave", "grid_two_dots", "sphere_nonlinear", "quartic_nonlinear"])
 def test_reference_demo(name):
     from contourist_amd import tetrahedral
     G = np.load(os.path.join(GD, name + ".npz"))
