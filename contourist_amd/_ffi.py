@@ -224,7 +224,7 @@ class Context(object):
     def set_reference_corner(self, corner=(0, 0, 0)):
         self._check(self.lib.cx_set_reference_corner(self.handle, *[int(c) for c in corner]))
 
-    def select_seeded(self, endpoints, voxel_range=None, all_in_range=False):
+    def select_seeded(self, endpoints, voxel_range=None, all_in_range=False, parallel=False):
         """restrict the next post-passes to the components reached from `endpoints` (n x 2 x 3 lattice points);
         voxel_range = (lo[3], hi[3]) in_range box of the growth (default: the whole array);
         -> dict(seed_voxels, groups_kept, triangles_kept)"""
@@ -234,7 +234,7 @@ class Context(object):
         if voxel_range is not None:
             box = np.ascontiguousarray(np.asarray(voxel_range, dtype=np.int64).reshape(6), dtype=np.int32)
         self._check(self.lib.cx_select_seeded3d_ex(self.handle, ep.ctypes.data, int(len(ep)),
-                                                   box.ctypes.data if box is not None else None, 1 if all_in_range else 0, out.ctypes.data))
+                                                   box.ctypes.data if box is not None else None, (1 if all_in_range else 0) | (2 if parallel else 0), out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), triangles_kept=int(out[2]))
 
     def seeded_masks(self, counts):

@@ -306,7 +306,8 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     int32_t* ep = nullptr;
     unsigned long long* visited = nullptr;
     unsigned long long vsize = 1024;
-    const int64_t CXS_SEQUENTIAL_MAX = 65536;   // beyond: one thread per pair, no shared visited set
+    // beyond this many pairs (or on request): one thread per pair, no shared visited set
+    const int64_t CXS_SEQUENTIAL_MAX = (flags & CX_SEED_PARALLEL) ? -1 : 65536;
     while (n <= CXS_SEQUENTIAL_MAX && vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
     int rc = CX_OK;
     uint32_t host_out[4] = {0, 0, 0, 0};

@@ -137,6 +137,15 @@ class Delta4DContour(tetrahedral.Delta3DContour):
                              linear_interpolate=self.linear_interpolate, device=self.device)
 
     def search_for_endpoints(self, skip=1):
+        """skip == 1: every component (the dense march contains the exhaustive search).  skip > 1: the coarse crossing
+        search of the reference (grid_field.py:64-84 over every skip-th lattice point) runs on the dense samples and its
+        segments seed the 80-neighbour growth (cx_select_seeded4d): components the coarse lattice misses stay out."""
+        if skip > 1:
+            (maxf, minf, segments) = self.grid.find_contour_crossing_grid_segments(self.value, skip)
+            self.grid_values = (minf, maxf)
+            self.contour_maker = self.get_contour_maker(segments if len(segments) else None)
+            self.grid_endpoints = segments
+            return
         self.contour_maker = self.get_contour_maker(None)
 
     def collect_morph_triangles(self):

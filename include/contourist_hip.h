@@ -125,6 +125,9 @@ int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, con
  * range-check the voxels it starts from (:396-441), so a surface that reaches the rim of the grid gets triangles in
  * the voxels one step outside, next to the crossing lattice segments on the rim. */
 #define CX_SEED_ALL_IN_RANGE 1u
+/* CX_SEED_PARALLEL: one thread per end point pair without the reference's shared `visited` set (what more than 65 536
+ * pairs get anyway); each point then yields its own voxel or its first border neighbour */
+#define CX_SEED_PARALLEL 2u
 int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
                           int64_t* out_counts);
 /* the masks of the last selection on the host (n_triangles and n_vertices bytes; all ones without a selection): for

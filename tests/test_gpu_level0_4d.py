@@ -230,3 +230,30 @@ def test_reference_test0_call_on_device():
     assert maker.seeded["groups_kept"] >= 1 and R["counts"]["n_after_tiny"] > 0
     MT = maker.collect_morph_triangles()
     assert len(MT.triangle_segment_indices) > 0
+
+
+def test_search_for_endpoints_with_skip_4d():
+    """skip > 1 in 4-D: the coarse crossing search seeds the growth; a blob that fits between the coarse lattice points is
+    not returned, the large one is (the reference's sparsity mode)"""
+    from contourist_amd import pentatopes
+    shape = (25, 25, 25, 9)
+    ax = [np.arange(n, dtype=np.float64) for n in shape]
+    X, Y, Z, T = np.meshgrid(*ax, indexing="ij")
+    big = np.sqrt((X - 9.3) ** 2 + (Y - 9.1) ** 2 + (Z - 9.2) ** 2 + 0.5 * (T - 4.0) ** 2) - 5.0
+    small = np.sqrt((X - 21.5) ** 2 + (Y - 21.5) ** 2 + (Z - 21.5) ** 2 + (T - 6.0) ** 2) - 1.1      # between the coarse points
+    A = np.minimum(big, small).astype(np.float32)
+    mins, delta = [0.0] * 4, [1.0] * 4
+
+    def tets(skip):
+        M = pentatopes.MorphingIsoSurfaces(mins, None, delta, A, 0.0, [])
+        M.search_for_endpoints(skip)
+        R = M.contour_maker.find_tetrahedra()
+        return R, M
+    R_all, _ = tets(1)
+    R_big, M = tets(4)
+    assert 0 < len(R_big["tetrahedra"]) < len(R_all["tetrahedra"])
+    used = np.unique(R_big["tetrahedra"])
+    assert np.all(np.linalg.norm(R_big["points4d"][used][:, :3] - np.array([9.3, 9.1, 9.2]), axis=1) < 6.5)   # only the big blob
+    used_all = np.unique(R_all["tetrahedra"])
+    assert (np.linalg.norm(R_all["points4d"][used_all][:, :3] - 21.5, axis=1) < 2.5).any()                    # exhaustive: both
+    assert M.contour_maker.seeded["groups_kept"] == 1

@@ -128,8 +128,8 @@ def test_search_for_endpoints_with_skip():
 
 
 def test_many_seeds_take_the_parallel_path():
-    """more than 1024 end point pairs: one thread per pair; same selection as the oracle on a field where
-    every candidate voxel of a pair belongs to one component"""
+    """the one-thread-per-pair seed kernel (what more than 65 536 end point pairs get; forced here): same selection
+    as the oracle on a field where every candidate voxel of a pair belongs to one component"""
     from oracle import level0, seeds
     G = np.load(os.path.join(GOLDEN_DIR, "blobs27.npz"))
     A, v = G["A"], float(G["value"])
@@ -148,7 +148,7 @@ def test_many_seeds_take_the_parallel_path():
         eps = [[tuple(int(x) for x in q[p]), tuple(int(x) for x in q[p] + dv[p])] for p in comp_vertices]
         while len(eps) <= 1024:
             eps = eps + eps
-        got = ctx.select_seeded(eps)
+        got = ctx.select_seeded(eps, parallel=True)
         assert got["triangles_kept"] == int(mask0.sum())
     finally:
         ctx.close()
