@@ -6,8 +6,6 @@ The reference builds one DxDy2DContourGrid per value and walks the lattice once 
 extracted in ONE pass over the samples on the GPU (csrc/cx_contour2d.hip: the levels each lattice edge crosses
 are found by bisection in the sorted values, exactly like classify_endpoint_values :48-59).
 """
-import bisect
-
 import numpy as np
 
 from . import _ffi
@@ -59,54 +57,61 @@ class Multiple2DContourGrid(object):
         """value -> the given segments that straddle it (multiple_2d_contour.py:32-42).  Returns True when some value
         has none, i.e. when the reference falls back to its exhaustive grid search (:39-41): the crossings that
         search finds are generated on the device and are not listed here."""
-        values = self.values
-        self.value_to_endpoints = {value: [] for value in values}
-        for (start_point, endpoint) in self.segment_end_points:
-            self.classify_endpoint(start_point, endpoint)
-        return any(len(self.value_to_endpoints[value]) == 0 for value in values)
+        self.value_to_endpoints = dict((level, []) for level in self.values)
+        field = self.grid.f
+        for (p, q) in self.segment_end_points:
+            self.classify_endpoint_values(p, field(*p), q, field(*q))
+        return min((len(found) for found in self.value_to_endpoints.values()), default=1) == 0
 
     def classify_endpoint(self, startpoint, endpoint):
-        f = self.grid.f
-        return self.classify_endpoint_values(startpoint, f(*startpoint), endpoint, f(*endpoint))
+        "one segment: evaluate the field at both ends and file it under the levels in between (:44-46)"
+        field = self.grid.f
+        return self.classify_endpoint_values(startpoint, field(*startpoint), endpoint, field(*endpoint))
 
     def classify_endpoint_values(self, startpoint, f_start, endpoint, f_end):
-        if f_end < f_start:
-            (startpoint, f_start, endpoint, f_end) = (endpoint, f_end, startpoint, f_start)
-        values = self.values
-        start_index = bisect.bisect_left(values, f_start)
-        end_index = bisect.bisect_right(values, f_end)
-        for value_index in range(start_index, end_index):
-            self.value_to_endpoints[values[value_index]].append((startpoint, endpoint))
+        """file the segment, oriented from its lower to its higher end, under every level v with
+        f(lower) <= v <= f(higher) (:48-59): a contiguous index range of the sorted levels"""
+        lower, upper = (startpoint, endpoint) if not f_end < f_start else (endpoint, startpoint)
+        levels = np.asarray(self.values, dtype=np.float64)
+        first = int(np.searchsorted(levels, min(f_start, f_end), side="left"))
+        last = int(np.searchsorted(levels, max(f_start, f_end), side="right"))
+        for level in self.values[first:last]:
+            self.value_to_endpoints[level].append((lower, upper))
+
+
+def _grid2d(xmin, ymin, xmax, ymax, dx, dy, function):
+    return field2d.Function2DGrid(xmin, ymin, xmax, ymax, dx, dy, function)
 
 
 class Multiple2DContour(Multiple2DContourGrid):
+    "levels given by the caller (multiple_2d_contour.py:78-82)"
 
     def __init__(self, xmin, ymin, xmax, ymax, dx, dy, function, values, segment_endpoints=()):
-        function_grid = field2d.Function2DGrid(xmin, ymin, xmax, ymax, dx, dy, function)
-        Multiple2DContourGrid.__init__(self, function_grid, values, segment_endpoints)
+        Multiple2DContourGrid.__init__(self, _grid2d(xmin, ymin, xmax, ymax, dx, dy, function), values, segment_endpoints)
 
 
 class Percentile2DContour(Multiple2DContourGrid):
+    "levels = every (N / breakpoints)-th sample of the sorted lattice samples (multiple_2d_contour.py:84-98)"
 
     def __init__(self, xmin, ymin, xmax, ymax, dx, dy, function, breakpoints=10, segment_endpoints=()):
-        function_grid = field2d.Function2DGrid(xmin, ymin, xmax, ymax, dx, dy, function)
-        self.function_grid = function_grid
-        values = self.values = self.get_values(breakpoints)
-        Multiple2DContourGrid.__init__(self, function_grid, values, segment_endpoints)
+        self.function_grid = _grid2d(xmin, ymin, xmax, ymax, dx, dy, function)
+        self.values = self.get_values(breakpoints)
+        Multiple2DContourGrid.__init__(self, self.function_grid, self.values, segment_endpoints)
 
     def _samples(self):
+        "the lattice samples the device contours (float64 view of the fp32 array)"
         return np.asarray(triangulated.grid_lattice(self.function_grid)[2], dtype=np.float64)
 
     def get_values(self, breakpoints):
-        samples = np.sort(self._samples().flatten())
-        (nsamples,) = samples.shape
-        skip = int(nsamples / breakpoints)
-        return [samples[index] for index in range(skip, nsamples, skip)]
+        ordered = np.sort(self._samples(), axis=None)
+        stride = int(ordered.size / breakpoints)
+        return list(ordered[stride::stride])
 
 
 class Linear2DContour(Percentile2DContour):
+    "levels = multiples of (max - min) / breakpoints, as the reference computes them (multiple_2d_contour.py:100-108)"
 
     def get_values(self, breakpoints):
         samples = self._samples()
-        offset = (samples.max() - samples.min()) * (1.0 / breakpoints)
-        return [offset * i for i in range(1, breakpoints)]
+        step = (samples.max() - samples.min()) * (1.0 / breakpoints)
+        return [step * k for k in range(1, breakpoints)]
