@@ -49,33 +49,27 @@ class MorphTriangles(object):
         return pos[used], remap[T[vis]]
 
     def to_json(self, min_value=None, max_value=None, maxint=999999, epsilon=1e-4):
-        "compact integer JSON consumed by misc/morph_triangles.js (morph_geometry.py:91-125)"
-        L = []
-        a = L.append
-        a("{\n")
-        a('"description": "Ordered 4d morphing triangles.",\n')
-        min_value = self.min_value if min_value is None else max(min_value, self.min_value)
-        max_value = self.max_value if max_value is None else min(max_value, self.max_value)
-        a('"max_value": %s,\n' % (max_value,))
-        a('"min_value": %s,\n' % (min_value))
-        points = self.points4d
-        segments = self.segment_point_indices
-        triangles = self.triangle_segment_indices
-        a('"counts": [%s, %s, %s],\n' % (len(points), len(segments), len(triangles),))
-        maxima = points.max(axis=0)
-        minima = points.min(axis=0)
-        diff = np.maximum(maxima - minima, epsilon)
-        a('"shift": [%s, %s, %s, %s],\n' % tuple(minima))
-        scale = diff / maxint
-        a('"scale": [%s, %s, %s, %s],\n' % tuple(scale))
-        invscale = (1.0 / scale).reshape((1, 4))
-        positions = ((points - minima.reshape(1, 4)) * invscale).astype(int)
-        a('"positions": %s,\n' % (flatten_json_list(positions),))
-        a('"segments": %s,\n' % (flatten_json_list(segments),))
-        a('"triangles": %s\n' % (flatten_json_list(triangles),))
-        a("}")
-        return "".join(L)
+        """the compact integer JSON that misc/morph_triangles.js reads (wire format of morph_geometry.py:91-125):
+        positions quantised to 0..maxint per axis with their shift and scale, then the flattened index lists"""
+        t_lo = self.min_value if min_value is None else max(min_value, self.min_value)
+        t_hi = self.max_value if max_value is None else min(max_value, self.max_value)
+        P = np.asarray(self.points4d, dtype=np.float64)
+        shift = P.min(axis=0)
+        scale = np.maximum(P.max(axis=0) - shift, epsilon) / maxint
+        quantised = ((P - shift[None, :]) * (1.0 / scale)[None, :]).astype(int)
+
+        def vector(values):
+            return "[" + ", ".join("%s" % (x,) for x in values) + "]"
+        fields = [("description", '"Ordered 4d morphing triangles."'),
+                  ("max_value", "%s" % (t_hi,)), ("min_value", "%s" % (t_lo,)),
+                  ("counts", vector((len(P), len(self.segment_point_indices), len(self.triangle_segment_indices)))),
+                  ("shift", vector(shift)), ("scale", vector(scale)),
+                  ("positions", flatten_json_list(quantised)),
+                  ("segments", flatten_json_list(self.segment_point_indices)),
+                  ("triangles", flatten_json_list(self.triangle_segment_indices))]
+        return "{\n" + ",\n".join('"%s": %s' % field for field in fields) + "\n}"
 
 
 def flatten_json_list(sequence, fmt=str):
-    return "[%s]" % (",\n".join(",".join(fmt(y) for y in x) for x in sequence),)
+    "rows joined by commas, one row per line, in one pair of brackets (morph_geometry.py:127-128)"
+    return "[" + ",\n".join(",".join(map(fmt, row)) for row in sequence) + "]"
