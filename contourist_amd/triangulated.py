@@ -212,34 +212,34 @@ class Grid2DContour(object):
 
 
 class ContourGrid(object):
-    "Shared functionality for 2d and 3d (triangulated.py:77-118)"
+    "what the 2-D and the 3-D world-coordinate facades share (triangulated.py:77-118)"
 
     def __init__(self, function_grid, value, segment_endpoints=None, linear_interpolate=True):
+        self.grid, self.value = function_grid, value
         self.linear_interpolate = linear_interpolate
-        self.grid = function_grid
-        self.value = value
         self.segment_endpoints = segment_endpoints
-        grid_endpoints = None
+        found = None
         if segment_endpoints is not None:
-            grid_endpoints = []
             for (start_xy, end_xy) in segment_endpoints:
-                assert len(start_xy) == len(end_xy) == 2
-                grid_endpoint = self.to_grid_endpoint(start_xy, end_xy)
-                if grid_endpoint is not None:
-                    grid_endpoints.append(grid_endpoint)
-            if len(grid_endpoints) < 1:
-                grid_endpoints = None   # default to grid search
-        self.contour_maker = self.get_contour_maker(grid_endpoints)
+                assert len(start_xy) == 2 and len(end_xy) == 2
+            found = [ge for ge in (self.to_grid_endpoint(p, q) for (p, q) in segment_endpoints) if ge is not None]
+        # no usable end point: the contour maker searches the grid itself (:104-106)
+        self.contour_maker = self.get_contour_maker(found if found else None)
         self.grid_values = None
 
     def to_grid_endpoint(self, start_xy, end_xy):
-        grid = self.grid
-        value = self.value
-        for start_grid in grid.surrounding_vertices(np.asarray(start_xy, dtype=float)):
-            for end_grid in grid.surrounding_vertices(np.asarray(end_xy, dtype=float)):
-                if not np.all(start_grid == end_grid):
-                    if (grid.grid_function(*start_grid) - value) * (grid.grid_function(*end_grid) - value) <= 0:
-                        return (start_grid.copy(), end_grid.copy())
+        """the first pair of distinct lattice points around the two world points whose samples do not lie on the same
+        side of the value (:109-118), or None"""
+        g, level = self.grid, self.value
+        around_start = list(g.surrounding_vertices(np.asarray(start_xy, dtype=float)))
+        around_end = list(g.surrounding_vertices(np.asarray(end_xy, dtype=float)))
+        for p in around_start:
+            fp = g.grid_function(*p) - level
+            for q in around_end:
+                if np.array_equal(p, q):
+                    continue
+                if fp * (g.grid_function(*q) - level) <= 0:
+                    return (p.copy(), q.copy())
         return None
 
 
@@ -287,37 +287,20 @@ class DxDy2DContour(DxDy2DContourGrid):
 
 
 def contour_sequences_to_svg(contour_sequences, html_width=300):
-    "contours as SVG paths (triangulated.py:16-54)"
-    mins = maxes = None
-    element_points = []
-    for (closed, sequence) in contour_sequences:
-        pointstrings = []
-        first = True
-        for point in sequence:
-            pointstring = "%4.2f %4.2f" % tuple(point)
-            pointstrings.append(("M" if first else "L") + pointstring)
-            point = np.array(point)
-            if mins is None:
-                mins = maxes = point
-            else:
-                mins = np.min([point, mins], axis=0)
-                maxes = np.max([point, maxes], axis=0)
-            first = False
+    "the contours as one SVG path each, in a viewBox that fits them (triangulated.py:16-54; same text)"
+    every = np.concatenate([np.asarray(seq, dtype=float).reshape(-1, 2) for (_, seq) in contour_sequences], axis=0)
+    lower, upper = every.min(axis=0), every.max(axis=0)
+    (width, height) = upper - lower
+    stroke = "%4.2f" % (0.01 * max(width, height),)
+    paths = []
+    for (closed, seq) in contour_sequences:
+        steps = [("L" if k else "M") + "%4.2f %4.2f" % (p[0], p[1]) for k, p in enumerate(np.asarray(seq, dtype=float).reshape(-1, 2))]
         if closed:
-            pointstrings.append("Z")
-        element_points.append(" ".join(pointstrings))
-    stroke_width_str = "%4.2f" % (0.01 * np.max(maxes - mins))
-    elements = ['<path stroke-width="%s" stroke="black" fill="none" d="%s" />' % (stroke_width_str, points) for points in element_points]
-    width, height = (maxes - mins)
-    scale = html_width * (1.0 / width)
-    return SVG_TEMPLATE % (height * scale, html_width, mins[0], mins[1], width, height, "\n".join(elements))
-
-
-SVG_TEMPLATE = """
-<svg height="%s" width="%s" viewBox="%s %s %s %s">
-%s
-</svg>
-"""
+            steps.append("Z")
+        paths.append('<path stroke-width="%s" stroke="black" fill="none" d="%s" />' % (stroke, " ".join(steps)))
+    scale = html_width * (1.0 / width)        # (this order of operations: the digits of the height match the reference's)
+    head = '\n<svg height="%s" width="%s" viewBox="%s %s %s %s">\n' % (height * scale, html_width, lower[0], lower[1], width, height)
+    return head + "\n".join(paths) + "\n</svg>\n"
 
 
 def svg_demo():
