@@ -38,19 +38,17 @@ class FunctionGrid(object):
     """FunctionGrid(mins, maxes, delta, function, materialize=False, cache=False)  (grid_field.py:10)"""
 
     def __init__(self, mins, maxes, delta, function, materialize=False, cache=False):
-        self.mins = np.array(mins, dtype=float)
-        minshape = self.mins.shape
-        self.maxes = np.zeros(minshape, dtype=float)
-        self.maxes[:] = maxes
-        self.delta = np.zeros(minshape, dtype=float)
-        self.delta[:] = delta
-        (self.dimension,) = minshape
+        lower = np.asarray(mins, dtype=float).copy()
+        assert lower.ndim == 1, "mins is one coordinate per axis"
+        self.dimension = int(lower.shape[0])
+        # maxes and delta may be scalars or one value per axis (the reference broadcasts them the same way, :11-16)
+        self.mins = lower
+        self.maxes = np.broadcast_to(np.asarray(maxes, dtype=float), lower.shape).copy()
+        self.delta = np.broadcast_to(np.asarray(delta, dtype=float), lower.shape).copy()
         self.f = function
-        self.cached = cache
-        self.materialize = materialize
-        self.materialized_array = None
-        self.cache = {}
-        self.grid_dimensions = self.to_grid_vertex(self.maxes) + 1
+        self.cached, self.cache = cache, {}
+        self.materialize, self.materialized_array = materialize, None
+        self.grid_dimensions = self.to_grid_vertex(self.maxes) + 1          # int((maxes - mins) / delta) + 1  (:26-27)
         assert np.all(self.grid_dimensions >= 2), "grid must have dimensions greater than 2"
         self._dense = None            # fp32 samples, shape grid_dimensions + 1 (numpy or torch-on-GPU)
         if materialize:
