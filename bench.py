@@ -2,16 +2,24 @@
 """bench.py -- Mvoxels/s of Level-0 isosurface extraction (marching tetrahedra) on MI355X.
 
 One "step" = one pass of the hot path over one volume resident in HBM: (N>1: one-plane halo
-exchange over RCCL) -> classify/interpolate kernel -> triangle emit kernel, leaving the indexed
-mesh (vertex records + index triples) in HBM.  Workload (BASELINE.json configs[2] shape at N=1):
-512^3 fp32 smooth-noise field, single isovalue 0; with N GPUs every rank owns one such 512^3
-slab of a (N*512) x 512 x 512 volume partitioned along array axis 0 ("z-slab"), weak scaling.
+exchange over RCCL) -> stream/classify -> scan -> vertex + triangle emit, leaving the indexed mesh
+(vertex records + index triples) in HBM.
 
-Prints ONE JSON line (rank 0).  `value` = samples of all ranks / max-over-ranks wall time.
+Workload: BASELINE.json's metric configuration -- ONE 512^3 fp32 smooth-noise volume, single isovalue 0.
+With N GPUs the volume is split into N slabs along array axis 0 ("z-slab", SURVEY config 3), one process
+per GPU, one-plane halo over RCCL: STRONG scaling (total work fixed).  `--weak` gives every rank its own
+512^3 slab instead; an N>1 strong run also reports the weak figure as a second field.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run`, as a CHILD process, before anything in this process touches a GPU).
+
+Prints ONE JSON line (rank 0).  `value` = samples of the whole job / max-over-ranks wall time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,19 +34,34 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=512, help="samples per axis of one rank's slab")
+    ap.add_argument("--size", type=int, default=512, help="samples per axis of the volume")
     ap.add_argument("--passes", type=int, default=1400, help="[1,2,1]/4 smoothing passes of the noise field")
     ap.add_argument("--value", type=float, default=0.0)
     ap.add_argument("--rotate", type=int, default=0, help="number of distinct grids cycled (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the Level-1 / API timing after the timed region")
     ap.add_argument("--generic", action="store_true", help="force the shape-agnostic classify kernel")
-    ap.add_argument("--strong", action="store_true",
-                    help="ONE size^3 volume split into N slabs (SURVEY config 3) instead of one size^3 slab per GPU")
+    ap.add_argument("--weak", action="store_true", help="one size^3 slab PER GPU instead of one volume split over the GPUs")
+    ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """start `args.gpus` ranks as a child torch.distributed.run; this process never touches a GPU"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(field_host, value, budget_s=20.0):
-    """time the C oracle (1 thread) on a bounded sub-volume of the same field"""
+    """time the C oracle (1 thread) on a bounded sub-volume of the same field; quote the real reference beside it"""
     import numpy as np
     from oracle import level0
     n0 = field_host.shape[0]
@@ -51,80 +74,68 @@ def cpu_baseline(field_host, value, budget_s=20.0):
     t0 = time.time()
     O = level0.march3d(sub, value, diag_mode=1)
     dt = time.time() - t0
-    return {"value": sub.size / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": "planes 0:%d of the %s field (%d samples, %d triangles) in %.1f s, oracle/march_oracle.c single thread"
-                      % (planes, "x".join(str(n) for n in field_host.shape), sub.size, len(O["tris"]), dt)}
+    out = {"value": sub.size / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+           "sample": "planes 0:%d of the %s field (%d samples, %d triangles) in %.1f s, oracle/march_oracle.c single thread"
+                     % (planes, "x".join(str(n) for n in field_host.shape), sub.size, len(O["tris"]), dt)}
+    tpath = os.path.join(ROOT, "tests", "golden", "reference_timings.json")
+    if os.path.exists(tpath):
+        # the reference's pure Python never travels to the GPU box: its rate was measured where the fixtures were
+        # made (oracle/make_reference_timings.py); scaled to this host by the port's rate on both machines
+        R = json.load(open(tpath))
+        ratio = R["port_over_reference_median"]
+        out["reference_python"] = {
+            "value": R["reference_Mvoxels_s_median"], "unit": "Mvoxels/s", "cores": 1,
+            "measured": R["where"] + "; median over %d fixtures of 16^3..33^3 samples" % len(R["fixtures"]),
+            "port_over_reference": ratio,
+            "reference_equivalent_here": out["value"] / ratio,
+            "note": "single-threaded pure Python (Level 0 + Level 1); the port is Level 0 only",
+        }
+    return out
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from contourist_amd import _ffi, synthetic
-    from contourist_amd import distributed as cxdist
+class Job(object):
+    """one rank's share of a volume (or, weak: its own volume), resident in HBM"""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    def __init__(self, args, torch, dist, cxdist, synthetic, dev, rank, world, strong, nrot):
+        n = args.size
+        self.n, self.rank, self.world, self.dist, self.cxdist = n, rank, world, dist, cxdist
+        self.has_upper = world > 1 and rank + 1 < world
+        self.i0, i1 = cxdist.slab_bounds(n, world, rank) if strong else (0, n)
+        self.n_own = i1 - self.i0
+        self.origin0 = self.i0 if strong else rank * n
+        self.slabs = []
+        for r in range(nrot):
+            if strong:
+                own = synthetic.smooth_noise_torch((n, n, n), 1235 + r, args.passes, dev)[self.i0:i1]
+            else:
+                own = synthetic.smooth_noise_torch((n, n, n), 1235 + 97 * rank + r, args.passes, dev)
+            buf = torch.empty((self.n_own + (1 if self.has_upper else 0), n, n), dtype=torch.float32, device=dev)
+            buf[:self.n_own] = own
+            del own
+            self.slabs.append(buf)
+        torch.cuda.synchronize()
+        self.total_samples = n ** 3 if strong else world * n ** 3
+
+
+def run_job(args, torch, dist, ctx, job, flags, overlap_halo, timing=True):
+    """size buffers, warm up, time args.steps steps; -> (elapsed max over ranks, timing dict, counts)"""
+    cxdist, rank, world = job.cxdist, job.rank, job.world
     distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    ndev = max(torch.cuda.device_count(), 1)
-    device_index = local_rank % ndev            # one rank per GPU; ranks only share a GPU in the 1-GPU rehearsal
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
-    if distributed:
-        backend = os.environ.get("BENCH_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 path on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    n = args.size
-    nrot = args.rotate or (1 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
-    overlap_halo = distributed and os.environ.get("BENCH_SYNC_HALO", "0") != "1"
-    if overlap_halo:
-        nrot = max(nrot, 2)      # the halo of the next volume is exchanged while the current one is extracted
-
-    # weak scaling (default): every rank owns `n` planes of its own field; strong scaling: the ranks own the
-    # axis-0 slabs of ONE n^3 field.  Either way +1 halo plane from the upper neighbour, except on the last rank.
-    has_upper = distributed and rank + 1 < world
-    i0, i1 = cxdist.slab_bounds(n, world, rank) if args.strong else (0, n)
-    n_own = i1 - i0
-    slabs = []
-    for r in range(nrot):
-        if args.strong:
-            own = synthetic.smooth_noise_torch((n, n, n), 1235 + r, args.passes, dev)[i0:i1]
-        else:
-            own = synthetic.smooth_noise_torch((n, n, n), 1235 + 97 * rank + r, args.passes, dev)
-        buf = torch.empty((n_own + (1 if has_upper else 0), n, n), dtype=torch.float32, device=dev)
-        buf[:n_own] = own
-        del own
-        slabs.append(buf)
-    torch.cuda.synchronize()
-
-    stream = torch.cuda.current_stream()
-    ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
-    ctx.set_origin(i0 if args.strong else rank * n, 0, 0)
-    flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
-
-    def halo_exchange(buf):
-        """lower plane of rank r+1 -> halo plane of rank r (RCCL send/recv over xGMI)"""
-        cxdist.exchange_halo(buf, n_own, rank, world, dist)
-
+    nrot = len(job.slabs)
+    ctx.set_origin(job.origin0, 0, 0)
     pending = {}
 
     def step(i):
-        buf = slabs[i % nrot]
+        buf = job.slabs[i % nrot]
         if overlap_halo:
-            # one process per GPU; the only exchange of the path is the 1-plane halo.  The exchange for volume i+1
-            # (another buffer) is posted before volume i is extracted and runs on RCCL's stream meanwhile.
+            # the only exchange of the path is the 1-plane halo.  The exchange for volume i+1 (another buffer) is
+            # posted before volume i is extracted and runs on RCCL's stream meanwhile.
             if i not in pending:
-                pending[i] = cxdist.HaloExchange(buf, n_own, rank, world, dist)
+                pending[i] = cxdist.HaloExchange(buf, job.n_own, rank, world, dist)
             pending.pop(i).finish()
-            pending[i + 1] = cxdist.HaloExchange(slabs[(i + 1) % nrot], n_own, rank, world, dist)
+            pending[i + 1] = cxdist.HaloExchange(job.slabs[(i + 1) % nrot], job.n_own, rank, world, dist)
         elif distributed:
-            halo_exchange(buf)
+            cxdist.exchange_halo(buf, job.n_own, rank, world, dist)
         ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
         ctx.extract3d_async(args.value, flags)
 
@@ -132,16 +143,15 @@ def main():
     counts = None
     for r in range(nrot):
         if distributed:
-            halo_exchange(slabs[r])
-        ctx.adopt_device_grid(slabs[r].data_ptr(), tuple(slabs[r].shape), keepalive=slabs[r])
+            cxdist.exchange_halo(job.slabs[r], job.n_own, rank, world, dist)
+        ctx.adopt_device_grid(job.slabs[r].data_ptr(), tuple(job.slabs[r].shape), keepalive=job.slabs[r])
         c = ctx.extract3d(args.value, flags)
         counts = c if counts is None else {k: max(counts[k], c[k]) for k in c}
     ctx.reserve(int(counts["n_cells"] * 1.05) + 1024, int(counts["n_vertices"] * 1.05) + 1024,
                 int(counts["n_triangles"] * 1.05) + 1024)
-
     for i in range(args.warmup):
         step(i)
-    ctx.timing_enable(True)
+    ctx.timing_enable(timing)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -155,79 +165,187 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timing = ctx.timing_read()
+    tm = ctx.timing_read()
+    ctx.timing_enable(False)
     final = ctx.counts()           # also verifies that the last extract fitted its buffers
     if distributed:
+        dev = job.slabs[0].device
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed, tm, final
 
-    samples_per_rank = n_own * n * n
-    total_samples = n ** 3 if args.strong else world * n ** 3
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    import torch
+    import torch.distributed as dist
+    from contourist_amd import _ffi, synthetic
+    from contourist_amd import distributed as cxdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("BENCH_DRY") == "1":
+        # plumbing rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous, one collective, the line's keys
+        if distributed:
+            dist.init_process_group("gloo")
+            world, rank = dist.get_world_size(), dist.get_rank()
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert int(t.item()) == world
+        lo, hi = cxdist.slab_bounds(args.size, world, rank) if not args.weak else (0, args.size)
+        if rank == 0:
+            print(json.dumps({"metric": "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % args.size, "value": None, "unit": "Mvoxels/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak" if args.weak else "strong",
+                              "dry_run": True, "planes_rank0": [lo, hi]}), flush=True)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    ndev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % ndev            # one rank per GPU; ranks only share a GPU in the 1-GPU rehearsal
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    if distributed:
+        backend = os.environ.get("BENCH_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        world = dist.get_world_size()
+        rank = dist.get_rank()
+    n = args.size
+    strong = not args.weak
+    # distinct volumes cycled through: a 512^3 grid (537 MB) is twice the Infinity Cache, but half of it could stay
+    # resident from step to step, so at least two are rotated; small grids need enough to exceed 256 MB several times
+    nrot = args.rotate or (2 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
+    overlap_halo = distributed and os.environ.get("BENCH_SYNC_HALO", "0") != "1"
+    if overlap_halo:
+        nrot = max(nrot, 2)      # the halo of the next volume is exchanged while the current one is extracted
+
+    stream = torch.cuda.current_stream()
+    ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
+    flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
+
+    job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, nrot)
+    elapsed, timing, final = run_job(args, torch, dist, ctx, job, flags, overlap_halo)
+
+    weak_line = None
+    if distributed and strong:
+        # second field: the weak-scaling figure (one size^3 slab per GPU) of the same build
+        host0 = None
+        del job.slabs[:]
+        torch.cuda.empty_cache()
+        wjob = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, False, nrot)
+        wel, _, _ = run_job(args, torch, dist, ctx, wjob, flags, overlap_halo, timing=False)
+        weak_line = {"value": wjob.total_samples * args.steps / wel / 1e6, "unit": "Mvoxels/s", "ms_per_step": wel / args.steps * 1e3,
+                     "workload": "one %d^3 slab per GPU (%d x %d x %d volume)" % (n, world * n, n, n)}
+        del wjob.slabs[:]
+        torch.cuda.empty_cache()
+        job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, 1)
+
     if rank == 0:
         nt = max(timing["n"], 1)
         k1_ms = timing["classify_ms"] / nt
         k2_ms = timing["emit_ms"] / nt
-        alg_bytes = 4.0 * slabs[0].numel()             # 4 B per input sample, read once
-        # per-kernel durations (HIP events on the extraction stream, inside the timed region) and the
-        # algorithmic bytes of each: stream = 4 B per sample read; vertex stage = 16 B per vertex record +
-        # 16 B per cell record written; triangle stage = 12 B per triangle written
-        kernels = [
-            {"name": "cx_k_stream", "ms": timing["stream_ms"] / nt, "alg_bytes": alg_bytes},
-            {"name": "cx_k_scan_waves+cx_k_list_batches", "ms": timing["scan_ms"] / nt, "alg_bytes": 0.0},
-            {"name": "cx_k_emit_vertices", "ms": timing["cells_ms"] / nt,
-             "alg_bytes": 16.0 * final["n_vertices"] + 16.0 * final["n_cells"]},
-            {"name": "cx_k_emit_triangles", "ms": k2_ms, "alg_bytes": 12.0 * final["n_triangles"]},
-        ]
-        if args.generic:
-            kernels = [{"name": "cx_k_classify_generic", "ms": k1_ms, "alg_bytes": alg_bytes}, kernels[3]]
+        level0_ms = k1_ms + k2_ms
+        local_samples = job.slabs[0].numel()
+        alg_bytes = 4.0 * local_samples             # 4 B per input sample, read once
+        # per-kernel durations (HIP events on the extraction stream, inside the timed region) with the algorithmic
+        # bytes of each: stream = 4 B per sample read; emit = 16 B per vertex record + 12 B per triangle written
+        names = ctx.kernel_names()
+        kernels = []
+        for key, name in names:
+            ms = timing[key] / nt
+            if key == "stream_ms":
+                ab = alg_bytes
+            elif key == "scan_ms":
+                ab = 0.0
+            elif key == "cells_ms":
+                ab = ctx.vertex_stage_bytes(final)
+            else:
+                ab = ctx.triangle_stage_bytes(final)
+            kernels.append({"name": name, "ms": ms, "alg_bytes": ab})
         for kk in kernels:
             kk["GBps"] = kk["alg_bytes"] / (kk["ms"] * 1e-3) / 1e9 if kk["ms"] > 0 else 0.0
             kk["frac"] = kk["GBps"] / HBM_PEAK_GBS
+        kernels = [kk for kk in kernels if kk["ms"] > 0]
         dom = max(kernels, key=lambda kk: kk["ms"])
-        achieved = dom["GBps"]
+        achieved = alg_bytes / (level0_ms * 1e-3) / 1e9 if level0_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_%d" % (dom["name"], n))
+                traffic = json.load(open(tpath)).get("level0_%d" % n)
             except Exception:
                 traffic = None
         out = {
             "metric": "Mvoxels/s isosurface extraction on 512^3 fp32 grid" if n == 512 else "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % n,
-            "value": total_samples * args.steps / elapsed / 1e6,
+            "value": job.total_samples * args.steps / elapsed / 1e6,
             "unit": "Mvoxels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "%dx%dx%d fp32 smooth-noise %s ([1,2,1]/4 x %d passes, closed interior), isovalue %g, marching tetrahedra Level-0 (classify+interpolate+emit indexed mesh)"
-                            % (n, n, n, "volume split over the GPUs" if args.strong else "slab per GPU", args.passes, args.value),
-                "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if args.strong else
+                            % (n, n, n, ("volume split over %d GPUs" % world if distributed else "volume") if strong else "slab per GPU", args.passes, args.value),
+                "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if strong else
                               "one slab per GPU (axis 0), 1-plane halo over RCCL") if distributed else "single GPU",
                 "halo_exchange": ("overlapped with the previous volume's extraction" if overlap_halo else "in line") if distributed else None,
-                "active_voxel_fraction": final["n_border_voxels"] / float((n - 1) ** 3),
-                "vertices": final["n_vertices"], "triangles": final["n_triangles"],
+                "active_voxel_fraction": final["n_border_voxels"] / float(max((job.n_own - (0 if job.has_upper else 1)) * (n - 1) ** 2, 1)),
+                "vertices_rank0": final["n_vertices"], "triangles_rank0": final["n_triangles"],
                 "grids_rotated": nrot,
                 "classify_kernel": "generic" if args.generic else "auto",
             },
+            # achieved = 4 B x samples of one launch sequence / sum of ALL Level-0 kernel durations of one
+            # extraction (HIP events on the extraction stream, rank 0); per-kernel figures under `kernels`
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": dom["name"] + " (longest of the Level-0 kernels)", "kernel_ms": dom["ms"],
+                "kernel": "all Level-0 kernels of one extraction (%s)" % " + ".join(kk["name"] for kk in kernels),
+                "kernel_ms": level0_ms,
+                "dominant_kernel": dom["name"], "dominant_kernel_ms": dom["ms"],
                 "kernels": kernels,
-                "level0_ms": k1_ms + k2_ms,
-                "level0_frac": alg_bytes / ((k1_ms + k2_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms + k2_ms > 0 else 0.0,
+                "level0_ms": level0_ms,
+                "level0_frac": achieved / HBM_PEAK_GBS,
             },
         }
+        if weak_line is not None:
+            out["weak"] = weak_line
+        if world == 1 and not args.no_api:
+            # what the reference's API returns: Level 0 + Level 1 (weld, tiny collapse, clean, orient) + download
+            buf = job.slabs[0]
+            ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c0 = ctx.extract3d(args.value, flags)
+            t1 = time.perf_counter()
+            post = ctx.postprocess3d()
+            t2 = time.perf_counter()
+            pts, tris = ctx.download_level1(post)
+            t3 = time.perf_counter()
+            out["level1_ms"] = (t2 - t1) * 1e3
+            out["api_ms"] = (t3 - t0) * 1e3
+            out["api"] = {"extract_sync_ms": (t1 - t0) * 1e3, "level1_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3,
+                          "level1_vertices": int(post["n_vertices"]), "level1_triangles": int(post["n_triangles"]),
+                          "Mvoxels_per_s_through_api": n ** 3 / (t3 - t0) / 1e6,
+                          "note": "get_points_and_triangles() equivalent: extract + post-pass + download of float64 points / int32 triangles"}
+            del pts, tris
         if world == 1 and not args.no_cpu_baseline:
-            host = slabs[0].cpu().numpy()
+            host = job.slabs[0].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, args.value)
         print(json.dumps(out), flush=True)
     if distributed:

@@ -16,12 +16,13 @@ CX_ERR_CAPACITY = -5
 CX_DIAG_CANONICAL = 0
 CX_DIAG_CPYTHON310 = 1
 CX_KERNEL_GENERIC = 0x100
+CX_KERNEL_STAGED = 0x200
 
 # every symbol include/contourist_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
-    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_download", "cx_level0_device_ptrs",
+    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
@@ -97,6 +98,7 @@ def load():
         "cx_extract3d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
         "cx_extract3d_async": [vp, dbl, u32],
         "cx_counts_get": [vp, ctypes.POINTER(CxCounts)],
+        "cx_level0_path": [vp, ctypes.POINTER(ctypes.c_int)],
         "cx_level0_download": [vp, vp, vp],
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_postprocess3d": [vp, u32, vp],
@@ -376,6 +378,31 @@ class Context(object):
         chains = np.empty((c.n_chains,), dtype=CHAIN2D_DTYPE)
         self._check(self.lib.cx_contour2d_download(self.handle, pts.ctypes.data, keys.ctypes.data, chains.ctypes.data))
         return pts, keys, chains, int(c.n_pairs)
+
+    # what cx_timing_read's slots measure, with the algorithmic bytes of each stage (bench.py)
+    def level0_path(self):
+        "kernels of the last extraction: 0 generic classify + triangle stage, 1 staged pipeline, 2 stream + scan + fused emit"
+        p = ctypes.c_int()
+        self._check(self.lib.cx_level0_path(self.handle, ctypes.byref(p)))
+        return p.value
+
+    def kernel_names(self):
+        path = self.level0_path()
+        if path == 2:
+            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_waves+cx_k_list_batches"), ("cells_ms", "cx_k_emit_mesh")]
+        if path == 1:
+            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_waves+cx_k_list_batches"),
+                    ("cells_ms", "cx_k_emit_vertices"), ("emit_ms", "cx_k_emit_triangles")]
+        return [("stream_ms", "cx_k_classify_generic"), ("emit_ms", "cx_k_emit_triangles")]
+
+    def vertex_stage_bytes(self, counts):
+        if self.level0_path() == 2:     # fused emit: 16 B per vertex record + 12 B per triangle written
+            return 16.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
+        return 16.0 * counts["n_vertices"] + 16.0 * counts["n_cells"]    # vertex records + cell records written
+
+    @staticmethod
+    def triangle_stage_bytes(counts):
+        return 12.0 * counts["n_triangles"]
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

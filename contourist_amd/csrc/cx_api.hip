@@ -71,6 +71,8 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (ctx->brec) (void)hipFree(ctx->brec);
     if (ctx->flat) (void)hipFree(ctx->flat);
     if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
+    if (ctx->sw) (void)hipFree(ctx->sw);
+    if (ctx->lp) (void)hipFree(ctx->lp);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -100,13 +102,6 @@ static int set_grid_dims(cx_ctx* ctx, int64_t n0, int64_t n1, int64_t n2) {
     if (n0 < 2 || n1 < 2 || n2 < 2) return fail(ctx, CX_ERR_INVALID, "grid must have at least 2 samples per axis");
     const int64_t N = n0 * n1 * n2;
     if (N > (1LL << 29)) return fail(ctx, CX_ERR_UNSUPPORTED, "more than 2^29 samples in one grid: partition into slabs");
-    // side tables sized for this grid
-    if (ctx->tables_for < (size_t)N) {
-        if (ctx->celltab) (void)hipFree(ctx->celltab);
-        ctx->celltab = nullptr; ctx->tables_for = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
-        ctx->tables_for = (size_t)N;
-    }
     ctx->n0 = n0; ctx->n1 = n1; ctx->n2 = n2;
     ctx->extracted = false;
     ctx->post_valid = false;
@@ -195,6 +190,10 @@ static float fp32_threshold(double value) {
 static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (!ctx->grid) return fail(ctx, CX_ERR_STATE, "no grid: call cx_grid_upload or cx_grid_adopt_device first");
     if (!(value == value)) return fail(ctx, CX_ERR_INVALID, "isovalue is NaN");
+    // the public flags are the documented ones; the ablation bits (CX_DBG_*) give partial meshes and are only honoured
+    // in a process started with CX_DEBUG=1 (tools/)
+    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310 | CX_KERNEL_GENERIC | CX_KERNEL_STAGED)) != 0u && !cx_debug_enabled())
+        return fail(ctx, CX_ERR_INVALID, "unknown flag bits in cx_extract3d");
     const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
     if (!ctx->cells || !ctx->verts || !ctx->tris) {
         int rc = cx_reserve(ctx, N / 16 + 4096, N / 8 + 4096, N / 4 + 4096);
@@ -215,7 +214,20 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.value = value;
     P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
     P.flags = flags;
+    const bool staged = !(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported_dims(ctx->n2, ctx->grid);
+    // fused emit (vertex indices computed, no per-cell table, no cell records) unless the staged kernels are asked for or
+    // the last extraction of this grid met the tolerance path (cx_counts_get then sends it through the staged kernels)
+    const bool fused = staged && !(flags & CX_KERNEL_STAGED) && !(flags & 0xFFFF0000u);
+    if (!fused && ctx->tables_for < (size_t)N) {
+        // the per-cell table of the staged / generic emit path (one 8-byte entry per sample): only when that path runs
+        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->celltab) (void)hipFree(ctx->celltab);
+        ctx->celltab = nullptr; ctx->tables_for = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
+        ctx->tables_for = (size_t)N;
+    }
     P.celltab = ctx->celltab;
+    P.fused = fused ? 1u : 0u;
     P.verts = ctx->verts; P.cells = ctx->cells; P.tris = ctx->tris;
     P.vcap = ctx->vcap; P.ccap = ctx->ccap; P.tcap = ctx->tcap;
     P.counters = ctx->counters;
@@ -236,7 +248,6 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
         ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
     }
-    const bool staged = !(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported(P);
     cx_task T;
     memset(&T, 0, sizeof(T));
     if (staged) {
@@ -261,8 +272,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         const size_t nbrec = nw * T.bcap;
         if (ctx->brec_cap < nbrec) {
             CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->tri_keep) (void)hipFree(ctx->tri_keep);
-    if (ctx->brec) (void)hipFree(ctx->brec);
+            if (ctx->brec) (void)hipFree(ctx->brec);
             ctx->brec = nullptr; ctx->brec_cap = 0;
             CX_HIP(ctx, hipMalloc(&ctx->brec, nbrec * sizeof(cx_brec)));
             ctx->brec_cap = nbrec;
@@ -279,10 +289,25 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             CX_HIP(ctx, hipMalloc(&ctx->flat, nflat * sizeof(cx_bdesc)));
             ctx->flat_cap = nflat;
         }
+        const size_t nsw = nw * CX_SWP * 64u + 64u;
+        if (ctx->sw_cap < nsw) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->sw) (void)hipFree(ctx->sw);
+            if (ctx->lp) (void)hipFree(ctx->lp);
+            ctx->sw = nullptr; ctx->lp = nullptr; ctx->sw_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->sw, nsw * sizeof(uint32_t)));
+            CX_HIP(ctx, hipMalloc(&ctx->lp, nsw * sizeof(uint32_t)));
+            ctx->sw_cap = nsw;
+        }
         P.queue = ctx->queue; P.wsum = ctx->wsum; P.wbase = ctx->wbase; P.brec = ctx->brec;
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
+        P.sw = ctx->sw; P.lp = ctx->lp;
         ctx->last = P;
     }
+    ctx->last_task = T;
+    ctx->last_flags = flags;
+    ctx->path = staged ? (fused ? 2 : 1) : 0;
+    ctx->records_valid = !fused;
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {
         if (ctx->nevents < (int)(sizeof(ctx->events) / sizeof(ctx->events[0]))) {
@@ -300,17 +325,19 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
         if (!(flags & CX_DBG_PHASE_A_ONLY)) cx_launch_scan_waves(P, T, ctx->stream);
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
-        if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_vertices(P, T, ctx->stream);
+        if (fused) cx_launch_emit_mesh(P, T, ctx->hash_xy, ctx->stream);
+        else if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_vertices(P, T, ctx->stream);
     } else {
         cx_launch_classify_generic(P, ctx->stream);
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
     }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[3], ctx->stream));
-    if (!(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
+    if (!fused && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[4], ctx->stream));
     CX_HIP(ctx, hipGetLastError());
     ctx->extracted = true;
+    ctx->counts_fetched = false;
     ctx->post_valid = false;
     ctx->keep_valid = false;
     return CX_OK;
@@ -325,6 +352,7 @@ extern "C" int cx_extract3d_async(cx_ctx* ctx, double value, uint32_t flags) {
 extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
     if (!ctx || !out) return CX_ERR_INVALID;
     if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no extraction enqueued");
+    if (ctx->counts_fetched) { *out = ctx->counts; return CX_OK; }   // the device counters may belong to a later 4-D march
     CX_HIP(ctx, hipSetDevice(ctx->device));
     CX_HIP(ctx, hipMemcpyAsync(ctx->counters_host, ctx->counters, CX_CNT_WORDS * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -339,6 +367,14 @@ extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
         ctx->extracted = false;
         return fail(ctx, CX_ERR_CAPACITY, "output buffers too small for this isosurface");
     }
+    if (ctx->path == 2 && ctx->counters_host[CX_CNT_NEAR] != 0u) {
+        // a sample within the reference's np.allclose tolerances of the isovalue: its rules may drop vertices, the fused
+        // kernel has written nothing -- the same extraction again through the staged kernels (exact per-cell path)
+        int rc = enqueue_extract(ctx, ctx->last.value, ctx->last_flags | CX_KERNEL_STAGED);
+        if (rc) return rc;
+        return cx_counts_get(ctx, out);
+    }
+    ctx->counts_fetched = true;
     return CX_OK;
 }
 
@@ -358,6 +394,27 @@ extern "C" int cx_extract3d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         if (rc) return rc;
     }
     return fail(ctx, CX_ERR_CAPACITY, "output buffers still too small after growing");
+}
+
+// cell records {lin, sign|tetskip<<8|ntri<<16|emask<<24, first triangle, first vertex} of the last extraction: the fused emit
+// kernel does not write them; callers that walk the surface voxels (seeded selection) get them from the vertex stage of the
+// staged kernels run over the same queues with its other stores switched off
+int cx_ensure_cell_records(cx_ctx* ctx) {
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
+    if (ctx->records_valid) return CX_OK;
+    cx_params P = ctx->last;
+    P.flags |= CX_DBG_NO_VERTS | CX_DBG_NO_CELLTAB;
+    P.ccap = ctx->ccap; P.cells = ctx->cells;
+    cx_launch_emit_vertices(P, ctx->last_task, ctx->stream);
+    CX_HIP(ctx, hipGetLastError());
+    ctx->records_valid = true;
+    return CX_OK;
+}
+
+extern "C" int cx_level0_path(cx_ctx* ctx, int* path) {
+    if (!ctx || !path) return CX_ERR_INVALID;
+    *path = ctx->path;
+    return CX_OK;
 }
 
 extern "C" int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris) {

@@ -175,6 +175,9 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
             }
             P.signbits = S->signbits;
         }
+        // the counter block is shared with the 3-D march: an enqueued 3-D extraction whose counts were never fetched
+        // (cx_extract3d_async without cx_counts_get) loses them here and has to be run again
+        if (ctx->extracted && !ctx->counts_fetched) ctx->extracted = false;
         CX4_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
         cx_launch_signbits4d(P, ctx->stream);
         cx_launch_classify4d(P, ctx->stream);

@@ -6,6 +6,19 @@
 #include "../../include/contourist_hip.h"
 #include "cx_tables.h"
 
+// debug / tuning switches are honoured only in a process started with CX_DEBUG=1 (tools/, never the product path)
+#include <cstdlib>
+#include <cstring>
+static inline bool cx_debug_enabled() {
+    static const bool on = [] { const char* e = getenv("CX_DEBUG"); return e && strcmp(e, "1") == 0; }();
+    return on;
+}
+static inline uint32_t cx_debug_knob(const char* name, uint32_t dflt) {
+    if (!cx_debug_enabled()) return dflt;
+    const char* e = getenv(name);
+    return (e && atoi(e) > 0) ? (uint32_t)atoi(e) : dflt;
+}
+
 // ---- exact 32-bit division by a runtime-constant divisor (host computes the magic) -------------
 struct cx_fdiv {
     uint32_t mul, sh1, sh2, d;
@@ -56,7 +69,13 @@ struct cx_params {
     struct cx_wbase* wbase;   // [nwaves] first vertex / triangle / record / batch index of each wave
     struct cx_bdesc* flat;    // [fcap] all batches, self-contained
     uint32_t fcap;
+    // fused emit (cx_k_emit_mesh): what the stream kernel leaves behind so that the vertex index of ANY lattice cell can
+    // be computed instead of looked up -- per streaming wave CX_SWP plane slots of 64 lanes each
+    uint32_t* sw;             // [nwaves][CX_SWP][64] packed sign words of the wave's sample planes (slot s = plane pstart + s)
+    uint32_t* lp;             // [nwaves][CX_SWP][64] vertices of the wave that precede lane l of plane step s (active steps only)
+    uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
 };
+#define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
 
 struct cx_wsum {   // 32 bytes
     uint32_t nb;           // batches
@@ -101,7 +120,9 @@ struct cx_task {
 #define CX_DBG_NO_NEAR 0x2000000u      // stream kernel: ignore the tolerance screen (never take the per-cell path)
 #define CX_DBG_NO_VLOADS 0x1000000u    // phase B (packed entries): no sample loads for the vertices
 
-enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4, CX_CNT_WORDS = 8 };
+enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4,
+       CX_CNT_NEAR = 5,   // streaming waves that met a sample inside the tolerance screen (their cells take the per-cell path)
+       CX_CNT_WORDS = 8 };
 
 // device tables (defined in cx_march3d.hip)
 extern __device__ __constant__ uint8_t cx_d_tet_corners[6][4];
@@ -111,9 +132,11 @@ extern __device__ __constant__ uint8_t cx_d_voxel_ntri[256];
 // kernel launchers (cx_march3d.hip)
 void cx_launch_classify_generic(const cx_params& P, hipStream_t s);
 bool cx_fast_classify_supported(const cx_params& P);
+bool cx_fast_classify_supported_dims(int64_t n2, const float* grid);
 cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2);
 void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
+void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

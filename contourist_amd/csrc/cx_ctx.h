@@ -30,6 +30,13 @@ struct cx_ctx {
     size_t brec_cap = 0;
     cx_bdesc* flat = nullptr;
     size_t flat_cap = 0;
+    uint32_t* sw = nullptr;            // fused emit: sign words and lane vertex prefixes of the streaming waves
+    uint32_t* lp = nullptr;
+    size_t sw_cap = 0;
+    cx_task last_task = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t last_flags = 0;
+    int path = 0;                      // kernels of the last extraction: 0 generic, 1 staged, 2 fused
+    bool records_valid = false;        // ctx->cells holds the cell records of the last extraction
     uint64_t* hash_xy = nullptr;       // CPython tuple-hash prefix per (i,j), for CX_DIAG_CPYTHON310
     size_t hash_xy_cap = 0;
     int64_t hash_xy_n0 = 0, hash_xy_n1 = 0, hash_xy_o0 = -1, hash_xy_o1 = -1;
@@ -46,6 +53,7 @@ struct cx_ctx {
     uint32_t* counters = nullptr;
     uint32_t* counters_host = nullptr;
     bool extracted = false;
+    bool counts_fetched = false;       // ctx->counts holds the counters of the last 3-D extraction (cx_counts_get)
     cx_counts counts = {0, 0, 0, 0};
     cx_params last;
     // seeded selection (cx_select_seeded3d): triangle mask followed by vertex mask, valid until the next extraction
@@ -64,6 +72,8 @@ struct cx_ctx {
     evset events[256];
 };
 
+// cx_api.hip
+int cx_ensure_cell_records(cx_ctx* ctx);
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);
 int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev,

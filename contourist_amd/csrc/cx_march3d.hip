@@ -325,6 +325,18 @@ __device__ __forceinline__ uint32_t cx_wave_sum(uint32_t x) {
     return x;
 }
 
+// inclusive prefix sum over the wave with DPP row shifts / broadcasts (no LDS crossbar round trips)
+__device__ __forceinline__ uint32_t cx_wave_incl_scan(uint32_t x, uint32_t lane) {
+    (void)lane;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // FAST phase A bit layout: one u32 per lane and sample plane, 6 bits per sample row r (0..RJ):
 //   bit 6r+m (m=0..3) : sample (row r, k = k0 + 4*lane + m) < isovalue
 //   bit 6r+4          : the same for k+1 of m=3 (next lane's m=0, the halo sample, or a clamped repeat)
@@ -336,6 +348,45 @@ constexpr uint32_t cx_rowmask(int rows, uint32_t bits) {
 }
 #define CX_M0_MASK cx_rowmask(CX_RJ + 1, 1u)    // bit 6r+0, r = 0..RJ
 #define CX_CELL_MASK cx_rowmask(CX_RJ, 0xFu)    // bits 6r+0..3, r = 0..RJ-1  (the 4*RJ cells of a lane)
+
+// which of the 4*RJ cells of streaming lane `lane` of the wave tile at (k0, j0) exist (mr), have a k+1 neighbour inside
+// the array (mk) and a j+1 neighbour (mj); bit layout of CX_CELL_MASK.  Used by the stream kernel and by the fused emit
+// kernel, which recomputes the stream kernel's vertex numbering for cells of OTHER waves: one definition for both.
+struct cx_lmasks {
+    uint32_t mr, mk, mj;
+};
+__device__ __forceinline__ cx_lmasks cx_lane_masks(const cx_params& P, uint32_t k0, uint32_t j0, uint32_t lane) {
+    const uint32_t kofs = k0 + 4u * lane;
+    const bool lane_valid = kofs < P.n2;
+    const uint32_t nvalid = lane_valid ? min(4u, P.n2 - kofs) : 0u;   // samples of the row this lane holds
+    const uint32_t nrows = (j0 < P.n1) ? min((uint32_t)CX_RJ, P.n1 - j0) : 0u;
+    const uint32_t last_lane = min(63u, (P.n2 - k0 - 1u) >> 2);       // lane that holds the last sample of the segment
+    const bool halo_in = (k0 + 256u) < P.n2;                          // a sample right of this segment exists
+    cx_lmasks M;
+    M.mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
+    M.mr &= cx_rowmask(CX_RJ, 1u) * ((1u << nvalid) - 1u);            // cells that exist in this lane
+    if (!lane_valid) M.mr = 0;                                        // lanes right of the array own no cells
+    M.mk = M.mr;
+    if (lane == last_lane && !halo_in) M.mk &= ~(CX_M0_MASK << (nvalid - 1u));   // the last sample of the row has no k+1
+    M.mj = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < CX_RJ; r++)
+        if (j0 + r + 1u < P.n1) M.mj |= 0xFu << (CX_ROWBITS * r);
+    M.mj &= M.mr;
+    return M;
+}
+// crossing words of a lane: bit b of x[d] set <=> the cell at bit b owns a crossing on its edge in direction d.
+// A, B = packed sign words of the cell plane and of the plane above; mi = M.mr if that plane exists, else 0.
+__device__ __forceinline__ void cx_cross_words(uint32_t A, uint32_t B, const cx_lmasks& M, uint32_t mi, uint32_t x[8]) {
+    x[0] = 0;
+    x[1] = (A ^ (A >> 1)) & M.mk;
+    x[2] = (A ^ (A >> CX_ROWBITS)) & M.mj;
+    x[3] = (A ^ (A >> (CX_ROWBITS + 1u))) & M.mk & M.mj;
+    x[4] = (A ^ B) & mi;
+    x[5] = (A ^ (B >> 1)) & M.mk & mi;
+    x[6] = (A ^ (B >> CX_ROWBITS)) & M.mj & mi;
+    x[7] = (A ^ (B >> (CX_ROWBITS + 1u))) & M.mk & M.mj & mi;
+}
 
 // =================================================================================================
 // generic classify kernel (any shape / alignment): one lane per cell, wave-private LDS queue, the
@@ -486,6 +537,8 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
+    __shared__ uint32_t s_sw[4][CX_SWP][64];   // sign words of the wave's planes and ...
+    __shared__ uint32_t s_lp[4][CX_SWP][64];   // ... vertex prefixes of its active steps, copied out at the end
     const uint32_t b = cx_task_of_block(T);
     if (b >= T.nblocks) return;
     const uint32_t lane = cx_lane_id();
@@ -505,6 +558,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the cells queued since the last batch record (b: all)
     uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
     uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
+    uint32_t vrun = 0;                     // wave-uniform: vertices of all cells queued so far
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
@@ -528,7 +582,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         nbl = 0;
     };
     auto close_batch = [&]() {
-        const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
+        const uint32_t bv = vrun - rv, bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
         if (nbl == CX_SBR) flush_brec();
         if (lane == 0) {
             s_br[wave][nbl][0] = qstart; s_br[wave][nbl][1] = qn - qstart; s_br[wave][nbl][2] = rv;
@@ -536,7 +590,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         }
         nbl++; nb++; rv += bv; rt += bt; rc += bc;
         qstart = qn;
-        acc.v = acc.t = acc.c = 0;
+        acc.t = acc.c = 0;
     };
     if (nrows != 0u && p < ib) {
         const uint32_t kofs = k0 + 4u * lane;
@@ -546,16 +600,9 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         const uint32_t kshift = kofs - kofs_c;                            // ... and shift them into place (1..3; garbage for lanes off the row)
         const uint32_t last_lane = (uint32_t)__popcll(__ballot(lane_valid)) - 1u;
         const bool halo_in = (k0 + 256u) < P.n2;                  // a sample right of this segment exists
-        // cells whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
-        uint32_t mr = (nrows >= CX_RJ) ? CX_CELL_MASK : (CX_CELL_MASK & ((1u << (CX_ROWBITS * nrows)) - 1u));   // rows that exist
-        if (!ALIGNED) mr &= cx_rowmask(CX_RJ, 1u) * ((1u << nvalid) - 1u);   // cells that exist in this lane
-        if (!lane_valid) mr = 0;   // lanes right of the array hold re-read samples: they own no cells
-        uint32_t mk = mr;
-        if (lane == last_lane && !halo_in) mk &= ~(CX_M0_MASK << (nvalid - 1u));   // the last sample of the row has no k+1
-        uint32_t mj = 0;
-        for (uint32_t r = 0; r < CX_RJ; r++)
-            if (j0 + r + 1u < P.n1) mj |= 0xFu << (CX_ROWBITS * r);
-        mj &= mr;
+        // cells that exist / whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
+        const cx_lmasks LM = cx_lane_masks(P, k0, j0, lane);
+        const uint32_t mr = LM.mr, mk = LM.mk, mj = LM.mj;
 
         // one sample plane of this lane: RJ+1 rows x 4 consecutive k-samples, plus the sample right of the segment
         struct plane_raw {
@@ -612,10 +659,13 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
         uint32_t wprev = plane_bits(rawB);
+        s_sw[wave][0][lane] = wprev;
         // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 2u, nxt);
             const uint32_t wcur = plane_bits(cur);
+            const uint32_t ps = p - G.pstart;          // plane step of this task (< CX_SWP - 1)
+            s_sw[wave][ps + 1u][lane] = wcur;
             // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
             const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
             const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
@@ -644,9 +694,15 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
                 const uint32_t real = mk & mj & mi;                           // cells that are voxels
                 const uint32_t b0 = wprev, b1 = wprev >> 1, b2 = wprev >> CX_ROWBITS, b3 = wprev >> (CX_ROWBITS + 1u);
                 const uint32_t b4 = wcur, b5 = wcur >> 1, b6 = wcur >> CX_ROWBITS, b7 = wcur >> (CX_ROWBITS + 1u);
-                const uint32_t x1 = (b0 ^ b1) & mk, x2 = (b0 ^ b2) & mj, x3 = (b0 ^ b3) & mk & mj;   // mk, mj subsets of mr
-                const uint32_t x4 = (b0 ^ b4) & mi, x5 = (b0 ^ b5) & mk & mi, x6 = (b0 ^ b6) & mj & mi, x7 = (b0 ^ b7) & real;
-                acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
+                uint32_t xw[8];
+                cx_cross_words(wprev, wcur, LM, mi, xw);
+                const uint32_t x1 = xw[1], x2 = xw[2], x3 = xw[3], x4 = xw[4], x5 = xw[5], x6 = xw[6], x7 = xw[7];
+                // vertices: the lane's count, and how many vertices of the wave precede the lane's first one -- the
+                // numbering the emit stages follow (queue order: plane, lane, bit), kept for the fused emit kernel
+                const uint32_t nvl = __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
+                const uint32_t vinc = cx_wave_incl_scan(nvl, lane);
+                s_lp[wave][ps][lane] = vrun + vinc - nvl;
+                vrun += (uint32_t)__builtin_amdgcn_readlane((int)vinc, 63);
                 const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
                 acc.c += __popc(owners | (act0 & real));
                 acc.b += __popc(act0 & real);
@@ -681,6 +737,16 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     if (qn > qstart) close_batch();
     flush_queue();
     flush_brec();
+    if (P.sw && nrows != 0u && p > G.pstart) {
+        // sign words of planes pstart .. pstart + nsteps and the vertex prefixes of the steps (garbage for steps without an
+        // active cell: nobody asks for those), for the fused emit kernel
+        const uint32_t nsteps = p - G.pstart;
+        uint32_t* __restrict__ gsw = P.sw + (size_t)w * (CX_SWP * 64u);
+        uint32_t* __restrict__ glp = P.lp + (size_t)w * (CX_SWP * 64u);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t sidx = 0; sidx <= nsteps; sidx++) gsw[sidx * 64u + lane] = s_sw[wave][sidx][lane];
+        for (uint32_t sidx = 0; sidx < nsteps; sidx++) glp[sidx * 64u + lane] = s_lp[wave][sidx][lane];
+    }
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
     cx_run run;
     run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
@@ -709,17 +775,6 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
 // ---- S2: exclusive scan of the per-wave totals (one workgroup of 16 waves; coalesced loads of
 // CX_SC chunks of 1024 waves at a time), output offsets per wave, the flat batch list, the counters.
 #define CX_SC 12
-// inclusive prefix sum over the wave with DPP row shifts / broadcasts (no LDS crossbar round trips)
-__device__ __forceinline__ uint32_t cx_wave_incl_scan(uint32_t x, uint32_t lane) {
-    (void)lane;
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
-    return x;
-}
 __global__ __launch_bounds__(1024) void cx_k_scan_waves(const cx_params P, const uint32_t nw) {
     __shared__ uint32_t s_part[5][CX_SC * 16];   // per (chunk, wave) totals, then their exclusive prefixes
     __shared__ uint32_t s_total[5];
@@ -727,14 +782,16 @@ __global__ __launch_bounds__(1024) void cx_k_scan_waves(const cx_params P, const
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = tid >> 6;
     uint32_t carry[5] = {0, 0, 0, 0, 0};   // v, t, c, b, nb of everything before this super-chunk
+    int near_any = 0;                      // this thread saw a wave whose cells take the per-cell (tolerance) path
     for (uint32_t base = 0; base < nw; base += 1024u * CX_SC) {
         uint32_t x[CX_SC][5], inc[CX_SC][5];
 #pragma unroll
         for (int k = 0; k < CX_SC; k++) {
             const uint32_t w = base + (uint32_t)k * 1024u + tid;
             cx_wsum S;
-            S.nb = S.v = S.t = S.c = S.b = 0;
+            S.nb = S.v = S.t = S.c = S.b = S.nq = S.near = 0;
             if (w < nw) S = P.wsum[w];
+            near_any |= (S.near != 0u && S.nq != 0u) ? 1 : 0;
             x[k][0] = S.v; x[k][1] = S.t; x[k][2] = S.c; x[k][3] = S.b; x[k][4] = S.nb;
         }
 #pragma unroll
@@ -776,7 +833,9 @@ __global__ __launch_bounds__(1024) void cx_k_scan_waves(const cx_params P, const
         for (int m = 0; m < 5; m++) carry[m] += s_total[m];
         __syncthreads();
     }
+    near_any = __syncthreads_or(near_any);
     if (tid == 0) {
+        P.counters[CX_CNT_NEAR] = near_any ? 1u : 0u;
         P.counters[CX_CNT_VERTS] = carry[0]; P.counters[CX_CNT_TRIS] = carry[1];
         P.counters[CX_CNT_CELLS] = carry[2]; P.counters[CX_CNT_BORDER] = carry[3];
         P.counters[CX_CNT_BATCHES] = carry[4];
@@ -1102,9 +1161,274 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
     }
 }
 
+// =================================================================================================
+// Fused emit: vertex records AND triangles of a batch in ONE pass over its queue entries.
+//
+// The staged kernels above hand vertex indices from the vertex stage to the triangle stage through memory: a sparse
+// 8-byte table entry per vertex-owning cell (scattered into a table of one entry per SAMPLE) plus a 16-byte record per
+// active cell, and the triangle stage gathers up to six table entries per cell.  Here nothing is handed over: the
+// index of the first vertex of ANY lattice cell Y follows from what the stream kernel left behind,
+//     first(Y) = wbase[wave of Y].v + lp[wave][plane step][lane of Y] + (vertices of the cells below Y in its lane),
+// the last term and Y's crossing mask being popcounts on the two packed sign words of that lane (cx_cross_words, the
+// very function the stream kernel counted with).  The six neighbour cells of a voxel that can own one of its edges
+// live in the same lane word, the next lane, the next wave (rows) or the next task (planes): cx_nb_locate.
+// One wave per batch; rounds of 64 cells, software-pipelined like the vertex stage: everything round s+1 loads is
+// issued -- and waited for -- before the stores of round s go out.
+// Only for extractions without a wave on the tolerance path (counters[CX_CNT_NEAR] == 0): there the reference's
+// np.allclose rules drop vertices and the numbering no longer follows from the signs (the host then runs the staged
+// kernels instead).
+// =================================================================================================
+struct cx_geomx {          // wave-uniform: the streaming wave tile a batch belongs to
+    uint32_t w, wave, k0, j0, pstart, nsteps;
+};
+// where cell X + c lives, X = (plane step ps, streaming lane ls, row r, sample m) of tile GX:
+// bits 0-5 lane, 6-10 bit in the lane word, 11 next k segment, 12 next row group, 13-19 plane step, 20 next plane chunk
+__device__ __forceinline__ uint32_t cx_nb_locate(const cx_geomx& GX, uint32_t ps, uint32_t ls, uint32_t r, uint32_t m, uint32_t c) {
+    uint32_t mY = m + (c & 1u), rY = r + ((c >> 1) & 1u), psY = ps + (c >> 2), laneY = ls;
+    uint32_t kf = 0, jf = 0, pf = 0;
+    if (mY == 4u) {
+        mY = 0; laneY++;
+        if (laneY == 64u) { laneY = 0; kf = 1; }
+    }
+    if (rY == (uint32_t)CX_RJ) { rY = 0; jf = 1; }
+    if (psY == GX.nsteps) { psY = 0; pf = 1; }
+    return laneY | ((CX_ROWBITS * rY + mY) << 6) | (kf << 11) | (jf << 12) | (psY << 13) | (pf << 20);
+}
+// streaming wave that holds the cell of a location word
+__device__ __forceinline__ uint32_t cx_nb_wave(const cx_geomx& GX, const cx_task& T, uint32_t loc) {
+    uint32_t wY = GX.w;
+    if ((loc >> 11) & 1u) wY += 4u;                                              // next block in k
+    if ((loc >> 12) & 1u) wY += (GX.wave == 3u) ? (4u * T.nks - 3u) : 1u;        // next wave / next block in j
+    if ((loc >> 20) & 1u) wY += 4u * T.nks * T.njg;                              // next chunk of planes
+    return wY;
+}
+// (first vertex index, crossing mask) of the cell at `loc` from its lane's prefix and sign words
+__device__ __forceinline__ uint2 cx_nb_finish(const cx_params& P, const cx_task& T, const cx_geomx& GX, uint32_t loc, uint32_t vb,
+                                              uint32_t lpv, uint32_t A, uint32_t B) {
+    const uint32_t laneY = loc & 63u, bitY = (loc >> 6) & 31u;
+    const uint32_t k0Y = GX.k0 + (((loc >> 11) & 1u) ? 256u : 0u);
+    const uint32_t j0Y = GX.j0 + (((loc >> 12) & 1u) ? (uint32_t)CX_RJ : 0u);
+    const uint32_t pabs = GX.pstart + (((loc >> 20) & 1u) ? T.ci : 0u) + ((loc >> 13) & 127u);
+    const cx_lmasks M = cx_lane_masks(P, k0Y, j0Y, laneY);
+    const uint32_t mi = (pabs + 1u < P.n0) ? M.mr : 0u;
+    uint32_t x[8];
+    cx_cross_words(A, B, M, mi, x);
+    const uint32_t below = (1u << bitY) - 1u;
+    uint32_t cnt = 0, em = 0;
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d++) {
+        cnt += __popc(x[d] & below);
+        em |= ((x[d] >> bitY) & 1u) << d;
+    }
+    return make_uint2(vb + lpv + cnt, em);
+}
+
+struct cx_mesh_lds {
+    cx_tri_lds tri;                // triangle stage tables (per wave) + the LUT
+    uint32_t vslot[4][2][448];     // per wave, double buffered: vertex o of a round -> (cell lane << 3) | direction
+    uint32_t vbt[4][8];            // per wave: wbase[].v of the 8 waves a neighbour cell can live in
+    uint8_t ntri[256];
+};
+// one round of 64 queued cells between its front half (decode, prefix sums, slot table, every load issued) and its
+// back half (interpolation, neighbour indices, triangle expansion, stores)
+struct cx_mround {
+    uint32_t e, e_next, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, real_voxel, ck;
+    cx_run base;
+    uint32_t e2[CX_VR], sl[CX_VR];
+    float f0[CX_VR], f1[CX_VR];
+    uint32_t loc[6], nlp[6], nA[6], nB[6];   // neighbour cells X + c, c = 1..6: location, lane prefix, sign words
+    uint64_t hxy[4];
+};
+__device__ __forceinline__ void cx_mround_front(const cx_params& P, const cx_task& T, const cx_fast_geom& G, const cx_geomx& GX,
+                                                const uint64_t* __restrict__ hash_xy, const uint32_t* q, uint32_t n, uint32_t b0,
+                                                uint32_t lane, uint32_t e, const cx_run& base, uint32_t* slot, const uint8_t* ntri_lut,
+                                                cx_mround& R) {
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+    const uint32_t idx = b0 + lane;
+    const bool have = idx < n;
+    R.e = e;
+    R.e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+    uint32_t i, j, k;
+    cx_decode_entry(P, G, e, i, j, k);
+    R.lin = (i * P.n1 + j) * P.n2 + k;
+    R.ck = k;
+    R.sm = cx_entry_signs(e);
+    const uint32_t vm = cx_corner_valid(P, i, j, k);
+    R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
+    const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
+    R.emask = have ? (((R.sm ^ s0) & vm) & 0xFEu) : 0u;
+    R.ntri = R.real_voxel ? (uint32_t)ntri_lut[R.sm] : 0u;
+    const uint32_t nv = __popc(R.emask);
+    R.vpre = cx_wave_prefix_small<3>(nv, R.vtot);
+    R.tpre = cx_wave_prefix_small<4>(R.ntri, R.ttot);
+    R.base = base;
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d++)
+        if ((R.emask >> d) & 1u) slot[R.vpre + __popc(R.emask & ((1u << d) - 1u))] = (lane << 3) | d;
+    __builtin_amdgcn_wave_barrier();
+    // sample loads of the first CX_VR x 64 vertices
+#pragma unroll
+    for (uint32_t r = 0; r < CX_VR; r++) {
+        R.sl[r] = 0; R.e2[r] = 0; R.f0[r] = 0.0f; R.f1[r] = 1.0f;
+        if (64u * r >= R.vtot) continue;   // wave-uniform
+        const uint32_t o = 64u * r + lane;
+        R.sl[r] = slot[(o < R.vtot) ? o : 0u];
+        R.e2[r] = (uint32_t)__shfl((int)e, (int)(R.sl[r] >> 3));
+        const uint32_t d = R.sl[r] & 7u;
+        const uint32_t lin2 = cx_entry_lin(P, G, R.e2[r]);
+        R.f0[r] = A[lin2];
+        R.f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
+    }
+    // the neighbour cells that own a crossing edge of this voxel: lane prefix and the two sign words of their lane
+    const uint32_t ps = (e >> 21) & 127u, ls = (e >> 15) & 63u, bit = (e >> 10) & 31u;
+    const uint32_t rr = (bit * 11u) >> 6, mm = bit - CX_ROWBITS * rr;
+#pragma unroll
+    for (uint32_t c = 1; c < 7; c++) {
+        const uint32_t sc = ((R.sm >> c) & 1u) ? 0xFFu : 0u;
+        uint32_t sup = 0;   // corners that are strict supersets of c: the far ends of the voxel edges corner c owns
+#pragma unroll
+        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
+        R.loc[c - 1u] = 0xFFFFFFFFu; R.nlp[c - 1u] = 0; R.nA[c - 1u] = 0; R.nB[c - 1u] = 0;
+        if (R.ntri && ((R.sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
+            const uint32_t loc = cx_nb_locate(GX, ps, ls, rr, mm, c);
+            const uint32_t wY = cx_nb_wave(GX, T, loc);
+            const size_t at = ((size_t)wY * CX_SWP + ((loc >> 13) & 127u)) * 64u + (loc & 63u);
+            R.loc[c - 1u] = loc;
+            R.nlp[c - 1u] = P.lp[at];
+            R.nA[c - 1u] = P.sw[at];
+            R.nB[c - 1u] = P.sw[at + 64u];
+        }
+    }
+    // CPython-order quad diagonals: hash prefixes of the 4 (i,j) columns of the voxel
+    R.hxy[0] = R.hxy[1] = R.hxy[2] = R.hxy[3] = 0;
+    if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(R.sm, 0u, R.ntri) != 0u) {
+        const uint32_t i1 = min(i + 1u, P.n0 - 1u), j1 = min(j + 1u, P.n1 - 1u);
+        R.hxy[0] = hash_xy[i * P.n1 + j]; R.hxy[1] = hash_xy[i * P.n1 + j1];
+        R.hxy[2] = hash_xy[i1 * P.n1 + j]; R.hxy[3] = hash_xy[i1 * P.n1 + j1];
+    }
+}
+__device__ __forceinline__ void cx_mround_pin(cx_mround& R) {
+#pragma unroll
+    for (uint32_t r = 0; r < CX_VR; r++) asm volatile("" : "+v"(R.f0[r]), "+v"(R.f1[r]) :: "memory");
+#pragma unroll
+    for (uint32_t c = 0; c < 6; c++) asm volatile("" : "+v"(R.nlp[c]), "+v"(R.nA[c]), "+v"(R.nB[c]) :: "memory");
+    asm volatile("" : "+v"(R.hxy[0]), "+v"(R.hxy[1]), "+v"(R.hxy[2]), "+v"(R.hxy[3]), "+v"(R.e_next) :: "memory");
+}
+
+#ifndef CX_EM_MIN_WAVES
+#define CX_EM_MIN_WAVES 1
+#endif
+template <bool NEG_ORIGIN>
+__global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_params P, const cx_task T, const uint64_t* __restrict__ hash_xy) {
+    __shared__ cx_mesh_lds L;
+    if (P.counters[CX_CNT_NEAR] != 0u) return;   // a wave on the tolerance path: the host runs the staged kernels instead
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;   // host re-runs with more room
+    const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
+    if (blockIdx.x * 4u >= nbatches) return;
+    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.tri.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    L.ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
+    __syncthreads();
+    const float* __restrict__ A = P.grid;
+    const uint32_t plane = P.n1 * P.n2;
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nw = T.nblocks * 4u;
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t f = blockIdx.x * 4u + wave;
+    if (f >= nbatches) return;
+    cx_bdesc D = P.flat[f];
+    for (;;) {   // waves are independent
+        const uint32_t fn = f + stride;
+        cx_bdesc Dn = D;
+        if (fn < nbatches) Dn = P.flat[fn];   // next descriptor in flight while this batch is processed
+        const cx_tile tile = cx_tile_of(P, T, D.w >> 2, D.w & 3u);
+        cx_fast_geom G;
+        G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
+        cx_geomx GX;
+        GX.w = D.w; GX.wave = D.w & 3u; GX.k0 = tile.k0; GX.j0 = tile.j0; GX.pstart = tile.p; GX.nsteps = tile.ib - tile.p;
+        // first-vertex bases of the 8 streaming waves a neighbour cell can live in (index: next k | next j << 1 | next chunk << 2)
+        if (lane < 8u) {
+            const uint32_t wY = cx_nb_wave(GX, T, ((lane & 1u) << 11) | (((lane >> 1) & 1u) << 12) | (((lane >> 2) & 1u) << 20));
+            L.vbt[wave][lane] = P.wbase[min(wY, nw - 1u)].v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t* __restrict__ q = P.queue + D.qofs;
+        const uint32_t n = D.n;
+        cx_run run;
+        run.v = D.vbase; run.t = D.tbase; run.c = 0; run.b = 0;
+        cx_mround Ra, Rb;
+        uint32_t e0 = (lane < n) ? q[lane] : 0u;
+        asm volatile("" : "+v"(e0) :: "memory");
+        cx_mround_front(P, T, G, GX, hash_xy, q, n, 0u, lane, e0, run, L.vslot[wave][0], L.ntri, Ra);
+        cx_mround_pin(Ra);
+        uint32_t par = 0;
+        for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+            const bool more = b0 + 64u < n;   // wave-uniform
+            if (more) {
+                cx_run nb = Ra.base;
+                nb.v += Ra.vtot; nb.t += Ra.ttot;
+                cx_mround_front(P, T, G, GX, hash_xy, q, n, b0 + 64u, lane, Ra.e_next, nb, L.vslot[wave][par ^ 1u], L.ntri, Rb);
+            }
+            // ---- back half of round b0, part 1: everything that needs no store
+            float4 rec4[CX_VR];
+#pragma unroll
+            for (uint32_t r = 0; r < CX_VR; r++) rec4[r] = cx_vertex_record(P, G, Ra.e2[r], Ra.sl[r] & 7u, Ra.f0[r], Ra.f1[r]);
+            cx_tri_in I;
+            I.rec = make_uint4(Ra.lin, Ra.sm | ((Ra.real_voxel ? 0u : 0x3Fu) << 8) | (Ra.ntri << 16) | (Ra.emask << 24),
+                               Ra.base.t + Ra.tpre, Ra.base.v + Ra.vpre);
+#pragma unroll
+            for (uint32_t c = 0; c < 6; c++) {
+                uint2 pr = make_uint2(0u, 0u);
+                if (Ra.loc[c] != 0xFFFFFFFFu) {
+                    const uint32_t loc = Ra.loc[c];
+                    const uint32_t vb = L.vbt[wave][((loc >> 11) & 3u) | (((loc >> 20) & 1u) << 2)];
+                    pr = cx_nb_finish(P, T, GX, loc, vb, Ra.nlp[c], Ra.nA[c], Ra.nB[c]);
+                }
+                I.nb[c] = pr;
+            }
+            I.hxy[0] = Ra.hxy[0]; I.hxy[1] = Ra.hxy[1]; I.hxy[2] = Ra.hxy[2]; I.hxy[3] = Ra.hxy[3];
+            I.ck = Ra.ck;
+            const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L.tri, lane, wave, I);
+            if (more) cx_mround_pin(Rb);
+            // ---- part 2: the stores
+            {
+#pragma unroll
+                for (uint32_t r = 0; r < CX_VR; r++) {
+                    const uint32_t o = 64u * r + lane;
+                    if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec4[r]);
+                }
+                const uint32_t* slot = L.vslot[wave][par];
+                for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
+                    const uint32_t o = o0 + lane;
+                    const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
+                    const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)(sl >> 3));
+                    const uint32_t d = sl & 7u;
+                    const uint32_t lin2 = cx_entry_lin(P, G, e2);
+                    const float f0 = A[lin2];
+                    const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
+                    const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
+                    if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], r4);
+                }
+            }
+            cx_tri_phase2(P, L.tri, lane, wave, ttot);
+            __builtin_amdgcn_wave_barrier();
+            if (more) Ra = Rb;
+            par ^= 1u;
+        }
+        if (fn >= nbatches) break;
+        f = fn;
+        D = Dn;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------------
 bool cx_fast_classify_supported(const cx_params& P) {
     return P.n2 >= 4u && ((reinterpret_cast<uintptr_t>(P.grid) & 3u) == 0u);   // a lane loads 4 samples of one row
+}
+
+bool cx_fast_classify_supported_dims(int64_t n2, const float* grid) {
+    return n2 >= 4 && ((reinterpret_cast<uintptr_t>(grid) & 3u) == 0u);
 }
 
 cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
@@ -1113,13 +1437,12 @@ cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
     T.njg = (n1 + 4u * CX_RJ - 1u) / (4u * CX_RJ);
     // planes per task: aim at ~3000 workgroups (12 per CU: measured best at 512^3), 2..64 planes each
     const uint32_t per_plane = T.nks * T.njg;
-    uint32_t target = 3072u;
-    if (const char* e = getenv("CX_TASKS")) target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : target;   // tuning knob
+    const uint32_t target = cx_debug_knob("CX_TASKS", 3072u);
     uint32_t want_chunks = (target + per_plane - 1u) / per_plane;
     if (want_chunks < 1u) want_chunks = 1u;
     uint32_t ci = (n0 + want_chunks - 1u) / want_chunks;
     if (ci < 2u) ci = 2u;
-    if (ci > 64u) ci = 64u;
+    if (ci > CX_SWP - 1u) ci = CX_SWP - 1u;   // the sign words of ci + 1 planes are staged in LDS (and the entry format has 7 bits)
     T.ci = ci;
     T.nic = (n0 + ci - 1u) / ci;
     T.nblocks = T.nks * T.njg * T.nic;
@@ -1144,8 +1467,7 @@ void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {
 // one wave per batch, grid-stride: the batch count lives on the device, so launch what fills the chip
 // a few times over (256 CUs) and let every wave walk the list
 static uint32_t cx_batch_grid(const cx_params& P, uint32_t per_cu) {
-    uint32_t g = 256u * per_cu;
-    if (const char* e = getenv("CX_BGRID")) g = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g;   // tuning knob
+    const uint32_t g = cx_debug_knob("CX_BGRID", 256u * per_cu);
     const uint32_t most = (P.fcap + 3u) / 4u;
     return g < most ? g : most;
 }
@@ -1165,12 +1487,17 @@ void cx_launch_classify_generic(const cx_params& P, hipStream_t s) {
 
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s) {
     // one lane per record, grid-stride: launch what fills the chip a few times over
-    uint32_t g = 256u * 8u;
-    if (const char* e = getenv("CX_TGRID")) g = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g;   // tuning knob
+    uint32_t g = cx_debug_knob("CX_TGRID", 256u * 8u);
     const uint32_t most = (P.ccap + 255u) / 256u;
     if (g > most) g = most;
     if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_triangles<true>, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
     else hipLaunchKernelGGL(cx_k_emit_triangles<false>, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
+}
+
+void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s) {
+    const dim3 grid(cx_batch_grid(P, 8u));
+    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_mesh<true>, grid, dim3(256), 0, s, P, T, hash_xy);
+    else hipLaunchKernelGGL(cx_k_emit_mesh<false>, grid, dim3(256), 0, s, P, T, hash_xy);
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {

@@ -279,6 +279,15 @@ __global__ void cxp_k_iota_prio(uint32_t* prio, uint32_t n) {
 struct cxp_weld_params {
     double ex[3];
 };
+// weld bucket of a point: trunc(p * expander) per axis as the reference's astype(int) does it (tetrahedral.py:192-196),
+// i.e. TOWARDS ZERO: on an array with a rim around the reference's grid the coordinates are the reference's own and
+// may be negative, and (-1/ex, 0) shares bucket 0 with [0, 1/ex).  Biased by 2^20 per axis so the fields stay unsigned.
+__device__ __forceinline__ u64 cxp_weld_key(const double* p, const cxp_weld_params& W) {
+    const u64 q0 = (u64)((long long)(p[0] * W.ex[0]) + (1LL << 20));
+    const u64 q1 = (u64)((long long)(p[1] * W.ex[1]) + (1LL << 20));
+    const u64 q2 = (u64)((long long)(p[2] * W.ex[2]) + (1LL << 20));
+    return (q0 << 42) | (q1 << 21) | q2;
+}
 
 // weld: bucket -> vertex with the LARGEST priority (= largest edge key).  The members of a bucket are crossings on the
 // upward edges of one lattice point (truncation puts everything in [V, V + 1/expander)^3 together), so the largest key
@@ -290,10 +299,7 @@ __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint3
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     if (vkeep && !vkeep[v]) return;   // seeded selection: vertices of dropped components do not exist
-    const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
-    const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
-    const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
-    const u64 key = (q0 << 42) | (q1 << 21) | q2;
+    const u64 key = cxp_weld_key(pts + (size_t)v * 3, W);
     u64 slot = cxp_mix(key) & mask;
     for (;;) {
         const u64 cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key);
@@ -307,10 +313,7 @@ __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_param
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     if (vkeep && !vkeep[v]) { rep[v] = v; return; }
-    const u64 q0 = (u64)(long long)(pts[(size_t)v * 3 + 0] * W.ex[0]);
-    const u64 q1 = (u64)(long long)(pts[(size_t)v * 3 + 1] * W.ex[1]);
-    const u64 q2 = (u64)(long long)(pts[(size_t)v * 3 + 2] * W.ex[2]);
-    const u64 key = (q0 << 42) | (q1 << 21) | q2;
+    const u64 key = cxp_weld_key(pts + (size_t)v * 3, W);
     u64 slot = cxp_mix(key) & mask;
     while (tkeys[slot] != key) slot = (slot + 1) & mask;
     rep[v] = (uint32_t)tvals[slot];
@@ -912,9 +915,15 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;
     const cx_params& P = ctx->last;
     const uint8_t* vkeep = nullptr;
+    // an array with a rim of samples around the reference's grid starts at a NEGATIVE lattice point (cx_set_origin):
+    // the post-pass then works in the reference's own lattice coordinates, so that the weld buckets truncate as the
+    // reference's do (towards zero) and the Level-1 points come back in its coordinates.  Slabs (origin >= 0) stay local.
+    cxp_origin3 org{{0.0, 0.0, 0.0}};
+    if (ctx->origin[0] < 0 || ctx->origin[1] < 0 || ctx->origin[2] < 0)
+        for (int a = 0; a < 3; a++) org.o[a] = (double)ctx->origin[a];
     if (nv && nt) {
         hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
-                           P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, cxp_origin3{{0.0, 0.0, 0.0}});
+                           P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
         CXP_HIP(ctx, hipMemcpyAsync(S->tri.p, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (ctx->keep_valid) {   // cx_select_seeded3d: only the triangles (and vertices) of the selected components exist
             CXP_HIP(ctx, hipMemcpyAsync(S->alive.p, ctx->tri_keep, nt, hipMemcpyDeviceToDevice, st));

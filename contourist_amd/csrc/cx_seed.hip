@@ -281,6 +281,10 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     if (!ctx->extracted) { ctx->err = "cx_select_seeded3d: no valid extraction"; return CX_ERR_STATE; }
     CXS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    {
+        const int rcr = cx_ensure_cell_records(ctx);   // the fused emit kernel leaves none behind
+        if (rcr) return rcr;
+    }
     const uint32_t ncells = (uint32_t)ctx->counts.n_cells, nt = (uint32_t)ctx->counts.n_triangles, nv = (uint32_t)ctx->counts.n_vertices;
     const cx_params& P = ctx->last;
     cxs_grid G;

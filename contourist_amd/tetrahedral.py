@@ -137,9 +137,9 @@ class GridContour3d(object):
                 self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0)
             else:
                 self._post = self._postprocess_refined(ctx, clean)
+        # an array with a rim (grid_shift, origin = -grid_shift) is post-processed in the reference's own lattice
+        # coordinates on the device (weld buckets truncate towards zero there as in the reference): nothing to shift back
         pts, tris = ctx.download_level1(self._post)
-        if self.grid_shift and len(pts):
-            pts = pts - float(self.grid_shift)          # back to the reference's own lattice coordinates
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
 
     # -- linear_interpolate=False (tetrahedral.py:488-505) ------------------------------------------------------
@@ -212,6 +212,8 @@ class GridContour3d(object):
         renum = -np.ones(len(keys), dtype=np.int64)
         renum[order] = np.arange(len(order))
         pts = self._refined_points(keys[order])
+        if self.grid_shift and len(pts):
+            pts = pts - float(self.grid_shift)          # the reference's own lattice coordinates (weld buckets, output)
         if self.voxel_range is not None:
             lo, hi = self.voxel_range
             corner = [int(h) - int(l) for l, h in zip(lo, hi)]

@@ -40,6 +40,9 @@ typedef enum {
 #define CX_DIAG_CPYTHON310 1u  /* quad split reproduces CPython 3.10 set iteration order, i.e. the
                                   reference as it runs today (tetrahedral.py:592-595) */
 #define CX_KERNEL_GENERIC 0x100u /* force the shape-agnostic classify kernel (default: auto) */
+#define CX_KERNEL_STAGED 0x200u  /* emit through the staged kernels (vertex stage + per-cell table + triangle stage) instead of
+                                    the fused emit kernel; same mesh, same numbering (A/B, and what an extraction with samples
+                                    inside the reference's np.allclose tolerances is sent through automatically) */
 
 typedef struct {
     int64_t n_cells;         /* lattice cells with a sign change among their corners */
@@ -88,6 +91,9 @@ int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max
 int cx_extract3d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
 int cx_extract3d_async(cx_ctx* ctx, double value, uint32_t flags);
 int cx_counts_get(cx_ctx* ctx, cx_counts* out);
+/* which kernels produced the last extraction: 0 generic classify + triangle stage, 1 staged pipeline (stream, scan, vertex
+ * stage, triangle stage), 2 stream, scan + fused emit kernel -- for measurement (bench.py names its kernels by it) */
+int cx_level0_path(cx_ctx* ctx, int* path);
 /* copy the Level-0 mesh to host: verts = n_vertices*4 floats, tris = n_triangles*3 int32 */
 int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris);
 /* device pointers of the Level-0 buffers (valid until the next extract / reserve / destroy) */

@@ -3,6 +3,7 @@
 import argparse
 import os
 import sys
+os.environ.setdefault("CX_DEBUG", "1")   # ablation flags and tuning knobs are refused otherwise
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """where a classify wave spends its life (diagnostic s_memtime stamps; shares, not absolute times)"""
 import os, sys
+os.environ.setdefault("CX_DEBUG", "1")   # ablation flags and tuning knobs are refused otherwise
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from contourist_amd import _ffi, synthetic

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """stream kernel alone: bench field at an isovalue nothing crosses vs the bench isovalue"""
 import os, sys
+os.environ.setdefault("CX_DEBUG", "1")   # ablation flags and tuning knobs are refused otherwise
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from contourist_amd import _ffi, synthetic
