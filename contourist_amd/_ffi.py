@@ -17,6 +17,7 @@ CX_DIAG_CANONICAL = 0
 CX_DIAG_CPYTHON310 = 1
 CX_KERNEL_GENERIC = 0x100
 CX_KERNEL_STAGED = 0x200
+CX_KERNEL_FUSED = 0x400
 
 # every symbol include/contourist_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [

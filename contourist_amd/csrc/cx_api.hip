@@ -71,8 +71,10 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (ctx->brec) (void)hipFree(ctx->brec);
     if (ctx->flat) (void)hipFree(ctx->flat);
     if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
-    if (ctx->sw) (void)hipFree(ctx->sw);
-    if (ctx->lp) (void)hipFree(ctx->lp);
+    if (ctx->qa) (void)hipFree(ctx->qa);
+    if (ctx->info) (void)hipFree(ctx->info);
+    if (ctx->info64) (void)hipFree(ctx->info64);
+    if (ctx->hbytes) (void)hipFree(ctx->hbytes);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -192,7 +194,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (!(value == value)) return fail(ctx, CX_ERR_INVALID, "isovalue is NaN");
     // the public flags are the documented ones; the ablation bits (CX_DBG_*) give partial meshes and are only honoured
     // in a process started with CX_DEBUG=1 (tools/)
-    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310 | CX_KERNEL_GENERIC | CX_KERNEL_STAGED)) != 0u && !cx_debug_enabled())
+    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310 | CX_KERNEL_GENERIC | CX_KERNEL_STAGED | CX_KERNEL_FUSED)) != 0u && !cx_debug_enabled())
         return fail(ctx, CX_ERR_INVALID, "unknown flag bits in cx_extract3d");
     const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
     if (!ctx->cells || !ctx->verts || !ctx->tris) {
@@ -215,10 +217,10 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
     P.flags = flags;
     const bool staged = !(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported_dims(ctx->n2, ctx->grid);
-    // fused emit (vertex indices computed, no per-cell table, no cell records) unless the staged kernels are asked for or
-    // the last extraction of this grid met the tolerance path (cx_counts_get then sends it through the staged kernels)
-    const bool fused = staged && !(flags & CX_KERNEL_STAGED) && !(flags & 0xFFFF0000u);
-    if (!fused && ctx->tables_for < (size_t)N) {
+    // fused emit kernel (no per-cell table, no cell records) only on request: measured slower than the staged kernels
+    // (DESIGN.md section 4); an extraction that meets the tolerance path is sent through the staged kernels by cx_counts_get
+    const bool fused = staged && (flags & CX_KERNEL_FUSED) && !(flags & CX_KERNEL_STAGED);
+    if (!staged && ctx->tables_for < (size_t)N) {
         // the per-cell table of the staged / generic emit path (one 8-byte entry per sample): only when that path runs
         CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->celltab) (void)hipFree(ctx->celltab);
@@ -247,6 +249,23 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         cx_launch_hash_xy(ctx->hash_xy, P.n0, P.n1, P.org0, P.org1, ctx->stream);
         ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
         ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
+        ctx->hbytes_valid = false;
+    }
+    P.hbytes = nullptr;
+    if ((flags & CX_DIAG_CPYTHON310) && (fused || cx_debug_knob("CX_HBYTES", 0u))) {   // staged kernels: measured slower than the hash arithmetic (byte gathers from a table of one byte per sample)
+        // one byte per lattice point: its slot (and alternative slot) in CPython's 8-slot set, built once per shape / origin
+        if (!ctx->hbytes_valid || ctx->hbytes_n2 != ctx->n2 || ctx->hbytes_o2 != ctx->origin[2]) {
+            if (ctx->hbytes_cap < (size_t)N + 64u) {
+                CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->hbytes) (void)hipFree(ctx->hbytes);
+                ctx->hbytes = nullptr; ctx->hbytes_cap = 0;
+                CX_HIP(ctx, hipMalloc(&ctx->hbytes, (size_t)N + 64u));
+                ctx->hbytes_cap = (size_t)N + 64u;
+            }
+            cx_launch_hash_bytes(ctx->hbytes, ctx->hash_xy, P.n0, P.n1, P.n2, P.org2, ctx->stream);
+            ctx->hbytes_valid = true; ctx->hbytes_n2 = ctx->n2; ctx->hbytes_o2 = ctx->origin[2];
+        }
+        P.hbytes = ctx->hbytes;
     }
     cx_task T;
     memset(&T, 0, sizeof(T));
@@ -289,19 +308,33 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             CX_HIP(ctx, hipMalloc(&ctx->flat, nflat * sizeof(cx_bdesc)));
             ctx->flat_cap = nflat;
         }
-        const size_t nsw = nw * CX_SWP * 64u + 64u;
-        if (ctx->sw_cap < nsw) {
+        const size_t nqa = nw * CX_SWP * 64u + 64u;
+        if (ctx->qa_cap < nqa) {
             CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->sw) (void)hipFree(ctx->sw);
-            if (ctx->lp) (void)hipFree(ctx->lp);
-            ctx->sw = nullptr; ctx->lp = nullptr; ctx->sw_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->sw, nsw * sizeof(uint32_t)));
-            CX_HIP(ctx, hipMalloc(&ctx->lp, nsw * sizeof(uint32_t)));
-            ctx->sw_cap = nsw;
+            if (ctx->qa) (void)hipFree(ctx->qa);
+            ctx->qa = nullptr; ctx->qa_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->qa, nqa * sizeof(uint32_t)));
+            ctx->qa_cap = nqa;
+        }
+        if (!fused && ctx->info64_cap < need) {   // staged kernels: (first vertex, crossing mask) per queue entry
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->info64) (void)hipFree(ctx->info64);
+            ctx->info64 = nullptr; ctx->info64_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->info64, need * sizeof(uint64_t)));
+            ctx->info64_cap = need;
+        }
+        if (fused && ctx->info_cap < need) {   // one word per queue entry (only the front of each wave's region is touched)
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->info) (void)hipFree(ctx->info);
+    if (ctx->info64) (void)hipFree(ctx->info64);
+            ctx->info = nullptr; ctx->info_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->info, need * sizeof(uint32_t)));
+            ctx->info_cap = need;
         }
         P.queue = ctx->queue; P.wsum = ctx->wsum; P.wbase = ctx->wbase; P.brec = ctx->brec;
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
-        P.sw = ctx->sw; P.lp = ctx->lp;
+        P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64;
+        P.div_ci = cx_fdiv_make(T.ci);
         ctx->last = P;
     }
     ctx->last_task = T;
@@ -325,7 +358,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[1], ctx->stream));
         if (!(flags & CX_DBG_PHASE_A_ONLY)) cx_launch_scan_waves(P, T, ctx->stream);
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
-        if (fused) cx_launch_emit_mesh(P, T, ctx->hash_xy, ctx->stream);
+        if (fused) cx_launch_emit_mesh(P, T, ctx->stream);
         else if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_vertices(P, T, ctx->stream);
     } else {
         cx_launch_classify_generic(P, ctx->stream);
@@ -333,7 +366,10 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
     }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[3], ctx->stream));
-    if (!fused && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
+    if (!fused && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) {
+        if (staged) cx_launch_emit_triangles_q(P, T, ctx->hash_xy, ctx->stream);
+        else cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
+    }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[4], ctx->stream));
     CX_HIP(ctx, hipGetLastError());
     ctx->extracted = true;
@@ -370,7 +406,7 @@ extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
     if (ctx->path == 2 && ctx->counters_host[CX_CNT_NEAR] != 0u) {
         // a sample within the reference's np.allclose tolerances of the isovalue: its rules may drop vertices, the fused
         // kernel has written nothing -- the same extraction again through the staged kernels (exact per-cell path)
-        int rc = enqueue_extract(ctx, ctx->last.value, ctx->last_flags | CX_KERNEL_STAGED);
+        int rc = enqueue_extract(ctx, ctx->last.value, (ctx->last_flags & ~(uint32_t)CX_KERNEL_FUSED) | CX_KERNEL_STAGED);
         if (rc) return rc;
         return cx_counts_get(ctx, out);
     }

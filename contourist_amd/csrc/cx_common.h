@@ -69,10 +69,14 @@ struct cx_params {
     struct cx_wbase* wbase;   // [nwaves] first vertex / triangle / record / batch index of each wave
     struct cx_bdesc* flat;    // [fcap] all batches, self-contained
     uint32_t fcap;
-    // fused emit (cx_k_emit_mesh): what the stream kernel leaves behind so that the vertex index of ANY lattice cell can
-    // be computed instead of looked up -- per streaming wave CX_SWP plane slots of 64 lanes each
-    uint32_t* sw;             // [nwaves][CX_SWP][64] packed sign words of the wave's sample planes (slot s = plane pstart + s)
-    uint32_t* lp;             // [nwaves][CX_SWP][64] vertices of the wave that precede lane l of plane step s (active steps only)
+    // fused emit (cx_k_emit_mesh): vertex indices of neighbour cells are looked up through the stream kernel's queues --
+    // per streaming wave CX_SWP plane steps of 64 lanes each
+    uint32_t* qa;             // [nwaves][CX_SWP][64] (position in the wave's queue of the lane's first active cell << 16) | its active cells, bit 4r+m
+    uint32_t* info;           // [queue size] per queue entry: first vertex of the cell relative to its wave's first | crossing mask >> 1 << 24
+    const uint8_t* hbytes;    // [nsamples] CPython set-order code of each lattice point (CX_DIAG_CPYTHON310), or null
+    uint64_t* info64;         // [queue size] staged kernels, per queue entry: (crossing mask << 32) | first vertex index -- the dense
+                              // successor of `celltab` (which only the generic classify kernel still fills)
+    cx_fdiv div_ci;           // / (cell planes per task)
     uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
 };
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
@@ -138,5 +142,7 @@ void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
-void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
+void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
+void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s);
+void cx_launch_hash_bytes(uint8_t* table, const uint64_t* hash_xy, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t org2, hipStream_t s);
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

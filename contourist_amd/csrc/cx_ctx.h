@@ -30,9 +30,16 @@ struct cx_ctx {
     size_t brec_cap = 0;
     cx_bdesc* flat = nullptr;
     size_t flat_cap = 0;
-    uint32_t* sw = nullptr;            // fused emit: sign words and lane vertex prefixes of the streaming waves
-    uint32_t* lp = nullptr;
-    size_t sw_cap = 0;
+    uint32_t* qa = nullptr;            // fused emit: queue positions / active cells per plane step and lane of the streaming waves
+    size_t qa_cap = 0;
+    uint32_t* info = nullptr;          // fused emit: per queue entry, first vertex of the cell in its wave | crossing mask
+    size_t info_cap = 0;
+    uint64_t* info64 = nullptr;        // staged kernels: per queue entry, (crossing mask << 32) | first vertex
+    size_t info64_cap = 0;
+    uint8_t* hbytes = nullptr;         // fused emit: CPython set-order code per lattice point (valid for hash_xy's shape and origin)
+    size_t hbytes_cap = 0;
+    bool hbytes_valid = false;
+    int64_t hbytes_n2 = 0, hbytes_o2 = 0;
     cx_task last_task = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t last_flags = 0;
     int path = 0;                      // kernels of the last extraction: 0 generic, 1 staged, 2 fused

@@ -41,15 +41,17 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 // ---- per-cell path ------------------------------------------------------------------------------
 struct cx_run {
     uint32_t v, t, c, b;   // running vertex / triangle / cell-record / border-voxel counts
+    uint32_t s;            // count pass: owned crossings whose two samples differ by <= 1e-8 (the reference's ratio = 0.5 rule)
 };
 
 // one sweep over queued cells, re-reading their corners and applying the reference's tolerance rules
 // exactly.  emit == false: only count into `run` (from zero); emit == true: `run` holds the bases and
 // advances as vertex records and table entries (RECORDS: and cell records) are written.
 #define CX_VSTAGE 256u   // vertex records a wave stages in LDS per batch of 64 cells (typical: ~200)
+#define CX_VSTAGE_LDS 384u   // float4 slots per wave in the vertex stage's LDS (fast path: 2 x 448 slot words + 64 x 9 corner samples)
 template <bool RECORDS, typename LinOf>
 __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_of, uint32_t n, uint32_t lane,
-                                                 bool emit, cx_run& run, float4* vstage) {
+                                                 bool emit, cx_run& run, float4* vstage, uint64_t* info = nullptr) {
     const uint32_t plane = P.n1 * P.n2;
     for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
         const uint32_t idx = b0 + lane;
@@ -75,6 +77,12 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_o
         const uint64_t recm = __ballot(rec);
         const uint32_t ctot = (uint32_t)__popcll(recm);
         const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
+        if (!emit) {
+            bool flat = false;   // a crossing the fp32 interpolation of the fast path must not take
+#pragma unroll
+            for (uint32_t d = 1; d < 8; d++) flat |= ((R.emask >> d) & 1u) && fabsf(f[d] - f[0]) <= 1.001e-8f;
+            run.s += (uint32_t)__popcll(__ballot(flat));
+        }
         if (emit) {
             const uint32_t vfirst = run.v + vpre;
             if (run.v + vtot <= P.vcap) {
@@ -87,7 +95,10 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_o
                 } else if (nv && !(P.flags & CX_DBG_NO_VERTS)) {
                     cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const float4& rec4) { P.verts[vfirst + r2] = rec4; });
                 }
-                if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+                // (first vertex, crossing mask) of the cell for the triangle stage: per queue entry (staged pipeline), or in
+                // the table of one entry per sample (generic classify kernel)
+                if (info) { if (have && !(P.flags & CX_DBG_NO_CELLTAB)) info[idx] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst; }
+                else if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
             if (RECORDS && rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
                 uint4 c4;
@@ -162,20 +173,18 @@ typedef float cx_v4f __attribute__((ext_vector_type(4)));
 #define CX_STORE_VERT(ptr, val) (*(ptr) = (val))
 #endif
 // one round of 64 queued cells, as the vertex stage carries it from its front half (decode, prefix
-// sums, slot table, sample loads issued) to its back half (interpolation, stores)
+// sums, slot table, corner loads issued) to its back half (interpolation, stores)
 struct cx_vround {
     uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, ctot, real_voxel;
     uint64_t recm;
     cx_run base;                       // first vertex / triangle / record of the round
-    uint32_t e2[CX_VR], sl[CX_VR];     // per vertex of the first CX_VR x 64: source cell entry, slot word
-    float f0[CX_VR], f1[CX_VR];        // ... and its two samples
+    float f[8];                        // the 8 corner samples of the lane's cell
     uint32_t e_next;                   // entries of the following round
 };
+#define CX_CORNER_ROW 9u               // dwords per cell in the LDS corner table (8 + 1: bank spread)
 __device__ __forceinline__ void cx_vround_front(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n, uint32_t b0,
                                                 uint32_t lane, uint32_t e, const cx_run& base, uint32_t* slot,
                                                 const uint8_t* ntri_lut, cx_vround& R) {
-    const float* __restrict__ A = P.grid;
-    const uint32_t plane = P.n1 * P.n2;
     const uint32_t idx = b0 + lane;
     const bool have = idx < n;
     R.e = e;
@@ -184,7 +193,19 @@ __device__ __forceinline__ void cx_vround_front(const cx_params& P, const cx_fas
     cx_decode_entry(P, G, e, i, j, k);
     R.lin = (i * P.n1 + j) * P.n2 + k;
     R.sm = cx_entry_signs(e);
-    const uint32_t vm = cx_corner_valid(P, i, j, k);
+    // The samples the round's vertices interpolate between, loaded per CELL: the (k, k+1) pairs of the 4 (i,j) rows of
+    // the voxel = 4 loads per lane whose addresses follow the queue order (runs along k inside a few rows).  One lane per
+    // VERTEX loading its own two samples, as this stage did first, touched 2.7 x the cache lines: the vector L1 takes
+    // about one line per 3-4 cycles per CU, and that -- not bytes -- bounds these kernels.
+    uint32_t vm;
+    if (P.flags & CX_DBG_NO_VLOADS) {
+        vm = cx_corner_valid(P, i, j, k);
+#pragma unroll
+        for (int c = 0; c < 8; c++) R.f[c] = (float)(c + 1);
+    } else {
+        vm = cx_load_corners(P, have ? R.lin : 0u, have ? i : 0u, have ? j : 0u, have ? k : 0u, R.f);
+        if (!have) vm = 0;
+    }
     R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
     const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
     R.emask = have ? (((R.sm ^ s0) & vm) & 0xFEu) : 0u;
@@ -200,35 +221,18 @@ __device__ __forceinline__ void cx_vround_front(const cx_params& P, const cx_fas
     for (uint32_t d = 1; d < 8; d++)
         if ((R.emask >> d) & 1u) slot[R.vpre + __popc(R.emask & ((1u << d) - 1u))] = (lane << 3) | d;
     __builtin_amdgcn_wave_barrier();
-    // sample loads of the first CX_VR x 64 vertices (all lanes stay active: the shuffles read any lane)
-#pragma unroll
-    for (uint32_t r = 0; r < CX_VR; r++) {
-        R.sl[r] = 0; R.e2[r] = 0; R.f0[r] = 0.0f; R.f1[r] = 1.0f;
-        if (64u * r >= R.vtot) continue;   // wave-uniform
-        const uint32_t o = 64u * r + lane;
-        R.sl[r] = slot[(o < R.vtot) ? o : 0u];
-        R.e2[r] = (uint32_t)__shfl((int)e, (int)(R.sl[r] >> 3));
-        const uint32_t d = R.sl[r] & 7u;
-        const uint32_t lin2 = cx_entry_lin(P, G, R.e2[r]);
-        if (P.flags & CX_DBG_NO_VLOADS) {
-            R.f0[r] = -1.0f; R.f1[r] = (float)lin2;
-        } else {
-            R.f0[r] = A[lin2];
-            R.f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
-        }
-    }
 }
 // the loads issued by the front half have to be complete here
 __device__ __forceinline__ void cx_vround_pin(cx_vround& R) {
 #pragma unroll
-    for (uint32_t r = 0; r < CX_VR; r++) asm volatile("" : "+v"(R.f0[r]), "+v"(R.f1[r]) :: "memory");
+    for (uint32_t c = 0; c < 8; c++) asm volatile("" : "+v"(R.f[c]) :: "memory");
     asm volatile("" : "+v"(R.e_next) :: "memory");
 }
 __device__ __forceinline__ float4 cx_vertex_record(const cx_params& P, const cx_fast_geom& G, uint32_t e2, uint32_t d, float f0, float f1) {
     uint32_t i2, j2, k2;
     cx_decode_entry(P, G, e2, i2, j2, k2);
     const uint32_t lin2 = (i2 * P.n1 + j2) * P.n2 + k2;
-    // same arithmetic as cx_emit_vertices; |f1 - f0| > 8e-8 here (both ends outside the screen)
+    // same arithmetic as cx_emit_vertices; |f1 - f0| > 1e-8 here (cx_k_stream keeps waves with flatter crossings off this path)
     const float t = __fdividef((P.vhi - f0) + P.vlo, f1 - f0);
     const float fi = (float)i2, fj = (float)j2, fk = (float)k2;
     float4 rec4;
@@ -239,16 +243,16 @@ __device__ __forceinline__ float4 cx_vertex_record(const cx_params& P, const cx_
     return rec4;
 }
 
-// vertex records, per-cell table entries and cell records of n queued cells, common case (no sample of
-// the streaming wave's region within the tolerance screen, so the corner signs decide everything): table
-// entries and cell records one lane per CELL, vertices one lane per VERTEX (two sample loads, one division,
-// one coalesced 16-byte store) -- no divergent per-direction loop.  Rounds of 64 cells are software-
-// pipelined: the sample loads of round s+1 are issued, and waited for, before the stores of round s go
+// vertex records, (first vertex, crossing mask) words and cell records of n queued cells, common case (no sample of
+// the streaming wave's region within the tolerance screen, or none that changes anything: the corner signs decide
+// everything): words and cell records one lane per CELL, vertices one lane per VERTEX (its two samples from the round's
+// corner table in LDS, one division, one coalesced 16-byte store) -- no divergent per-direction loop.  Rounds of 64 cells
+// are software-pipelined: the corner loads of round s+1 are issued, and waited for, before the stores of round s go
 // out (`s_waitcnt vmcnt` retires loads and stores in issue order: a load behind a store waits for it).
+// LDS per wave: two slot tables of 448 words (double buffered) and the corner table of 64 x CX_CORNER_ROW words.
 __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
-                                                   uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut) {
-    const float* __restrict__ A = P.grid;
-    const uint32_t plane = P.n1 * P.n2;
+                                                   uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut, uint64_t* info) {
+    float* corners = reinterpret_cast<float*>(slot2 + 2u * 448u);
     cx_vround Ra, Rb;
     uint32_t e0 = (lane < n) ? q[lane] : 0u;
     asm volatile("" : "+v"(e0) :: "memory");
@@ -262,11 +266,24 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             nb.v += Ra.vtot; nb.t += Ra.ttot; nb.c += Ra.ctot;
             cx_vround_front(P, G, q, n, b0 + 64u, lane, Ra.e_next, nb, slot2 + (par ^ 1u) * 448u, ntri_lut, Rb);
         }
-        // back half of round b0: interpolate what is loaded ...
+        // back half of round b0: the corner samples of the 64 cells go to LDS ...
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) corners[lane * CX_CORNER_ROW + c] = Ra.f[c];
+        __builtin_amdgcn_wave_barrier();
         const bool vroom = Ra.base.v + Ra.vtot <= P.vcap;   // wave-uniform
+        const uint32_t* slot = slot2 + par * 448u;
+        // ... the first CX_VR x 64 vertices are interpolated before the next round's loads are waited for ...
         float4 rec4[CX_VR];
 #pragma unroll
-        for (uint32_t r = 0; r < CX_VR; r++) rec4[r] = cx_vertex_record(P, G, Ra.e2[r], Ra.sl[r] & 7u, Ra.f0[r], Ra.f1[r]);
+        for (uint32_t r = 0; r < CX_VR; r++) {
+            rec4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (64u * r >= Ra.vtot) continue;   // wave-uniform
+            const uint32_t o = 64u * r + lane;
+            const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
+            const uint32_t cell = sl >> 3, d = sl & 7u;
+            const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
+            rec4[r] = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
+        }
         if (more) cx_vround_pin(Rb);
         // ... then the stores
         if (vroom) {
@@ -275,19 +292,17 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
                 const uint32_t o = 64u * r + lane;
                 if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec4[r]);
             }
-            const uint32_t* slot = slot2 + par * 448u;
             for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
                 const uint32_t o = o0 + lane;
                 const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
-                const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)(sl >> 3));
-                const uint32_t d = sl & 7u;
-                const uint32_t lin2 = cx_entry_lin(P, G, e2);
-                const float f0 = A[lin2];
-                const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
-                const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
+                const uint32_t cell = sl >> 3, d = sl & 7u;
+                const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
+                const float4 r4 = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
                 if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], r4);
             }
-            if (Ra.emask && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[Ra.lin] = ((uint64_t)Ra.emask << 32) | (uint64_t)(Ra.base.v + Ra.vpre);
+            // (first vertex, crossing mask) of every queued cell, one 8-byte word per queue entry: 512 contiguous bytes per round
+            // (was: scattered into a table of one entry per sample -- a cache line per cell, written and later gathered)
+            if (b0 + lane < n && !(P.flags & CX_DBG_NO_CELLTAB)) info[b0 + lane] = ((uint64_t)Ra.emask << 32) | (uint64_t)(Ra.base.v + Ra.vpre);
         }
         if ((Ra.emask | Ra.ntri) != 0u && Ra.base.c + Ra.ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
             uint4 c4;
@@ -537,8 +552,7 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
-    __shared__ uint32_t s_sw[4][CX_SWP][64];   // sign words of the wave's planes and ...
-    __shared__ uint32_t s_lp[4][CX_SWP][64];   // ... vertex prefixes of its active steps, copied out at the end
+    __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
     const uint32_t b = cx_task_of_block(T);
     if (b >= T.nblocks) return;
     const uint32_t lane = cx_lane_id();
@@ -558,7 +572,6 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the cells queued since the last batch record (b: all)
     uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
     uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
-    uint32_t vrun = 0;                     // wave-uniform: vertices of all cells queued so far
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         nbl = 0;
     };
     auto close_batch = [&]() {
-        const uint32_t bv = vrun - rv, bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
+        const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
         if (nbl == CX_SBR) flush_brec();
         if (lane == 0) {
             s_br[wave][nbl][0] = qstart; s_br[wave][nbl][1] = qn - qstart; s_br[wave][nbl][2] = rv;
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         }
         nbl++; nb++; rv += bv; rt += bt; rc += bc;
         qstart = qn;
-        acc.t = acc.c = 0;
+        acc.v = acc.t = acc.c = 0;
     };
     if (nrows != 0u && p < ib) {
         const uint32_t kofs = k0 + 4u * lane;
@@ -659,13 +672,10 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
         uint32_t wprev = plane_bits(rawB);
-        s_sw[wave][0][lane] = wprev;
         // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 2u, nxt);
             const uint32_t wcur = plane_bits(cur);
-            const uint32_t ps = p - G.pstart;          // plane step of this task (< CX_SWP - 1)
-            s_sw[wave][ps + 1u][lane] = wcur;
             // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
             const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
             const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
@@ -679,6 +689,9 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
                 uint32_t act = act0;
                 uint32_t pos = ql + pre;
                 const uint32_t ebase = (lane << 15) | ((p - G.pstart) << 21);
+                // where the lane's cells of this step sit in the wave's queue, and which they are (bit 4r+m): lets the
+                // fused emit kernel find the queue entry of ANY active cell of the volume without a table per sample
+                s_qa[wave][p - G.pstart][lane] = ((qn + pre) << 16) | (act0 & 0xFu) | ((act0 >> 2) & 0xF0u) | ((act0 >> 4) & 0xF00u) | ((act0 >> 6) & 0xF000u);
                 while (act) {
                     const uint32_t bit = __ffs(act) - 1u;
                     act &= act - 1u;
@@ -697,12 +710,7 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
                 uint32_t xw[8];
                 cx_cross_words(wprev, wcur, LM, mi, xw);
                 const uint32_t x1 = xw[1], x2 = xw[2], x3 = xw[3], x4 = xw[4], x5 = xw[5], x6 = xw[6], x7 = xw[7];
-                // vertices: the lane's count, and how many vertices of the wave precede the lane's first one -- the
-                // numbering the emit stages follow (queue order: plane, lane, bit), kept for the fused emit kernel
-                const uint32_t nvl = __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
-                const uint32_t vinc = cx_wave_incl_scan(nvl, lane);
-                s_lp[wave][ps][lane] = vrun + vinc - nvl;
-                vrun += (uint32_t)__builtin_amdgcn_readlane((int)vinc, 63);
+                acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
                 const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
                 acc.c += __popc(owners | (act0 & real));
                 acc.b += __popc(act0 & real);
@@ -737,37 +745,43 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
     if (qn > qstart) close_batch();
     flush_queue();
     flush_brec();
-    if (P.sw && nrows != 0u && p > G.pstart) {
-        // sign words of planes pstart .. pstart + nsteps and the vertex prefixes of the steps (garbage for steps without an
-        // active cell: nobody asks for those), for the fused emit kernel
+    if (P.qa && nrows != 0u && p > G.pstart) {
+        // the queue positions of the active steps (garbage for steps without an active cell: nobody asks for those)
         const uint32_t nsteps = p - G.pstart;
-        uint32_t* __restrict__ gsw = P.sw + (size_t)w * (CX_SWP * 64u);
-        uint32_t* __restrict__ glp = P.lp + (size_t)w * (CX_SWP * 64u);
+        uint32_t* __restrict__ gqa = P.qa + (size_t)w * (CX_SWP * 64u);
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t sidx = 0; sidx <= nsteps; sidx++) gsw[sidx * 64u + lane] = s_sw[wave][sidx][lane];
-        for (uint32_t sidx = 0; sidx < nsteps; sidx++) glp[sidx * 64u + lane] = s_lp[wave][sidx][lane];
+        for (uint32_t sidx = 0; sidx < nsteps; sidx++) gqa[sidx * 64u + lane] = s_qa[wave][sidx][lane];
     }
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
     cx_run run;
     run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
     const bool near = __ballot(dnear <= P.near_abs) != 0ULL && !(P.flags & CX_DBG_NO_NEAR);   // wave-uniform
+    bool really_near = false;
     if (near && qn != 0u) {
         // a sample inside the screen: the reference's tolerance rules may drop tetrahedra or vertices.
         // Count exactly (per-cell path over the wave's own queue; its stores are complete after the
         // fence) and hand the whole queue over as ONE batch that takes the per-cell path downstream.
         __threadfence();
-        run.v = run.t = run.c = run.b = 0;
-        cx_process_queue<false>(P, [&](uint32_t x) { return cx_entry_lin(P, G, __builtin_nontemporal_load(gq + x)); }, qn, lane, false, run, nullptr);
-        nb = 1;
-        if (lane == 0) {
-            cx_brec R;
-            R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
-            brec[0] = R;
+        cx_run ex = {0, 0, 0, 0, 0};
+        cx_process_queue<false>(P, [&](uint32_t x) { return cx_entry_lin(P, G, __builtin_nontemporal_load(gq + x)); }, qn, lane, false, ex, nullptr);
+        // The tolerance rules only ever REMOVE crossings and triangles from what the signs give.  Equal totals therefore
+        // mean equal masks in every cell: the wave stays on the common path (its batches, its numbering), only the border
+        // voxel count is the exact one.  Otherwise: ONE batch that takes the per-cell path downstream.
+        really_near = !(ex.v == rv && ex.t == rt && ex.c == rc && ex.s == 0u);
+        run.b = ex.b;
+        if (really_near) {
+            run.v = ex.v; run.t = ex.t; run.c = ex.c;
+            nb = 1;
+            if (lane == 0) {
+                cx_brec R;
+                R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
+                brec[0] = R;
+            }
         }
     }
     if (lane == 0) {
         cx_wsum S;
-        S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = near ? 1u : 0u; S.pad = 0;
+        S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = really_near ? 1u : 0u; S.pad = 0;
         P.wsum[w] = S;
     }
 }
@@ -860,12 +874,83 @@ __global__ __launch_bounds__(256) void cx_k_list_batches(const cx_params P, cons
     }
 }
 
+// ---- S2 in one launch: workgroup g owns the streaming waves [256 g, 256 g + 256).  It sums the totals of ALL waves before its
+// chunk itself (every thread reads one wave of each earlier chunk: g x 8 KB per workgroup out of L2 -- no partial sums to
+// wait for, no second kernel, no atomics), scans its own 256 waves, and writes their output offsets and batch descriptors;
+// the last workgroup, which has seen every wave, writes the counters.  (One workgroup scanning all 12 k waves of a 512^3
+// grid was bound by what a single CU can pull: 22 us + 5 us for the list kernel.)
+__global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {
+    __shared__ uint32_t s_part[4][6];    // per wave of the workgroup: totals of the earlier chunks (5) + near flag
+    __shared__ uint32_t s_own[4][5];     // per wave: inclusive totals of its 64 streaming waves
+    const uint32_t tid = threadIdx.x, lane = cx_lane_id(), wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    uint32_t acc[5] = {0, 0, 0, 0, 0}, near_any = 0;   // v, t, c, b, nb
+    for (uint32_t c0 = 0; c0 < g; c0 += 8u) {            // 8 independent loads in flight per thread
+        cx_wsum E[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            E[u].nb = E[u].v = E[u].t = E[u].c = E[u].b = E[u].nq = E[u].near = 0;
+            if (c0 + u < g) E[u] = P.wsum[(c0 + u) * 256u + tid];      // chunks before the last one are full
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            acc[0] += E[u].v; acc[1] += E[u].t; acc[2] += E[u].c; acc[3] += E[u].b; acc[4] += E[u].nb;
+            near_any |= (E[u].near != 0u && E[u].nq != 0u) ? 1u : 0u;
+        }
+    }
+    const uint32_t w = g * 256u + tid;
+    cx_wsum S;
+    S.nb = S.v = S.t = S.c = S.b = S.nq = S.near = 0;
+    if (w < nw) S = P.wsum[w];
+    near_any |= (S.near != 0u && S.nq != 0u) ? 1u : 0u;
+    const uint32_t x[5] = {S.v, S.t, S.c, S.b, S.nb};
+    uint32_t inc[5];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        inc[m] = cx_wave_incl_scan(x[m], lane);
+        const uint32_t before = cx_wave_sum(acc[m]);
+        if (lane == 63u) { s_own[wave][m] = inc[m]; s_part[wave][m] = before; }
+    }
+    {
+        const uint32_t nr = (__ballot(near_any != 0u) != 0ULL) ? 1u : 0u;
+        if (lane == 63u) s_part[wave][5] = nr;
+    }
+    __syncthreads();
+    uint32_t ex[5];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        uint32_t base = s_part[0][m] + s_part[1][m] + s_part[2][m] + s_part[3][m];
+        for (uint32_t ww = 0; ww < wave; ww++) base += s_own[ww][m];
+        ex[m] = base + inc[m] - x[m];
+    }
+    if (w < nw) {
+        cx_wbase B;
+        B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
+        P.wbase[w] = B;
+        // the flat batch list: self-contained descriptors
+        for (uint32_t i = 0; i < S.nb; i++) {
+            if (ex[4] + i >= P.fcap) break;
+            const cx_brec R = P.brec[(size_t)w * T.bcap + i];
+            cx_bdesc D;
+            D.w = w; D.qofs = w * T.wcap + R.qoff; D.n = R.n; D.near = R.near;
+            D.vbase = ex[0] + R.vpre; D.tbase = ex[1] + R.tpre; D.cbase = ex[2] + R.cpre; D.pad = 0;
+            P.flat[ex[4] + i] = D;
+        }
+    }
+    if (g == gridDim.x - 1u && tid == 255u) {   // this thread's inclusive totals are the grand totals
+        P.counters[CX_CNT_VERTS] = ex[0] + x[0]; P.counters[CX_CNT_TRIS] = ex[1] + x[1];
+        P.counters[CX_CNT_CELLS] = ex[2] + x[2]; P.counters[CX_CNT_BORDER] = ex[3] + x[3];
+        P.counters[CX_CNT_BATCHES] = ex[4] + x[4];
+        P.counters[CX_CNT_NEAR] = (s_part[0][5] | s_part[1][5] | s_part[2][5] | s_part[3][5]) ? 1u : 0u;
+    }
+}
+
 // ---- S3: vertex records, per-cell table entries and cell records; one wave per batch, grid-stride
 #ifndef CX_S3_MIN_WAVES
 #define CX_S3_MIN_WAVES 1
 #endif
 __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
-    __shared__ float4 s_vstage[4][CX_VSTAGE];
+    __shared__ float4 s_vstage[4][CX_VSTAGE_LDS];
     __shared__ uint8_t s_ntri[256];
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
     __syncthreads();
@@ -886,8 +971,9 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
         const uint32_t* __restrict__ q = P.queue + D.qofs;
         cx_run run;
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
-        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri);
-        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave]);
+        uint64_t* __restrict__ info = P.info64 + D.qofs;
+        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
+        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave], info);
         if (fn >= nbatches) break;
         f = fn;
         D = Dn;
@@ -936,6 +1022,16 @@ __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
     return s2 < s1;
 }
 
+// The same decision from one byte per lattice point (cx_k_hash_bytes, built once per grid shape and origin): bits 0-2 = slot
+// of hash((i,j,k)) in an 8-slot table, bits 3-5 = the first slot of its probe sequence that differs from it (what it takes
+// when another element sits in its slot; the same slot again if 16 probes never leave it).
+// py_set2_swapped(h1, h2) == (t2 != s1 ? t2 < s1 : alt2 < s1): the loop above stops at the first probe of h2 that differs
+// from s1 == t2.  Second element iterates first?  (set built by inserting a then b)
+__device__ __forceinline__ bool cx_set2_swapped(uint32_t ca, uint32_t cb) {
+    const uint32_t sa = ca & 7u, tb = cb & 7u, ab = (cb >> 3) & 7u;
+    return ((tb != sa) ? tb : ab) < sa;
+}
+
 // tet vertex m of tet t -> cube corner, as compile-time constants (same data as cx_d_tet_corners)
 __device__ constexpr uint8_t CX_TC[6][4] = CX_TET_CORNERS_INIT;
 #define CX_TC_MASK(t) ((1u << CX_TC[t][0]) | (1u << CX_TC[t][1]) | (1u << CX_TC[t][2]) | (1u << CX_TC[t][3]))
@@ -966,8 +1062,9 @@ struct cx_tri_lds {
 struct cx_tri_in {
     uint4 rec;            // cell record (zero: no record)
     uint2 nb[6];          // table entries (first vertex, crossing mask) of corners 1..6
-    uint64_t hxy[4];      // CPython hash prefixes of the 4 (i,j) columns of the voxel (CX_DIAG_CPYTHON310)
+    uint64_t hxy[4];      // CPython hash prefixes of the 4 (i,j) columns of the voxel (CX_DIAG_CPYTHON310 without P.hbytes)
     uint32_t ck;          // k of the cell
+    uint32_t hb[4];       // set-order codes of the 8 corners, (k, k+1) pairs of the 4 (i,j) columns (P.hbytes)
 };
 __device__ __forceinline__ uint32_t cx_need_hash(uint32_t sm, uint32_t tetskip, uint32_t ntri) {
     uint32_t need = 0;   // corners whose hash decides a quad diagonal
@@ -1001,7 +1098,16 @@ __device__ __forceinline__ void cx_tri_fetch(const cx_params& P, const uint64_t*
     }
     I.ck = 0;
     I.hxy[0] = I.hxy[1] = I.hxy[2] = I.hxy[3] = 0;
-    if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(sm, tetskip, ntri) != 0u) {
+    I.hb[0] = I.hb[1] = I.hb[2] = I.hb[3] = 0;
+    if (P.hbytes) {
+        if (cx_need_hash(sm, tetskip, ntri) != 0u) {   // only voxels: all 8 corners are inside the array
+            const uint8_t* __restrict__ hb = P.hbytes + lin;
+            uint16_t t0, t1, t2, t3;
+            __builtin_memcpy(&t0, hb, 2); __builtin_memcpy(&t1, hb + P.n2, 2);
+            __builtin_memcpy(&t2, hb + plane, 2); __builtin_memcpy(&t3, hb + plane + P.n2, 2);
+            I.hb[0] = t0; I.hb[1] = t1; I.hb[2] = t2; I.hb[3] = t3;
+        }
+    } else if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(sm, tetskip, ntri) != 0u) {
         const uint32_t ci = cx_div(lin, P.div_plane);
         const uint32_t r = lin - ci * plane;
         const uint32_t cj = cx_div(r, P.div_row);
@@ -1018,6 +1124,7 @@ __device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
     asm volatile("" : "+v"(I.nb[0].x), "+v"(I.nb[0].y), "+v"(I.nb[1].x), "+v"(I.nb[1].y), "+v"(I.nb[2].x), "+v"(I.nb[2].y) :: "memory");
     asm volatile("" : "+v"(I.nb[3].x), "+v"(I.nb[3].y), "+v"(I.nb[4].x), "+v"(I.nb[4].y), "+v"(I.nb[5].x), "+v"(I.nb[5].y) :: "memory");
     asm volatile("" : "+v"(I.hxy[0]), "+v"(I.hxy[1]), "+v"(I.hxy[2]), "+v"(I.hxy[3]), "+v"(I.ck) :: "memory");
+    asm volatile("" : "+v"(I.hb[0]), "+v"(I.hb[1]), "+v"(I.hb[2]), "+v"(I.hb[3]) :: "memory");
 }
 
 // phase 1 of one record per lane: LDS tables and slot words; returns the wave's triangle count
@@ -1031,7 +1138,25 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
     for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u];
     // quad diagonal variants of the 2-2 tetrahedra (bit t of `variants`)
     uint32_t variants = 0;
-    if (P.flags & CX_DIAG_CPYTHON310) {
+    if (P.hbytes) {
+        // code of corner c = byte (c & 1) of column c >> 1
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+            if (__popc(pat) != 2) continue;
+            uint32_t l0 = 0, l1 = 0, h0 = 0, h1 = 0;
+            int nl = 0, nh = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t cc = CX_TC[t][m];
+                const uint32_t code = (I.hb[cc >> 1] >> (8u * (cc & 1u))) & 0xFFu;
+                if ((pat >> m) & 1u) { if (nl == 0) l0 = code; else l1 = code; nl++; }
+                else { if (nh == 0) h0 = code; else h1 = code; nh++; }
+            }
+            if (cx_set2_swapped(l0, l1) != cx_set2_swapped(h0, h1)) variants |= 1u << t;
+        }
+    } else if (P.flags & CX_DIAG_CPYTHON310) {
         const uint32_t need = cx_need_hash(sm, tetskip, ntri);
         if (__ballot(need != 0u) != 0ULL) {
             uint64_t h[8];
@@ -1162,27 +1287,179 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
 }
 
 // =================================================================================================
+// K2 for the staged pipeline: the same triangle stage, but the (first vertex, crossing mask) pairs of the neighbour cells come
+// from the vertex stage's word per QUEUE ENTRY (P.info64) instead of a table of one entry per sample.  The queue entry of
+// any active lattice cell Y is found by arithmetic: the stream kernel left, per plane step and streaming lane, the queue
+// position of the lane's first active cell and the 16-bit set of its active cells (P.qa), so
+//     entry(Y) = wave(Y) * wcap + (qa >> 16) + popc(qa & cells below Y).
+// Both tables are dense where they are used: a round of 64 records touches a few cache lines per lookup instead of one per
+// cell and neighbour (the vector L1 handles about one line per 3-4 cycles per CU whatever the bytes asked for: these kernels
+// are bound by the NUMBER of lines their gathers and scatters touch, not by bytes -- DESIGN.md section 4).
+// Three records are in flight per lane: record s+2 has its queue words requested, record s+1 its info words, record s is
+// expanded and stored.
+// =================================================================================================
+static_assert(CX_RJ == 4, "the wave / row arithmetic below assumes 4 rows per streaming wave");
+struct cx_tri_qa {          // a record between its first stage (queue words requested) and its second
+    uint4 rec;
+    uint32_t qa[6];         // per neighbour: (queue position of the lane's first cell << 16) | active cells below the neighbour
+    uint32_t nbw, w;        // 3 bits per neighbour (next k | next j << 1 | next chunk << 2), bit 18 + c: wanted; streaming wave of the cell
+    uint32_t ci, cj, ck;    // lattice point of the cell
+};
+__device__ __forceinline__ uint32_t cx_wave_of_neighbour(const cx_task& T, uint32_t w, uint32_t wsel) {
+    uint32_t wY = w;
+    if (wsel & 1u) wY += 4u;                                              // next block in k
+    if (wsel & 2u) wY += ((w & 3u) == 3u) ? (4u * T.nks - 3u) : 1u;       // next wave / next block in j
+    if (wsel & 4u) wY += 4u * T.nks * T.njg;                              // next chunk of planes
+    return wY;
+}
+__device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const uint64_t* __restrict__ hash_xy, const uint4& rec,
+                                               cx_tri_qa& A) {
+    const uint32_t plane = P.n1 * P.n2;
+    A.rec = rec;
+    const uint32_t lin = rec.x, sm = rec.y & 0xFFu, tetskip = (rec.y >> 8) & 0x3Fu, ntri = (rec.y >> 16) & 0xFFu;
+    const uint32_t ci = cx_div(lin, P.div_plane);
+    const uint32_t rem = lin - ci * plane;
+    const uint32_t cj = cx_div(rem, P.div_row);
+    const uint32_t ck = rem - cj * P.n2;
+    // where the cell sits in the streaming layout
+    const uint32_t ic = cx_div(ci, P.div_ci);
+    const uint32_t ps = ci - ic * T.ci;
+    const uint32_t nsteps = min(T.ci, P.n0 - ic * T.ci);
+    const uint32_t rr = cj & 3u, ls = (ck >> 2) & 63u, mm = ck & 3u;
+    A.w = 4u * ((ck >> 8) + T.nks * ((cj >> 4) + T.njg * ic)) + ((cj >> 2) & 3u);
+    const uint32_t m3 = (mm == 3u) ? 1u : 0u, r3 = (rr == 3u) ? 1u : 0u, pl = (ps + 1u == nsteps) ? 1u : 0u;
+    const uint32_t kfl = m3 & ((ls == 63u) ? 1u : 0u);
+    const uint32_t lane_k[2] = {ls, m3 ? ((ls + 1u) & 63u) : ls};
+    const uint32_t cm[2] = {mm, (mm + 1u) & 3u};
+    const uint32_t cr[2] = {4u * rr, 4u * ((rr + 1u) & 3u)};
+    const uint32_t pofs[2] = {ps << 6, pl ? 0u : ((ps + 1u) << 6)};
+    A.nbw = 0;
+#pragma unroll
+    for (uint32_t c = 1; c < 7; c++) {
+        const uint32_t dk = c & 1u, dj = (c >> 1) & 1u, di = c >> 2;
+        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
+        uint32_t sup = 0;
+#pragma unroll
+        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
+        A.qa[c - 1u] = 0;
+        if (ntri && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
+            const uint32_t wsel = (dk ? kfl : 0u) | ((dj ? r3 : 0u) << 1) | ((di ? pl : 0u) << 2);
+            const uint32_t wY = cx_wave_of_neighbour(T, A.w, wsel);
+            const uint32_t qa = P.qa[(size_t)wY * (CX_SWP * 64u) + pofs[di] + lane_k[dk]];
+            A.qa[c - 1u] = (qa & 0xFFFF0000u) | (qa & ((1u << (cr[dj] + cm[dk])) - 1u));
+            A.nbw |= (wsel << (3u * (c - 1u))) | (1u << (18u + c));
+        }
+    }
+    A.ci = ci; A.cj = cj; A.ck = ck;
+    (void)hash_xy; (void)tetskip;
+}
+__device__ __forceinline__ void cx_triq_pin1(cx_tri_qa& A, uint4& nxt) {
+    asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) :: "memory");
+    asm volatile("" : "+v"(A.qa[0]), "+v"(A.qa[1]), "+v"(A.qa[2]), "+v"(A.qa[3]), "+v"(A.qa[4]), "+v"(A.qa[5]) :: "memory");
+}
+__device__ __forceinline__ void cx_triq_stage2(const cx_params& P, const cx_task& T, const uint64_t* __restrict__ hash_xy, const cx_tri_qa& A,
+                                               cx_tri_in& I) {
+    I.rec = A.rec;
+#pragma unroll
+    for (uint32_t c = 0; c < 6; c++) {
+        uint2 pr = make_uint2(0u, 0u);
+        if ((A.nbw >> (19u + c)) & 1u) {
+            const uint32_t wY = cx_wave_of_neighbour(T, A.w, (A.nbw >> (3u * c)) & 7u);
+            const uint32_t qa = A.qa[c];
+            const uint64_t e = P.info64[(size_t)wY * T.wcap + (qa >> 16) + __popc(qa & 0xFFFFu)];
+            pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+        }
+        I.nb[c] = pr;
+    }
+    I.ck = A.ck;
+    I.hb[0] = I.hb[1] = I.hb[2] = I.hb[3] = 0;
+    I.hxy[0] = I.hxy[1] = I.hxy[2] = I.hxy[3] = 0;
+    const uint32_t sm = A.rec.y & 0xFFu, tetskip = (A.rec.y >> 8) & 0x3Fu, ntri = (A.rec.y >> 16) & 0xFFu;
+    if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(sm, tetskip, ntri) != 0u) {
+        // only voxels get here (cj + 1 < n1, ci + 1 < n0): the prefixes of columns (i, j), (i, j+1) are neighbours in the
+        // table, ONE 16-byte load per plane (8-byte aligned)
+        struct __attribute__((packed, aligned(8))) u64x2 { uint64_t a, b; };
+        const u64x2 p0 = *reinterpret_cast<const u64x2*>(hash_xy + (A.ci * P.n1 + A.cj));
+        const u64x2 p1 = *reinterpret_cast<const u64x2*>(hash_xy + ((A.ci + 1u) * P.n1 + A.cj));
+        I.hxy[0] = p0.a; I.hxy[1] = p0.b; I.hxy[2] = p1.a; I.hxy[3] = p1.b;
+    }
+}
+__device__ __forceinline__ void cx_triq_pin2(cx_tri_in& I) {
+    asm volatile("" : "+v"(I.hxy[0]), "+v"(I.hxy[1]), "+v"(I.hxy[2]), "+v"(I.hxy[3]) :: "memory");
+    asm volatile("" : "+v"(I.nb[0].x), "+v"(I.nb[0].y), "+v"(I.nb[1].x), "+v"(I.nb[1].y), "+v"(I.nb[2].x), "+v"(I.nb[2].y) :: "memory");
+    asm volatile("" : "+v"(I.nb[3].x), "+v"(I.nb[3].y), "+v"(I.nb[4].x), "+v"(I.nb[4].y), "+v"(I.nb[5].x), "+v"(I.nb[5].y) :: "memory");
+}
+#ifndef CX_K2Q_MIN_WAVES
+#define CX_K2Q_MIN_WAVES 5   // 96 registers: one more wave per SIMD than the allocator takes on its own (98)
+#endif
+template <bool NEG_ORIGIN>
+__global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(const cx_params P, const cx_task T, const uint64_t* __restrict__ hash_xy) {
+    __shared__ cx_tri_lds L;
+    const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
+    if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
+    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    __syncthreads();
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    auto record = [&](uint32_t at) { return (at < ncells) ? cx_load_record(P.cells + at) : zero; };
+    // prologue: record idx through both stages, record idx + stride through the first, record idx + 2 stride loaded
+    cx_tri_qa Ab, Ac;
+    cx_tri_in Ia, Ib;
+    uint4 rec_c = record(idx + 2u * stride);
+    {
+        uint4 r0 = record(idx), r1 = record(idx + stride);
+        asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w) :: "memory");
+        cx_triq_stage1(P, T, hash_xy, r0, Ac);
+        cx_triq_stage1(P, T, hash_xy, r1, Ab);
+        cx_triq_pin1(Ac, rec_c);
+        cx_triq_pin1(Ab, rec_c);
+        cx_triq_stage2(P, T, hash_xy, Ac, Ia);
+        cx_triq_pin2(Ia);
+    }
+    while (idx - lane < ncells) {   // wave-uniform
+        const uint32_t nidx = idx + stride;
+        uint4 rec_d = record(nidx + 2u * stride);          // the record three steps ahead
+        cx_triq_stage1(P, T, hash_xy, rec_c, Ac);           // queue words of the record two steps ahead
+        cx_triq_stage2(P, T, hash_xy, Ab, Ib);              // info words (and hash prefixes) of the next record
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
+        cx_triq_pin1(Ac, rec_d);                            // ... all back before the stores go out
+        cx_triq_pin2(Ib);
+        cx_tri_phase2(P, L, lane, wave, ttot);
+        Ia = Ib;
+        Ab = Ac;
+        rec_c = rec_d;
+        idx = nidx;
+    }
+}
+
+// =================================================================================================
 // Fused emit: vertex records AND triangles of a batch in ONE pass over its queue entries.
 //
 // The staged kernels above hand vertex indices from the vertex stage to the triangle stage through memory: a sparse
 // 8-byte table entry per vertex-owning cell (scattered into a table of one entry per SAMPLE) plus a 16-byte record per
-// active cell, and the triangle stage gathers up to six table entries per cell.  Here nothing is handed over: the
-// index of the first vertex of ANY lattice cell Y follows from what the stream kernel left behind,
-//     first(Y) = wbase[wave of Y].v + lp[wave][plane step][lane of Y] + (vertices of the cells below Y in its lane),
-// the last term and Y's crossing mask being popcounts on the two packed sign words of that lane (cx_cross_words, the
-// very function the stream kernel counted with).  The six neighbour cells of a voxel that can own one of its edges
-// live in the same lane word, the next lane, the next wave (rows) or the next task (planes): cx_nb_locate.
-// One wave per batch; rounds of 64 cells, software-pipelined like the vertex stage: everything round s+1 loads is
-// issued -- and waited for -- before the stores of round s go out.
+// active cell, and the triangle stage gathers up to six table entries per cell.  Here the hand-over is dense: a small
+// kernel (cx_k_cell_info) writes ONE u32 per queue entry -- first vertex of the cell relative to its streaming wave and
+// its crossing mask -- and the queue entry of ANY active lattice cell Y is found by arithmetic: the stream kernel left,
+// per plane step and streaming lane, the queue position of the lane's first active cell and the 16-bit set of its active
+// cells (P.qa), so position(Y) = qa >> 16 + popc(active cells below Y).  The six neighbour cells of a voxel that can own
+// one of its edges live in the same lane word, the next lane, the next wave (rows) or the next task (planes):
+// cx_nb_locate.  One wave per batch; rounds of 64 cells, software-pipelined like the vertex stage: everything round s+1
+// loads is issued -- and waited for -- before the stores of round s go out.
+// The CPython-order quad diagonals come from a byte per lattice point (cx_k_hash_bytes, built once per grid shape):
+// the slot the point's tuple hash takes in an 8-slot set and the slot it moves to when that one is taken, which is all
+// a two-element set's iteration order depends on.
 // Only for extractions without a wave on the tolerance path (counters[CX_CNT_NEAR] == 0): there the reference's
-// np.allclose rules drop vertices and the numbering no longer follows from the signs (the host then runs the staged
-// kernels instead).
+// np.allclose rules drop vertices and triangles per cell (the host then runs the staged kernels instead).
 // =================================================================================================
 struct cx_geomx {          // wave-uniform: the streaming wave tile a batch belongs to
-    uint32_t w, wave, k0, j0, pstart, nsteps;
+    uint32_t w, wave, nsteps;
 };
-// where cell X + c lives, X = (plane step ps, streaming lane ls, row r, sample m) of tile GX:
-// bits 0-5 lane, 6-10 bit in the lane word, 11 next k segment, 12 next row group, 13-19 plane step, 20 next plane chunk
+// where cell X + c lives, X = (plane step ps, streaming lane ls, row r, sample m) of the tile:
+// bits 0-5 lane, 6-9 cell in the lane (4r+m), 11 next k segment, 12 next row group, 13-19 plane step, 20 next plane chunk
 __device__ __forceinline__ uint32_t cx_nb_locate(const cx_geomx& GX, uint32_t ps, uint32_t ls, uint32_t r, uint32_t m, uint32_t c) {
     uint32_t mY = m + (c & 1u), rY = r + ((c >> 1) & 1u), psY = ps + (c >> 2), laneY = ls;
     uint32_t kf = 0, jf = 0, pf = 0;
@@ -1192,7 +1469,7 @@ __device__ __forceinline__ uint32_t cx_nb_locate(const cx_geomx& GX, uint32_t ps
     }
     if (rY == (uint32_t)CX_RJ) { rY = 0; jf = 1; }
     if (psY == GX.nsteps) { psY = 0; pf = 1; }
-    return laneY | ((CX_ROWBITS * rY + mY) << 6) | (kf << 11) | (jf << 12) | (psY << 13) | (pf << 20);
+    return laneY | ((4u * rY + mY) << 6) | (kf << 11) | (jf << 12) | (psY << 13) | (pf << 20);
 }
 // streaming wave that holds the cell of a location word
 __device__ __forceinline__ uint32_t cx_nb_wave(const cx_geomx& GX, const cx_task& T, uint32_t loc) {
@@ -1202,67 +1479,166 @@ __device__ __forceinline__ uint32_t cx_nb_wave(const cx_geomx& GX, const cx_task
     if ((loc >> 20) & 1u) wY += 4u * T.nks * T.njg;                              // next chunk of planes
     return wY;
 }
-// (first vertex index, crossing mask) of the cell at `loc` from its lane's prefix and sign words
-__device__ __forceinline__ uint2 cx_nb_finish(const cx_params& P, const cx_task& T, const cx_geomx& GX, uint32_t loc, uint32_t vb,
-                                              uint32_t lpv, uint32_t A, uint32_t B) {
-    const uint32_t laneY = loc & 63u, bitY = (loc >> 6) & 31u;
-    const uint32_t k0Y = GX.k0 + (((loc >> 11) & 1u) ? 256u : 0u);
-    const uint32_t j0Y = GX.j0 + (((loc >> 12) & 1u) ? (uint32_t)CX_RJ : 0u);
-    const uint32_t pabs = GX.pstart + (((loc >> 20) & 1u) ? T.ci : 0u) + ((loc >> 13) & 127u);
-    const cx_lmasks M = cx_lane_masks(P, k0Y, j0Y, laneY);
-    const uint32_t mi = (pabs + 1u < P.n0) ? M.mr : 0u;
-    uint32_t x[8];
-    cx_cross_words(A, B, M, mi, x);
-    const uint32_t below = (1u << bitY) - 1u;
-    uint32_t cnt = 0, em = 0;
-#pragma unroll
-    for (uint32_t d = 1; d < 8; d++) {
-        cnt += __popc(x[d] & below);
-        em |= ((x[d] >> bitY) & 1u) << d;
+
+// ---- per queue entry: first vertex of the cell relative to its wave's first vertex (24 bits) | crossing mask >> 1 << 24
+__global__ __launch_bounds__(256) void cx_k_cell_info(const cx_params P, const cx_task T) {
+    if (P.counters[CX_CNT_NEAR] != 0u) return;
+    const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t stride = gridDim.x * 4u;
+    for (uint32_t f = blockIdx.x * 4u + wave; f < nbatches; f += stride) {
+        const cx_bdesc D = P.flat[f];
+        const cx_tile tile = cx_tile_of(P, T, D.w >> 2, D.w & 3u);
+        cx_fast_geom G;
+        G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
+        const uint32_t* __restrict__ q = P.queue + D.qofs;
+        uint32_t* __restrict__ info = P.info + D.qofs;
+        uint32_t vrel = D.vbase - P.wbase[D.w].v;
+        for (uint32_t b0 = 0; b0 < D.n; b0 += 64u) {
+            const uint32_t idx = b0 + lane;
+            const bool have = idx < D.n;
+            const uint32_t e = have ? q[idx] : 0u;
+            uint32_t i, j, k;
+            cx_decode_entry(P, G, e, i, j, k);
+            const uint32_t sm = cx_entry_signs(e);
+            const uint32_t vm = cx_corner_valid(P, i, j, k);
+            const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+            const uint32_t emask = have ? (((sm ^ s0) & vm) & 0xFEu) : 0u;
+            uint32_t vtot;
+            const uint32_t vpre = cx_wave_prefix_small<3>(__popc(emask), vtot);
+            if (have) info[idx] = (vrel + vpre) | (emask << 23);
+            vrel += vtot;
+        }
     }
-    return make_uint2(vb + lpv + cnt, em);
+}
+
+// ---- CPython 3.10 set order of a lattice point, one byte: bits 0-2 = slot of hash((i,j,k)) in an 8-slot table, bits 3-5 =
+// the first slot of its probe sequence that differs from it (what it takes when another element sits in its slot; the same
+// slot again if 16 probes never leave it).  py_set2_swapped(h1, h2) == (t2 != s1 ? t2 < s1 : alt2 < s1) with s = slot(h1),
+// t2 = slot(h2), alt2 = alternative of h2: the loop there stops at the first probe of h2 that differs from s1 == t2.
+__global__ void cx_k_hash_bytes(uint8_t* __restrict__ table, const uint64_t* __restrict__ hash_xy, uint32_t nrows, uint32_t n2, int32_t org2) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t row = idx / n2;
+    if (row >= nrows) return;
+    const uint32_t k = idx - row * n2;
+    const uint64_t h = py_finish3(py_round_signed(hash_xy[row], (int32_t)k + org2));
+    const uint32_t s0 = (uint32_t)h & 7u;
+    uint32_t s = s0;
+    uint64_t perturb = h;
+    for (int guard = 0; guard < 16 && s == s0; guard++) {
+        perturb >>= 5;
+        s = (uint32_t)((s * 5u + 1u + perturb) & 7u);
+    }
+    table[idx] = (uint8_t)(s0 | (s << 3));
 }
 
 struct cx_mesh_lds {
     cx_tri_lds tri;                // triangle stage tables (per wave) + the LUT
     uint32_t vslot[4][2][448];     // per wave, double buffered: vertex o of a round -> (cell lane << 3) | direction
     uint32_t vbt[4][8];            // per wave: wbase[].v of the 8 waves a neighbour cell can live in
+    uint32_t qbt[4][8];            // per wave: first queue entry of those waves
+    uint32_t qab[4][8];            // per wave: offset of their plane-step tables in P.qa
     uint8_t ntri[256];
 };
-// one round of 64 queued cells between its front half (decode, prefix sums, slot table, every load issued) and its
-// back half (interpolation, neighbour indices, triangle expansion, stores)
+// A round of 64 queued cells passes three stages, one per loop iteration of the wave:
+//   stage 1 (round s+2)  decode, locate the neighbour cells, request the queue words of their lanes
+//   stage 2 (round s+1)  queue words -> queue positions -> request the info words; prefix sums, vertex slot table, sample
+//                        loads, set-order codes
+//   stage 3 (round s)    interpolation, triangle expansion, stores
+// Everything an iteration loads is waited for ONCE, after the arithmetic of stage 3 and before its stores (`s_waitcnt
+// vmcnt` retires loads and stores in issue order, and the number of stores varies: a load waited for behind them would
+// wait for all of them).
+struct cx_mstage1 {
+    uint32_t e, e_next;
+    uint32_t nb[6];            // neighbour cells X + c, c = 1..6: (queue position of the lane's first cell << 16) | active cells below Y
+    uint32_t nbw;              // 3 bits per neighbour: which of the 8 candidate waves; bit 18+c: neighbour c is wanted
+};
 struct cx_mround {
-    uint32_t e, e_next, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, real_voxel, ck;
-    cx_run base;
+    uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot;
+    uint32_t vbase, tbase;
     uint32_t e2[CX_VR], sl[CX_VR];
     float f0[CX_VR], f1[CX_VR];
-    uint32_t loc[6], nlp[6], nA[6], nB[6];   // neighbour cells X + c, c = 1..6: location, lane prefix, sign words
-    uint64_t hxy[4];
+    uint32_t nb[6];            // info words of the neighbour cells
+    uint32_t nbw;
+    uint32_t hb[4];            // set-order codes of the 8 corners, (k, k+1) pairs of the 4 (i,j) columns
 };
-__device__ __forceinline__ void cx_mround_front(const cx_params& P, const cx_task& T, const cx_fast_geom& G, const cx_geomx& GX,
-                                                const uint64_t* __restrict__ hash_xy, const uint32_t* q, uint32_t n, uint32_t b0,
-                                                uint32_t lane, uint32_t e, const cx_run& base, uint32_t* slot, const uint8_t* ntri_lut,
-                                                cx_mround& R) {
+__device__ __forceinline__ void cx_mesh_stage1(const cx_params& P, const cx_task& T, const cx_fast_geom& G, const cx_geomx& GX,
+                                               const uint32_t* q, uint32_t n, uint32_t b0, uint32_t lane, uint32_t e,
+                                               const uint8_t* ntri_lut, const uint32_t* qab, cx_mstage1& S) {
+    const uint32_t idx = b0 + lane;
+    const bool have = idx < n;
+    S.e = e;
+    S.e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+    uint32_t i, j, k;
+    cx_decode_entry(P, G, e, i, j, k);
+    const uint32_t sm = cx_entry_signs(e);
+    const bool voxel = have && cx_corner_valid(P, i, j, k) == 0xFFu && ntri_lut[sm] != 0;   // emits triangles
+    // the neighbour cells that own a crossing edge of this voxel: the queue word of their lane.  X + c sits in the same
+    // lane word unless X is in the last sample column (m == 3: next lane, or lane 0 of the next k segment), the last row
+    // (r == 3: next wave) or the last plane step (next task); `qab` holds the table offsets of the 8 waves that can be.
+    const uint32_t ps = (e >> 21) & 127u, ls = (e >> 15) & 63u, bit = (e >> 10) & 31u;
+    const uint32_t rr = (bit * 11u) >> 6, mm = bit - CX_ROWBITS * rr;
+    const uint32_t m3 = (mm == 3u) ? 1u : 0u, r3 = (rr == (uint32_t)CX_RJ - 1u) ? 1u : 0u, pl = (ps + 1u == GX.nsteps) ? 1u : 0u;
+    const uint32_t kfl = m3 & ((ls == 63u) ? 1u : 0u);
+    const uint32_t lane_k[2] = {ls, m3 ? ((ls + 1u) & 63u) : ls};              // lane of X + dk
+    const uint32_t cm[2] = {mm, (mm + 1u) & 3u};                               // sample column of X + dk
+    const uint32_t cr[2] = {4u * rr, 4u * ((rr + 1u) & 3u)};                   // 4 * row of X + dj
+    const uint32_t pofs[2] = {ps << 6, pl ? 0u : ((ps + 1u) << 6)};            // plane step of X + di, times 64
+    S.nbw = 0;
+#pragma unroll
+    for (uint32_t c = 1; c < 7; c++) {
+        const uint32_t dk = c & 1u, dj = (c >> 1) & 1u, di = c >> 2;
+        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
+        uint32_t sup = 0;   // corners that are strict supersets of c: the far ends of the voxel edges corner c owns
+#pragma unroll
+        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
+        S.nb[c - 1u] = 0;
+        if (voxel && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
+            const uint32_t wsel = (dk ? kfl : 0u) | ((dj ? r3 : 0u) << 1) | ((di ? pl : 0u) << 2);
+            const uint32_t qa = P.qa[qab[wsel] + pofs[di] + lane_k[dk]];
+            // low 16 bits: the active cells below Y in its lane (their count completes the queue position)
+            S.nb[c - 1u] = (qa & 0xFFFF0000u) | (qa & ((1u << (cr[dj] + cm[dk])) - 1u));
+            S.nbw |= (wsel << (3u * (c - 1u))) | (1u << (18u + c));
+        }
+    }
+}
+__device__ __forceinline__ void cx_mesh_pin1(cx_mstage1& S) {
+#pragma unroll
+    for (uint32_t c = 0; c < 6; c++) asm volatile("" : "+v"(S.nb[c]) :: "memory");
+    asm volatile("" : "+v"(S.e_next) :: "memory");
+}
+__device__ __forceinline__ void cx_mesh_stage2(const cx_params& P, const cx_task& T, const cx_fast_geom& G, const cx_mstage1& S,
+                                               uint32_t n, uint32_t b0, uint32_t lane, uint32_t vbase, uint32_t tbase, uint32_t* slot,
+                                               const uint8_t* ntri_lut, const uint32_t* qbt, cx_mround& R) {
     const float* __restrict__ A = P.grid;
     const uint32_t plane = P.n1 * P.n2;
     const uint32_t idx = b0 + lane;
     const bool have = idx < n;
+    const uint32_t e = S.e;
     R.e = e;
-    R.e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+    // the queue words are back: queue positions of the neighbour cells -> their info words
+    R.nbw = S.nbw;
+#pragma unroll
+    for (uint32_t c = 0; c < 6; c++) {
+        const uint32_t w = S.nb[c];
+        uint32_t infow = 0;
+        if ((S.nbw >> (19u + c)) & 1u) infow = P.info[qbt[(S.nbw >> (3u * c)) & 7u] + (w >> 16) + __popc(w & 0xFFFFu)];
+        R.nb[c] = infow;
+    }
     uint32_t i, j, k;
     cx_decode_entry(P, G, e, i, j, k);
     R.lin = (i * P.n1 + j) * P.n2 + k;
-    R.ck = k;
     R.sm = cx_entry_signs(e);
     const uint32_t vm = cx_corner_valid(P, i, j, k);
-    R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
+    const bool real_voxel = have && vm == 0xFFu;
     const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
     R.emask = have ? (((R.sm ^ s0) & vm) & 0xFEu) : 0u;
-    R.ntri = R.real_voxel ? (uint32_t)ntri_lut[R.sm] : 0u;
+    R.ntri = real_voxel ? (uint32_t)ntri_lut[R.sm] : 0u;
     const uint32_t nv = __popc(R.emask);
     R.vpre = cx_wave_prefix_small<3>(nv, R.vtot);
     R.tpre = cx_wave_prefix_small<4>(R.ntri, R.ttot);
-    R.base = base;
+    R.vbase = vbase; R.tbase = tbase;
 #pragma unroll
     for (uint32_t d = 1; d < 8; d++)
         if ((R.emask >> d) & 1u) slot[R.vpre + __popc(R.emask & ((1u << d) - 1u))] = (lane << 3) | d;
@@ -1277,50 +1653,80 @@ __device__ __forceinline__ void cx_mround_front(const cx_params& P, const cx_tas
         R.e2[r] = (uint32_t)__shfl((int)e, (int)(R.sl[r] >> 3));
         const uint32_t d = R.sl[r] & 7u;
         const uint32_t lin2 = cx_entry_lin(P, G, R.e2[r]);
+        if (P.flags & CX_DBG_NO_VLOADS) { R.f0[r] = -1.0f; R.f1[r] = (float)lin2; continue; }
         R.f0[r] = A[lin2];
         R.f1[r] = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
     }
-    // the neighbour cells that own a crossing edge of this voxel: lane prefix and the two sign words of their lane
-    const uint32_t ps = (e >> 21) & 127u, ls = (e >> 15) & 63u, bit = (e >> 10) & 31u;
-    const uint32_t rr = (bit * 11u) >> 6, mm = bit - CX_ROWBITS * rr;
-#pragma unroll
-    for (uint32_t c = 1; c < 7; c++) {
-        const uint32_t sc = ((R.sm >> c) & 1u) ? 0xFFu : 0u;
-        uint32_t sup = 0;   // corners that are strict supersets of c: the far ends of the voxel edges corner c owns
-#pragma unroll
-        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
-        R.loc[c - 1u] = 0xFFFFFFFFu; R.nlp[c - 1u] = 0; R.nA[c - 1u] = 0; R.nB[c - 1u] = 0;
-        if (R.ntri && ((R.sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
-            const uint32_t loc = cx_nb_locate(GX, ps, ls, rr, mm, c);
-            const uint32_t wY = cx_nb_wave(GX, T, loc);
-            const size_t at = ((size_t)wY * CX_SWP + ((loc >> 13) & 127u)) * 64u + (loc & 63u);
-            R.loc[c - 1u] = loc;
-            R.nlp[c - 1u] = P.lp[at];
-            R.nA[c - 1u] = P.sw[at];
-            R.nB[c - 1u] = P.sw[at + 64u];
-        }
-    }
-    // CPython-order quad diagonals: hash prefixes of the 4 (i,j) columns of the voxel
-    R.hxy[0] = R.hxy[1] = R.hxy[2] = R.hxy[3] = 0;
-    if ((P.flags & CX_DIAG_CPYTHON310) && cx_need_hash(R.sm, 0u, R.ntri) != 0u) {
-        const uint32_t i1 = min(i + 1u, P.n0 - 1u), j1 = min(j + 1u, P.n1 - 1u);
-        R.hxy[0] = hash_xy[i * P.n1 + j]; R.hxy[1] = hash_xy[i * P.n1 + j1];
-        R.hxy[2] = hash_xy[i1 * P.n1 + j]; R.hxy[3] = hash_xy[i1 * P.n1 + j1];
+    // CPython-order quad diagonals: the codes of the 8 corners, one 2-byte load per (i,j) column
+    R.hb[0] = R.hb[1] = R.hb[2] = R.hb[3] = 0;
+    if (P.hbytes && cx_need_hash(R.sm, 0u, R.ntri) != 0u) {   // only voxels: all 8 corners are inside the array
+        const uint8_t* __restrict__ hb = P.hbytes + R.lin;
+        uint16_t t0, t1, t2, t3;
+        __builtin_memcpy(&t0, hb, 2); __builtin_memcpy(&t1, hb + P.n2, 2);
+        __builtin_memcpy(&t2, hb + plane, 2); __builtin_memcpy(&t3, hb + plane + P.n2, 2);
+        R.hb[0] = t0; R.hb[1] = t1; R.hb[2] = t2; R.hb[3] = t3;
     }
 }
-__device__ __forceinline__ void cx_mround_pin(cx_mround& R) {
+__device__ __forceinline__ void cx_mesh_pin2(cx_mround& R) {
 #pragma unroll
     for (uint32_t r = 0; r < CX_VR; r++) asm volatile("" : "+v"(R.f0[r]), "+v"(R.f1[r]) :: "memory");
 #pragma unroll
-    for (uint32_t c = 0; c < 6; c++) asm volatile("" : "+v"(R.nlp[c]), "+v"(R.nA[c]), "+v"(R.nB[c]) :: "memory");
-    asm volatile("" : "+v"(R.hxy[0]), "+v"(R.hxy[1]), "+v"(R.hxy[2]), "+v"(R.hxy[3]), "+v"(R.e_next) :: "memory");
+    for (uint32_t c = 0; c < 6; c++) asm volatile("" : "+v"(R.nb[c]) :: "memory");
+    asm volatile("" : "+v"(R.hb[0]), "+v"(R.hb[1]), "+v"(R.hb[2]), "+v"(R.hb[3]) :: "memory");
+}
+
+// phase 1 of the triangle stage for the fused kernel: like cx_tri_phase1, with the quad diagonals from the corner codes
+__device__ __forceinline__ uint32_t cx_mesh_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_mround& R,
+                                                   const uint32_t* vbt) {
+    const uint32_t sm = R.sm, ntri = R.ntri;
+    L.ve[wave][0][lane] = make_uint2(R.vbase + R.vpre, R.emask);
+#pragma unroll
+    for (uint32_t c = 1; c < 7; c++) {
+        const uint32_t w = R.nb[c - 1u];
+        const bool want = (R.nbw >> (18u + c)) & 1u;
+        L.ve[wave][c][lane] = want ? make_uint2(vbt[(R.nbw >> (3u * (c - 1u))) & 7u] + (w & 0xFFFFFFu), (w >> 23) & 0xFEu) : make_uint2(0u, 0u);
+    }
+    uint32_t variants = 0;
+    if (P.hbytes) {
+        // code of corner c = byte (c & 1) of column c >> 1
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+            if (__popc(pat) != 2) continue;
+            uint32_t l0 = 0, l1 = 0, h0 = 0, h1 = 0;
+            int nl = 0, nh = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t cc = CX_TC[t][m];
+                const uint32_t code = (R.hb[cc >> 1] >> (8u * (cc & 1u))) & 0xFFu;
+                if ((pat >> m) & 1u) { if (nl == 0) l0 = code; else l1 = code; nl++; }
+                else { if (nh == 0) h0 = code; else h1 = code; nh++; }
+            }
+            if (cx_set2_swapped(l0, l1) != cx_set2_swapped(h0, h1)) variants |= 1u << t;
+        }
+    }
+    L.tfirst[wave][lane] = R.tbase;   // triangle j of the round goes to tbase + j
+    uint32_t pos = R.tpre;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+        const uint32_t np = __popc(pat);
+        const uint32_t nt = (ntri == 0u) ? 0u : ((np == 2u) ? 2u : (np & 1u));
+        const uint32_t word = lane | (((uint32_t)t * 32u + pat * 2u + ((variants >> t) & 1u)) << 7);
+        if (nt >= 1u) L.slot[wave][pos] = (uint16_t)word;
+        if (nt == 2u) L.slot[wave][pos + 1u] = (uint16_t)(word | (1u << 6));
+        pos += nt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return R.ttot;
 }
 
 #ifndef CX_EM_MIN_WAVES
 #define CX_EM_MIN_WAVES 1
 #endif
-template <bool NEG_ORIGIN>
-__global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_params P, const cx_task T, const uint64_t* __restrict__ hash_xy) {
+__global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_params P, const cx_task T) {
     __shared__ cx_mesh_lds L;
     if (P.counters[CX_CNT_NEAR] != 0u) return;   // a wave on the tolerance path: the host runs the staged kernels instead
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;   // host re-runs with more room
@@ -1346,57 +1752,47 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
         cx_fast_geom G;
         G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
         cx_geomx GX;
-        GX.w = D.w; GX.wave = D.w & 3u; GX.k0 = tile.k0; GX.j0 = tile.j0; GX.pstart = tile.p; GX.nsteps = tile.ib - tile.p;
-        // first-vertex bases of the 8 streaming waves a neighbour cell can live in (index: next k | next j << 1 | next chunk << 2)
+        GX.w = D.w; GX.wave = D.w & 3u; GX.nsteps = tile.ib - tile.p;
+        // first vertex and first queue entry of the 8 streaming waves a neighbour cell can live in
+        // (index: next k | next j << 1 | next chunk << 2)
         if (lane < 8u) {
-            const uint32_t wY = cx_nb_wave(GX, T, ((lane & 1u) << 11) | (((lane >> 1) & 1u) << 12) | (((lane >> 2) & 1u) << 20));
-            L.vbt[wave][lane] = P.wbase[min(wY, nw - 1u)].v;
+            const uint32_t wY = min(cx_nb_wave(GX, T, ((lane & 1u) << 11) | (((lane >> 1) & 1u) << 12) | (((lane >> 2) & 1u) << 20)), nw - 1u);
+            L.vbt[wave][lane] = P.wbase[wY].v;
+            L.qbt[wave][lane] = wY * T.wcap;
+            L.qab[wave][lane] = wY * (CX_SWP * 64u);
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t* __restrict__ q = P.queue + D.qofs;
         const uint32_t n = D.n;
-        cx_run run;
-        run.v = D.vbase; run.t = D.tbase; run.c = 0; run.b = 0;
+        cx_mstage1 Sb, Sc;
         cx_mround Ra, Rb;
         uint32_t e0 = (lane < n) ? q[lane] : 0u;
         asm volatile("" : "+v"(e0) :: "memory");
-        cx_mround_front(P, T, G, GX, hash_xy, q, n, 0u, lane, e0, run, L.vslot[wave][0], L.ntri, Ra);
-        cx_mround_pin(Ra);
+        cx_mesh_stage1(P, T, G, GX, q, n, 0u, lane, e0, L.ntri, L.qab[wave], Sb);
+        cx_mesh_pin1(Sb);
+        cx_mesh_stage2(P, T, G, Sb, n, 0u, lane, D.vbase, D.tbase, L.vslot[wave][0], L.ntri, L.qbt[wave], Ra);
+        if (64u < n) cx_mesh_stage1(P, T, G, GX, q, n, 64u, lane, Sb.e_next, L.ntri, L.qab[wave], Sc);
+        cx_mesh_pin2(Ra);
+        if (64u < n) { cx_mesh_pin1(Sc); Sb = Sc; }
         uint32_t par = 0;
         for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
-            const bool more = b0 + 64u < n;   // wave-uniform
-            if (more) {
-                cx_run nb = Ra.base;
-                nb.v += Ra.vtot; nb.t += Ra.ttot;
-                cx_mround_front(P, T, G, GX, hash_xy, q, n, b0 + 64u, lane, Ra.e_next, nb, L.vslot[wave][par ^ 1u], L.ntri, Rb);
-            }
-            // ---- back half of round b0, part 1: everything that needs no store
+            const bool more1 = b0 + 64u < n, more2 = b0 + 128u < n;   // wave-uniform
+            if (more2) cx_mesh_stage1(P, T, G, GX, q, n, b0 + 128u, lane, Sb.e_next, L.ntri, L.qab[wave], Sc);
+            if (more1) cx_mesh_stage2(P, T, G, Sb, n, b0 + 64u, lane, Ra.vbase + Ra.vtot, Ra.tbase + Ra.ttot, L.vslot[wave][par ^ 1u],
+                                      L.ntri, L.qbt[wave], Rb);
+            // ---- stage 3 of round b0: what needs no store
             float4 rec4[CX_VR];
 #pragma unroll
             for (uint32_t r = 0; r < CX_VR; r++) rec4[r] = cx_vertex_record(P, G, Ra.e2[r], Ra.sl[r] & 7u, Ra.f0[r], Ra.f1[r]);
-            cx_tri_in I;
-            I.rec = make_uint4(Ra.lin, Ra.sm | ((Ra.real_voxel ? 0u : 0x3Fu) << 8) | (Ra.ntri << 16) | (Ra.emask << 24),
-                               Ra.base.t + Ra.tpre, Ra.base.v + Ra.vpre);
-#pragma unroll
-            for (uint32_t c = 0; c < 6; c++) {
-                uint2 pr = make_uint2(0u, 0u);
-                if (Ra.loc[c] != 0xFFFFFFFFu) {
-                    const uint32_t loc = Ra.loc[c];
-                    const uint32_t vb = L.vbt[wave][((loc >> 11) & 3u) | (((loc >> 20) & 1u) << 2)];
-                    pr = cx_nb_finish(P, T, GX, loc, vb, Ra.nlp[c], Ra.nA[c], Ra.nB[c]);
-                }
-                I.nb[c] = pr;
-            }
-            I.hxy[0] = Ra.hxy[0]; I.hxy[1] = Ra.hxy[1]; I.hxy[2] = Ra.hxy[2]; I.hxy[3] = Ra.hxy[3];
-            I.ck = Ra.ck;
-            const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L.tri, lane, wave, I);
-            if (more) cx_mround_pin(Rb);
-            // ---- part 2: the stores
+            const uint32_t ttot = cx_mesh_phase1(P, L.tri, lane, wave, Ra, L.vbt[wave]);
+            if (more2) cx_mesh_pin1(Sc);
+            if (more1) cx_mesh_pin2(Rb);
+            // ---- the stores
             {
 #pragma unroll
                 for (uint32_t r = 0; r < CX_VR; r++) {
                     const uint32_t o = 64u * r + lane;
-                    if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec4[r]);
+                    if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.vbase + o], rec4[r]);
                 }
                 const uint32_t* slot = L.vslot[wave][par];
                 for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
@@ -1408,12 +1804,13 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
                     const float f0 = A[lin2];
                     const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
                     const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
-                    if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], r4);
+                    if (o < Ra.vtot) CX_STORE_VERT(&P.verts[Ra.vbase + o], r4);
                 }
             }
             cx_tri_phase2(P, L.tri, lane, wave, ttot);
             __builtin_amdgcn_wave_barrier();
-            if (more) Ra = Rb;
+            if (more1) Ra = Rb;
+            if (more2) Sb = Sc;
             par ^= 1u;
         }
         if (fn >= nbatches) break;
@@ -1460,8 +1857,12 @@ void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
 
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {
     const uint32_t nw = T.nblocks * 4u;
-    hipLaunchKernelGGL(cx_k_scan_waves, dim3(1), dim3(1024), 0, s, P, nw);
-    hipLaunchKernelGGL(cx_k_list_batches, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
+    if (cx_debug_knob("CX_SCAN2", 0u)) {   // A/B: the two-kernel scan
+        hipLaunchKernelGGL(cx_k_scan_waves, dim3(1), dim3(1024), 0, s, P, nw);
+        hipLaunchKernelGGL(cx_k_list_batches, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
+        return;
+    }
+    hipLaunchKernelGGL(cx_k_scan_list, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
 }
 
 // one wave per batch, grid-stride: the batch count lives on the device, so launch what fills the chip
@@ -1494,10 +1895,22 @@ void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipSt
     else hipLaunchKernelGGL(cx_k_emit_triangles<false>, dim3(g ? g : 1u), dim3(256), 0, s, P, hash_xy);
 }
 
-void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s) {
-    const dim3 grid(cx_batch_grid(P, 8u));
-    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_mesh<true>, grid, dim3(256), 0, s, P, T, hash_xy);
-    else hipLaunchKernelGGL(cx_k_emit_mesh<false>, grid, dim3(256), 0, s, P, T, hash_xy);
+void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s) {
+    hipLaunchKernelGGL(cx_k_cell_info, dim3(cx_batch_grid(P, 8u)), dim3(256), 0, s, P, T);
+    hipLaunchKernelGGL(cx_k_emit_mesh, dim3(cx_batch_grid(P, 8u)), dim3(256), 0, s, P, T);
+}
+
+void cx_launch_hash_bytes(uint8_t* table, const uint64_t* hash_xy, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t org2, hipStream_t s) {
+    const uint64_t n = (uint64_t)n0 * n1 * n2;
+    hipLaunchKernelGGL(cx_k_hash_bytes, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, s, table, hash_xy, n0 * n1, n2, (int32_t)org2);
+}
+
+void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s) {
+    uint32_t g = cx_debug_knob("CX_TGRID", 256u * 8u);
+    const uint32_t most = (P.ccap + 255u) / 256u;
+    if (g > most) g = most;
+    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_triangles_q<true>, dim3(g ? g : 1u), dim3(256), 0, s, P, T, hash_xy);
+    else hipLaunchKernelGGL(cx_k_emit_triangles_q<false>, dim3(g ? g : 1u), dim3(256), 0, s, P, T, hash_xy);
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {

@@ -3,6 +3,6 @@
 set -e
 for flags in "$@"; do
   CX_EXTRA_FLAGS="$flags" python3 contourist_amd/build.py > /dev/null 2>&1
-  TAG="[$flags]" timeout -k 10 120 python3 ${AB_TOOL:-tools/quick_time.py} 512 2>/dev/null | grep -v "^{"
+  TAG="[$flags]" timeout -k 10 120 python3 ${AB_TOOL:-tools/quick_time.py} 512 ${AB_ARGS:-} 2>/dev/null | grep -v "^{"
 done
 python3 contourist_amd/build.py > /dev/null 2>&1
