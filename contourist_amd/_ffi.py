@@ -23,7 +23,7 @@ CX_KERNEL_FUSED = 0x400
 SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
-    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
+    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
@@ -100,6 +100,8 @@ def load():
         "cx_extract3d_async": [vp, dbl, u32],
         "cx_counts_get": [vp, ctypes.POINTER(CxCounts)],
         "cx_level0_path": [vp, ctypes.POINTER(ctypes.c_int)],
+        "cx_extract3d_levels": [vp, vp, ctypes.c_int32, u32, vp],
+        "cx_levels_select": [vp, ctypes.c_int32],
         "cx_level0_download": [vp, vp, vp],
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_postprocess3d": [vp, u32, vp],
@@ -205,6 +207,17 @@ class Context(object):
         self._check(self.lib.cx_extract3d(self.handle, float(value), int(flags), ctypes.byref(c)))
         return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_triangles=c.n_triangles,
                     n_border_voxels=c.n_border_voxels)
+
+    def extract3d_levels(self, values, flags=CX_DIAG_CPYTHON310):
+        """all isovalues of `values` in one call (one pass over the samples for all of them) -> list of counts dicts;
+        select_level(i) then makes level i the current extraction for download_level0 / postprocess3d / ..."""
+        vals = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        out = (CxCounts * len(vals))()
+        self._check(self.lib.cx_extract3d_levels(self.handle, vals.ctypes.data, len(vals), int(flags), ctypes.cast(out, ctypes.c_void_p)))
+        return [dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_triangles=c.n_triangles, n_border_voxels=c.n_border_voxels) for c in out]
+
+    def select_level(self, index):
+        self._check(self.lib.cx_levels_select(self.handle, int(index)))
 
     def extract3d_async(self, value, flags=CX_DIAG_CPYTHON310):
         self._check(self.lib.cx_extract3d_async(self.handle, float(value), int(flags)))

@@ -58,6 +58,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (!ctx) return CX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    cx_levels_free(ctx);
     cx_post_free(ctx);
     cx_state4_free(ctx);
     cx_state2_free(ctx);
@@ -105,6 +106,7 @@ static int set_grid_dims(cx_ctx* ctx, int64_t n0, int64_t n1, int64_t n2) {
     const int64_t N = n0 * n1 * n2;
     if (N > (1LL << 29)) return fail(ctx, CX_ERR_UNSUPPORTED, "more than 2^29 samples in one grid: partition into slabs");
     ctx->n0 = n0; ctx->n1 = n1; ctx->n2 = n2;
+    cx_levels_invalidate(ctx);
     ctx->extracted = false;
     ctx->post_valid = false;
     return CX_OK;
@@ -189,6 +191,37 @@ static float fp32_threshold(double value) {
     return t;
 }
 
+// CPython tuple-hash prefixes per (i,j) column (CX_DIAG_CPYTHON310), rebuilt when the shape or the origin changed
+int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags) {
+    if (!(flags & CX_DIAG_CPYTHON310)) return CX_OK;
+    if (ctx->hash_xy_n0 == ctx->n0 && ctx->hash_xy_n1 == ctx->n1 && ctx->hash_xy_o0 == ctx->origin[0] && ctx->hash_xy_o1 == ctx->origin[1])
+        return CX_OK;
+    const size_t need = (size_t)(ctx->n0 * ctx->n1);
+    if (ctx->hash_xy_cap < need) {
+        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
+        ctx->hash_xy = nullptr; ctx->hash_xy_cap = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->hash_xy, need * sizeof(uint64_t)));
+        ctx->hash_xy_cap = need;
+    }
+    cx_launch_hash_xy(ctx->hash_xy, (uint32_t)ctx->n0, (uint32_t)ctx->n1, (uint32_t)ctx->origin[0], (uint32_t)ctx->origin[1], ctx->stream);
+    ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
+    ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
+    ctx->hbytes_valid = false;
+    return CX_OK;
+}
+
+// the value-dependent fields of one extraction
+void cx_fill_value_params(cx_params& P, double value) {
+    P.vcmp = fp32_threshold(value);
+    // |f-v| <= 1e-8 + 1e-5*max(|f|,|v|)  =>  |f - vcmp| <= 2.2e-5*|v| + 4e-8  (vcmp within 1 ulp of v)
+    P.near_abs = std::nextafterf((float)(2.2e-5 * std::fabs(value) + 4e-8), INFINITY);
+    P.vhi = (float)value;
+    P.vlo = (float)(value - (double)P.vhi);
+    P.value = value;
+    P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
+}
+
 static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (!ctx->grid) return fail(ctx, CX_ERR_STATE, "no grid: call cx_grid_upload or cx_grid_adopt_device first");
     if (!(value == value)) return fail(ctx, CX_ERR_INVALID, "isovalue is NaN");
@@ -208,13 +241,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     P.nsamples = (uint32_t)N;
     P.div_plane = cx_fdiv_make(P.n1 * P.n2);
     P.div_row = cx_fdiv_make(P.n2);
-    P.vcmp = fp32_threshold(value);
-    // |f-v| <= 1e-8 + 1e-5*max(|f|,|v|)  =>  |f - vcmp| <= 2.2e-5*|v| + 4e-8  (vcmp within 1 ulp of v)
-    P.near_abs = std::nextafterf((float)(2.2e-5 * std::fabs(value) + 4e-8), INFINITY);
-    P.vhi = (float)value;
-    P.vlo = (float)(value - (double)P.vhi);
-    P.value = value;
-    P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
+    cx_fill_value_params(P, value);
     P.flags = flags;
     const bool staged = !(flags & CX_KERNEL_GENERIC) && cx_fast_classify_supported_dims(ctx->n2, ctx->grid);
     // fused emit kernel (no per-cell table, no cell records) only on request: measured slower than the staged kernels
@@ -237,19 +264,9 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     ctx->last = P;
     P.org0 = (uint32_t)ctx->origin[0]; P.org1 = (uint32_t)ctx->origin[1]; P.org2 = (uint32_t)ctx->origin[2];
     ctx->last = P;
-    if ((flags & CX_DIAG_CPYTHON310) && (ctx->hash_xy_n0 != ctx->n0 || ctx->hash_xy_n1 != ctx->n1 ||
-                                         ctx->hash_xy_o0 != ctx->origin[0] || ctx->hash_xy_o1 != ctx->origin[1])) {
-        const size_t need = (size_t)(ctx->n0 * ctx->n1);
-        if (ctx->hash_xy_cap < need) {
-            if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
-            ctx->hash_xy = nullptr; ctx->hash_xy_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->hash_xy, need * sizeof(uint64_t)));
-            ctx->hash_xy_cap = need;
-        }
-        cx_launch_hash_xy(ctx->hash_xy, P.n0, P.n1, P.org0, P.org1, ctx->stream);
-        ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
-        ctx->hash_xy_o0 = ctx->origin[0]; ctx->hash_xy_o1 = ctx->origin[1];
-        ctx->hbytes_valid = false;
+    {
+        const int rch = cx_ensure_hash_xy(ctx, flags);
+        if (rch) return rch;
     }
     P.hbytes = nullptr;
     if ((flags & CX_DIAG_CPYTHON310) && (fused || cx_debug_knob("CX_HBYTES", 0u))) {   // staged kernels: measured slower than the hash arithmetic (byte gathers from a table of one byte per sample)
@@ -326,7 +343,6 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (fused && ctx->info_cap < need) {   // one word per queue entry (only the front of each wave's region is touched)
             CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->info) (void)hipFree(ctx->info);
-    if (ctx->info64) (void)hipFree(ctx->info64);
             ctx->info = nullptr; ctx->info_cap = 0;
             CX_HIP(ctx, hipMalloc(&ctx->info, need * sizeof(uint32_t)));
             ctx->info_cap = need;
@@ -376,6 +392,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     ctx->counts_fetched = false;
     ctx->post_valid = false;
     ctx->keep_valid = false;
+    cx_levels_invalidate(ctx); // the context's output buffers hold this extraction now, not a level of cx_extract3d_levels
     return CX_OK;
 }
 

@@ -7,6 +7,7 @@
 struct cx_post_state;  // Level-1 buffers (cx_post.hip)
 struct cx_state4;       // 4-D march state (cx_api4d.hip)
 struct cx_state2;       // 2-D contour lines (cx_contour2d.hip)
+struct cx_levels_state; // several isovalues of one grid (cx_levels.hip)
 
 struct cx_ctx {
     int device = 0;
@@ -52,6 +53,8 @@ struct cx_ctx {
     int64_t origin4[4] = {0, 0, 0, 0};
     cx_state4* s4 = nullptr;
     cx_state2* s2 = nullptr;
+    cx_levels_state* lv = nullptr;
+    int lv_current = -1;               // level of cx_extract3d_levels whose mesh the context's output buffers hold (-1: none)
     // Level-0 outputs
     float4* verts = nullptr;
     uint4* cells = nullptr;
@@ -81,6 +84,11 @@ struct cx_ctx {
 
 // cx_api.hip
 int cx_ensure_cell_records(cx_ctx* ctx);
+int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags);
+void cx_fill_value_params(cx_params& P, double value);
+// cx_levels.hip
+void cx_levels_free(cx_ctx* ctx);
+void cx_levels_invalidate(cx_ctx* ctx);
 // cx_post.hip
 void cx_post_free(cx_ctx* ctx);
 int cx_scan_u32(cx_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums_tmp, uint32_t* total_dev,

@@ -1,0 +1,278 @@
+// cx_levels.hip -- several isovalues of ONE grid in one call (BASELINE.json config 5; the reference has the idea only in
+// 2-D: multiple_2d_contour.Multiple2DContourGrid classifies an edge against all sorted levels at once,
+// multiple_2d_contour.py:48-59).
+//
+// The stream kernel -- the pass over the samples -- runs ONCE for all levels: its workgroups are numbered (tile, level) with
+// the level running fastest inside an XCD's sequence, so the workgroups that stream one tile for the different levels run
+// next to each other on one XCD and the tile comes from HBM once (cx_k_stream_levels).  Every level has its own queues and
+// side tables; scan, vertex stage and triangle stage then run per level exactly as for a single extraction, so each level's
+// mesh is bit for bit what cx_extract3d gives for that isovalue (tests/test_gpu_levels.py).
+// cx_levels_select makes one level the context's current extraction: download, post-passes and seeded selection act on it.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cx_ctx.h"
+
+#define CXL_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return (e__ == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;                      \
+        }                                                                                        \
+    } while (0)
+
+struct cx_level_slot {
+    double value = 0.0;
+    cx_params P;                       // parameters of the level (valid after cx_extract3d_levels)
+    cx_counts counts = {0, 0, 0, 0};
+    // per-level side tables of the staged pipeline
+    uint32_t* queue = nullptr;
+    size_t queue_cap = 0;
+    cx_wsum* wsum = nullptr;
+    cx_wbase* wbase = nullptr;
+    size_t waves_cap = 0;
+    cx_brec* brec = nullptr;
+    size_t brec_cap = 0;
+    cx_bdesc* flat = nullptr;
+    size_t flat_cap = 0;
+    uint32_t* qa = nullptr;
+    size_t qa_cap = 0;
+    uint32_t* counters = nullptr;
+    // Level-0 outputs of the level (swapped with the context's while the level is selected)
+    float4* verts = nullptr;
+    uint4* cells = nullptr;
+    int32_t* tris = nullptr;
+    uint32_t vcap = 0, ccap = 0, tcap = 0;
+};
+
+struct cx_levels_state {
+    std::vector<cx_level_slot> slots;
+    int nvalid = 0;                    // levels of the last cx_extract3d_levels
+    cx_params* dparams = nullptr;      // device copy of the levels' parameters
+    size_t dparams_cap = 0;
+    uint32_t* hcounters = nullptr;     // pinned: CX_CNT_WORDS per level
+    size_t hcounters_cap = 0;
+    cx_task T;
+    uint32_t flags = 0;
+};
+
+static void free_slot(cx_level_slot& S) {
+    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.verts, S.cells, S.tris};
+    for (void* p : all)
+        if (p) (void)hipFree(p);
+    S = cx_level_slot();
+}
+
+void cx_levels_free(cx_ctx* ctx) {
+    cx_levels_state* L = ctx->lv;
+    if (!L) return;
+    // the buffers of the selected level sit in the context (and the context's own in that slot): give them back first so that
+    // both sides free what they own
+    if (ctx->lv_current >= 0 && ctx->lv_current < (int)L->slots.size()) {
+        cx_level_slot& S = L->slots[ctx->lv_current];
+        std::swap(ctx->verts, S.verts); std::swap(ctx->cells, S.cells); std::swap(ctx->tris, S.tris);
+        std::swap(ctx->vcap, S.vcap); std::swap(ctx->ccap, S.ccap); std::swap(ctx->tcap, S.tcap);
+        ctx->lv_current = -1;
+    }
+    for (auto& S : L->slots) free_slot(S);
+    if (L->dparams) (void)hipFree(L->dparams);
+    if (L->hcounters) (void)hipHostFree(L->hcounters);
+    delete L;
+    ctx->lv = nullptr;
+}
+
+template <typename Tp>
+static int grow(cx_ctx* ctx, Tp*& ptr, size_t& cap, size_t need) {
+    if (cap >= need) return CX_OK;
+    CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; cap = 0;
+    CXL_HIP(ctx, hipMalloc(&ptr, need * sizeof(Tp)));
+    cap = need;
+    return CX_OK;
+}
+
+// a single-level extraction is about to overwrite the context's output buffers: the levels are gone
+void cx_levels_invalidate(cx_ctx* ctx) {
+    if (ctx->lv) ctx->lv->nvalid = 0;
+    ctx->lv_current = -1;
+}
+
+static void unselect(cx_ctx* ctx) {
+    cx_levels_state* L = ctx->lv;
+    if (!L || ctx->lv_current < 0 || ctx->lv_current >= (int)L->slots.size()) { ctx->lv_current = -1; return; }
+    cx_level_slot& S = L->slots[ctx->lv_current];
+    std::swap(ctx->verts, S.verts); std::swap(ctx->cells, S.cells); std::swap(ctx->tris, S.tris);
+    std::swap(ctx->vcap, S.vcap); std::swap(ctx->ccap, S.ccap); std::swap(ctx->tcap, S.tcap);
+    ctx->lv_current = -1;
+}
+
+extern "C" int cx_levels_select(cx_ctx* ctx, int32_t index) {
+    if (!ctx) return CX_ERR_INVALID;
+    cx_levels_state* L = ctx->lv;
+    if (!L || index < 0 || index >= L->nvalid) { ctx->err = "cx_levels_select: no such level (call cx_extract3d_levels first)"; return CX_ERR_STATE; }
+    CXL_HIP(ctx, hipSetDevice(ctx->device));
+    CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unselect(ctx);
+    cx_level_slot& S = L->slots[index];
+    std::swap(ctx->verts, S.verts); std::swap(ctx->cells, S.cells); std::swap(ctx->tris, S.tris);
+    std::swap(ctx->vcap, S.vcap); std::swap(ctx->ccap, S.ccap); std::swap(ctx->tcap, S.tcap);
+    ctx->lv_current = index;
+    ctx->last = S.P;
+    ctx->last_task = L->T;
+    ctx->last_flags = L->flags;
+    ctx->counts = S.counts;
+    ctx->extracted = true;
+    ctx->counts_fetched = true;
+    ctx->post_valid = false;
+    ctx->keep_valid = false;
+    ctx->records_valid = true;
+    ctx->path = 1;
+    return CX_OK;
+}
+
+extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nlevels, uint32_t flags, cx_counts* out_counts) {
+    if (!ctx || !values || nlevels < 1 || nlevels > 64) return CX_ERR_INVALID;
+    if (!ctx->grid) { ctx->err = "no grid: call cx_grid_upload or cx_grid_adopt_device first"; return CX_ERR_STATE; }
+    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310)) != 0u) { ctx->err = "cx_extract3d_levels: only the diagonal flag is accepted"; return CX_ERR_INVALID; }
+    for (int l = 0; l < nlevels; l++)
+        if (!(values[l] == values[l])) { ctx->err = "isovalue is NaN"; return CX_ERR_INVALID; }
+    CXL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!cx_fast_classify_supported_dims(ctx->n2, ctx->grid)) {
+        ctx->err = "cx_extract3d_levels needs rows of at least 4 samples: extract the levels one by one with cx_extract3d";
+        return CX_ERR_UNSUPPORTED;
+    }
+    if (!ctx->lv) ctx->lv = new cx_levels_state();
+    cx_levels_state* L = ctx->lv;
+    unselect(ctx);
+    L->nvalid = 0;
+    if ((int)L->slots.size() < nlevels) L->slots.resize(nlevels);
+    const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
+    int rc = cx_ensure_hash_xy(ctx, flags);
+    if (rc) return rc;
+    const cx_task T = cx_fast_task((uint32_t)ctx->n0, (uint32_t)ctx->n1, (uint32_t)ctx->n2);
+    L->T = T;
+    L->flags = flags;
+    const size_t nw = (size_t)T.nblocks * 4u, need = nw * T.wcap;
+    const size_t boundary = (size_t)(ctx->n0 * ctx->n1 + ctx->n0 * ctx->n2 + ctx->n1 * ctx->n2);
+    // batches: one short batch per streaming wave + one per CX_BATCH_MIN queued cells; the cell count is not known yet, so
+    // room for a surface through a quarter of all cells (more: CX_ERR_CAPACITY, extract such levels one by one)
+    const size_t nflat = nw + (size_t)N / 4u / 512u + boundary / 128u + 4096u;
+    for (int l = 0; l < nlevels; l++) {
+        cx_level_slot& S = L->slots[l];
+        S.value = values[l];
+        if ((rc = grow(ctx, S.queue, S.queue_cap, need))) return rc;
+        if (S.waves_cap < nw) {
+            CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (S.wsum) (void)hipFree(S.wsum);
+            if (S.wbase) (void)hipFree(S.wbase);
+            S.wsum = nullptr; S.wbase = nullptr; S.waves_cap = 0;
+            CXL_HIP(ctx, hipMalloc(&S.wsum, nw * sizeof(cx_wsum)));
+            CXL_HIP(ctx, hipMalloc(&S.wbase, nw * sizeof(cx_wbase)));
+            S.waves_cap = nw;
+        }
+        if ((rc = grow(ctx, S.brec, S.brec_cap, nw * T.bcap))) return rc;
+        if ((rc = grow(ctx, S.flat, S.flat_cap, nflat))) return rc;
+        if ((rc = grow(ctx, S.qa, S.qa_cap, nw * CX_SWP * 64u + 64u))) return rc;
+        if (!S.counters) CXL_HIP(ctx, hipMalloc(&S.counters, CX_CNT_WORDS * sizeof(uint32_t)));
+        cx_params& P = S.P;
+        memset(&P, 0, sizeof(P));
+        P.grid = ctx->grid;
+        P.n0 = (uint32_t)ctx->n0; P.n1 = (uint32_t)ctx->n1; P.n2 = (uint32_t)ctx->n2;
+        P.nsamples = (uint32_t)N;
+        P.div_plane = cx_fdiv_make(P.n1 * P.n2);
+        P.div_row = cx_fdiv_make(P.n2);
+        P.div_ci = cx_fdiv_make(T.ci);
+        cx_fill_value_params(P, values[l]);
+        P.flags = flags;
+        P.org0 = (uint32_t)ctx->origin[0]; P.org1 = (uint32_t)ctx->origin[1]; P.org2 = (uint32_t)ctx->origin[2];
+        P.counters = S.counters;
+        P.queue = S.queue; P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
+        P.qa = S.qa;
+        P.verts = S.verts; P.cells = S.cells; P.tris = S.tris;
+        P.vcap = S.vcap; P.ccap = S.ccap; P.tcap = S.tcap;
+    }
+    // the staged kernels' word per queue entry is shared: the levels' vertex and triangle stages run one level after the other
+    if (ctx->info64_cap < need) {
+        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->info64) (void)hipFree(ctx->info64);
+        ctx->info64 = nullptr; ctx->info64_cap = 0;
+        CXL_HIP(ctx, hipMalloc(&ctx->info64, need * sizeof(uint64_t)));
+        ctx->info64_cap = need;
+    }
+    if (L->dparams_cap < (size_t)nlevels) {
+        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (L->dparams) (void)hipFree(L->dparams);
+        L->dparams = nullptr; L->dparams_cap = 0;
+        CXL_HIP(ctx, hipMalloc(&L->dparams, (size_t)nlevels * sizeof(cx_params)));
+        L->dparams_cap = (size_t)nlevels;
+    }
+    if (L->hcounters_cap < (size_t)nlevels) {
+        if (L->hcounters) (void)hipHostFree(L->hcounters);
+        L->hcounters = nullptr; L->hcounters_cap = 0;
+        CXL_HIP(ctx, hipHostMalloc(&L->hcounters, (size_t)nlevels * CX_CNT_WORDS * sizeof(uint32_t)));
+        L->hcounters_cap = (size_t)nlevels;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        std::vector<cx_params> hp(nlevels);
+        for (int l = 0; l < nlevels; l++) {
+            cx_level_slot& S = L->slots[l];
+            S.P.verts = S.verts; S.P.cells = S.cells; S.P.tris = S.tris;
+            S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
+            S.P.info64 = ctx->info64;
+            hp[l] = S.P;
+        }
+        CXL_HIP(ctx, hipMemcpyAsync(L->dparams, hp.data(), (size_t)nlevels * sizeof(cx_params), hipMemcpyHostToDevice, ctx->stream));
+        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // hp goes out of scope
+        // ONE pass over the samples for all levels, then the scans
+        cx_launch_stream_levels(L->dparams, L->slots[0].P, T, (uint32_t)nlevels, ctx->stream);
+        cx_launch_scan_levels(L->dparams, T, (uint32_t)nlevels, ctx->stream);
+        for (int l = 0; l < nlevels; l++)
+            CXL_HIP(ctx, hipMemcpyAsync(L->hcounters + (size_t)l * CX_CNT_WORDS, L->slots[l].counters, CX_CNT_WORDS * sizeof(uint32_t),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // output buffers of every level, sized by what its surface needs
+        for (int l = 0; l < nlevels; l++) {
+            cx_level_slot& S = L->slots[l];
+            const uint32_t* hc = L->hcounters + (size_t)l * CX_CNT_WORDS;
+            S.counts.n_cells = hc[CX_CNT_CELLS]; S.counts.n_vertices = hc[CX_CNT_VERTS];
+            S.counts.n_triangles = hc[CX_CNT_TRIS]; S.counts.n_border_voxels = hc[CX_CNT_BORDER];
+            if (hc[CX_CNT_BATCHES] > nflat) {
+                ctx->err = "cx_extract3d_levels: a level's surface passes through too many cells for the batch list: extract it with cx_extract3d";
+                return CX_ERR_CAPACITY;
+            }
+            if ((uint64_t)S.counts.n_vertices > 0xFFFFFFF0ULL || (uint64_t)S.counts.n_triangles > 0x7FFFFFF0ULL) {
+                ctx->err = "capacity beyond 32-bit indices";
+                return CX_ERR_UNSUPPORTED;
+            }
+            size_t c = S.ccap, v = S.vcap, t = S.tcap;
+            if ((rc = grow(ctx, S.cells, c, (size_t)S.counts.n_cells + 64u))) return rc;
+            if ((rc = grow(ctx, S.verts, v, (size_t)S.counts.n_vertices + 64u))) return rc;
+            {
+                size_t t3 = (size_t)S.tcap * 3u;
+                if ((rc = grow(ctx, S.tris, t3, ((size_t)S.counts.n_triangles + 64u) * 3u))) return rc;
+                t = t3 / 3u;
+            }
+            S.ccap = (uint32_t)c; S.vcap = (uint32_t)v; S.tcap = (uint32_t)t;
+            S.P.verts = S.verts; S.P.cells = S.cells; S.P.tris = S.tris;
+            S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
+            S.P.info64 = ctx->info64;
+        }
+        // vertex and triangle stages, level by level (each fills the chip on its own)
+        for (int l = 0; l < nlevels; l++) {
+            cx_level_slot& S = L->slots[l];
+            cx_launch_emit_vertices(S.P, T, ctx->stream);
+            cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, ctx->stream);
+        }
+        CXL_HIP(ctx, hipGetLastError());
+        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        break;
+    }
+    L->nvalid = nlevels;
+    if (out_counts)
+        for (int l = 0; l < nlevels; l++) out_counts[l] = L->slots[l].counts;
+    return cx_levels_select(ctx, 0);
+}

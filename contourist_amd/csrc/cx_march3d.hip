@@ -549,11 +549,10 @@ __device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task&
 // of one row).  Otherwise the 16-byte loads are only 4-byte aligned and the lane that holds the end of a row
 // loads the row's last 4 samples and shifts them into place, repeating the last one (a clamped corner).
 template <bool ALIGNED>
-__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
+__device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task& T, const uint32_t b) {
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
     __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
-    const uint32_t b = cx_task_of_block(T);
     if (b >= T.nblocks) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -785,6 +784,21 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
         P.wsum[w] = S;
     }
 }
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_params P, const cx_task T) {
+    cx_stream_tile<ALIGNED>(P, T, cx_task_of_block(T));
+}
+// Several isovalues of ONE grid: the same pass, with workgroups numbered (tile, level), the level running fastest
+// inside an XCD's sequence: the nlevels workgroups that stream one tile run next to each other on one XCD, so the tile comes
+// from HBM once and from that XCD's L2 / the Infinity Cache for the other levels.  LP[level] = parameters of a level
+// (isovalue, its queues and side tables).
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream_levels(const cx_params* __restrict__ LP, const cx_task T, const uint32_t nlevels) {
+    const uint32_t seq = blockIdx.x >> 3;                   // position in this XCD's sequence of workgroups
+    const uint32_t tile_seq = seq / nlevels, level = seq - tile_seq * nlevels;
+    const cx_params P = LP[level];
+    cx_stream_tile<ALIGNED>(P, T, (blockIdx.x & 7u) * T.chunk + tile_seq);
+}
 
 // ---- S2: exclusive scan of the per-wave totals (one workgroup of 16 waves; coalesced loads of
 // CX_SC chunks of 1024 waves at a time), output offsets per wave, the flat batch list, the counters.
@@ -879,11 +893,10 @@ __global__ __launch_bounds__(256) void cx_k_list_batches(const cx_params P, cons
 // wait for, no second kernel, no atomics), scans its own 256 waves, and writes their output offsets and batch descriptors;
 // the last workgroup, which has seen every wave, writes the counters.  (One workgroup scanning all 12 k waves of a 512^3
 // grid was bound by what a single CU can pull: 22 us + 5 us for the list kernel.)
-__global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {
+__device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_task& T, const uint32_t nw, const uint32_t g, const uint32_t nchunks) {
     __shared__ uint32_t s_part[4][6];    // per wave of the workgroup: totals of the earlier chunks (5) + near flag
     __shared__ uint32_t s_own[4][5];     // per wave: inclusive totals of its 64 streaming waves
     const uint32_t tid = threadIdx.x, lane = cx_lane_id(), wave = tid >> 6;
-    const uint32_t g = blockIdx.x;
     uint32_t acc[5] = {0, 0, 0, 0, 0}, near_any = 0;   // v, t, c, b, nb
     for (uint32_t c0 = 0; c0 < g; c0 += 8u) {            // 8 independent loads in flight per thread
         cx_wsum E[8];
@@ -937,12 +950,19 @@ __global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const c
             P.flat[ex[4] + i] = D;
         }
     }
-    if (g == gridDim.x - 1u && tid == 255u) {   // this thread's inclusive totals are the grand totals
+    if (g == nchunks - 1u && tid == 255u) {   // this thread's inclusive totals are the grand totals
         P.counters[CX_CNT_VERTS] = ex[0] + x[0]; P.counters[CX_CNT_TRIS] = ex[1] + x[1];
         P.counters[CX_CNT_CELLS] = ex[2] + x[2]; P.counters[CX_CNT_BORDER] = ex[3] + x[3];
         P.counters[CX_CNT_BATCHES] = ex[4] + x[4];
         P.counters[CX_CNT_NEAR] = (s_part[0][5] | s_part[1][5] | s_part[2][5] | s_part[3][5]) ? 1u : 0u;
     }
+}
+__global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {
+    cx_scan_list_chunk(P, T, nw, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void cx_k_scan_list_levels(const cx_params* __restrict__ LP, const cx_task T, const uint32_t nw) {
+    const cx_params P = LP[blockIdx.y];
+    cx_scan_list_chunk(P, T, nw, blockIdx.x, gridDim.x);
 }
 
 // ---- S3: vertex records, per-cell table entries and cell records; one wave per batch, grid-stride
@@ -1853,6 +1873,16 @@ void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
     const bool aligned = (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
     if (aligned) hipLaunchKernelGGL(cx_k_stream<true>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
     else hipLaunchKernelGGL(cx_k_stream<false>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
+}
+
+void cx_launch_stream_levels(const cx_params* device_params, const cx_params& P0, const cx_task& T, uint32_t nlevels, hipStream_t s) {
+    const bool aligned = (P0.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P0.grid) & 15u) == 0u);
+    if (aligned) hipLaunchKernelGGL(cx_k_stream_levels<true>, dim3(T.chunk * 8u * nlevels), dim3(256), 0, s, device_params, T, nlevels);
+    else hipLaunchKernelGGL(cx_k_stream_levels<false>, dim3(T.chunk * 8u * nlevels), dim3(256), 0, s, device_params, T, nlevels);
+}
+void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uint32_t nlevels, hipStream_t s) {
+    const uint32_t nw = T.nblocks * 4u;
+    hipLaunchKernelGGL(cx_k_scan_list_levels, dim3((nw + 255u) / 256u, nlevels), dim3(256), 0, s, device_params, T, nw);
 }
 
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {

@@ -488,24 +488,44 @@ class TriangulatedIsosurfaces(Delta3DContour):
 
 class MultiLevelIsosurfaces(object):
     """Several isovalues of ONE field (BASELINE.json config 5; the reference has this only in 2-D,
-    contourist/multiple_2d_contour.py:17-75).  The dense samples are bound to the device once and every
-    level is marched against the resident grid; levels run back to back on one stream because they share
-    the per-cell lookup table.  `levels()` yields (value, points, triangles) in ascending value order."""
+    contourist/multiple_2d_contour.py:17-75).  The dense samples are bound to the device once and ALL levels are
+    marched in one call: one pass over the samples classifies every level (`cx_extract3d_levels`), then the
+    vertex / triangle stages and the Level-1 post-pass run per level.  `levels()` yields (value, points, triangles)
+    in ascending value order; every level equals what a TriangulatedIsosurfaces of that value returns."""
 
-    def __init__(self, mins, maxes, delta, function, values, device=None):
+    def __init__(self, mins, maxes, delta, function, values, device=None, diagonal="cpython310"):
         self.values = sorted(float(v) for v in values)
         if callable(function):
             self.grid = grid_field.FunctionGrid(mins, maxes, delta, function)
         else:
             self.grid = grid_field.FunctionGrid.from_array(function, mins, delta)
         self.device = _DEFAULT_DEVICE[0] if device is None else int(device)
+        self.flags = {"cpython310": _ffi.CX_DIAG_CPYTHON310, "canonical": _ffi.CX_DIAG_CANONICAL}[diagonal]
         self._ctx = _ffi.Context(self.device)
+        self.counts = None
 
     def levels(self, clean=True):
         samples = self.grid.dense_samples()
         corner = tuple(int(n) for n in self.grid.grid_dimensions)
-        for v in self.values:
-            maker = GridContour3d(corner, samples, v, None, context=self._ctx)
-            grid_points, triangles = maker.get_points_and_triangles(clean)
-            points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
-            yield (v, points, triangles)
+        shape = tuple(int(n) for n in samples.shape)
+        ctx = self._ctx
+        if shape[2] < 4:          # rows shorter than 4 samples take the shape-agnostic kernel: one level at a time
+            for v in self.values:
+                maker = GridContour3d(corner, samples, v, None, context=ctx)
+                grid_points, triangles = maker.get_points_and_triangles(clean)
+                yield (v, self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3)), triangles)
+            return
+        if grid_field._is_torch(samples):
+            ctx.adopt_device_grid(samples.data_ptr(), shape, keepalive=samples)
+        else:
+            ctx.upload_grid(samples)
+        ctx.set_origin(0, 0, 0)
+        ctx.set_reference_corner((0, 0, 0))
+        self.counts = ctx.extract3d_levels(self.values, self.flags)
+        for n, v in enumerate(self.values):
+            ctx.select_level(n)
+            post = ctx.postprocess3d(0 if clean else 1)
+            grid_points, triangles = ctx.download_level1(post)
+            geometry = surface_geometry.SurfaceGeometry._from_device(grid_points, triangles, ctx)   # sorted rows, as the reference returns them
+            points = self.grid.from_grid_coordinates(geometry.vertices) if len(grid_points) else np.zeros((0, 3))
+            yield (v, points, geometry.oriented_triangles)

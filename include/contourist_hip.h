@@ -93,6 +93,17 @@ int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max
 int cx_extract3d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
 int cx_extract3d_async(cx_ctx* ctx, double value, uint32_t flags);
 int cx_counts_get(cx_ctx* ctx, cx_counts* out);
+/* Several isovalues of ONE grid in one call (BASELINE config 5; the reference classifies against all sorted levels at once only
+ * in 2-D, multiple_2d_contour.py:17-30, 48-59).  The pass over the samples runs once for all levels (the levels' workgroups
+ * stream a tile side by side: it comes from HBM once); scan, vertex and triangle stages then run per level, so every level's
+ * mesh is bit for bit the cx_extract3d mesh of that isovalue.  values: nlevels (1..64) isovalues in any order;
+ * flags: CX_DIAG_CANONICAL / CX_DIAG_CPYTHON310; out_counts: nlevels entries (may be NULL).  Every level keeps its own
+ * device buffers, sized to its surface.  Needs rows of at least 4 samples (CX_ERR_UNSUPPORTED otherwise).
+ * cx_levels_select makes level `index` the context's current extraction: cx_level0_download, cx_level0_points_f64,
+ * cx_postprocess3d*, cx_select_seeded3d* ... then act on that level (level 0 is selected on return).  The levels stay valid
+ * until the next cx_extract3d* / cx_grid_* call on the context. */
+int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nlevels, uint32_t flags, cx_counts* out_counts);
+int cx_levels_select(cx_ctx* ctx, int32_t index);
 /* which kernels produced the last extraction: 0 generic classify + triangle stage, 1 staged pipeline (stream, scan, vertex
  * stage, triangle stage), 2 stream, scan + fused emit kernel -- for measurement (bench.py names its kernels by it) */
 int cx_level0_path(cx_ctx* ctx, int* path);

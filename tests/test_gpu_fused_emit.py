@@ -149,3 +149,26 @@ def test_seeded_selection_after_fused_extraction():
         assert got["triangles_kept"] == int(want.sum()) and 0 < got["triangles_kept"] < len(tris)
     finally:
         ctx.close()
+
+
+def test_fused_and_staged_alternate_on_one_context():
+    """both emit paths on ONE context, alternating, on grids of different sizes: each keeps its own side tables (a stray
+    hipFree of the staged path's table in the fused path's regrow branch made the next staged extraction fault)"""
+    from contourist_amd import _ffi
+    ctx = _ffi.Context(0)
+    try:
+        for shape, seed in (((33, 33, 36), 1), ((70, 48, 132), 2), ((24, 20, 300), 3), ((96, 96, 96), 4)):
+            A = field(shape, seed)
+            ctx.upload_grid(A)
+            ref = None
+            for flags in (1, 1 | _ffi.CX_KERNEL_FUSED, 1 | _ffi.CX_KERNEL_STAGED, _ffi.CX_KERNEL_FUSED, 0, 1 | _ffi.CX_KERNEL_FUSED, 1):
+                c = ctx.extract3d(0.07, flags)
+                xyz, keys, tris = ctx.download_level0(c)
+                if flags & 1:
+                    if ref is None:
+                        ref = (c, keys.copy(), tris.copy(), xyz.copy())
+                    else:
+                        assert c == ref[0] and np.array_equal(keys, ref[1]) and np.array_equal(tris, ref[2])
+                        assert np.array_equal(xyz.view(np.uint32), ref[3].view(np.uint32))
+    finally:
+        ctx.close()
