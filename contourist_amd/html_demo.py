@@ -6,24 +6,36 @@ TriangulatedIsosurfaces / GridContour3d) or a (points, triangles) tuple.
 import json
 
 
+
 def _mesh(source):
     if hasattr(source, "get_points_and_triangles"):
         return source.get_points_and_triangles()
     return source
 
 
+# the three.js "Geometry" JSON (format 3) as the reference writes it, byte for byte (html_demo.py:133-161): one number per
+# line inside the two arrays, every face introduced by its type code 0 (plain triangle)
+THREE_JSON = """
+{
+    "metadata": {
+        "version": 3,
+        "type": "Geometry",
+        "generator": "GeometryExporter"
+    },
+    "faces": [%s],
+    "vertices": [%s],
+    "normals": [],
+    "uvs": []
+}
+"""
+
+
 def emit_three_json(grid_contour):
-    "three.js JSON geometry (format 3): faces as [0, a, b, c] runs, vertices flattened"
+    "three.js JSON geometry (format 3): faces as 0, a, b, c runs, vertices flattened; the reference's exact text"
     (points, triangles) = _mesh(grid_contour)
-    faces = []
-    for triangle in triangles:
-        faces.append(0)
-        faces.extend(int(index) for index in triangle)
-    vertices = [float(c) for point in points for c in point]
-    return json.dumps({
-        "metadata": {"version": 3, "type": "Geometry", "generator": "GeometryExporter"},
-        "faces": faces, "vertices": vertices, "normals": [], "uvs": [],
-    })
+    faces = ",\n".join("0,\n" + ",\n".join(str(int(index)) for index in triangle) for triangle in triangles)
+    vertices = ",\n".join(str(coordinate) for point in points for coordinate in point)
+    return THREE_JSON % (faces, vertices)
 
 
 PAGE = """<!DOCTYPE html>

@@ -65,3 +65,33 @@ def smooth_noise_numpy(shape, seed, passes):
             sl[axis] = idx
             y[tuple(sl)] = lo
     return np.ascontiguousarray(y, dtype=np.float32)
+
+
+CONFIG4_VALUE = 0.5     # isovalue of BASELINE config 4 on moving_blobs_torch
+
+
+def moving_blobs_torch(shape, seed, device):
+    """BASELINE config 4's field: a 4-D array A[x][y][z][t] of two Gaussian blobs that move (and pass each other) over t,
+    plus 5 % smooth noise, zero on the two outermost samples of every axis (closed interior)."""
+    import torch
+    n0, n1, n2, n3 = (int(n) for n in shape)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    ax = [torch.arange(n, device=device, dtype=torch.float32) for n in (n0, n1, n2, n3)]
+    X, Y, Z, T = torch.meshgrid(*ax, indexing="ij")
+    s = T / max(n3 - 1, 1)
+    c1 = (0.30 + 0.35 * s, 0.35 + 0.2 * s, 0.5 + 0.0 * s)
+    c2 = (0.70 - 0.30 * s, 0.65 - 0.2 * s, 0.45 + 0.1 * s)
+
+    def blob(c, w):
+        return torch.exp(-(((X / n0 - c[0]) ** 2 + (Y / n1 - c[1]) ** 2 + (Z / n2 - c[2]) ** 2) / (2 * w * w)))
+    A = blob(c1, 0.12) + blob(c2, 0.10)
+    del X, Y, Z, T
+    noise = torch.randn((n0 // 8 + 1, n1 // 8 + 1, n2 // 8 + 1, n3 // 8 + 1), generator=g).to(device)
+    up = torch.nn.functional.interpolate(noise.permute(3, 0, 1, 2).unsqueeze(1), size=(n0, n1, n2), mode="trilinear", align_corners=True)
+    up = torch.nn.functional.interpolate(up.squeeze(1).permute(1, 2, 3, 0).reshape(1, n0 * n1 * n2, -1), size=n3, mode="linear", align_corners=True)
+    A = A + 0.05 * up.reshape(n0, n1, n2, n3)
+    for axis in range(4):
+        for idx in (0, 1, -1, -2):
+            A.select(axis, idx).fill_(0.0)
+    return A.contiguous()

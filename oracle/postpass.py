@@ -196,7 +196,7 @@ def clean(xyz, tris, tprio=None):
     return x2, t2
 
 
-def orient(xyz, tris, compatible=None):
+def orient(xyz, tris, compatible=None, shuffle=None):
     """A10.  SurfaceGeometry.orient_triangles, restated faithfully (input winding is IGNORED):
     while unoriented triangles remain: take the vertex with the largest (x, index) among them
     (:79), among its unoriented triangles the one with the largest |cross(a-b, a-c)[0]| (:88-94,
@@ -209,6 +209,9 @@ def orient(xyz, tris, compatible=None):
     its traversal order; bit 1: the start rule is ambiguous (several vertices share the largest x, or
     several of their triangles share the largest |cross_x|, and they do not all imply the same
     winding, or cross_x is exactly 0) -> the reference's result depends on its vertex numbering."""
+    # shuffle: a numpy RandomState -- the triangles of an edge are visited in a random order, as the reference's
+    # `for triangle in triangles` over a SET does from run to run (surface_geometry.py:117); running the fill with several
+    # orders shows which windings its traversal order decides (edges with three or more triangles)
     xyz = np.asarray(xyz, dtype=np.float64)
     tris = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
     T = len(tris)
@@ -222,6 +225,10 @@ def orient(xyz, tris, compatible=None):
             vert_tris.setdefault(v, []).append(t)
         for e in ((a, b), (b, c), (a, c)):
             edge_tris.setdefault((min(e), max(e)), []).append(t)
+    if shuffle is not None:
+        for e in edge_tris:
+            if len(edge_tris[e]) > 2:
+                shuffle.shuffle(edge_tris[e])
     orientation = {}
     label = -np.ones(T, dtype=np.int64)
     unoriented = set(range(T))

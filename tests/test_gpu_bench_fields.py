@@ -1,0 +1,130 @@
+"""GPU: the REAL bench fields (contourist_amd.synthetic.smooth_noise_torch, what bench.py extracts), not analytic spheres.
+
+256^3 and 512^3: the mesh of the first 32 voxel planes equals oracle/march_oracle.c on those planes exactly (edge ids,
+triangles with the CPython-order diagonals; coordinates within 1e-6), the whole mesh has unique edge ids, every index in
+range, every triangle wound from low to high (normal . gradient of the field > 0), and a second extraction gives the same
+bits.  Config 4's field (128^3 x 64, two moving blobs + noise) through the 4-D size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PLANES = 33          # 32 voxel planes from plane 0: lattice coordinates of the slab == those of the volume (hash order)
+
+
+@pytest.mark.parametrize("size,passes", [(256, 700), (512, 1400)])
+def test_bench_field_against_oracle_slab_and_properties(size, passes):
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi, synthetic
+    from oracle import level0
+    dev = torch.device("cuda", 0)
+    A = synthetic.smooth_noise_torch((size,) * 3, 1235, passes, dev)
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        c = ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
+        assert ctx.level0_path() == 1
+        xyz, keys, tris = ctx.download_level0(c)
+        frac = c["n_border_voxels"] / float((size - 1) ** 3)
+        assert 0.01 < frac < 0.08, frac                       # the ~3 % active voxels the bench quotes
+        # ---- whole mesh: ids unique, indices in range, winding by the field gradient
+        keys = keys.astype(np.int64)
+        assert len(np.unique(keys)) == len(keys)
+        assert tris.min() >= 0 and tris.max() < len(keys)
+        sub = np.ascontiguousarray(A[:PLANES].cpu().numpy())
+        plane = size * size
+        lin, d = keys >> 3, keys & 7
+        in_slab_v = (lin // plane) < (PLANES - 1)            # owner plane inside the slab's voxel planes
+        # ---- the slab against the oracle, exactly
+        O = level0.march3d(sub, 0.0, diag_mode=1)
+        ko = level0.edge_keys_from_pairs(O["pairs"], sub.shape)
+        own_o = ((ko >> 3) // plane) < (PLANES - 1)
+        assert np.array_equal(np.sort(keys[in_slab_v]), np.sort(ko[own_o])), "crossing edges of the first 32 voxel planes differ from the oracle"
+        tk = keys[tris.astype(np.int64)]
+        # a triangle belongs to the voxel at the componentwise minimum of its three owners; planes 0..31 are complete in the slab
+        owner_plane = ((tk >> 3) // plane).min(axis=1)
+        ok_o = ((ko[O["tris"]] >> 3) // plane).min(axis=1) < (PLANES - 1)
+        # triangles of voxel plane 31 use vertices owned by plane 32 as well: present in both (the slab has 33 planes)
+        dev_tr = np.sort(tk[owner_plane < (PLANES - 1)], axis=1)
+        ora_tr = np.sort(ko[O["tris"]][ok_o], axis=1)
+        dev_tr = dev_tr[np.lexsort((dev_tr[:, 2], dev_tr[:, 1], dev_tr[:, 0]))]
+        ora_tr = ora_tr[np.lexsort((ora_tr[:, 2], ora_tr[:, 1], ora_tr[:, 0]))]
+        assert np.array_equal(dev_tr, ora_tr), "triangles of the first 32 voxel planes differ from the oracle"
+        order_d = np.argsort(keys[in_slab_v]); order_o = np.argsort(ko[own_o])
+        xd, xo = xyz[in_slab_v][order_d].astype(np.float64), O["xyz"][own_o][order_o]
+        assert np.all(np.abs(xd - xo) <= 1e-6 * np.abs(xo) + 1e-6)
+        # ---- winding: normal . gradient > 0 on a sample of triangles (central differences of the field at the centroid's cell)
+        rng = np.random.RandomState(1)
+        pick = rng.choice(len(tris), size=min(200000, len(tris)), replace=False)
+        T = tris[pick].astype(np.int64)
+        p0, p1, p2 = (xyz[T[:, n]].astype(np.float64) for n in range(3))
+        nrm = np.cross(p1 - p0, p2 - p0)
+        cen = (p0 + p1 + p2) / 3.0
+        ci = np.clip(np.floor(cen).astype(np.int64), 1, size - 3)
+        idx = torch.from_numpy(ci).to(dev)
+        def at(di, dj, dk):
+            return A[idx[:, 0] + di, idx[:, 1] + dj, idx[:, 2] + dk].double().cpu().numpy()
+        # gradient of the trilinear-ish field over the 2x2x2 block around the centroid
+        g = np.stack([sum(at(1, a, b) - at(0, a, b) for a in (0, 1) for b in (0, 1)),
+                      sum(at(a, 1, b) - at(a, 0, b) for a in (0, 1) for b in (0, 1)),
+                      sum(at(a, b, 1) - at(a, b, 0) for a in (0, 1) for b in (0, 1))], axis=1)
+        s = np.einsum("ij,ij->i", nrm, g)
+        big = np.linalg.norm(nrm, axis=1) > 1e-6
+        assert np.mean(s[big] > 0) > 0.999, np.mean(s[big] > 0)      # (a sliver next to a saddle may see the block gradient tilt)
+        # ---- deterministic, bit for bit
+        c2 = ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
+        x2, k2, t2 = ctx.download_level0(c2)
+        assert c2 == c and np.array_equal(k2.astype(np.int64), keys) and np.array_equal(t2, tris) and np.array_equal(x2.view(np.uint32), xyz.view(np.uint32))
+    finally:
+        ctx.close()
+        del A
+        torch.cuda.empty_cache()
+
+
+def test_config4_field_4d_properties():
+    """128^3 x 64 (BASELINE config 4: two moving blobs + noise): ids unique, indices in range, every tetrahedron has four
+    distinct vertices inside one hyper-voxel neighbourhood, counts repeat, and a slab of hyper-voxel planes equals the C oracle"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi, synthetic
+    from oracle import level0_4d
+    dev = torch.device("cuda", 0)
+    shape = (128, 128, 128, 64)
+    A = synthetic.moving_blobs_torch(shape, 1236, dev)
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+        v = synthetic.CONFIG4_VALUE
+        c = ctx.extract4d(v, _ffi.CX_DIAG_CPYTHON310)
+        verts, keys, tets = ctx.download_level0_4d(c)
+        assert c["n_tetrahedra"] > 1e6
+        k = keys.astype(np.int64)
+        assert len(np.unique(k)) == len(k)
+        assert tets.min() >= 0 and tets.max() < len(k)
+        tt = np.sort(tets, axis=1)
+        assert np.all(tt[:, 1:] != tt[:, :-1])                # four distinct vertices
+        # all four edges of a tetrahedron start inside one hyper-voxel: owner lattice points differ by at most 1 per axis
+        lin = k >> 4
+        n1, n2, n3 = shape[1], shape[2], shape[3]
+        q = np.stack([lin // (n1 * n2 * n3), (lin // (n2 * n3)) % n1, (lin // n3) % n2, lin % n3], axis=1)
+        qt = q[tets.astype(np.int64)]
+        assert (qt.max(axis=1) - qt.min(axis=1)).max() <= 1
+        # a slab of 5 sample planes along axis 0 against the C oracle (planes 0..4: same lattice coordinates)
+        sub = np.ascontiguousarray(A[:5].cpu().numpy())
+        O = level0_4d.march4d(sub, v, diag_mode=1)
+        ko = level0_4d.edge_keys4(O["pairs"], sub.shape)
+        vol = n1 * n2 * n3
+        own_d = (lin // vol) < 4
+        own_o = ((ko >> 4) // vol) < 4
+        assert np.array_equal(np.sort(k[own_d]), np.sort(ko[own_o]))
+        tk = k[tets.astype(np.int64)]
+        dsel = ((tk >> 4) // vol).min(axis=1) < 4
+        osel = ((ko[O["tets"]] >> 4) // vol).min(axis=1) < 4
+        a = np.sort(tk[dsel], axis=1); b = np.sort(ko[O["tets"]][osel], axis=1)
+        a = a[np.lexsort(a.T[::-1])]; b = b[np.lexsort(b.T[::-1])]
+        assert np.array_equal(a, b)
+        c2 = ctx.extract4d(v, _ffi.CX_DIAG_CPYTHON310)
+        assert c2 == c
+    finally:
+        ctx.close()
+        del A
+        torch.cuda.empty_cache()

@@ -122,6 +122,19 @@ def test_morph_triangles_device(name):
         postpass4d.morph_polygons(kh, MT.segment_point_indices, MT.triangle_segment_indices)
     common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, rk, G["mt_segments"], G["mt_triangles"])
     assert common > 0.7 * len(ot) and agree >= 0.97 * common
+    # What is known about the rest (B5 stays "partial" in DESIGN.md): the reference's flood fill is reproduced exactly by the
+    # oracle (100 % of the common triangles on every fixture, also when the triangles of a crowded segment are visited in
+    # shuffled orders: its result is order-independent there), so the <= 3 % are a deviation of the device's rule (winding by
+    # the field gradient) and not a hash-order artefact.  Where two triangles are alone on a segment at some time, both
+    # windings are consistent (opposite directions along the shared edge) -- for the device and for the reference:
+    bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
+    bad_r, seen_r = postpass4d.forced_pair_violations(rk, G["mt_segments"], G["mt_triangles"], G["mt_points4d"])
+    # (test0_style has samples exactly EQUAL to the isovalue: tetrahedra with zero-length edges, where the determinant that
+    # winds a slice by the field gradient vanishes -- the device then leaves a few pairs inconsistent, the reference none)
+    assert bad_r == 0 and seen_d > 0
+    assert bad_d == 0 or (name.startswith("test0_style") and bad_d <= 0.002 * len(MT.triangle_segment_indices)), (bad_d, seen_d)
+    print(name, "4-D winding: common", common, "agree", agree, "(%.2f %%)" % (100.0 * agree / common), "forced pairs checked", seen_d, seen_r,
+          "inconsistent on the device", bad_d)
     assert np.array_equal(MT.points4d[np.argsort(kh)], G["mt_points4d"][np.argsort(rk)])
     # B6: the surface at a time t is a closed 3-D mesh where it exists (every edge shared by two triangles)
     tmid = 0.5 * (MT.min_value + MT.max_value) + 0.013
@@ -130,23 +143,47 @@ def test_morph_triangles_device(name):
 
 
 @pytest.mark.parametrize("name", names())
-def test_per_t_surfaces_on_device_equal_host_evaluation(name):
-    """B6: the surface at time t from the morph triangles -- device kernel vs MorphTriangles.triangles_at (numpy)"""
-    from contourist_amd import pentatopes
+def test_per_t_surfaces_against_the_viewer_oracle(name):
+    """B6: the surface at time t from the morph triangles -- cx_morph_eval against oracle/morph_eval.py, the restatement of
+    the reference's viewer (misc/morph_triangles.js:53-84 triangle intervals, :117-147 active set, :156-178 points on the
+    segments), on the device's own morph triangles AND on the reference's (tests/golden4d: mt_*)."""
+    from contourist_amd import pentatopes, morph_geometry
+    from oracle import morph_eval
     G = np.load(os.path.join(G4, name + ".npz"))
     A, v = G["A"], float(G["value"])
     maker = pentatopes.GridContour4D(tuple(np.array(A.shape) - 1), A, v)
     maker.find_tetrahedra()
     MT = maker.collect_morph_triangles()
+
+    def tri_points(points, tris):
+        "triangles as triples of 3-D points, rotated to start at the smallest one (winding kept), sorted"
+        out = []
+        for t in np.asarray(tris):
+            p = [tuple(np.round(points[k], 9).tolist()) for k in t]
+            r = p.index(min(p))
+            out.append((p[r], p[(r + 1) % 3], p[(r + 2) % 3]))
+        return sorted(out)
     n_nonempty = 0
-    for t in np.linspace(MT.min_value, MT.max_value, 9):
-        ph, th = MT.triangles_at(float(t))
-        pd, td = maker.triangles_at(float(t))
-        assert len(ph) == len(pd) and len(th) == len(td)
-        assert np.array_equal(th, td)
-        assert np.allclose(ph, pd, rtol=0, atol=1e-12)
+    lo, hi = float(MT.min_value), float(MT.max_value)
+    for frac in (0.013, 0.137, 0.291, 0.419, 0.503, 0.677, 0.811, 0.953):      # generic times: no vertex time is hit exactly
+        t = lo + frac * (hi - lo)
+        pd, td = maker.triangles_at(t)                                          # device: cx_morph_eval
+        W = morph_eval.surface_at(MT.points4d, MT.segment_point_indices, MT.triangle_segment_indices, t)
+        assert len(td) == len(W["faces"]) and len(pd) == len(W["points"])
+        assert tri_points(pd, td) == tri_points(W["points"], W["faces"])
+        # the host-side numpy evaluation of the mirrored class agrees as well
+        ph, th = MT.triangles_at(t)
+        assert np.array_equal(th, td) and np.allclose(ph, pd, rtol=0, atol=1e-12)
         n_nonempty += len(td) > 0
     assert n_nonempty >= 3
+    if "mt_points4d" in G:
+        # the reference's own morph triangles through the mirrored class (host) and the oracle
+        R = morph_geometry.MorphTriangles(G["mt_points4d"], G["mt_segments"], G["mt_triangles"])
+        for frac in (0.213, 0.577):
+            t = lo + frac * (hi - lo)
+            ph, th = R.triangles_at(t)
+            W = morph_eval.surface_at(R.points4d, R.segment_point_indices, R.triangle_segment_indices, t)
+            assert tri_points(ph, th) == tri_points(W["points"], W["faces"])
 
 
 def test_time_slices_are_consistently_wound_at_size():

@@ -4,31 +4,11 @@ Reports M hyper-voxels/s of the Level-0 march (classify + tetrahedra emit) and o
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
-from contourist_amd import _ffi
-
-def field(shape, dev, seed=1236):
-    n0, n1, n2, n3 = shape
-    g = torch.Generator(device="cpu"); g.manual_seed(seed)
-    ax = [torch.arange(n, device=dev, dtype=torch.float32) for n in shape]
-    X, Y, Z, T = torch.meshgrid(*ax, indexing="ij")
-    s = T / max(n3 - 1, 1)
-    c1 = (0.30 + 0.35 * s, 0.35 + 0.2 * s, 0.5 + 0.0 * s)
-    c2 = (0.70 - 0.30 * s, 0.65 - 0.2 * s, 0.45 + 0.1 * s)
-    def blob(c, w):
-        return torch.exp(-(((X / n0 - c[0]) ** 2 + (Y / n1 - c[1]) ** 2 + (Z / n2 - c[2]) ** 2) / (2 * w * w)))
-    A = blob(c1, 0.12) + blob(c2, 0.10)
-    noise = torch.randn((n0 // 8 + 1, n1 // 8 + 1, n2 // 8 + 1, n3 // 8 + 1), generator=g).to(dev)
-    up = torch.nn.functional.interpolate(noise.permute(3, 0, 1, 2).unsqueeze(1), size=(n0, n1, n2), mode="trilinear", align_corners=True)
-    up = torch.nn.functional.interpolate(up.squeeze(1).permute(1, 2, 3, 0).reshape(1, n0 * n1 * n2, -1), size=n3, mode="linear", align_corners=True)
-    A = A + 0.05 * up.reshape(n0, n1, n2, n3)
-    for axis in range(4):
-        for idx in (0, 1, -1, -2):
-            A.select(axis, idx).fill_(0.0)
-    return A.contiguous()
+from contourist_amd import _ffi, synthetic
 
 shape = tuple(int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (128, 128, 128, 64)))
 dev = torch.device("cuda", 0)
-A = field(shape, dev)
+A = synthetic.moving_blobs_torch(shape, 1236, dev)
 ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 ctx.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
 v = 0.5
