@@ -159,11 +159,43 @@ def extract_slabs(own_planes, value, rank, world, extract_fn, global_shape, dist
         return part
     if world == 1:
         return assemble([part])
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(part, gathered, dst=0)
+    gathered = gather_parts(part, rank, world, dist, local.device if local.is_cuda else None)
     if rank == 0:
         return assemble(gathered)
     return None
+
+
+def gather_parts(part, rank, world, dist, device=None):
+    """(gkeys (V,) int64, gxyz (V,3) float64, tri_gkeys (T,3) int64) of every rank -> list of them on rank 0 (None elsewhere).
+    Tensors, not pickles: the sizes go round with one all_gather, then every rank sends ONE flat 8-byte-word buffer
+    (keys | coordinates as their bit patterns | triangle keys) to rank 0 -- over RCCL (device buffers) with backend "nccl",
+    host buffers with gloo.  A 512^3 surface is ~0.5 GB per volume: this is what `gather_object` used to pickle."""
+    import torch
+    gkeys, gxyz, tk = part
+    gkeys = np.ascontiguousarray(gkeys, dtype=np.int64).reshape(-1)
+    gxyz = np.ascontiguousarray(gxyz, dtype=np.float64).reshape(-1, 3)
+    tk = np.ascontiguousarray(tk, dtype=np.int64).reshape(-1, 3)
+    on_device = dist.get_backend() == "nccl"
+    dev = device if (on_device and device is not None) else (torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
+    sizes = torch.tensor([len(gkeys), len(tk)], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [tuple(int(x) for x in t.cpu()) for t in all_sizes]
+    flat = np.concatenate([gkeys, gxyz.reshape(-1).view(np.int64), tk.reshape(-1)])
+    if rank != 0:
+        if len(flat):
+            dist.send(torch.from_numpy(flat).to(dev), dst=0)
+        return None
+    out = [part]
+    for r in range(1, world):
+        nv, nt = all_sizes[r]
+        n = nv * 4 + nt * 3
+        buf = torch.empty(n, dtype=torch.int64, device=dev)
+        if n:
+            dist.recv(buf, src=r)
+        h = buf.cpu().numpy()
+        out.append((h[:nv].copy(), h[nv:nv * 4].view(np.float64).reshape(-1, 3).copy(), h[nv * 4:].reshape(-1, 3).copy()))
+    return out
 
 
 def level1_slabs(own_planes, value, rank, world, global_shape, device=0, clean=True, smooth=None, dist=None):

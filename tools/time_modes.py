@@ -18,6 +18,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "quick":
     modes = [(1 | 0x400, "fused"), (0x400, "fused canon"), (1, "staged"), (0, "staged canon")]
 if len(sys.argv) > 2 and sys.argv[2] == "staged":
     modes = [(1, "staged"), (0, "staged canon")]
+if len(sys.argv) > 2 and sys.argv[2] == "hash":
+    modes = [(1, "staged"), (0, "staged canon"), (1 | 0x200000, "cpython no_lookup"), (0x200000, "canon no_lookup")]
 if len(sys.argv) > 2 and sys.argv[2] == "fused":
     modes = [(1 | 0x400, "fused"), (0x400, "fused canon")]
 if len(sys.argv) > 2 and sys.argv[2] == "ablate_staged":
