@@ -403,16 +403,17 @@ class Context(object):
     def kernel_names(self):
         path = self.level0_path()
         if path == 2:
-            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_waves+cx_k_list_batches"), ("cells_ms", "cx_k_emit_mesh")]
+            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_list"), ("cells_ms", "cx_k_cell_info+cx_k_emit_mesh")]
         if path == 1:
-            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_waves+cx_k_list_batches"),
-                    ("cells_ms", "cx_k_emit_vertices"), ("emit_ms", "cx_k_emit_triangles")]
+            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_list"),
+                    ("cells_ms", "cx_k_emit_vertices"), ("emit_ms", "cx_k_emit_triangles_q")]
         return [("stream_ms", "cx_k_classify_generic"), ("emit_ms", "cx_k_emit_triangles")]
 
     def vertex_stage_bytes(self, counts):
         if self.level0_path() == 2:     # fused emit: 16 B per vertex record + 12 B per triangle written
             return 16.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
-        return 16.0 * counts["n_vertices"] + 16.0 * counts["n_cells"]    # vertex records + cell records written
+        # vertex records + cell records + one 8-byte word per queue entry written
+        return 16.0 * counts["n_vertices"] + 24.0 * counts["n_cells"]
 
     @staticmethod
     def triangle_stage_bytes(counts):

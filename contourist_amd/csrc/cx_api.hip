@@ -75,6 +75,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (ctx->qa) (void)hipFree(ctx->qa);
     if (ctx->info) (void)hipFree(ctx->info);
     if (ctx->info64) (void)hipFree(ctx->info64);
+    if (ctx->chunksum) (void)hipFree(ctx->chunksum);
     if (ctx->hbytes) (void)hipFree(ctx->hbytes);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
@@ -333,6 +334,15 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             CX_HIP(ctx, hipMalloc(&ctx->qa, nqa * sizeof(uint32_t)));
             ctx->qa_cap = nqa;
         }
+        const size_t nchunk_words = ((nw + 255u) / 256u) * 8u;
+        if (ctx->chunksum_cap < nchunk_words) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->chunksum) (void)hipFree(ctx->chunksum);
+            ctx->chunksum = nullptr; ctx->chunksum_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->chunksum, nchunk_words * sizeof(uint32_t)));
+            ctx->chunksum_cap = nchunk_words;
+        }
+        CX_HIP(ctx, hipMemsetAsync(ctx->chunksum, 0, nchunk_words * sizeof(uint32_t), ctx->stream));
         if (!fused && ctx->info64_cap < need) {   // staged kernels: (first vertex, crossing mask) per queue entry
             CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->info64) (void)hipFree(ctx->info64);
@@ -349,7 +359,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         }
         P.queue = ctx->queue; P.wsum = ctx->wsum; P.wbase = ctx->wbase; P.brec = ctx->brec;
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
-        P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64;
+        P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
         ctx->last = P;
     }

@@ -77,6 +77,7 @@ struct cx_params {
     uint64_t* info64;         // [queue size] staged kernels, per queue entry: (crossing mask << 32) | first vertex index -- the dense
                               // successor of `celltab` (which only the generic classify kernel still fills)
     cx_fdiv div_ci;           // / (cell planes per task)
+    uint32_t* chunksum;       // [ceil(nwaves / 256)][8] totals (v, t, c, b, nb, near) of every 256 streaming waves, added up by the stream kernel
     uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
 };
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15

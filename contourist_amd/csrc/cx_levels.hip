@@ -41,6 +41,8 @@ struct cx_level_slot {
     uint32_t* qa = nullptr;
     size_t qa_cap = 0;
     uint32_t* counters = nullptr;
+    uint32_t* chunksum = nullptr;
+    size_t chunksum_cap = 0;
     // Level-0 outputs of the level (swapped with the context's while the level is selected)
     float4* verts = nullptr;
     uint4* cells = nullptr;
@@ -60,7 +62,7 @@ struct cx_levels_state {
 };
 
 static void free_slot(cx_level_slot& S) {
-    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.verts, S.cells, S.tris};
+    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.verts, S.cells, S.tris};
     for (void* p : all)
         if (p) (void)hipFree(p);
     S = cx_level_slot();
@@ -178,6 +180,8 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         if ((rc = grow(ctx, S.flat, S.flat_cap, nflat))) return rc;
         if ((rc = grow(ctx, S.qa, S.qa_cap, nw * CX_SWP * 64u + 64u))) return rc;
         if (!S.counters) CXL_HIP(ctx, hipMalloc(&S.counters, CX_CNT_WORDS * sizeof(uint32_t)));
+        if ((rc = grow(ctx, S.chunksum, S.chunksum_cap, ((nw + 255u) / 256u) * 8u))) return rc;
+        CXL_HIP(ctx, hipMemsetAsync(S.chunksum, 0, ((nw + 255u) / 256u) * 8u * sizeof(uint32_t), ctx->stream));
         cx_params& P = S.P;
         memset(&P, 0, sizeof(P));
         P.grid = ctx->grid;
@@ -192,6 +196,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         P.counters = S.counters;
         P.queue = S.queue; P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
         P.qa = S.qa;
+        P.chunksum = S.chunksum;
         P.verts = S.verts; P.cells = S.cells; P.tris = S.tris;
         P.vcap = S.vcap; P.ccap = S.ccap; P.tcap = S.tcap;
     }

@@ -553,6 +553,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
     __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
+    __shared__ uint32_t s_tot[4][6];
     if (b >= T.nblocks) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -782,6 +783,17 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         cx_wsum S;
         S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = really_near ? 1u : 0u; S.pad = 0;
         P.wsum[w] = S;
+        s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b; s_tot[wave][4] = nb;
+        s_tot[wave][5] = (really_near && qn != 0u) ? 1u : 0u;
+    }
+    // totals of every 256 waves (64 workgroups), so that the scan needs ONE round of loads for everything before its chunk
+    // (the per-wave totals were just written by CUs all over the chip: each dependent round of loads from them costs ~2 us).
+    // One atomic per workgroup and counter.
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t sum = s_tot[0][threadIdx.x] + s_tot[1][threadIdx.x] + s_tot[2][threadIdx.x] + s_tot[3][threadIdx.x];
+        uint32_t* cs = P.chunksum + (size_t)(b >> 6) * 8u;
+        if (sum) atomicAdd(cs + threadIdx.x, sum);      // (slot 5: number of waves on the tolerance path; non-zero = flag)
     }
 }
 template <bool ALIGNED>
@@ -898,18 +910,11 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
     __shared__ uint32_t s_own[4][5];     // per wave: inclusive totals of its 64 streaming waves
     const uint32_t tid = threadIdx.x, lane = cx_lane_id(), wave = tid >> 6;
     uint32_t acc[5] = {0, 0, 0, 0, 0}, near_any = 0;   // v, t, c, b, nb
-    for (uint32_t c0 = 0; c0 < g; c0 += 8u) {            // 8 independent loads in flight per thread
-        cx_wsum E[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
-            E[u].nb = E[u].v = E[u].t = E[u].c = E[u].b = E[u].nq = E[u].near = 0;
-            if (c0 + u < g) E[u] = P.wsum[(c0 + u) * 256u + tid];      // chunks before the last one are full
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
-            acc[0] += E[u].v; acc[1] += E[u].t; acc[2] += E[u].c; acc[3] += E[u].b; acc[4] += E[u].nb;
-            near_any |= (E[u].near != 0u && E[u].nq != 0u) ? 1u : 0u;
-        }
+    for (uint32_t c = tid; c < nchunks; c += 256u) {     // thread c: the totals of chunk c (the last workgroup looks at all of them for the near flag)
+        const uint4 lo = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u);
+        const uint4 hi = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u + 4u);
+        if (c < g) { acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w; acc[4] += hi.x; }
+        near_any |= hi.y;
     }
     const uint32_t w = g * 256u + tid;
     cx_wsum S;

@@ -27,6 +27,12 @@ for kk, d in vals.items():
         "note": "FETCH_SIZE*1024 (+ x2 upper bound for 16-B/lane streams on gfx950) + WRITE_SIZE*1024, mean of launches 2..N",
     }
 json.dump(out, open("profiles/traffic_detail.json", "w"), indent=1)
-# the numbers bench.py reports as roofline.traffic: upper-bound HBM bytes per launch, per kernel
-json.dump({k: v["hbm_bytes_high"] for k, v in out.items()}, open("profiles/traffic.json", "w"), indent=1)
+# the number bench.py reports as roofline.traffic: HBM bytes of ONE extraction = all Level-0 kernels of the staged pipeline.
+# The stream kernel's loads are 16 B per lane (FETCH_SIZE counts them at half: x2, MI355X_MICROARCH.md); the emit kernels
+# gather 4-16 B per lane (uncalibrated: counted as reported, a lower bound) -- both sums are kept
+level0 = ["cx_k_stream", "cx_k_scan_list", "cx_k_emit_vertices", "cx_k_emit_triangles_q"]
+summary = {k: v["hbm_bytes_high"] if k.startswith("cx_k_stream") else v["hbm_bytes_low"] for k, v in out.items()}
+summary["level0_512"] = sum(summary.get(k + "_512", 0.0) for k in level0)
+summary["level0_512_upper"] = sum(out[k + "_512"]["hbm_bytes_high"] for k in level0 if k + "_512" in out)
+json.dump(summary, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
