@@ -4,6 +4,7 @@ Level-0 kernels, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRI
 units of 1024 B; on gfx950 FETCH_SIZE counts wide coalesced streaming reads at half their bytes)."""
 import collections, csv, glob, json, os, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+dest = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 out = {}
 vals = collections.defaultdict(dict)
 for name in ("fetch", "write"):
@@ -26,7 +27,7 @@ for kk, d in vals.items():
         "hbm_bytes_low": fetch_raw + write, "hbm_bytes_high": 2.0 * fetch_raw + write,
         "note": "FETCH_SIZE*1024 (+ x2 upper bound for 16-B/lane streams on gfx950) + WRITE_SIZE*1024, mean of launches 2..N",
     }
-json.dump(out, open("profiles/traffic_detail.json", "w"), indent=1)
+json.dump(out, open(os.path.join(dest, "traffic_detail.json"), "w"), indent=1)
 # the number bench.py reports as roofline.traffic: HBM bytes of ONE extraction = all Level-0 kernels of the staged pipeline.
 # The stream kernel's loads are 16 B per lane (FETCH_SIZE counts them at half: x2, MI355X_MICROARCH.md); the emit kernels
 # gather 4-16 B per lane (uncalibrated: counted as reported, a lower bound) -- both sums are kept
@@ -34,5 +35,5 @@ level0 = ["cx_k_stream", "cx_k_scan_list", "cx_k_emit_vertices", "cx_k_emit_tria
 summary = {k: v["hbm_bytes_high"] if k.startswith("cx_k_stream") else v["hbm_bytes_low"] for k, v in out.items()}
 summary["level0_512"] = sum(summary.get(k + "_512", 0.0) for k in level0)
 summary["level0_512_upper"] = sum(out[k + "_512"]["hbm_bytes_high"] for k in level0 if k + "_512" in out)
-json.dump(summary, open("profiles/traffic.json", "w"), indent=1)
+json.dump(summary, open(os.path.join(dest, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
