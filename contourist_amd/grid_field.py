@@ -133,20 +133,29 @@ class FunctionGrid(object):
 
     def find_contour_crossing_grid_segments(self, value, skip=1):
         """(maxf, minf, [(vertex0, vertex1), ...]) for lattice segments to the 2^d-1 forward neighbours
-        with (f0-value)*(f1-value) < 0 (grid_field.py:64-84).  Evaluated on the dense samples with
-        array operations (the device march does not need this list; it is kept for API parity)."""
-        S = np.asarray(self.dense_samples_host(), dtype=np.float64)
+        with (f0-value)*(f1-value) < 0 (grid_field.py:64-84), in the reference's order: lattice points in
+        lexicographic order (iter_indices), their neighbours by offset index (surrounding_vertices: bit `shift` of the index
+        moves axis `shift`).  Evaluated with array operations (the device march does not need this list; the
+        seeded growth of search_for_endpoints(skip > 1) does, and it is order-sensitive).
+        With skip > 1 the forward neighbour of the last strided point lies up to skip-1 steps beyond the grid: the
+        reference evaluates f there; so does this for a callable field (a sample array cannot be evaluated outside
+        itself: those segments are left out)."""
         gd = tuple(int(n) for n in self.grid_dimensions)
         dim = self.dimension
+        ext = skip - 1 if (skip > 1 and not getattr(self, "array_backed", False)) else 0
+        if ext:
+            S = np.asarray(self._evaluate(tuple(n + 1 + ext for n in gd)), dtype=np.float64)
+        else:
+            S = np.asarray(self.dense_samples_host(), dtype=np.float64)
         base = tuple(slice(0, gd[a], skip) for a in range(dim))
         f0 = S[base]
         maxf = minf = None
-        result = []
+        hits = []
         for index in range(1, 2 ** dim):
             off = [((index >> shift) & 1) * skip for shift in range(dim)]
             sl = tuple(slice(off[a], off[a] + gd[a], skip) for a in range(dim))
             f1 = S[sl]
-            # the forward neighbour of the last strided index can fall outside the samples
+            # without samples beyond the grid the forward neighbour of the last strided index is missing
             common = tuple(slice(0, min(f0.shape[a], f1.shape[a])) for a in range(dim))
             a0, a1 = f0[common], f1[common]
             if a0.size:
@@ -154,11 +163,12 @@ class FunctionGrid(object):
                 lo = min(a0.min(), a1.min())
                 maxf = hi if maxf is None else max(maxf, hi)
                 minf = lo if minf is None else min(minf, lo)
-            hit = np.argwhere((a0 - value) * (a1 - value) < 0)
-            for idx in hit:
+            for idx in np.argwhere((a0 - value) * (a1 - value) < 0):
+                rank = int(np.ravel_multi_index(tuple(idx), f0.shape))
                 v0 = idx * skip
-                result.append((v0.astype(int), (v0 + off).astype(int)))
-        return (maxf, minf, result)
+                hits.append((rank, index, v0.astype(int), (v0 + off).astype(int)))
+        hits.sort(key=lambda h: (h[0], h[1]))
+        return (maxf, minf, [(h[2], h[3]) for h in hits])
 
     # ---- dense samples for the device path -----------------------------------------------------
     def _evaluate(self, shape, first=0):

@@ -18,7 +18,8 @@ def golden_names():
     if not os.path.isdir(GOLDEN_DIR):
         return []
     # (two_dots and coarse_* have their own tests: they carry parameters of a field, not a small sample array)
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "two_dots.npz" and not f.startswith("coarse_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "two_dots.npz" and not f.startswith("coarse_")
+                  and not f.startswith("crossing_"))
 
 
 @pytest.fixture(scope="session")

@@ -79,3 +79,21 @@ def test_bad_grid_asserts_like_the_reference():
         grid_field.FunctionGrid([0, 0], [0.5, 0.5], [1, 1], lambda x, y: 0.0)      # grid_field.py:28
     with pytest.raises(AssertionError):
         grid_field.FunctionGrid([0, 0], [4, 4], [1, 1], lambda x, y: 0.0, materialize=True, cache=True)   # :31
+
+
+def test_crossing_segments_in_the_references_order():
+    """find_contour_crossing_grid_segments against what the real reference listed (tests/golden/crossing_segments.npz, by
+    oracle/make_goldens_segments.py): same segments in the SAME order -- also with skip > 1, where the forward neighbour
+    of the last strided lattice point lies beyond the grid and the reference evaluates the callable there"""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    from contourist_amd import grid_field
+    from oracle.make_goldens_segments import field, MINS, MAXES, DELTA, VALUE
+    G = np.load(os.path.join(GOLDEN_DIR, "crossing_segments.npz"))
+    for skip in (1, 2, 3):
+        g = grid_field.FunctionGrid(MINS, MAXES, DELTA, field)
+        maxf, minf, segs = g.find_contour_crossing_grid_segments(VALUE, skip)
+        got = np.array([list(p) + list(q) for p, q in segs], dtype=np.int32).reshape(-1, 6)
+        assert np.array_equal(got, G["skip%d" % skip])
+        assert np.allclose([maxf, minf], G["range%d" % skip], rtol=1e-6)
