@@ -24,7 +24,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -113,6 +113,7 @@ def load():
         "cx_seeded_masks_download": [vp, vp, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
+        "cx_level1_write": [vp, ctypes.c_int, ctypes.c_char_p, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
         "cx_debug_stamps": [vp, i64, vp],
         "cx_grid4d_upload": [vp, vp, i64, i64, i64, i64],
@@ -289,6 +290,19 @@ class Context(object):
         tris = np.empty((int(counts["n_triangles"]), 3), dtype=np.int32)
         self._check(self.lib.cx_level1_download(self.handle, pts.ctypes.data, tris.ctypes.data))
         return pts, tris
+
+    def write_level1(self, path, fmt="ply", mins=None, delta=None):
+        """the Level-1 mesh of the last post-pass as a binary file written straight from the device buffers (no numpy arrays):
+        fmt "ply" (float64 positions, int32 faces) or "gltf_bin" (float32 positions + uint32 indices); mins / delta: world
+        coordinates = grid * delta + mins.  -> dict(n_vertices, n_triangles, bytes, min, max)"""
+        md = None
+        if mins is not None or delta is not None:
+            md = np.ascontiguousarray(np.concatenate([np.asarray(mins if mins is not None else [0, 0, 0], dtype=np.float64).reshape(3),
+                                                      np.asarray(delta if delta is not None else [1, 1, 1], dtype=np.float64).reshape(3)]))
+        info = np.zeros(9, dtype=np.float64)
+        self._check(self.lib.cx_level1_write(self.handle, {"ply": 0, "gltf_bin": 1}[fmt], os.fsencode(path),
+                                             None if md is None else md.ctypes.data, info.ctypes.data))
+        return dict(n_vertices=int(info[0]), n_triangles=int(info[1]), bytes=int(info[2]), min=info[3:6].copy(), max=info[6:9].copy())
 
     def surface_geometry(self, points, triangles, do_clean):
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()

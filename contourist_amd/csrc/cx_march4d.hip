@@ -391,6 +391,29 @@ __device__ __forceinline__ void py_slots3(const uint64_t h[3], int m, uint32_t s
     }
 }
 
+// the same from the LOW 32 bits of the hashes: a probe step reads three bits five places further up, so five steps fit.
+// Returns false when an element is still on a used slot after five steps, or when a hash word is all ones (possibly the hash
+// CPython replaces by a constant): the caller then takes the 64-bit path for the whole wave.
+__device__ __forceinline__ bool py_slots3_lo(const uint32_t h[3], int m, uint32_t slot[3]) {
+    uint32_t used = 0;
+    bool ok = true;
+    for (int n = 0; n < m; n++) {
+        uint32_t perturb = h[n];
+        uint32_t i = h[n] & 7u;
+        ok = ok && (h[n] != 0xFFFFFFFFu);
+#pragma unroll
+        for (int guard = 0; guard < 5; guard++)
+            if ((used >> i) & 1u) {
+                perturb >>= 5;
+                i = (i * 5u + 1u + perturb) & 7u;
+            }
+        ok = ok && !((used >> i) & 1u);
+        used |= 1u << i;
+        slot[n] = i;
+    }
+    return ok;
+}
+
 // =================================================================================================
 // K2: tetrahedra.  Phase 0, one lane per cell record: table entries of the 15 owner corners and the
 // corner hashes go to LDS.  Then, for 4 groups of 6 pentatopes: phase 1 (per cell) decides pattern and
@@ -402,7 +425,7 @@ __device__ __forceinline__ void py_slots3(const uint64_t h[3], int m, uint32_t s
 struct cx_tet_lds {
     uint32_t vf[4][16][64];
     uint16_t em[4][16][64];
-    uint64_t h[4][16][64];
+    uint32_t h[4][16][64];         // low 32 bits of the corner hashes (five probe steps of the set order fit; the rest: exact fallback)
     uint16_t slot[4][18 * 64];     // per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9
     uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
     uint32_t tfirst[4][64];        // first tetrahedron of the cell in this group minus its rank in the wave
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
             const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
             const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
             const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
-            L.h[wave][c][lane] = py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
+            L.h[wave][c][lane] = (uint32_t)py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
         }
     }
     uint32_t done = 0;   // tetrahedra of this cell already written
@@ -474,17 +497,35 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
             if (emulate && (nlow == 2u || nlow == 3u)) {
                 // least = the 2-set, most = the 3-set, each in insertion (path) order
                 const bool low_is_two = (nlow == 2u);
-                uint64_t h2[3], h3[3];
-                int n2 = 0, n3 = 0;
-                for (int m = 0; m < 5; m++) {
-                    const uint64_t hm = L.h[wave][CX_PC[n][m]][lane];
-                    const bool is_low = (pat >> m) & 1u;
-                    if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                    else { if (n3 < 3) h3[n3] = hm; n3++; }
-                }
                 uint32_t s2[3], s3[3];
-                py_slots3(h2, 2, s2);
-                py_slots3(h3, 3, s3);
+                bool resolved;
+                {
+                    uint32_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+                    int n2 = 0, n3 = 0;
+                    for (int m = 0; m < 5; m++) {
+                        const uint32_t hm = L.h[wave][CX_PC[n][m]][lane];
+                        const bool is_low = (pat >> m) & 1u;
+                        if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                        else { if (n3 < 3) h3[n3] = hm; n3++; }
+                    }
+                    resolved = py_slots3_lo(h2, 2, s2);
+                    resolved = py_slots3_lo(h3, 3, s3) && resolved;
+                }
+                if (!resolved) {   // rare (about one set in 10^3): the full hashes of this pentatope's corners
+                    uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+                    int n2 = 0, n3 = 0;
+                    for (int m = 0; m < 5; m++) {
+                        const uint32_t c = CX_PC[n][m];
+                        const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
+                        const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
+                        const uint64_t hm = py_finish4(py_round4(P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck], q[3] + (c & 1u) + P.org[3]));
+                        const bool is_low = (pat >> m) & 1u;
+                        if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                        else { if (n3 < 3) h3[n3] = hm; n3++; }
+                    }
+                    py_slots3(h2, 2, s2);
+                    py_slots3(h3, 3, s3);
+                }
                 const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
                 // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
                 uint32_t o0 = 0, o1 = 1, o2 = 2;

@@ -1013,6 +1013,122 @@ extern "C" int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris
     return CX_OK;
 }
 
+// ---- binary mesh files straight from the Level-1 device buffers (what every caller of the reference does next,
+// html_demo.py:118-161, without the detour through Python arrays).  The file's records are laid out ON THE DEVICE, a chunk at a
+// time (world coordinates = grid * delta + mins, rounded as numpy rounds them: no fused multiply-add), and streamed through two
+// pinned staging buffers: the copy of chunk i+1 runs while chunk i is written to the file.
+__global__ void cxw_k_points(const double* __restrict__ pts, uint32_t first, uint32_t n, double m0, double m1, double m2, double d0, double d1,
+                             double d2, int as_f32, void* out) {
+#pragma clang fp contract(off)   // grid * delta + mins with two roundings, as numpy computes it (a fused multiply-add differs in the last bit)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = pts + (size_t)(first + i) * 3;
+    const double x = p[0] * d0 + m0, y = p[1] * d1 + m1, z = p[2] * d2 + m2;
+    if (as_f32) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)i * 3;
+        o[0] = (float)x; o[1] = (float)y; o[2] = (float)z;
+    } else {
+        double* o = reinterpret_cast<double*>(out) + (size_t)i * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+// PLY faces: uchar 3 + three little-endian int32 = 13 bytes per triangle
+__global__ void cxw_k_faces13(const int32_t* __restrict__ tri, uint32_t first, uint32_t n, uint8_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* o = out + (size_t)i * 13;
+    o[0] = 3;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = (uint32_t)tri[(size_t)(first + i) * 3 + k];
+        o[1 + 4 * k] = (uint8_t)v; o[2 + 4 * k] = (uint8_t)(v >> 8); o[3 + 4 * k] = (uint8_t)(v >> 16); o[4 + 4 * k] = (uint8_t)(v >> 24);
+    }
+}
+#include <cstdio>
+extern "C" int cx_level1_write(cx_ctx* ctx, int format, const char* path, const double* mins_delta, double* out_info) {
+    if (!ctx || !path || (format != CX_FILE_PLY && format != CX_FILE_GLTF_BIN)) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post_valid) { ctx->err = "cx_level1_write: run cx_postprocess3d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    hipStream_t st = ctx->stream;
+    const uint32_t nv = (uint32_t)S->nv_out, nt = (uint32_t)S->nt_out;
+    double m[3] = {0, 0, 0}, d[3] = {1, 1, 1};
+    if (mins_delta) for (int a = 0; a < 3; a++) { m[a] = mins_delta[a]; d[a] = mins_delta[3 + a]; }
+    const uint32_t CHUNK = 1u << 20;                       // elements per chunk
+    const size_t stage_bytes = (size_t)CHUNK * 24u;         // the widest record: 3 doubles
+    uint8_t* dstage = nullptr;
+    uint8_t* hstage[2] = {nullptr, nullptr};
+    FILE* f = fopen(path, "wb");
+    if (!f) { ctx->err = std::string("cx_level1_write: cannot open ") + path; return CX_ERR_INVALID; }
+    int rc = CX_OK;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    size_t written = 0;
+    do {
+        hipError_t e;
+#define CXW_TRY(call) if ((e = (call)) != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP; break; }
+        CXW_TRY(hipMalloc(&dstage, 2 * stage_bytes));
+        CXW_TRY(hipHostMalloc(&hstage[0], stage_bytes));
+        CXW_TRY(hipHostMalloc(&hstage[1], stage_bytes));
+        if (format == CX_FILE_PLY) {
+            char header[512];
+            const int hl = snprintf(header, sizeof(header),
+                                    "ply\nformat binary_little_endian 1.0\ncomment contourist_amd isosurface\nelement vertex %u\n"
+                                    "property double x\nproperty double y\nproperty double z\n"
+                                    "element face %u\nproperty list uchar int vertex_indices\nend_header\n", nv, nt);
+            if (fwrite(header, 1, (size_t)hl, f) != (size_t)hl) { rc = CX_ERR_INVALID; ctx->err = "cx_level1_write: write failed"; break; }
+            written += (size_t)hl;
+        }
+        // section 0: points, section 1: faces / indices.  Chunk c of a section is prepared on the device into half c & 1 of
+        // dstage and copied to hstage[c & 1]; the previous chunk is written to the file meanwhile.
+        for (int section = 0; section < 2 && rc == CX_OK; section++) {
+            const uint32_t count = section == 0 ? nv : nt;
+            const size_t rec = section == 0 ? (format == CX_FILE_PLY ? 24u : 12u) : (format == CX_FILE_PLY ? 13u : 12u);
+            size_t pending_bytes = 0;
+            int pending = -1;
+            for (uint32_t first = 0, c = 0; rc == CX_OK; first += CHUNK, c++) {
+                const bool more = first < count;
+                const uint32_t n = more ? std::min(CHUNK, count - first) : 0u;
+                const int half = (int)(c & 1u);
+                if (more) {
+                    uint8_t* dst = dstage + (size_t)half * stage_bytes;
+                    if (section == 0)
+                        hipLaunchKernelGGL(cxw_k_points, dim3(cxp_blocks(n)), dim3(256), 0, st, (const double*)S->pts_out.p, first, n, m[0], m[1], m[2],
+                                           d[0], d[1], d[2], format == CX_FILE_PLY ? 0 : 1, (void*)dst);
+                    else if (format == CX_FILE_PLY)
+                        hipLaunchKernelGGL(cxw_k_faces13, dim3(cxp_blocks(n)), dim3(256), 0, st, (const int32_t*)S->tri_out.p, first, n, dst);
+                    const void* src = (section == 1 && format != CX_FILE_PLY) ? (const void*)((const int32_t*)S->tri_out.p + (size_t)first * 3) : (const void*)dst;
+                    e = hipMemcpyAsync(hstage[half], src, (size_t)n * rec, hipMemcpyDeviceToHost, st);
+                    if (e != hipSuccess) { ctx->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CX_ERR_HIP; break; }
+                }
+                if (pending >= 0) {   // the previous chunk is complete (synchronised below, last iteration); the one just enqueued copies meanwhile
+                    if (fwrite(hstage[pending], 1, pending_bytes, f) != pending_bytes) { rc = CX_ERR_INVALID; ctx->err = "cx_level1_write: write failed"; break; }
+                    written += pending_bytes;
+                }
+                if (!more) break;
+                e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { ctx->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = CX_ERR_HIP; break; }
+                if (section == 0 && format != CX_FILE_PLY) {   // glTF wants the bounds of the positions
+                    const float* q = reinterpret_cast<const float*>(hstage[half]);
+                    for (uint32_t i = 0; i < n; i++)
+                        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)q[3 * i + a]); hi[a] = std::max(hi[a], (double)q[3 * i + a]); }
+                }
+                pending = half;
+                pending_bytes = (size_t)n * rec;
+            }
+        }
+#undef CXW_TRY
+    } while (0);
+    fclose(f);
+    if (dstage) (void)hipFree(dstage);
+    for (int k = 0; k < 2; k++)
+        if (hstage[k]) (void)hipHostFree(hstage[k]);
+    if (rc) return rc;
+    if (out_info) {
+        out_info[0] = (double)nv; out_info[1] = (double)nt; out_info[2] = (double)written;
+        for (int a = 0; a < 3; a++) { out_info[3 + a] = nv ? lo[a] : 0.0; out_info[6 + a] = nv ? hi[a] : 0.0; }
+    }
+    return CX_OK;
+}
+
 // SurfaceGeometry(vertices, triangles) on a caller's mesh.  mode: 0 = orient only, 1 = clean + orient, 2 = clean only.
 extern "C" int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv_io, int32_t* tris, int64_t* nt_io, int mode) {
     if (!ctx || !points_xyz || !tris || !nv_io || !nt_io || mode < 0 || mode > 2) return CX_ERR_INVALID;

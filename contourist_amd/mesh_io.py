@@ -1,6 +1,9 @@
-"""Binary mesh writers fed from the arrays the device path returns (the step right after
-get_points_and_triangles for every caller of the reference, html_demo.py:118-161, next to the three.js
-emitters of contourist_amd/html_demo.py)."""
+"""Binary mesh writers (the step right after get_points_and_triangles for every caller of the reference,
+html_demo.py:118-161, next to the three.js emitters of contourist_amd/html_demo.py).
+
+Two kinds: `write_ply` / `write_gltf_bin` take host arrays; `write_ply_device` / `write_gltf_device` take an isosurface object of
+`contourist_amd.tetrahedral` and let the library write the file straight from the Level-1 DEVICE buffers (`cx_level1_write`:
+records laid out on the GPU, streamed through pinned staging buffers) -- no (points, triangles) arrays in Python."""
 import struct
 
 import numpy as np
@@ -63,6 +66,39 @@ def write_gltf_bin(path_gltf, points, triangles):
     }
     with open(os.path.join(os.path.dirname(path_gltf) or ".", bin_name), "wb") as f:
         f.write(blob)
+    with open(path_gltf, "w") as f:
+        json.dump(doc, f)
+    return path_gltf
+
+
+def write_ply_device(surface, path):
+    """`surface`: TriangulatedIsosurfaces / Delta3DContour (world coordinates) or GridContour3d (grid coordinates).
+    Same bytes as write_ply(path, points, triangles) of the downloaded mesh with the faces in device order."""
+    return surface.write_mesh(path, "ply")
+
+
+def write_gltf_device(surface, path_gltf):
+    "minimal glTF 2.0: the .bin payload comes straight from the device buffers, the JSON from the bounds the writer returns"
+    import json
+    import os
+    bin_name = os.path.splitext(os.path.basename(path_gltf))[0] + ".bin"
+    bin_path = os.path.join(os.path.dirname(path_gltf) or ".", bin_name)
+    if hasattr(surface, "contour_maker"):
+        info = surface.contour_maker.write_mesh(bin_path, "gltf_bin", surface.grid.mins, surface.grid.delta)
+    else:
+        info = surface.write_mesh(bin_path, "gltf_bin")
+    nv, nt = info["n_vertices"], info["n_triangles"]
+    doc = {
+        "asset": {"version": "2.0", "generator": "contourist_amd"},
+        "buffers": [{"uri": bin_name, "byteLength": info["bytes"]}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": nv * 12, "target": 34962},
+                        {"buffer": 0, "byteOffset": nv * 12, "byteLength": nt * 12, "target": 34963}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": nv, "type": "VEC3",
+                       "min": [float(x) for x in info["min"]], "max": [float(x) for x in info["max"]]},
+                      {"bufferView": 1, "componentType": 5125, "count": nt * 3, "type": "SCALAR"}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "mode": 4}]}],
+        "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0,
+    }
     with open(path_gltf, "w") as f:
         json.dump(doc, f)
     return path_gltf

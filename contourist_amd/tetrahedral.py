@@ -142,6 +142,28 @@ class GridContour3d(object):
         pts, tris = ctx.download_level1(self._post)
         return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
 
+    def _ensure_post(self, clean=True):
+        "Level 1 on the device, left there (no download); returns the context"
+        self.march()
+        ctx = self.context()
+        if self._post is None:
+            if self.end_points is not None and len(self.end_points):
+                self.seeded = ctx.select_seeded(self.end_points, self.voxel_range, self.keep_in_range)
+            if self.voxel_range is not None:
+                lo, hi = self.voxel_range
+                ctx.set_reference_corner([int(h) - int(l) for l, h in zip(lo, hi)])
+            else:
+                ctx.set_reference_corner((0, 0, 0))
+            self._post = ctx.postprocess3d(0 if clean else 1, self.smooth or 0.0) if self.linear_interpolate else self._postprocess_refined(ctx, clean)
+        return ctx
+
+    def write_mesh(self, path, fmt="ply", mins=None, delta=None, clean=True):
+        """the welded, cleaned, oriented mesh as a binary file written STRAIGHT FROM THE DEVICE BUFFERS (cx_level1_write: no
+        (points, triangles) arrays on the host) -- the step every caller of the reference takes next (html_demo.py:118-161).
+        fmt "ply" | "gltf_bin"; mins / delta: world = grid * delta + mins.  Faces in device order (the Python API sorts rows)."""
+        ctx = self._ensure_post(clean)
+        return ctx.write_level1(path, fmt, mins, delta)
+
     # -- linear_interpolate=False (tetrahedral.py:488-505) ------------------------------------------------------
     def _feval(self, P):
         "function at the rows of P (N,3), float64: one broadcast call if the function allows it, else one call per row"
@@ -362,6 +384,13 @@ class Delta3DContour(object):
         def lattice_f(i, j, k):
             return f((i - shift) * delta[0] + mins[0], (j - shift) * delta[1] + mins[1], (k - shift) * delta[2] + mins[2])
         return lattice_f
+
+    def write_mesh(self, path, fmt="ply"):
+        "binary mesh file in WORLD coordinates straight from the device buffers (GridContour3d.write_mesh)"
+        if fmt == "gltf":
+            from . import mesh_io
+            return mesh_io.write_gltf_device(self, path)
+        return self.contour_maker.write_mesh(path, fmt, self.grid.mins, self.grid.delta)
 
     def search_for_endpoints(self, skip=1):
         """Reference: crossing search over every skip-th lattice point + new contour maker (tetrahedral.py:74-81,

@@ -168,6 +168,18 @@ int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv, con
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
 
+/* Binary mesh file straight from the Level-1 device buffers -- the step right after get_points_and_triangles() for every caller
+ * of the reference (html_demo.py:118-161), without materialising the mesh in the caller's address space: the file's records are
+ * laid out on the device and streamed through pinned staging buffers.  format CX_FILE_PLY: binary little-endian PLY, float64
+ * x y z per vertex, faces as uchar 3 + three int32 (what contourist_amd.mesh_io.write_ply writes from host arrays, byte for
+ * byte); CX_FILE_GLTF_BIN: the .bin payload of a glTF 2.0 mesh, float32 positions followed by uint32 indices.
+ * mins_delta: NULL (grid coordinates) or {min_x, min_y, min_z, delta_x, delta_y, delta_z} for FunctionGrid.from_grid_coordinates
+ * (grid_field.py:89-93).  out_info (9 doubles, may be NULL): vertices, triangles, bytes written, min xyz, max xyz of the
+ * positions as written (glTF accessor bounds; PLY: not computed).  Face order is the device's (the Python API sorts the rows). */
+#define CX_FILE_PLY 0
+#define CX_FILE_GLTF_BIN 1
+int cx_level1_write(cx_ctx* ctx, int format, const char* path, const double* mins_delta, double* out_info);
+
 /* ---- standalone SurfaceGeometry operator ---------------------------------------------------------
  * SurfaceGeometry(vertices, triangles).clean_triangles() / .orient_triangles()
  * (surface_geometry.py:6-12, 14-50, 52-140) on caller-supplied host arrays.
