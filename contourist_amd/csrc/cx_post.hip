@@ -1659,7 +1659,10 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
         G4.A = G->grid;
         for (int k = 0; k < 4; k++) G4.n[k] = (int)G->n[k];
         G4.value = G->value;
-        hipLaunchKernelGGL(cxp_k_tets_orient, dim3(cxp_blocks(nt)), dim3(256), 0, st, (int32_t*)S->tri_out.p, nt, prio, G4);
+        // the march's table already emits every tetrahedron in that order (tools/gen_tables.py orient_tet: exact, and valid
+        // where samples EQUAL the isovalue and the determinant below vanishes); CX_TETS_ORIENT=1 (debug) recomputes it from the data
+        if (cx_debug_knob("CX_TETS_ORIENT", 0))
+            hipLaunchKernelGGL(cxp_k_tets_orient, dim3(cxp_blocks(nt)), dim3(256), 0, st, (int32_t*)S->tri_out.p, nt, prio, G4);
         hipLaunchKernelGGL(cxp_k_morph_count, dim3(cxp_blocks(nt)), dim3(256), 0, st, tets, nt, pts, prio, mm, cnt);
         if ((rc = cxp_scan(ctx, S, cnt, off, nt, misc + 1))) return rc;
         uint32_t ntri = 0;

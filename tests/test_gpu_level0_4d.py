@@ -111,28 +111,22 @@ def test_morph_triangles_device(name):
     assert tri_sets(kh, MT.segment_point_indices, MT.triangle_segment_indices) == tri_sets(M["keys"], M["segments"], M["triangles"])
     ot, label, flags = postpass4d.orient_morph_triangles(M)
     common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, M["keys"], M["segments"], ot)
-    # patches that hang on edges shared by 3+ triangles flood in the reference's own order there; the device winds
-    # every slice by the field gradient instead (cx_post.hip: cxp_k_tets_orient, cxp_morph_slices).  The fixture with
-    # samples equal to the isovalue (test0) has the most of them: 97.97 % agree
-    assert common == len(ot) and agree >= 0.97 * common
+    # the march's table emits every tetrahedron wound low -> high (tools/gen_tables.py orient_tet, exact for any sample values
+    # of a sign pattern) and every slice is wound from that (cx_post.hip cxp_morph_slices): the same windings as the
+    # reference's flood fill, also on the fixture with samples EQUAL to the isovalue (test0_style: zero-length edges)
+    assert common == len(ot) and agree == common, (common, agree)
     # and against the real reference
     rk = level0_4d.edge_keys4(G["mt_point_pairs"], A.shape)
     assert set((int(rk[i]), int(rk[j])) for i, j in G["mt_segments"]) == got_seg
     assert postpass4d.morph_polygons(rk, G["mt_segments"], G["mt_triangles"]) == \
         postpass4d.morph_polygons(kh, MT.segment_point_indices, MT.triangle_segment_indices)
     common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, rk, G["mt_segments"], G["mt_triangles"])
-    assert common > 0.7 * len(ot) and agree >= 0.97 * common
-    # What is known about the rest (B5 stays "partial" in DESIGN.md): the reference's flood fill is reproduced exactly by the
-    # oracle (100 % of the common triangles on every fixture, also when the triangles of a crowded segment are visited in
-    # shuffled orders: its result is order-independent there), so the <= 3 % are a deviation of the device's rule (winding by
-    # the field gradient) and not a hash-order artefact.  Where two triangles are alone on a segment at some time, both
-    # windings are consistent (opposite directions along the shared edge) -- for the device and for the reference:
+    assert common > 0.7 * len(ot) and agree == common, (common, agree)
+    # Where two triangles are alone on a segment at some time, both windings are consistent (opposite directions along the
+    # shared edge) -- for the device and for the reference:
     bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
     bad_r, seen_r = postpass4d.forced_pair_violations(rk, G["mt_segments"], G["mt_triangles"], G["mt_points4d"])
-    # (test0_style has samples exactly EQUAL to the isovalue: tetrahedra with zero-length edges, where the determinant that
-    # winds a slice by the field gradient vanishes -- the device then leaves a few pairs inconsistent, the reference none)
-    assert bad_r == 0 and seen_d > 0
-    assert bad_d == 0 or (name.startswith("test0_style") and bad_d <= 0.002 * len(MT.triangle_segment_indices)), (bad_d, seen_d)
+    assert bad_r == 0 and seen_d > 0 and bad_d == 0, (bad_d, seen_d)
     print(name, "4-D winding: common", common, "agree", agree, "(%.2f %%)" % (100.0 * agree / common), "forced pairs checked", seen_d, seen_r,
           "inconsistent on the device", bad_d)
     assert np.array_equal(MT.points4d[np.argsort(kh)], G["mt_points4d"][np.argsort(rk)])

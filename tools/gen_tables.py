@@ -141,7 +141,7 @@ def pent_entry(pent, pattern, perm_id):
     least, most = (low, high) if len(low) <= len(high) else (high, low)
     if len(least) == 1:
         a = least[0]
-        return [[edge_ref4(a, x) for x in most]]
+        return [[edge_ref4(*p) for p in orient_tet(pent, pattern, [(a, x) for x in most])]]
     a, b = least
     if perm_id & 1:
         a, b = b, a
@@ -150,7 +150,60 @@ def pent_entry(pent, pattern, perm_id):
     ac, ad, ae = (a, c), (a, d), (a, e)
     bc, bd, be = (b, c), (b, d), (b, e)
     tets = [(ac, be, ad, bd), (ac, be, ad, ae), (ac, be, bd, bc)]
-    return [[edge_ref4(*p) for p in t] for t in tets]
+    return [[edge_ref4(*p) for p in orient_tet(pent, pattern, t)] for t in tets]
+
+
+def corner_xyzt(c):
+    return [(c >> 3) & 1, (c >> 2) & 1, (c >> 1) & 1, c & 1]
+
+
+def orient_tet(pent, pattern, tet):
+    """the four crossing edges of a tetrahedron in the order that makes det[p1-p0, p2-p0, p3-p0, gradient] POSITIVE for the
+    linear interpolant of the pentatope -- whatever the sample values, as long as they have the signs of `pattern` (checked on
+    several random assignments).  The march then emits every tetrahedron wound from low to high without looking at the samples:
+    tetrahedra with coincident vertices (samples EQUAL to the isovalue), where a determinant computed from the data vanishes,
+    get the winding of their non-degenerate neighbours.  (Exact rational arithmetic.)"""
+    from fractions import Fraction
+    import random
+    rng = random.Random(12345 + pattern * 131 + sum(pent))
+    sign = None
+    for trial in range(4):
+        f = {}
+        for m, c in enumerate(pent):
+            mag = Fraction(rng.randint(1, 1000), rng.randint(1, 1000)) + 1
+            f[c] = -mag if (pattern >> m) & 1 else mag
+        # gradient: the path sets one axis per step
+        g = [Fraction(0)] * 4
+        for m in range(4):
+            a, b = corner_xyzt(pent[m]), corner_xyzt(pent[m + 1])
+            axis = [k for k in range(4) if a[k] != b[k]][0]
+            g[axis] = f[pent[m + 1]] - f[pent[m]]
+        pts = []
+        for (c1, c2) in tet:
+            t = (0 - f[c1]) / (f[c2] - f[c1])
+            p1, p2 = corner_xyzt(c1), corner_xyzt(c2)
+            pts.append([Fraction(p1[k]) + t * (p2[k] - p1[k]) for k in range(4)])
+        rows = [[pts[k][a] - pts[0][a] for a in range(4)] for k in (1, 2, 3)] + [g]
+        d = det4(rows)
+        assert d != 0
+        sg = 1 if d > 0 else -1
+        assert sign is None or sign == sg, "orientation depends on the sample values?"
+        sign = sg
+    tet = list(tet)
+    if sign < 0:
+        tet[2], tet[3] = tet[3], tet[2]
+    return tet
+
+
+def det4(m):
+    def det3(r):
+        return (r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) +
+                r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]))
+    total = 0
+    for col in range(4):
+        minor = [[row[k] for k in range(4) if k != col] for row in m[1:]]
+        total += (-1) ** col * m[0][col] * det3(minor)
+    return total
 
 
 def main(out_path):
