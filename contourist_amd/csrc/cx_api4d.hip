@@ -20,7 +20,7 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep};
+    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep, S->queue};
     for (void* p : all)
         if (p) (void)hipFree(p);
     delete S;
@@ -81,9 +81,15 @@ extern "C" int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64
     return CX_OK;
 }
 
-static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t nt) {
-    if (nc > 0xFFFFFFF0LL || nv > 0xFFFFFFF0LL || nt > 0x7FFFFFF0LL) { ctx->err = "capacity beyond 32-bit indices"; return CX_ERR_UNSUPPORTED; }
+static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t nt, int64_t nq) {
+    if (nq > 0xFFFFFFF0LL || nc > 0xFFFFFFF0LL || nv > 0xFFFFFFF0LL || nt > 0x7FFFFFF0LL) { ctx->err = "capacity beyond 32-bit indices"; return CX_ERR_UNSUPPORTED; }
     CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nq > (int64_t)S->qcap) {
+        if (S->queue) (void)hipFree(S->queue);
+        S->queue = nullptr; S->qcap = 0;
+        CX4_HIP(ctx, hipMalloc(&S->queue, (size_t)nq * sizeof(uint32_t)));
+        S->qcap = (uint32_t)nq;
+    }
     if (nc > (int64_t)S->ccap) {
         if (S->cells) (void)hipFree(S->cells);
         S->cells = nullptr; S->ccap = 0;
@@ -117,10 +123,10 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
     if (!(value == value)) { ctx->err = "isovalue is NaN"; return CX_ERR_INVALID; }
     const int64_t N = S->n[0] * S->n[1] * S->n[2] * S->n[3];
     if (!S->cells) {
-        if ((rc = reserve4(ctx, S, N / 8 + 4096, N / 2 + 4096, 4 * N + 4096))) return rc;
+        if ((rc = reserve4(ctx, S, N / 8 + 4096, N / 2 + 4096, 4 * N + 4096, N / 8 + 4096))) return rc;
     }
     for (int d = 0; d < 4; d++) S->origin[d] = ctx->origin4[d];
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 4; attempt++) {
         cx_params4 P;
         memset(&P, 0, sizeof(P));
         P.grid = S->grid;
@@ -137,10 +143,11 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.vlo = (float)(value - (double)P.vhi);
         P.value = value;
         P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
-        P.flags = flags;
+        P.flags = flags | (cx_debug_knob("CX4_ABL", 0) << 16);
         for (int d = 0; d < 4; d++) P.org[d] = (uint32_t)S->origin[d];
         P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
+        P.queue = S->queue; P.qcap = S->qcap;
         P.counters = ctx->counters;
         P.lut = cx_pent_lut_device();
         if (!P.lut) { ctx->err = "pentatope table symbol not found"; return CX_ERR_HIP; }
@@ -192,6 +199,11 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         c.n_border_voxels = ctx->counters_host[CX_CNT_BORDER];
         S->counts = c;
         if (out) *out = c;
+        const uint32_t nq = ctx->counters_host[CX4_CNT_QUEUE];
+        if (nq > S->qcap) {   // nothing was classified: only the queue length is known
+            if ((rc = reserve4(ctx, S, 0, 0, 0, (int64_t)nq + nq / 20 + 1024))) return rc;
+            continue;
+        }
         if (c.n_cells <= S->ccap && c.n_vertices <= S->vcap && c.n_triangles <= S->tcap) {
             S->extracted = true;
             S->post_valid = false;
@@ -200,7 +212,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
             return CX_OK;
         }
         if ((rc = reserve4(ctx, S, c.n_cells + c.n_cells / 20 + 1024, c.n_vertices + c.n_vertices / 20 + 1024,
-                           c.n_triangles + c.n_triangles / 20 + 1024)))
+                           c.n_triangles + c.n_triangles / 20 + 1024, 0)))
             return rc;
     }
     ctx->err = "4-D output buffers still too small after growing";

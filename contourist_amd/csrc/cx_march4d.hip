@@ -8,12 +8,11 @@
 //
 // Same plan as the 3-D march (cx_march3d.hip): a lattice cell q = (i,j,k,l) owns the 15 edges q -> q+d,
 // d = 8di+4dj+2dk+dl in 1..15, and the 24 pentatopes of its hyper-voxel; vertex id = (lin(q) << 4) | d.
-//   K1  cx_k_classify4d   phase A: one lane per cell, active cells into a wave-private LDS queue;
-//                         phase B: per workgroup ONE reservation per counter, then vertex records
+//   K0  cx_k_signbits4    one streaming pass over the samples: sign bitmap (1 bit per sample).
+//   K1a cx_k_queue4       active cells (sign change among the 16 corners) from the bitmap, 32 per lane -> one flat queue.
+//   K1b cx_k_cells4       flat over the queue: exact classification, ONE reservation per workgroup, vertex records
 //                         (x,y,z,t), edge ids, the per-cell lookup word and one record per active cell.
-//   K2  cx_k_emit_tets    one lane per record: 24 pentatopes -> tetrahedra as 4 vertex indices.
-// This first version streams with 16 scalar-pair loads per cell (any shape); the bit-packed fast path
-// of the 3-D kernel is the next step for this kernel.
+//   K2  cx_k_emit_tets    one lane per record, then one lane per tetrahedron: 24 pentatopes -> 4 vertex indices each.
 #include <cstdlib>
 
 #include "cx_cell.h"
@@ -152,77 +151,7 @@ __device__ __forceinline__ cx_cell4 cx_classify_cell4(const cx_params4& P, const
     return R;
 }
 
-#define CX4_QCAP 2048u   // one step of the classify kernel adds at most 64 x 32 cells
-
-struct cx_run4 {
-    uint32_t v, t, c, b;
-};
-
-__device__ __forceinline__ void cx_process_queue4(const cx_params4& P, const uint32_t* qq, uint32_t n, uint32_t lane, bool emit,
-                                                  cx_run4& run) {
-    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
-        const uint32_t idx = b0 + lane;
-        const bool have = idx < n;
-        const uint32_t lin = have ? qq[idx] : 0u;
-        uint32_t q[4];
-        cx_unravel4(P, lin, q);
-        float f[16];
-        const uint32_t vm = cx_load_corners4(P, lin, q, f);
-        uint32_t sm = 0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
-        const uint32_t smv = sm & vm;
-        const bool active = have && smv != 0u && smv != vm;
-        cx_cell4 R;
-        R.emask = 0; R.ntets = 0; R.pskip = 0; R.border = 0;
-        if (active) R = cx_classify_cell4(P, f, vm, sm, q);
-        const uint32_t nv = __popc(R.emask);
-        const bool rec = active && (nv != 0u || R.ntets != 0u);
-        uint32_t vtot, ttot;
-        const uint32_t vpre = cx_wave_prefix_small<4>(nv, vtot);
-        const uint32_t tpre = cx_wave_prefix_small<7>(R.ntets, ttot);
-        const uint64_t recm = __ballot(rec);
-        const uint32_t ctot = (uint32_t)__popcll(recm);
-        const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
-        if (emit) {
-            const uint32_t vfirst = run.v + vpre;
-            if (nv && run.v + vtot <= P.vcap) {
-                const float num = (P.vhi - f[0]) + P.vlo;
-                uint32_t slot = vfirst;
-                for (uint32_t d = 1; d < 16; d++) {
-                    if (!((R.emask >> d) & 1u)) continue;
-                    float fd = f[0];
-#pragma unroll
-                    for (uint32_t c = 1; c < 16; c++) fd = (c == d) ? f[c] : fd;
-                    const float den = fd - f[0];
-                    float t = __fdividef(num, den);
-                    if (fabsf(den) <= 1.001e-8f) {
-                        const double dd = (double)fd - (double)f[0];
-                        t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f[0]) / dd);
-                    }
-                    float4 r4;
-                    r4.x = (float)q[0] + ((d & 8u) ? t : 0.f);
-                    r4.y = (float)q[1] + ((d & 4u) ? t : 0.f);
-                    r4.z = (float)q[2] + ((d & 2u) ? t : 0.f);
-                    r4.w = (float)q[3] + ((d & 1u) ? t : 0.f);
-                    P.verts[slot] = r4;
-                    P.vkeys[slot] = (lin << 4) | d;
-                    slot++;
-                }
-                P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
-            }
-            if (rec && run.c + ctot <= P.ccap) {
-                uint4 c4;
-                c4.x = lin;
-                c4.y = sm | ((R.pskip != 0u) ? 0x10000u : 0u);
-                c4.z = run.t + tpre;
-                c4.w = vfirst;
-                P.cells[run.c + cx_mbcnt(recm)] = c4;
-            }
-        }
-        run.v += vtot; run.t += ttot; run.c += ctot; run.b += btot;
-    }
-}
+#define CX4_QCAP 2048u   // one step of the queue kernel adds at most 64 x 32 cells
 
 // ---- sign bitmap: one pass over the samples at streaming speed.  A wave takes 8 consecutive chunks of
 // 64 samples of a row (8 loads in flight); a chunk's 64 comparison results are one ballot = 2 words.
@@ -253,13 +182,16 @@ __global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const 
     }
 }
 
-// ---- classify: phase A finds the active cells (sign change among the 16 clamped corners) from the sign
-// bitmap, 32 cells per lane with word-wide OR / AND over the 8 rows of a hyper-voxel and over (l, l+1);
-// phase B re-reads the corners of the queued cells only (a fraction of a percent of the grid).
-__global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const uint32_t items_per_block) {
+// ---- queue: the active cells (sign change among the 16 clamped corners) from the sign bitmap, 32 cells per lane with
+// word-wide OR / AND over the 8 rows of a hyper-voxel and over (l, l+1).  Their linear indices go to ONE flat queue in
+// global memory (a wave collects up to 2048 in LDS; one reservation per workgroup at the end, one per wave when its LDS
+// queue fills up), so that the stages after this one are spread evenly over the chip however the surface is distributed
+// over the grid (the first version processed its cells inside this kernel: a workgroup that sat on the surface
+// processed thousands of cells while most others had none -- 0.23 of its 0.28 ms).
+__global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uint32_t items_per_block) {
     __shared__ uint32_t s_queue[4][CX4_QCAP];
-    __shared__ uint32_t s_tot[4][4];
-    __shared__ uint32_t s_base[4];
+    __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_base;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* qq = s_queue[wave];
@@ -302,7 +234,7 @@ __global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const
             const uint32_t cnt = __popc(act);
             const uint32_t incl = cx_wave_incl_scan4(cnt);
             const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
-            if (qn + tot > CX4_QCAP) break;                   // wave-uniform: emit what is queued, then redo this step
+            if (qn + tot > CX4_QCAP) break;                   // wave-uniform: flush what is queued, then redo this step
             uint32_t pos = qn + incl - cnt;
             const uint32_t lin0 = row * P.n3 + lw * 32u;
             while (act) {
@@ -315,45 +247,142 @@ __global__ __launch_bounds__(256) void cx_k_classify4d(const cx_params4 P, const
             streaming = gbase < gend;
         }
         const bool final_round = !streaming;
-        cx_run4 run = {0, 0, 0, 0};
-        for (int pass = 0; pass < 2; pass++) {
-            cx_process_queue4(P, qq, qn, lane, pass == 1, run);
-            if (pass == 1) break;
-            if (final_round) {
-                if (lane == 0) {
-                    s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const uint32_t v = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
-                    const uint32_t t = s_tot[0][1] + s_tot[1][1] + s_tot[2][1] + s_tot[3][1];
-                    const uint32_t c = s_tot[0][2] + s_tot[1][2] + s_tot[2][2] + s_tot[3][2];
-                    const uint32_t bb = s_tot[0][3] + s_tot[1][3] + s_tot[2][3] + s_tot[3][3];
-                    s_base[0] = v ? atomicAdd(&P.counters[CX_CNT_VERTS], v) : 0u;
-                    s_base[1] = t ? atomicAdd(&P.counters[CX_CNT_TRIS], t) : 0u;
-                    s_base[2] = c ? atomicAdd(&P.counters[CX_CNT_CELLS], c) : 0u;
-                    if (bb) atomicAdd(&P.counters[CX_CNT_BORDER], bb);
-                }
-                __syncthreads();
-                run.v = s_base[0]; run.t = s_base[1]; run.c = s_base[2];
-                for (uint32_t w = 0; w < wave; w++) {
-                    run.v += s_tot[w][0]; run.t += s_tot[w][1]; run.c += s_tot[w][2];
-                }
-            } else {
-                cx_run4 base = {0, 0, 0, 0};
-                if (lane == 0) {
-                    if (run.v) base.v = atomicAdd(&P.counters[CX_CNT_VERTS], run.v);
-                    if (run.t) base.t = atomicAdd(&P.counters[CX_CNT_TRIS], run.t);
-                    if (run.c) base.c = atomicAdd(&P.counters[CX_CNT_CELLS], run.c);
-                    if (run.b) atomicAdd(&P.counters[CX_CNT_BORDER], run.b);
-                }
-                run.v = __builtin_amdgcn_readfirstlane(base.v);
-                run.t = __builtin_amdgcn_readfirstlane(base.t);
-                run.c = __builtin_amdgcn_readfirstlane(base.c);
+        uint32_t base;
+        if (final_round) {
+            if (lane == 0) s_tot[wave] = qn;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t t = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+                s_base = t ? atomicAdd(&P.counters[CX4_CNT_QUEUE], t) : 0u;
             }
+            __syncthreads();
+            base = s_base;
+            for (uint32_t w = 0; w < wave; w++) base += s_tot[w];
+        } else {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&P.counters[CX4_CNT_QUEUE], qn);
+            base = __builtin_amdgcn_readfirstlane(b0);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (base + qn <= P.qcap)
+            for (uint32_t x = lane; x < qn; x += 64u) P.queue[base + x] = qq[x];
+        __builtin_amdgcn_wave_barrier();
         qn = 0;
         if (final_round) break;
+    }
+}
+
+// ---- cells: one lane per queued cell, flat over the queue.  Exact classification (the reference's tolerances), ONE
+// reservation per workgroup (two 64-bit adds: vertices | records, border voxels | tetrahedra), then the cell record, the
+// lookup word, and the vertices -- one lane per VERTEX through an LDS slot table and an LDS corner table, so that a
+// round's vertex records leave as a few coalesced 16-byte stores (the first version stored them from a per-cell loop
+// over the 15 directions: up to 64 cache lines per store instruction).
+#define CX4_CELLS_WAVES 8u
+struct cx_cells_lds {
+    float f[CX4_CELLS_WAVES][16][64];
+    uint16_t slot[CX4_CELLS_WAVES][15 * 64];
+    uint32_t tot[CX4_CELLS_WAVES][4];
+    unsigned long long base[2];
+};
+__global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
+    __shared__ cx_cells_lds L;
+    const uint32_t nq = P.counters[CX4_CNT_QUEUE];
+    if (nq > P.qcap) return;                      // the host grows the queue and runs again
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t per_block = CX4_CELLS_WAVES * 64u;
+    for (uint32_t blk = blockIdx.x; blk * per_block < nq; blk += gridDim.x) {   // uniform over the workgroup
+        const uint32_t idx = blk * per_block + threadIdx.x;
+        const bool have = idx < nq;
+        const uint32_t lin = have ? P.queue[idx] : 0u;
+        uint32_t q[4];
+        cx_unravel4(P, lin, q);
+        float f[16];
+        const uint32_t vm = cx_load_corners4(P, lin, q, f);
+        uint32_t sm = 0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) sm |= (f[c] < P.vcmp) ? (1u << c) : 0u;
+        const uint32_t smv = sm & vm;
+        const bool active = have && smv != 0u && smv != vm;
+        cx_cell4 R;
+        R.emask = 0; R.ntets = 0; R.pskip = 0; R.border = 0;
+        if (active) R = cx_classify_cell4(P, f, vm, sm, q);
+        const uint32_t nv = __popc(R.emask);
+        const bool rec = active && (nv != 0u || R.ntets != 0u);
+        uint32_t vtot, ttot;
+        const uint32_t vpre = cx_wave_prefix_small<4>(nv, vtot);
+        const uint32_t tpre = cx_wave_prefix_small<7>(R.ntets, ttot);
+        const uint64_t recm = __ballot(rec);
+        const uint32_t ctot = (uint32_t)__popcll(recm);
+        const uint32_t btot = (uint32_t)__popcll(__ballot(R.border != 0u));
+        if (lane == 0) { L.tot[wave][0] = vtot; L.tot[wave][1] = ttot; L.tot[wave][2] = ctot; L.tot[wave][3] = btot; }
+        // corner table and slot table of this wave's round
+#pragma unroll
+        for (int c = 0; c < 16; c++) L.f[wave][c][lane] = f[c];
+        {
+            uint32_t m = R.emask, pos = vpre;
+            while (m) {
+                const uint32_t d = __ffs(m) - 1u;
+                m &= m - 1u;
+                L.slot[wave][pos++] = (uint16_t)((lane << 4) | d);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t v = 0, t = 0, c = 0, bb = 0;
+            for (uint32_t w = 0; w < CX4_CELLS_WAVES; w++) { v += L.tot[w][0]; t += L.tot[w][1]; c += L.tot[w][2]; bb += L.tot[w][3]; }
+            unsigned long long* C64 = reinterpret_cast<unsigned long long*>(P.counters);   // words (cells, verts), (tets, border)
+            L.base[0] = (v | c) ? atomicAdd(&C64[0], ((unsigned long long)v << 32) | c) : 0ULL;
+            L.base[1] = (t | bb) ? atomicAdd(&C64[1], ((unsigned long long)bb << 32) | t) : 0ULL;
+        }
+        __syncthreads();
+        uint32_t vbase = (uint32_t)(L.base[0] >> 32), cbase = (uint32_t)L.base[0], tbase = (uint32_t)L.base[1];
+        uint32_t vblock = 0, cblock = 0;
+        for (uint32_t w = 0; w < CX4_CELLS_WAVES; w++) {
+            if (w < wave) { vbase += L.tot[w][0]; tbase += L.tot[w][1]; cbase += L.tot[w][2]; }
+            vblock += L.tot[w][0]; cblock += L.tot[w][2];
+        }
+        const bool vfits = (L.base[0] >> 32) + (unsigned long long)vblock <= (unsigned long long)P.vcap;
+        const bool cfits = (L.base[0] & 0xFFFFFFFFULL) + (unsigned long long)cblock <= (unsigned long long)P.ccap;
+        const uint32_t vfirst = vbase + vpre;
+        if (vfits && nv) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+        if (cfits && rec) {
+            uint4 c4;
+            c4.x = lin;
+            c4.y = sm | ((R.pskip != 0u) ? 0x10000u : 0u);
+            c4.z = tbase + tpre;
+            c4.w = vfirst;
+            P.cells[cbase + cx_mbcnt(recm)] = c4;
+        }
+        if (vfits) {
+            for (uint32_t j0 = 0; j0 < vtot; j0 += 64u) {   // wave-uniform
+                const uint32_t j = j0 + lane;
+                const bool ok = j < vtot;
+                const uint32_t w = L.slot[wave][ok ? j : 0u];
+                const uint32_t cell = w >> 4, d = w & 15u;
+                const float f0 = L.f[wave][0][cell], fd = L.f[wave][d][cell];
+                const uint32_t clin = (uint32_t)__shfl((int)lin, (int)cell);
+                uint32_t cq[4];
+                cx_unravel4(P, clin, cq);
+                const float num = (P.vhi - f0) + P.vlo;
+                const float den = fd - f0;
+                float t = __fdividef(num, den);
+                if (fabsf(den) <= 1.001e-8f) {
+                    const double dd = (double)fd - (double)f0;
+                    t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f0) / dd);
+                }
+                float4 r4;
+                r4.x = (float)cq[0] + ((d & 8u) ? t : 0.f);
+                r4.y = (float)cq[1] + ((d & 4u) ? t : 0.f);
+                r4.z = (float)cq[2] + ((d & 2u) ? t : 0.f);
+                r4.w = (float)cq[3] + ((d & 1u) ? t : 0.f);
+                if (ok) {
+                    P.verts[vbase + j] = r4;
+                    P.vkeys[vbase + j] = (clin << 4) | d;
+                }
+            }
+        }
+        __syncthreads();   // the tables are rewritten by the next round
     }
 }
 
@@ -415,178 +444,215 @@ __device__ __forceinline__ bool py_slots3_lo(const uint32_t h[3], int m, uint32_
 }
 
 // =================================================================================================
-// K2: tetrahedra.  Phase 0, one lane per cell record: table entries of the 15 owner corners and the
-// corner hashes go to LDS.  Then, for 4 groups of 6 pentatopes: phase 1 (per cell) decides pattern and
-// set-order permutation of each pentatope and writes one slot word per tetrahedron; phase 2, one lane
-// per TETRAHEDRON, reads the 4 (owner corner, direction) references from the table and stores 16
-// bytes next to its neighbours' (the first version stored 4 bytes per lane and cell: 64 cache lines
-// per store instruction).
+// K2: tetrahedra.  Phase 0, one lane per cell record: the lookup words of the 15 owner corners go to LDS, the corner
+// hashes stay in the lane's registers.  Then, for 4 groups of 6 pentatopes: phase 1 (per cell, pentatope loop unrolled:
+// corners and masks are compile-time constants) decides pattern and set-order permutation of each pentatope and writes
+// one slot word per tetrahedron; phase 2, one lane per TETRAHEDRON, takes the tetrahedron's four pentatope-local edges
+// from the factored table in LDS (3 KB: [pattern][permutation]; the pentatope's corners are one word), turns them into
+// (owner corner, direction) and stores 16 bytes next to its neighbours'.  (The first version read the unfactored 147 KB
+// table from global memory inside phase 2 -- a dependent gather per tetrahedron round -- and kept the hashes in LDS.)
 // =================================================================================================
+__device__ uint64_t cx_d_pent_local[32][12] = CX_PENT_LOCAL_INIT;
+#define CX_PCW(n) (uint32_t)(CX_PC[n][0] | (CX_PC[n][1] << 4) | (CX_PC[n][2] << 8) | (CX_PC[n][3] << 12) | (CX_PC[n][4] << 16))
 struct cx_tet_lds {
-    uint32_t vf[4][16][64];
+    uint32_t vf[4][15][64];
     uint16_t em[4][16][64];
-    uint32_t h[4][16][64];         // low 32 bits of the corner hashes (five probe steps of the set order fit; the rest: exact fallback)
     uint16_t slot[4][18 * 64];     // per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9
     uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
     uint32_t tfirst[4][64];        // first tetrahedron of the cell in this group minus its rank in the wave
+    uint64_t local[32 * 12];
 };
+
+// pattern, set-order permutation and tetrahedron count of pentatope N of a cell
+template <int N>
+__device__ __forceinline__ void cx_pent_decide(const cx_params4& P, const uint32_t (&h)[16], const uint32_t q[4], uint32_t sm, bool skip,
+                                               bool emulate, uint32_t& pat_out, uint32_t& perm_out, uint32_t& nt_out) {
+    pat_out = 0; perm_out = 0; nt_out = 0;
+    if (skip) return;
+    const uint32_t pat = cx_pent_pattern(sm, N);
+    const uint32_t nlow = __popc(pat);
+    if (nlow == 0u || nlow == 5u) return;
+    uint32_t perm_id = 0;
+    if (emulate && (nlow == 2u || nlow == 3u)) {
+        // least = the 2-set, most = the 3-set, each in insertion (path) order
+        const bool low_is_two = (nlow == 2u);
+        uint32_t s2[3], s3[3];
+        bool resolved;
+        {
+            uint32_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+            int n2 = 0, n3 = 0;
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                const uint32_t hm = h[CX_PC[N][m]];
+                const bool is_low = (pat >> m) & 1u;
+                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                else { if (n3 < 3) h3[n3] = hm; n3++; }
+            }
+            resolved = py_slots3_lo(h2, 2, s2);
+            resolved = py_slots3_lo(h3, 3, s3) && resolved;
+        }
+        if (!resolved) {   // rare (about one set in 10^3): the full hashes of this pentatope's corners
+            uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+            int n2 = 0, n3 = 0;
+            for (int m = 0; m < 5; m++) {
+                const uint32_t c = CX_PC[N][m];
+                const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
+                const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
+                const uint64_t hm = py_finish4(py_round4(P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck], q[3] + (c & 1u) + P.org[3]));
+                const bool is_low = (pat >> m) & 1u;
+                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+                else { if (n3 < 3) h3[n3] = hm; n3++; }
+            }
+            py_slots3(h2, 2, s2);
+            py_slots3(h3, 3, s3);
+        }
+        const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
+        // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
+        const bool ab = s3[0] < s3[1], ac = s3[0] < s3[2], bc = s3[1] < s3[2];
+        const uint32_t p3 = (ab && ac) ? (bc ? 0u : 1u) : ((!ab && bc) ? (ac ? 2u : 3u) : (ab ? 4u : 5u));
+        perm_id = (p3 << 1) | swapped;
+    }
+    pat_out = pat; perm_out = perm_id;
+    nt_out = (nlow == 2u || nlow == 3u) ? 3u : 1u;
+}
+
+template <int G>
+__device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L, uint32_t wave, uint32_t lane, const uint32_t (&h)[16],
+                                              const uint32_t q[4], uint32_t sm, bool real_voxel, uint32_t pskip, bool emulate,
+                                              uint32_t tcell, uint32_t& done) {
+    // ---- phase 1: slot words of the group's tetrahedra
+    uint32_t cnt = 0;
+    uint32_t pats[6], perms[6], nts[6];
+    cx_pent_decide<G * 6 + 0>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 0)) & 1u), emulate, pats[0], perms[0], nts[0]);
+    cx_pent_decide<G * 6 + 1>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 1)) & 1u), emulate, pats[1], perms[1], nts[1]);
+    cx_pent_decide<G * 6 + 2>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 2)) & 1u), emulate, pats[2], perms[2], nts[2]);
+    cx_pent_decide<G * 6 + 3>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 3)) & 1u), emulate, pats[3], perms[3], nts[3]);
+    cx_pent_decide<G * 6 + 4>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 4)) & 1u), emulate, pats[4], perms[4], nts[4]);
+    cx_pent_decide<G * 6 + 5>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 5)) & 1u), emulate, pats[5], perms[5], nts[5]);
+#pragma unroll
+    for (int pn = 0; pn < 6; pn++) cnt += nts[pn];
+    const uint32_t incl = cx_wave_incl_scan4(cnt);
+    const uint32_t ttot = (uint32_t)__shfl((int)incl, 63);
+    uint32_t pos = incl - cnt;
+    L.tfirst[wave][lane] = tcell + done - pos;   // tetrahedron j of the wave's group goes to tfirst[cell] + j
+#pragma unroll
+    for (int pn = 0; pn < 6; pn++) {
+        L.pinfo[wave][pn][lane] = (uint16_t)(pats[pn] | (perms[pn] << 5));
+        for (uint32_t k = 0; k < nts[pn]; k++) L.slot[wave][pos++] = (uint16_t)(lane | ((uint32_t)pn << 6) | (k << 9));
+    }
+    done += cnt;
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: one lane per tetrahedron
+    for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
+        const uint32_t j = j0 + lane;
+        const bool ok = j < ttot;
+        const uint32_t w = L.slot[wave][ok ? j : 0u];
+        const uint32_t cell = w & 63u, pn = (w >> 6) & 7u, k = (w >> 9) & 3u;
+        const uint32_t pi = L.pinfo[wave][pn][cell];
+        // corners of the pentatope (a nibble per local vertex) and its orientation: 6 candidates, compile-time words
+        uint32_t pcw = CX_PCW(G * 6 + 0);
+        pcw = (pn == 1u) ? CX_PCW(G * 6 + 1) : pcw;
+        pcw = (pn == 2u) ? CX_PCW(G * 6 + 2) : pcw;
+        pcw = (pn == 3u) ? CX_PCW(G * 6 + 3) : pcw;
+        pcw = (pn == 4u) ? CX_PCW(G * 6 + 4) : pcw;
+        pcw = (pn == 5u) ? CX_PCW(G * 6 + 5) : pcw;
+        const bool flip = ((CX_PENT_FLIP_MASK >> (G * 6)) >> pn) & 1u;
+        const uint64_t lw = L.local[(pi & 31u) * 12u + (pi >> 5)];
+        const uint32_t t16 = (uint32_t)(lw >> (16u * k)) & 0xFFFFu;
+        int32_t tv[4];
+#pragma unroll
+        for (uint32_t s_ = 0; s_ < 4; s_++) {
+            const uint32_t e = (t16 >> (4u * s_)) & 15u;
+            // local edge id -> (x, y), x < y in 0..4 : pairs in lexicographic order (0,1)(0,2)(0,3)(0,4)(1,2)(1,3)(1,4)(2,3)(2,4)(3,4)
+            const uint32_t x = (uint32_t)((0x3221110000ULL >> (4u * e)) & 15u);
+            const uint32_t y = (uint32_t)((0x4434324321ULL >> (4u * e)) & 15u);
+            const uint32_t c1 = (pcw >> (4u * x)) & 15u, c2 = (pcw >> (4u * y)) & 15u;
+            const uint32_t d = c1 ^ c2;
+            const uint32_t vf = L.vf[wave][c1][cell], em = L.em[wave][c1][cell];
+            tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
+        }
+        // 32-bit wrap-around on purpose (tfirst = first - rank can be "negative" across reservations)
+        if (ok && !((P.flags & (1u << 17)) && tv[0] != 0x7FFFFFF)) {   // not read again by the pipeline: nontemporal (see cx_march3d.hip)
+            typedef int32_t cx_v4i __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(cx_v4i{tv[0], tv[1], flip ? tv[3] : tv[2], flip ? tv[2] : tv[3]},
+                                        reinterpret_cast<cx_v4i*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
     __shared__ cx_tet_lds L;
+    for (uint32_t x = threadIdx.x; x < 32u * 12u; x += 256u) L.local[x] = P.lut[x];
+    __syncthreads();
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
-    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap || P.counters[CX4_CNT_QUEUE] > P.qcap) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    // waves walk the record array grid-stride: a workgroup holds 69 KB of LDS, so launching one per 256 records of
-    // CAPACITY (262 k mostly idle waves on config 4) kept the chip busy with empty workgroups
+    // waves walk the record array grid-stride
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx - lane < ncells; idx += gridDim.x * blockDim.x) {
-    const bool have = idx < ncells;
-    uint4 c4 = make_uint4(0, 0, 0, 0);
-    if (have) c4 = P.cells[idx];
-    const uint32_t lin = c4.x, sm = c4.y & 0xFFFFu;
-    uint32_t q[4];
-    cx_unravel4(P, lin, q);
-    const bool real_voxel = have && q[0] + 1 < P.n0 && q[1] + 1 < P.n1 && q[2] + 1 < P.n2 && q[3] + 1 < P.n3;
-    // pentatopes skipped by the reference's tolerances: recomputed exactly for the rare flagged records
-    uint32_t pskip = 0;
-    if (have && (c4.y & 0x10000u)) {
-        float f[16];
-        const uint32_t vm = cx_load_corners4(P, lin, q, f);
-        const cx_cell4 R = cx_classify_cell4(P, f, vm, sm, q);
-        pskip = R.pskip;
-    }
-    if (!real_voxel) pskip = 0xFFFFFFu;
-    // first-vertex index and crossing mask of the 15 corners that can own an edge of this hyper-voxel
-    const uint32_t st[4] = {P.n1 * P.n2 * P.n3, P.n2 * P.n3, P.n3, 1u};
-    for (uint32_t c = 0; c < 15; c++) {
-        uint32_t vf = 0, em = 0;
-        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFFFu : 0u;
-        uint32_t sup = 0;
-        for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
-        if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
-            const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
-            const uint64_t e = P.celltab[lc];
-            vf = (uint32_t)e;
-            em = (uint32_t)(e >> 32);
+        const bool have = idx < ncells;
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        if (have) c4 = P.cells[idx];
+        const uint32_t lin = c4.x, sm = c4.y & 0xFFFFu;
+        uint32_t q[4];
+        cx_unravel4(P, lin, q);
+        const bool real_voxel = have && q[0] + 1 < P.n0 && q[1] + 1 < P.n1 && q[2] + 1 < P.n2 && q[3] + 1 < P.n3;
+        // pentatopes skipped by the reference's tolerances: recomputed exactly for the rare flagged records
+        uint32_t pskip = 0;
+        if (have && (c4.y & 0x10000u)) {
+            float f[16];
+            const uint32_t vm = cx_load_corners4(P, lin, q, f);
+            const cx_cell4 R = cx_classify_cell4(P, f, vm, sm, q);
+            pskip = R.pskip;
         }
-        L.vf[wave][c][lane] = vf;
-        L.em[wave][c][lane] = (uint16_t)em;
-    }
-    // corner hashes (absolute lattice coordinates) for the set-order emulation
-    if (emulate) {
-        for (uint32_t c = 0; c < 16; c++) {
-            const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
-            const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
-            const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
-            L.h[wave][c][lane] = (uint32_t)py_finish4(py_round4(pre, q[3] + (c & 1u) + P.org[3]));
-        }
-    }
-    uint32_t done = 0;   // tetrahedra of this cell already written
-    for (int g = 0; g < 4; g++) {
-        // ---- phase 1: slot words of the group's tetrahedra
-        uint32_t cnt = 0;
-        uint32_t pats[6], perms[6], nts[6];
-        for (int pn = 0; pn < 6; pn++) {
-            const int n = g * 6 + pn;
-            pats[pn] = 0; perms[pn] = 0; nts[pn] = 0;
-            if (!real_voxel || ((pskip >> n) & 1u)) continue;
-            const uint32_t pat = cx_pent_pattern(sm, n);
-            const uint32_t nlow = __popc(pat);
-            if (nlow == 0u || nlow == 5u) continue;
-            uint32_t perm_id = 0;
-            if (emulate && (nlow == 2u || nlow == 3u)) {
-                // least = the 2-set, most = the 3-set, each in insertion (path) order
-                const bool low_is_two = (nlow == 2u);
-                uint32_t s2[3], s3[3];
-                bool resolved;
-                {
-                    uint32_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
-                    int n2 = 0, n3 = 0;
-                    for (int m = 0; m < 5; m++) {
-                        const uint32_t hm = L.h[wave][CX_PC[n][m]][lane];
-                        const bool is_low = (pat >> m) & 1u;
-                        if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                        else { if (n3 < 3) h3[n3] = hm; n3++; }
-                    }
-                    resolved = py_slots3_lo(h2, 2, s2);
-                    resolved = py_slots3_lo(h3, 3, s3) && resolved;
-                }
-                if (!resolved) {   // rare (about one set in 10^3): the full hashes of this pentatope's corners
-                    uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
-                    int n2 = 0, n3 = 0;
-                    for (int m = 0; m < 5; m++) {
-                        const uint32_t c = CX_PC[n][m];
-                        const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
-                        const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
-                        const uint64_t hm = py_finish4(py_round4(P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck], q[3] + (c & 1u) + P.org[3]));
-                        const bool is_low = (pat >> m) & 1u;
-                        if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                        else { if (n3 < 3) h3[n3] = hm; n3++; }
-                    }
-                    py_slots3(h2, 2, s2);
-                    py_slots3(h3, 3, s3);
-                }
-                const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
-                // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
-                uint32_t o0 = 0, o1 = 1, o2 = 2;
-                if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
-                if (s3[o1] > s3[o2]) { const uint32_t t = o1; o1 = o2; o2 = t; }
-                if (s3[o0] > s3[o1]) { const uint32_t t = o0; o0 = o1; o1 = t; }
-                const uint32_t p3 = o0 * 2u + ((o1 > o2) ? 1u : 0u);   // (0,1,2)=0 (0,2,1)=1 (1,0,2)=2 (1,2,0)=3 (2,0,1)=4 (2,1,0)=5
-                perm_id = (p3 << 1) | swapped;
-            }
-            pats[pn] = pat; perms[pn] = perm_id;
-            nts[pn] = (nlow == 2u || nlow == 3u) ? 3u : 1u;
-            cnt += nts[pn];
-        }
-        const uint32_t incl = cx_wave_incl_scan4(cnt);
-        const uint32_t ttot = (uint32_t)__shfl((int)incl, 63);
-        uint32_t pos = incl - cnt;
-        L.tfirst[wave][lane] = c4.z + done - pos;   // tetrahedron j of the wave's group goes to tfirst[cell] + j
-        for (int pn = 0; pn < 6; pn++) {
-            L.pinfo[wave][pn][lane] = (uint16_t)(pats[pn] | (perms[pn] << 5));
-            for (uint32_t k = 0; k < nts[pn]; k++) L.slot[wave][pos++] = (uint16_t)(lane | ((uint32_t)pn << 6) | (k << 9));
-        }
-        done += cnt;
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2: one lane per tetrahedron
-        for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
-            const uint32_t j = j0 + lane;
-            const bool ok = j < ttot;
-            const uint32_t w = L.slot[wave][ok ? j : 0u];
-            const uint32_t cell = w & 63u, pn = (w >> 6) & 7u, k = (w >> 9) & 3u;
-            const uint32_t pi = L.pinfo[wave][pn][cell];
-            const uint32_t n = (uint32_t)g * 6u + pn;
-            const uint64_t* e = P.lut + (((size_t)n * 32u + (pi & 31u)) * 12u + (pi >> 5)) * 2u;
-            const uint64_t wsel = (k == 2u) ? e[1] : e[0];
-            const uint32_t word = (k == 1u) ? (uint32_t)(wsel >> 32) : (uint32_t)wsel;
-            int4 t4;
-            int32_t* tv = reinterpret_cast<int32_t*>(&t4);
+        if (!real_voxel) pskip = 0xFFFFFFu;
+        // first-vertex index and crossing mask of the 15 corners that can own an edge of this hyper-voxel
+        const uint32_t st[4] = {P.n1 * P.n2 * P.n3, P.n2 * P.n3, P.n3, 1u};
 #pragma unroll
-            for (uint32_t s_ = 0; s_ < 4; s_++) {
-                const uint32_t ref = (word >> (8u * s_)) & 0xFFu;
-                const uint32_t c1 = ref >> 4, d = ref & 15u;
-                const uint32_t vf = L.vf[wave][c1][cell], em = L.em[wave][c1][cell];
-                tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
+        for (uint32_t c = 0; c < 15; c++) {
+            uint32_t vf = 0, em = 0;
+            const uint32_t sc = ((sm >> c) & 1u) ? 0xFFFFu : 0u;
+            uint32_t sup = 0;
+#pragma unroll
+            for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
+            if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
+                const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
+                const uint64_t e = (P.flags & (1u << 18)) ? 0x0000FFFE00000000ULL : P.celltab[lc];
+                vf = (uint32_t)e;
+                em = (uint32_t)(e >> 32);
             }
-            // 32-bit wrap-around on purpose (tfirst = first - rank can be "negative" across reservations)
-            if (ok) {   // not read again by the pipeline: nontemporal (see cx_march3d.hip)
-                typedef int32_t cx_v4i __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(cx_v4i{t4.x, t4.y, t4.z, t4.w},
-                                            reinterpret_cast<cx_v4i*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u));
+            L.vf[wave][c][lane] = vf;
+            L.em[wave][c][lane] = (uint16_t)em;
+        }
+        // corner hashes (absolute lattice coordinates) for the set-order emulation: low 32 bits (five probe steps of the
+        // set order fit; the rest: exact fallback)
+        uint32_t h[16];
+#pragma unroll
+        for (uint32_t c = 0; c < 16; c++) h[c] = 0;
+        if (emulate) {
+#pragma unroll
+            for (uint32_t c = 0; c < 16; c += 2) {
+                const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
+                const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
+                const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
+                h[c] = (uint32_t)py_finish4(py_round4(pre, q[3] + P.org[3]));
+                h[c + 1] = (uint32_t)py_finish4(py_round4(pre, q[3] + 1u + P.org[3]));
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
+        uint32_t done = 0;   // tetrahedra of this cell already written
+        cx_tets_group<0>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
+        cx_tets_group<1>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
+        cx_tets_group<2>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
+        cx_tets_group<3>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
     }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-__device__ uint64_t cx_d_pent_lut[24][32][12][2] = CX_PENT_TETS_INIT;
-
 const uint64_t* cx_pent_lut_device() {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cx_d_pent_lut)) != hipSuccess) return nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cx_d_pent_local)) != hipSuccess) return nullptr;
     return (const uint64_t*)p;
 }
 
@@ -602,7 +668,10 @@ void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
     ipb = (ipb + 255u) & ~255u;
     if (ipb < 256u) ipb = 256u;
     const uint32_t blocks = (nitems + ipb - 1u) / ipb;
-    hipLaunchKernelGGL(cx_k_classify4d, dim3(blocks), dim3(256), 0, s, P, ipb);
+    hipLaunchKernelGGL(cx_k_queue4, dim3(blocks), dim3(256), 0, s, P, ipb);
+    uint32_t cblocks = (P.qcap + CX4_CELLS_WAVES * 64u - 1u) / (CX4_CELLS_WAVES * 64u);
+    if (cblocks > 1024u) cblocks = 1024u;         // grid-stride: four workgroups per CU
+    hipLaunchKernelGGL(cx_k_cells4, dim3(cblocks ? cblocks : 1u), dim3(CX4_CELLS_WAVES * 64u), 0, s, P);
 }
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s) {
     uint32_t blocks = (P.ccap + 255u) / 256u;

@@ -19,12 +19,15 @@ struct cx_params4 {
     uint32_t* counters;
     const uint64_t* hash_xyz;
     const uint64_t* lut;
+    uint32_t* queue;           // linear indices of the cells with a sign change among their corners
+    uint32_t qcap;
     // sign bitmap: bit l%32 of word [row(i,j,k)][l/32] <=> sample < isovalue
     uint32_t* signbits;
     uint32_t nw3;              // words per row
     uint32_t nrows;            // n0*n1*n2
     cx_fdiv div_w, div_r2, div_r1;   // / nw3, / (n1*n2), / n2
 };
+#define CX4_CNT_QUEUE 6   // counter word: cells in the queue
 void cx_launch_signbits4d(const cx_params4& P, hipStream_t s);
 void cx_launch_classify4d(const cx_params4& P, hipStream_t s);
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s);
@@ -45,6 +48,8 @@ struct cx_state4 {
     uint32_t vcap = 0, ccap = 0, tcap = 0;
     uint64_t* hash_xyz = nullptr;
     size_t hash_cap = 0;
+    uint32_t* queue = nullptr;
+    uint32_t qcap = 0;
     uint32_t* signbits = nullptr;
     size_t signbits_cap = 0;
     int64_t hash_key[7] = {-1, -1, -1, -1, -1, -1, -1};

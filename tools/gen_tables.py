@@ -313,6 +313,54 @@ def main(out_path):
         a("  {" + ",".join(rows) + "}, \\")
     a("}")
     a("")
+    # the same table FACTORED (small enough for LDS): the tetrahedra of a pattern / permutation in pentatope-LOCAL terms
+    # (edges as pairs of local vertices 0..4, 10 of them), a per-pentatope map local edge -> edge ref, and the parity of
+    # the pentatope's axis permutation, which flips the orientation (swap of the last two refs)
+    pairs = [(x, y) for x in range(5) for y in range(x + 1, 5)]
+    pair_id = dict((pr, k) for k, pr in enumerate(pairs))
+    ref_local = {}
+    for n, p in enumerate(P):
+        for (x, y) in pairs:
+            ref_local[(n, edge_ref4(p[x], p[y]))] = pair_id[(x, y)]
+    def local_words(n, pat, perm_id):
+        return [[ref_local[(n, r)] for r in tet] for tet in pent_entry(P[n], pat, perm_id)]
+    base = [[local_words(0, pat, perm_id) for perm_id in range(12)] for pat in range(32)]
+    parity = []
+    for n in range(len(P)):
+        flips = set()
+        for pat in range(32):
+            for perm_id in range(12):
+                got = local_words(n, pat, perm_id)
+                assert len(got) == len(base[pat][perm_id])
+                for tg, tb in zip(got, base[pat][perm_id]):
+                    if tg == tb:
+                        flips.add(0)
+                    else:
+                        assert tg == [tb[0], tb[1], tb[3], tb[2]], (n, pat, perm_id, tg, tb)
+                        flips.add(1)
+        assert len(flips) == 1, (n, flips)
+        parity.append(flips.pop())
+    a("// [pattern(32)][perm_id(12)]: up to 3 tetrahedra x 4 LOCAL edges (4 bits each: index into the pairs (0,1),(0,2)..(3,4))")
+    a("// = 16 bits per tetrahedron, bits 48..49 = count; oriented for pentatope 0")
+    a("#define CX_PENT_LOCAL_INIT { \\")
+    for pat in range(32):
+        cols = []
+        for perm_id in range(12):
+            w = 0
+            for k, tet in enumerate(base[pat][perm_id]):
+                w |= (tet[0] | (tet[1] << 4) | (tet[2] << 8) | (tet[3] << 12)) << (16 * k)
+            w |= len(base[pat][perm_id]) << 48
+            cols.append("0x%xULL" % w)
+        a("  {" + ",".join(cols) + "}, \\")
+    a("}")
+    a("// [pentatope][local edge] -> edge ref (owner corner << 4 | direction)")
+    a("#define CX_PENT_EDGE_REF_INIT { \\")
+    for n, p in enumerate(P):
+        a("  {" + ",".join("0x%x" % edge_ref4(p[x], p[y]) for (x, y) in pairs) + "}, \\")
+    a("}")
+    a("// bit n: pentatope n has the orientation opposite to pentatope 0 (swap the last two refs of every tetrahedron)")
+    a("#define CX_PENT_FLIP_MASK 0x%xu" % sum(b << n for n, b in enumerate(parity)))
+    a("")
     with open(out4, "w") as f:
         f.write("\n".join(L) + "\n")
     print("wrote", out4)
