@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcontourist_hip.so")
+if os.environ.get("CX_DEBUG") == "1" and os.environ.get("CX_LIB_PATH"):   # A/B builds of the tools (tools/variants.sh)
+    LIB_PATH = os.environ["CX_LIB_PATH"]
 
 CX_OK = 0
 CX_ERR_CAPACITY = -5

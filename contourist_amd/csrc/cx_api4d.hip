@@ -20,7 +20,7 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep, S->queue};
+    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep, S->queue, S->rounds};
     for (void* p : all)
         if (p) (void)hipFree(p);
     delete S;
@@ -86,8 +86,10 @@ static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t n
     CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (nq > (int64_t)S->qcap) {
         if (S->queue) (void)hipFree(S->queue);
-        S->queue = nullptr; S->qcap = 0;
+        if (S->rounds) (void)hipFree(S->rounds);
+        S->queue = nullptr; S->rounds = nullptr; S->qcap = 0;
         CX4_HIP(ctx, hipMalloc(&S->queue, (size_t)nq * sizeof(uint32_t)));
+        CX4_HIP(ctx, hipMalloc(&S->rounds, ((size_t)nq / 64 + 8) * sizeof(uint4)));
         S->qcap = (uint32_t)nq;
     }
     if (nc > (int64_t)S->ccap) {
@@ -147,7 +149,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         for (int d = 0; d < 4; d++) P.org[d] = (uint32_t)S->origin[d];
         P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
-        P.queue = S->queue; P.qcap = S->qcap;
+        P.queue = S->queue; P.qcap = S->qcap; P.rounds = S->rounds;
         P.counters = ctx->counters;
         P.lut = cx_pent_lut_device();
         if (!P.lut) { ctx->err = "pentatope table symbol not found"; return CX_ERR_HIP; }

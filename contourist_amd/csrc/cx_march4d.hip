@@ -20,6 +20,7 @@
 #include "cx_tables4d.h"
 
 __device__ constexpr uint8_t CX_PC[24][5] = CX_PENT_CORNERS_INIT;
+__device__ const uint8_t cx_d_pent_corners[24][5] = CX_PENT_CORNERS_INIT;   // the same for run-time indices
 // inclusive prefix sum over the wave (DPP row shifts / broadcasts)
 __device__ __forceinline__ uint32_t cx_wave_incl_scan4(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
@@ -345,6 +346,8 @@ __global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
         const bool vfits = (L.base[0] >> 32) + (unsigned long long)vblock <= (unsigned long long)P.vcap;
         const bool cfits = (L.base[0] & 0xFFFFFFFFULL) + (unsigned long long)cblock <= (unsigned long long)P.ccap;
         const uint32_t vfirst = vbase + vpre;
+        // the round's records and tetrahedra are contiguous: the tetrahedra kernel works round by round
+        if (lane == 0) P.rounds[idx >> 6] = make_uint4(cbase, cfits ? ctot : 0u, tbase, ttot);
         if (vfits && nv) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
         if (cfits && rec) {
             uint4 c4;
@@ -454,95 +457,145 @@ __device__ __forceinline__ bool py_slots3_lo(const uint32_t h[3], int m, uint32_
 // =================================================================================================
 __device__ uint64_t cx_d_pent_local[32][12] = CX_PENT_LOCAL_INIT;
 #define CX_PCW(n) (uint32_t)(CX_PC[n][0] | (CX_PC[n][1] << 4) | (CX_PC[n][2] << 8) | (CX_PC[n][3] << 12) | (CX_PC[n][4] << 16))
-struct cx_tet_lds {
-    uint32_t vf[4][15][64];
-    uint16_t em[4][16][64];
-    uint16_t slot[4][18 * 64];     // per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9
-    uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
-    uint32_t tfirst[4][64];        // first tetrahedron of the cell in this group minus its rank in the wave
-    uint64_t local[32 * 12];
-};
 
-// pattern, set-order permutation and tetrahedron count of pentatope N of a cell
+// ---- set order from probe codes ---------------------------------------------------------------------------
+// CPython inserts an element with hash h into an 8-slot set at the first free slot of the sequence i0 = h & 7,
+// i_k = (5 i_(k-1) + 1 + (h >> 5k)) & 7 (setobject.c: no linear probes when the table has 8 slots).  The sequence
+// depends on the element only, so it is computed ONCE per corner of the hyper-voxel -- ten slots, three bits each, in one
+// word -- and every pentatope that contains the corner (each corner is in 6..24 of them) reads its members' slots off
+// the codes: XOR with the occupied slot replicated into all ten fields, first non-zero field.  (The first version ran the
+// probing recurrence per pentatope and member: ~240 of the kernel's VALU instructions per pentatope, 60 % of the kernel.)
+#define CX4_REP 0x09249249u      // bit 0 of each of the ten 3-bit fields
+__device__ __forceinline__ uint32_t cx_probe_code(uint64_t h) {
+    const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 30);
+    uint32_t i = lo & 7u, code = i;
+#pragma unroll
+    for (uint32_t k = 1; k < 10; k++) {
+        const uint32_t p = (k <= 5u) ? (lo >> (5u * k)) : (hi >> (5u * (k - 6u)));
+        i = (i * 5u + 1u + p) & 7u;
+        code |= i << (3u * k);
+    }
+    return code;
+}
+// fields of x that are non-zero, as their bit 0
+__device__ __forceinline__ uint32_t cx_nz_fields(uint32_t x) { return (x | (x >> 1) | (x >> 2)) & CX4_REP; }
+
+// exact set order of one pentatope from the full hashes (after ten occupied probes: about once in 10^6 sets)
+__device__ __forceinline__ uint32_t cx_pent_perm_exact(const cx_params4& P, const uint32_t q[4], uint32_t n, uint32_t pat) {
+    const bool low_is_two = (__popc(pat) == 2);
+    uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+    uint32_t s2[3], s3[3];
+    int n2 = 0, n3 = 0;
+    for (int m = 0; m < 5; m++) {
+        const uint32_t c = cx_d_pent_corners[n][m];
+        const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
+        const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
+        const uint64_t hm = py_finish4(py_round4(P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck], q[3] + (c & 1u) + P.org[3]));
+        const bool is_low = (pat >> m) & 1u;
+        if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
+        else { if (n3 < 3) h3[n3] = hm; n3++; }
+    }
+    py_slots3(h2, 2, s2);
+    py_slots3(h3, 3, s3);
+    const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
+    const bool ab = s3[0] < s3[1], ac = s3[0] < s3[2], bc = s3[1] < s3[2];
+    const uint32_t p3 = (ab && ac) ? (bc ? 0u : 1u) : ((!ab && bc) ? (ac ? 2u : 3u) : (ab ? 4u : 5u));
+    return (p3 << 1) | swapped;
+}
+
+// pattern, set-order permutation and tetrahedron count of pentatope N of a cell; `unres`: the codes ran out
 template <int N>
-__device__ __forceinline__ void cx_pent_decide(const cx_params4& P, const uint32_t (&h)[16], const uint32_t q[4], uint32_t sm, bool skip,
-                                               bool emulate, uint32_t& pat_out, uint32_t& perm_out, uint32_t& nt_out) {
-    pat_out = 0; perm_out = 0; nt_out = 0;
+__device__ __forceinline__ void cx_pent_decide(const uint32_t (&S)[16], uint32_t sm, bool skip, bool emulate, uint32_t& pat_out,
+                                               uint32_t& perm_out, uint32_t& nt_out, bool& unres) {
+    pat_out = 0; perm_out = 0; nt_out = 0; unres = false;
     if (skip) return;
     const uint32_t pat = cx_pent_pattern(sm, N);
     const uint32_t nlow = __popc(pat);
     if (nlow == 0u || nlow == 5u) return;
     uint32_t perm_id = 0;
     if (emulate && (nlow == 2u || nlow == 3u)) {
-        // least = the 2-set, most = the 3-set, each in insertion (path) order
-        const bool low_is_two = (nlow == 2u);
-        uint32_t s2[3], s3[3];
-        bool resolved;
-        {
-            uint32_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
-            int n2 = 0, n3 = 0;
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                const uint32_t hm = h[CX_PC[N][m]];
-                const bool is_low = (pat >> m) & 1u;
-                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                else { if (n3 < 3) h3[n3] = hm; n3++; }
-            }
-            resolved = py_slots3_lo(h2, 2, s2);
-            resolved = py_slots3_lo(h3, 3, s3) && resolved;
-        }
-        if (!resolved) {   // rare (about one set in 10^3): the full hashes of this pentatope's corners
-            uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
-            int n2 = 0, n3 = 0;
-            for (int m = 0; m < 5; m++) {
-                const uint32_t c = CX_PC[N][m];
-                const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
-                const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
-                const uint64_t hm = py_finish4(py_round4(P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck], q[3] + (c & 1u) + P.org[3]));
-                const bool is_low = (pat >> m) & 1u;
-                if (is_low == low_is_two) { if (n2 < 2) h2[n2] = hm; n2++; }
-                else { if (n3 < 3) h3[n3] = hm; n3++; }
-            }
-            py_slots3(h2, 2, s2);
-            py_slots3(h3, 3, s3);
-        }
-        const uint32_t swapped = (s2[1] < s2[0]) ? 1u : 0u;
+        // the 2-set (A, B) and the 3-set (C, D, E), each in insertion (path) order
+        const uint32_t m2 = (nlow == 2u) ? pat : (pat ^ 31u);
+        const uint32_t S0 = S[CX_PC[N][0]], S1 = S[CX_PC[N][1]], S2 = S[CX_PC[N][2]], S3 = S[CX_PC[N][3]], S4 = S[CX_PC[N][4]];
+        const bool c0 = m2 & 1u, c1 = m2 & 2u, c2 = m2 & 4u, c3 = m2 & 8u, c4 = m2 & 16u;
+        const uint32_t A = c0 ? S0 : (c1 ? S1 : (c2 ? S2 : S3));
+        const uint32_t B = c4 ? S4 : (c3 ? S3 : (c2 ? S2 : S1));
+        const uint32_t C = !c0 ? S0 : (!c1 ? S1 : S2);
+        const uint32_t E = !c4 ? S4 : (!c3 ? S3 : S2);
+        const uint32_t D = S0 ^ S1 ^ S2 ^ S3 ^ S4 ^ A ^ B ^ C ^ E;
+        const uint32_t sA = A & 7u, sC = C & 7u;
+        const uint32_t zB = cx_nz_fields(B ^ (sA * CX4_REP));
+        const uint32_t sB = (B >> (__ffs(zB) - 1)) & 7u;
+        const uint32_t repC = sC * CX4_REP;
+        const uint32_t zD = cx_nz_fields(D ^ repC);
+        const uint32_t sD = (D >> (__ffs(zD) - 1)) & 7u;
+        const uint32_t zE = cx_nz_fields(E ^ repC) & cx_nz_fields(E ^ (sD * CX4_REP));
+        const uint32_t sE = (E >> (__ffs(zE) - 1)) & 7u;
+        unres = (zB == 0u) || (zD == 0u) || (zE == 0u);
+        const uint32_t swapped = (sB < sA) ? 1u : 0u;
         // iteration order of the 3-set as (first, second, third) insertion indices -> itertools.permutations index
-        const bool ab = s3[0] < s3[1], ac = s3[0] < s3[2], bc = s3[1] < s3[2];
-        const uint32_t p3 = (ab && ac) ? (bc ? 0u : 1u) : ((!ab && bc) ? (ac ? 2u : 3u) : (ab ? 4u : 5u));
+        const uint32_t idx = ((sC < sD) ? 1u : 0u) | ((sC < sE) ? 2u : 0u) | ((sD < sE) ? 4u : 0u);   // ab | ac << 1 | bc << 2
+        // idx: 7 -> 0, 3 -> 1, 6 -> 2, 4 -> 3, 1 -> 4, 0 -> 5 (2 and 5 cannot happen)
+        const uint32_t p3 = (0x02031045u >> (4u * idx)) & 7u;
         perm_id = (p3 << 1) | swapped;
     }
     pat_out = pat; perm_out = perm_id;
     nt_out = (nlow == 2u || nlow == 3u) ? 3u : 1u;
 }
 
+#ifndef CX4_TETS_WAVES
+#define CX4_TETS_WAVES 4
+#endif
+// LDS of the tetrahedra kernel (per workgroup of 4 waves)
+struct cx_tet_lds {
+    uint32_t vf[4][15][64];        // first vertex of the cells at the 15 owner corners
+    uint16_t em[4][16][64];        // their crossing masks
+    uint16_t slot[4][18 * 64 + 64];// per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9 (+ a dump row)
+    uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
+    uint64_t local[32 * 12];
+};
+
 template <int G>
-__device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L, uint32_t wave, uint32_t lane, const uint32_t (&h)[16],
+__device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L, uint32_t wave, uint32_t lane, const uint32_t (&S)[16],
                                               const uint32_t q[4], uint32_t sm, bool real_voxel, uint32_t pskip, bool emulate,
-                                              uint32_t tcell, uint32_t& done) {
+                                              uint32_t& tnext) {
     // ---- phase 1: slot words of the group's tetrahedra
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, unres = 0;
     uint32_t pats[6], perms[6], nts[6];
-    cx_pent_decide<G * 6 + 0>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 0)) & 1u), emulate, pats[0], perms[0], nts[0]);
-    cx_pent_decide<G * 6 + 1>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 1)) & 1u), emulate, pats[1], perms[1], nts[1]);
-    cx_pent_decide<G * 6 + 2>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 2)) & 1u), emulate, pats[2], perms[2], nts[2]);
-    cx_pent_decide<G * 6 + 3>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 3)) & 1u), emulate, pats[3], perms[3], nts[3]);
-    cx_pent_decide<G * 6 + 4>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 4)) & 1u), emulate, pats[4], perms[4], nts[4]);
-    cx_pent_decide<G * 6 + 5>(P, h, q, sm, !real_voxel || ((pskip >> (G * 6 + 5)) & 1u), emulate, pats[5], perms[5], nts[5]);
+    bool u;
+    cx_pent_decide<G * 6 + 0>(S, sm, !real_voxel || ((pskip >> (G * 6 + 0)) & 1u), emulate, pats[0], perms[0], nts[0], u); unres |= u ? 1u : 0u;
+    cx_pent_decide<G * 6 + 1>(S, sm, !real_voxel || ((pskip >> (G * 6 + 1)) & 1u), emulate, pats[1], perms[1], nts[1], u); unres |= u ? 2u : 0u;
+    cx_pent_decide<G * 6 + 2>(S, sm, !real_voxel || ((pskip >> (G * 6 + 2)) & 1u), emulate, pats[2], perms[2], nts[2], u); unres |= u ? 4u : 0u;
+    cx_pent_decide<G * 6 + 3>(S, sm, !real_voxel || ((pskip >> (G * 6 + 3)) & 1u), emulate, pats[3], perms[3], nts[3], u); unres |= u ? 8u : 0u;
+    cx_pent_decide<G * 6 + 4>(S, sm, !real_voxel || ((pskip >> (G * 6 + 4)) & 1u), emulate, pats[4], perms[4], nts[4], u); unres |= u ? 16u : 0u;
+    cx_pent_decide<G * 6 + 5>(S, sm, !real_voxel || ((pskip >> (G * 6 + 5)) & 1u), emulate, pats[5], perms[5], nts[5], u); unres |= u ? 32u : 0u;
 #pragma unroll
     for (int pn = 0; pn < 6; pn++) cnt += nts[pn];
     const uint32_t incl = cx_wave_incl_scan4(cnt);
     const uint32_t ttot = (uint32_t)__shfl((int)incl, 63);
     uint32_t pos = incl - cnt;
-    L.tfirst[wave][lane] = tcell + done - pos;   // tetrahedron j of the wave's group goes to tfirst[cell] + j
+    const uint32_t dump = 18u * 64u + lane;      // where the slot words of absent tetrahedra go (no branches, no loops)
 #pragma unroll
     for (int pn = 0; pn < 6; pn++) {
         L.pinfo[wave][pn][lane] = (uint16_t)(pats[pn] | (perms[pn] << 5));
-        for (uint32_t k = 0; k < nts[pn]; k++) L.slot[wave][pos++] = (uint16_t)(lane | ((uint32_t)pn << 6) | (k << 9));
+        const uint32_t w = lane | ((uint32_t)pn << 6);
+        L.slot[wave][nts[pn] ? pos : dump] = (uint16_t)w;
+        L.slot[wave][nts[pn] == 3u ? pos + 1u : dump] = (uint16_t)(w | (1u << 9));
+        L.slot[wave][nts[pn] == 3u ? pos + 2u : dump] = (uint16_t)(w | (2u << 9));
+        pos += nts[pn];
     }
-    done += cnt;
+    // pentatopes whose probe codes ran out: exact order from the full hashes (one copy of the code per group)
+    while (unres) {
+        const uint32_t pn = __ffs(unres) - 1u;
+        unres &= unres - 1u;
+        const uint32_t pi = L.pinfo[wave][pn][lane];
+        L.pinfo[wave][pn][lane] = (uint16_t)((pi & 31u) | (cx_pent_perm_exact(P, q, (uint32_t)G * 6u + pn, pi & 31u) << 5));
+    }
     __builtin_amdgcn_wave_barrier();
     // ---- phase 2: one lane per tetrahedron
+#ifdef CX4_ABL_P2
+    if (P.tcap != 12345u) return;
+#endif
     for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
         const uint32_t j = j0 + lane;
         const bool ok = j < ttot;
@@ -558,43 +611,48 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
         pcw = (pn == 5u) ? CX_PCW(G * 6 + 5) : pcw;
         const bool flip = ((CX_PENT_FLIP_MASK >> (G * 6)) >> pn) & 1u;
         const uint64_t lw = L.local[(pi & 31u) * 12u + (pi >> 5)];
-        const uint32_t t16 = (uint32_t)(lw >> (16u * k)) & 0xFFFFu;
+        const uint32_t t20 = (uint32_t)(lw >> (20u * k)) & 0xFFFFFu;   // 4 local edges: x (2 bits) | y (3 bits), x < y vertices of the pentatope
         int32_t tv[4];
 #pragma unroll
         for (uint32_t s_ = 0; s_ < 4; s_++) {
-            const uint32_t e = (t16 >> (4u * s_)) & 15u;
-            // local edge id -> (x, y), x < y in 0..4 : pairs in lexicographic order (0,1)(0,2)(0,3)(0,4)(1,2)(1,3)(1,4)(2,3)(2,4)(3,4)
-            const uint32_t x = (uint32_t)((0x3221110000ULL >> (4u * e)) & 15u);
-            const uint32_t y = (uint32_t)((0x4434324321ULL >> (4u * e)) & 15u);
+            const uint32_t x = (t20 >> (5u * s_)) & 3u, y = (t20 >> (5u * s_ + 2u)) & 7u;
             const uint32_t c1 = (pcw >> (4u * x)) & 15u, c2 = (pcw >> (4u * y)) & 15u;
             const uint32_t d = c1 ^ c2;
             const uint32_t vf = L.vf[wave][c1][cell], em = L.em[wave][c1][cell];
             tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
         }
-        // 32-bit wrap-around on purpose (tfirst = first - rank can be "negative" across reservations)
-        if (ok && !((P.flags & (1u << 17)) && tv[0] != 0x7FFFFFF)) {   // not read again by the pipeline: nontemporal (see cx_march3d.hip)
+#ifndef CX4_ABL_STORE
+#define CX4_ABL_STORE 0
+#endif
+        if (ok && (CX4_ABL_STORE != 1 || tv[0] == 0x7FFFFFF)) {   // not read again by the pipeline: nontemporal (see cx_march3d.hip)
             typedef int32_t cx_v4i __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(cx_v4i{tv[0], tv[1], flip ? tv[3] : tv[2], flip ? tv[2] : tv[3]},
-                                        reinterpret_cast<cx_v4i*>(P.tets + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 4u));
+            cx_v4i* dst = reinterpret_cast<cx_v4i*>(P.tets + (size_t)(tnext + j) * 4u);   // the round's tetrahedra, group after group
+            const cx_v4i val = cx_v4i{tv[0], tv[1], flip ? tv[3] : tv[2], flip ? tv[2] : tv[3]};
+            if (CX4_ABL_STORE == 2) *dst = val; else __builtin_nontemporal_store(val, dst);
         }
     }
+    tnext += ttot;
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
+__global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_params4 P) {
     __shared__ cx_tet_lds L;
     for (uint32_t x = threadIdx.x; x < 32u * 12u; x += 256u) L.local[x] = P.lut[x];
     __syncthreads();
-    const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
-    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap || P.counters[CX4_CNT_QUEUE] > P.qcap) return;
+    const uint32_t nq = P.counters[CX4_CNT_QUEUE];
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap || P.counters[CX_CNT_CELLS] > P.ccap || nq > P.qcap) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    // waves walk the record array grid-stride
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx - lane < ncells; idx += gridDim.x * blockDim.x) {
-        const bool have = idx < ncells;
+    // one wave per round of the cells kernel (<= 64 records, their tetrahedra one contiguous range), grid-stride
+    const uint32_t nrounds = (nq + 63u) >> 6;
+    for (uint32_t r = blockIdx.x * 4u + wave; r < nrounds; r += gridDim.x * 4u) {
+        const uint4 rd = P.rounds[r];
+        const uint32_t cbase = __builtin_amdgcn_readfirstlane(rd.x), ctot = __builtin_amdgcn_readfirstlane(rd.y);
+        uint32_t tnext = __builtin_amdgcn_readfirstlane(rd.z);
+        const bool have = lane < ctot;
         uint4 c4 = make_uint4(0, 0, 0, 0);
-        if (have) c4 = P.cells[idx];
+        if (have) c4 = P.cells[cbase + lane];
         const uint32_t lin = c4.x, sm = c4.y & 0xFFFFu;
         uint32_t q[4];
         cx_unravel4(P, lin, q);
@@ -619,33 +677,31 @@ __global__ __launch_bounds__(256) void cx_k_emit_tets(const cx_params4 P) {
             for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
             if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
                 const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
-                const uint64_t e = (P.flags & (1u << 18)) ? 0x0000FFFE00000000ULL : P.celltab[lc];
+                const uint64_t e = P.celltab[lc];
                 vf = (uint32_t)e;
                 em = (uint32_t)(e >> 32);
             }
             L.vf[wave][c][lane] = vf;
             L.em[wave][c][lane] = (uint16_t)em;
         }
-        // corner hashes (absolute lattice coordinates) for the set-order emulation: low 32 bits (five probe steps of the
-        // set order fit; the rest: exact fallback)
-        uint32_t h[16];
+        // probe codes of the corner hashes (absolute lattice coordinates) for the set-order emulation
+        uint32_t S[16];
 #pragma unroll
-        for (uint32_t c = 0; c < 16; c++) h[c] = 0;
+        for (uint32_t c = 0; c < 16; c++) S[c] = 0;
         if (emulate) {
 #pragma unroll
             for (uint32_t c = 0; c < 16; c += 2) {
                 const uint32_t ci = min(q[0] + ((c >> 3) & 1u), P.n0 - 1u), cj = min(q[1] + ((c >> 2) & 1u), P.n1 - 1u);
                 const uint32_t ck = min(q[2] + ((c >> 1) & 1u), P.n2 - 1u);
                 const uint64_t pre = P.hash_xyz[(ci * P.n1 + cj) * P.n2 + ck];
-                h[c] = (uint32_t)py_finish4(py_round4(pre, q[3] + P.org[3]));
-                h[c + 1] = (uint32_t)py_finish4(py_round4(pre, q[3] + 1u + P.org[3]));
+                S[c] = cx_probe_code(py_finish4(py_round4(pre, q[3] + P.org[3])));
+                S[c + 1] = cx_probe_code(py_finish4(py_round4(pre, q[3] + 1u + P.org[3])));
             }
         }
-        uint32_t done = 0;   // tetrahedra of this cell already written
-        cx_tets_group<0>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
-        cx_tets_group<1>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
-        cx_tets_group<2>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
-        cx_tets_group<3>(P, L, wave, lane, h, q, sm, real_voxel, pskip, emulate, c4.z, done);
+        cx_tets_group<0>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
+        cx_tets_group<1>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
+        cx_tets_group<2>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
+        cx_tets_group<3>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
     }
 }
 
@@ -674,7 +730,7 @@ void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
     hipLaunchKernelGGL(cx_k_cells4, dim3(cblocks ? cblocks : 1u), dim3(CX4_CELLS_WAVES * 64u), 0, s, P);
 }
 void cx_launch_emit_tets(const cx_params4& P, hipStream_t s) {
-    uint32_t blocks = (P.ccap + 255u) / 256u;
+    uint32_t blocks = (P.qcap + 255u) / 256u;
     if (blocks > 256u * 4u) blocks = 256u * 4u;   // grid-stride: a few workgroups per CU
     hipLaunchKernelGGL(cx_k_emit_tets, dim3(blocks ? blocks : 1u), dim3(256), 0, s, P);
 }

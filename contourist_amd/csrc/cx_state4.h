@@ -21,6 +21,7 @@ struct cx_params4 {
     const uint64_t* lut;
     uint32_t* queue;           // linear indices of the cells with a sign change among their corners
     uint32_t qcap;
+    uint4* rounds;             // per 64 queue entries: first record, records, first tetrahedron, tetrahedra
     // sign bitmap: bit l%32 of word [row(i,j,k)][l/32] <=> sample < isovalue
     uint32_t* signbits;
     uint32_t nw3;              // words per row
@@ -49,6 +50,7 @@ struct cx_state4 {
     uint64_t* hash_xyz = nullptr;
     size_t hash_cap = 0;
     uint32_t* queue = nullptr;
+    uint4* rounds = nullptr;
     uint32_t qcap = 0;
     uint32_t* signbits = nullptr;
     size_t signbits_cap = 0;

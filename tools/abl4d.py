@@ -20,8 +20,7 @@ torch.cuda.synchronize()
 print((time.perf_counter() - t0) / 10 * 1e3, c)
 ''' % ROOT
 for name, abl, flags in (("full cpython", 0, 1), ("canonical diagonals", 0, 0), ("no tet stores", 2, 1), ("no celltab gathers", 4, 1),
-                         ("no stores, no gathers", 6, 1), ("no stores/gathers/hash", 6, 0),
-                         ("classify: no emit pass", 8, 1), ("classify: phase A only", 16, 1)):
+                         ("no stores, no gathers", 6, 1), ("no stores/gathers/hash", 6, 0)):
     env = dict(os.environ, CX_DEBUG="1", CX4_ABL=str(abl))
     out = subprocess.run([sys.executable, "-c", CHILD, str(flags)], env=env, capture_output=True, text=True)
     print("%-28s %s %s" % (name, out.stdout.strip(), out.stderr.strip()[-300:]), flush=True)

@@ -340,16 +340,18 @@ def main(out_path):
                         flips.add(1)
         assert len(flips) == 1, (n, flips)
         parity.append(flips.pop())
-    a("// [pattern(32)][perm_id(12)]: up to 3 tetrahedra x 4 LOCAL edges (4 bits each: index into the pairs (0,1),(0,2)..(3,4))")
-    a("// = 16 bits per tetrahedron, bits 48..49 = count; oriented for pentatope 0")
+    a("// [pattern(32)][perm_id(12)]: up to 3 tetrahedra x 4 LOCAL edges, an edge = x | y << 2 with x < y the local vertices")
+    a("// (5 bits), 20 bits per tetrahedron, bits 60..61 = count; oriented for pentatope 0")
     a("#define CX_PENT_LOCAL_INIT { \\")
     for pat in range(32):
         cols = []
         for perm_id in range(12):
             w = 0
             for k, tet in enumerate(base[pat][perm_id]):
-                w |= (tet[0] | (tet[1] << 4) | (tet[2] << 8) | (tet[3] << 12)) << (16 * k)
-            w |= len(base[pat][perm_id]) << 48
+                for s_, e in enumerate(tet):
+                    x, y = pairs[e]
+                    w |= (x | (y << 2)) << (20 * k + 5 * s_)
+            w |= len(base[pat][perm_id]) << 60
             cols.append("0x%xULL" % w)
         a("  {" + ",".join(cols) + "}, \\")
     a("}")
