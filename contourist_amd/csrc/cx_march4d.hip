@@ -159,27 +159,52 @@ __device__ __forceinline__ cx_cell4 cx_classify_cell4(const cx_params4& P, const
 __global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const uint32_t nchunk, const cx_fdiv div_chunk,
                                                       const uint32_t nchunks_total) {
     const uint32_t lane = cx_lane_id();
-    const uint32_t wave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c0 = wave * 8u;
-    if (c0 >= nchunks_total) return;
+    const uint32_t wave0 = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ A = P.grid;
-    float f[8];
-    bool ok[8];
-    uint32_t row[8], ch[8];
+    // grid-stride over groups of 8 chunks (one wave per group and 262 k waves made the launch rate the limit)
+    for (uint32_t c0 = wave0 * 8u; c0 < nchunks_total; c0 += gridDim.x * 32u) {
+        float f[8];
+        bool ok[8];
+        uint32_t row[8], ch[8];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) {
-        const uint32_t c = min(c0 + u, nchunks_total - 1u);
-        row[u] = (nchunk == 1u) ? c : cx_div(c, div_chunk);   // no 8 integer divisions per wave (they were 2/3 of its instructions)
-        ch[u] = c - row[u] * nchunk;
-        const uint32_t l = ch[u] * 64u + lane;
-        ok[u] = l < P.n3;
-        f[u] = A[(size_t)row[u] * P.n3 + min(l, P.n3 - 1u)];   // unconditional: all 8 loads in flight
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t c = min(c0 + u, nchunks_total - 1u);
+            row[u] = (nchunk == 1u) ? c : cx_div(c, div_chunk);   // no 8 integer divisions per wave (they were 2/3 of its instructions)
+            ch[u] = c - row[u] * nchunk;
+            const uint32_t l = ch[u] * 64u + lane;
+            ok[u] = l < P.n3;
+            f[u] = A[(size_t)row[u] * P.n3 + min(l, P.n3 - 1u)];   // unconditional: all 8 loads in flight
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint64_t m = __ballot(ok[u] && f[u] < P.vcmp);
+            if (c0 + u < nchunks_total && lane < 2u && 2u * ch[u] + lane < P.nw3)
+                P.signbits[(size_t)row[u] * P.nw3 + 2u * ch[u] + lane] = lane ? (uint32_t)(m >> 32) : (uint32_t)m;
+        }
     }
+}
+
+// The same for rows that are a whole number of bitmap words (n3 % 32 == 0) on a 16-byte aligned grid: the bitmap is then the
+// flat array's, bit for sample.  A lane loads FOUR consecutive samples with one 16-byte load, four loads in flight (4 KB per
+// wave); the four comparison bits of 8 neighbouring lanes are joined into a word with three DPP steps.
+__global__ __launch_bounds__(256) void cx_k_signbits4_flat(const cx_params4 P, const uint32_t nquads) {
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave0 = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    typedef float cx_f4 __attribute__((ext_vector_type(4)));
+    const cx_f4* __restrict__ A = reinterpret_cast<const cx_f4*>(P.grid);
+    for (uint32_t q0 = wave0 * 256u; q0 < nquads; q0 += gridDim.x * 1024u) {   // uniform
+        cx_f4 f[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) {
-        const uint64_t m = __ballot(ok[u] && f[u] < P.vcmp);
-        if (c0 + u < nchunks_total && lane < 2u && 2u * ch[u] + lane < P.nw3)
-            P.signbits[(size_t)row[u] * P.nw3 + 2u * ch[u] + lane] = lane ? (uint32_t)(m >> 32) : (uint32_t)m;
+        for (uint32_t u = 0; u < 4; u++) f[u] = A[min(q0 + u * 64u + lane, nquads - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            uint32_t v = ((f[u].x < P.vcmp) ? 1u : 0u) | ((f[u].y < P.vcmp) ? 2u : 0u) | ((f[u].z < P.vcmp) ? 4u : 0u) | ((f[u].w < P.vcmp) ? 8u : 0u);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true) << 4;    // row_shl:1: lane + 1
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, true) << 8;    // row_shl:2
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true) << 16;   // row_shl:4
+            const uint32_t quad = q0 + u * 64u + lane;
+            if ((lane & 7u) == 0u && quad < nquads) P.signbits[quad >> 3] = v;
+        }
     }
 }
 
@@ -713,10 +738,19 @@ const uint64_t* cx_pent_lut_device() {
 }
 
 void cx_launch_signbits4d(const cx_params4& P, hipStream_t s) {
+    if (P.n3 % 32u == 0u && ((uintptr_t)P.grid & 15u) == 0u && !cx_debug_knob("CX4_SB_ROWS", 0)) {
+        const uint32_t nquads = P.nsamples / 4u;
+        uint32_t blocks = (nquads + 1023u) / 1024u;
+        if (blocks > 256u * 8u) blocks = 256u * 8u;
+        hipLaunchKernelGGL(cx_k_signbits4_flat, dim3(blocks), dim3(256), 0, s, P, nquads);
+        return;
+    }
     const uint32_t nchunk = (P.n3 + 63u) / 64u;
     const uint32_t total = P.nrows * nchunk;
     const uint32_t waves = (total + 7u) / 8u;
-    hipLaunchKernelGGL(cx_k_signbits4, dim3((waves + 3u) / 4u), dim3(256), 0, s, P, nchunk, cx_fdiv_make(nchunk), total);
+    uint32_t blocks = (waves + 3u) / 4u;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;   // grid-stride
+    hipLaunchKernelGGL(cx_k_signbits4, dim3(blocks), dim3(256), 0, s, P, nchunk, cx_fdiv_make(nchunk), total);
 }
 void cx_launch_classify4d(const cx_params4& P, hipStream_t s) {
     const uint32_t nitems = P.nrows * P.nw3;

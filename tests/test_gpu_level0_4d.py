@@ -47,7 +47,8 @@ def test_golden4d(name):
 
 
 @pytest.mark.parametrize("shape,seed", [((3, 4, 5, 6), 1), ((2, 2, 2, 2), 2), ((9, 5, 4, 7), 3), ((6, 6, 6, 17), 4),
-                                        ((5, 4, 3, 33), 5), ((4, 3, 5, 64), 6), ((3, 3, 4, 70), 7), ((18, 17, 16, 20), 8)])
+                                        ((5, 4, 3, 33), 5), ((4, 3, 5, 64), 6), ((3, 3, 4, 70), 7), ((18, 17, 16, 20), 8),
+                                        ((5, 4, 3, 32), 9), ((3, 2, 2, 96), 10), ((12, 11, 10, 32), 11)])
 def test_random_open_boundary_4d(shape, seed):
     rng = np.random.RandomState(seed)
     A = rng.standard_normal(shape).astype(np.float32)
