@@ -123,6 +123,7 @@ struct cx_task {
 #define CX_DBG_NO_TRIS 0x400000u       // emit kernel: skip triangle stores
 #define CX_DBG_NO_EMIT 0x800000u       // skip the emit kernel
 #define CX_DBG_NO_NEAR 0x2000000u      // stream kernel: ignore the tolerance screen (never take the per-cell path)
+#define CX_DBG_HASH64 0x4000000u       // triangle kernels: corner hashes in full 64-bit arithmetic (no table, no 32-bit fast form)
 #define CX_DBG_NO_VLOADS 0x1000000u    // phase B (packed entries): no sample loads for the vertices
 
 enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4,

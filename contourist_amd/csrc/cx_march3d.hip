@@ -1047,6 +1047,19 @@ __device__ __forceinline__ bool py_set2_swapped(uint64_t h1, uint64_t h2) {
     return s2 < s1;
 }
 
+// the same from the low 32 bits of the hashes (five probe steps fit); `unres`: still on one slot after five steps
+__device__ __forceinline__ bool py_set2_swapped_lo(uint32_t h1, uint32_t h2, bool& unres) {
+    const uint32_t s1 = h1 & 7u;
+    uint32_t s2 = h2 & 7u;
+    uint32_t perturb = h2;
+    for (int guard = 0; guard < 5 && s2 == s1; guard++) {
+        perturb >>= 5;
+        s2 = (s2 * 5u + 1u + perturb) & 7u;
+    }
+    unres = (s2 == s1);
+    return s2 < s1;
+}
+
 // The same decision from one byte per lattice point (cx_k_hash_bytes, built once per grid shape and origin): bits 0-2 = slot
 // of hash((i,j,k)) in an 8-slot table, bits 3-5 = the first slot of its probe sequence that differs from it (what it takes
 // when another element sits in its slot; the same slot again if 16 probes never leave it).
@@ -1072,6 +1085,7 @@ __device__ constexpr uint32_t CX_TRI_CD[6][16][2][2] = CX_TET_TRIS_CD_INIT;
 #ifndef CX_VE_ROW
 #define CX_VE_ROW 65
 #endif
+#define CX_T2_MAX 1024u
 struct cx_tri_lds {
     uint2 ve[4][7][CX_VE_ROW];   // per wave: (first vertex, crossing mask) of corner c of each cell (rows padded: bank spread)
     uint16_t slot[4][12 * 64];   // per wave: one word per triangle
@@ -1156,7 +1170,8 @@ __device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
 // NEG_ORIGIN: the array starts at a negative lattice point (rim of extra samples): signed hash lanes.  A kernel of its
 // own, because the extra path costs the common one ~9 % when it is a run-time branch (registers, code size)
 template <bool NEG_ORIGIN>
-__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
+__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I,
+                                                  const uint64_t* t2 = nullptr) {
     const uint32_t sm = I.rec.y & 0xFFu, tetskip = (I.rec.y >> 8) & 0x3Fu, ntri = (I.rec.y >> 16) & 0xFFu;
     L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
 #pragma unroll
@@ -1184,8 +1199,49 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
     } else if (P.flags & CX_DIAG_CPYTHON310) {
         const uint32_t need = cx_need_hash(sm, tetskip, ntri);
         if (__ballot(need != 0u) != 0ULL) {
-            uint64_t h[8];
-            if (!NEG_ORIGIN) {
+            // Fast form: only the LOW 32 bits of the corner hashes -- a probe step of the set order reads three bits five places
+            // further up, so five steps fit -- with k * P2 from a table in LDS (t2): one 32-bit multiplication per corner
+            // instead of seven (integer multiplications run at a quarter of the VALU rate, and this kernel is bound by VALU
+            // issue: DESIGN.md section 4).  A pair still on one slot after five steps, or a hash word of all ones (possibly
+            // the hash CPython replaces by a constant), sends the whole wave through the 64-bit form below.
+            bool exact = (t2 == nullptr);
+            if (!exact) {
+                uint32_t h[8];
+                bool bad = false;
+#pragma unroll
+                for (uint32_t c = 0; c < 8; c++) {
+                    h[c] = 0;
+                    if ((need >> c) & 1u) {
+                        const uint64_t sacc = I.hxy[c >> 1] + t2[I.ck + (c & 1u)];
+                        const uint32_t rot = __builtin_amdgcn_alignbit((uint32_t)sacc, (uint32_t)(sacc >> 32), 1);   // low word of rotl64(s, 31)
+                        h[c] = rot * (uint32_t)CX_PY_P1 + (uint32_t)(3ULL ^ (CX_PY_P5 ^ 3527539ULL));
+                        bad = bad || (h[c] == 0xFFFFFFFFu);
+                    }
+                }
+                uint32_t var32 = 0;
+#pragma unroll
+                for (int t = 0; t < 6; t++) {
+                    const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
+                                         (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
+                    if (__popc(pat) != 2) continue;
+                    uint32_t hl0 = 0, hl1 = 0, hh0 = 0, hh1 = 0;
+                    int nl = 0, nh = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const uint32_t hm = h[CX_TC[t][m]];
+                        if ((pat >> m) & 1u) { if (nl == 0) hl0 = hm; else hl1 = hm; nl++; }
+                        else { if (nh == 0) hh0 = hm; else hh1 = hm; nh++; }
+                    }
+                    bool u1, u2;
+                    if (py_set2_swapped_lo(hl0, hl1, u1) != py_set2_swapped_lo(hh0, hh1, u2)) var32 |= 1u << t;
+                    bad = bad || u1 || u2;
+                }
+                variants = var32;
+                exact = __ballot(bad && need != 0u) != 0ULL;
+            }
+            if (exact) {
+            variants = 0;
+            uint64_t h[8];            if (!NEG_ORIGIN) {
 #pragma unroll
                 for (uint32_t c = 0; c < 8; c++) {
                     h[c] = 0;
@@ -1213,6 +1269,7 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
                     else { if (nh == 0) hh0 = hm; else hh1 = hm; nh++; }
                 }
                 if (py_set2_swapped(hl0, hl1) != py_set2_swapped(hh0, hh1)) variants |= 1u << t;
+            }
             }
         }
     }
@@ -1287,6 +1344,14 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
+    // k -> (k + origin) * P2 of the tuple hash's last round (as CPython sees the lattice coordinate: hash(-1) == -2)
+    __shared__ uint64_t s_t2[CX_T2_MAX];
+    const bool use_t2 = (P.flags & CX_DIAG_CPYTHON310) && P.n2 <= CX_T2_MAX && !(P.flags & CX_DBG_HASH64);
+    if (use_t2)
+        for (uint32_t x = threadIdx.x; x < P.n2; x += blockDim.x) {
+            const int32_t v = (int32_t)x + (int32_t)P.org2;
+            s_t2[x] = ((v == -1) ? ~1ULL : (uint64_t)(int64_t)v) * CX_PY_P2;
+        }
     for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
     __syncthreads();
     const uint32_t lane = cx_lane_id();
@@ -1302,7 +1367,7 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
         const uint32_t nidx = idx + stride;
         cx_tri_fetch(P, hash_xy, rec_b, Ib);                                    // loads of the next record ...
         uint4 rec_c = (nidx + stride < ncells) ? cx_load_record(P.cells + nidx + stride) : zero;   // ... and the record after it
-        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia, use_t2 ? s_t2 : nullptr);
         cx_tri_pin(Ib, rec_c);                                                  // ... are back before the stores go out
         cx_tri_phase2(P, L, lane, wave, ttot);
         Ia = Ib;
@@ -1423,6 +1488,14 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
+    // k -> (k + origin) * P2 of the tuple hash's last round (as CPython sees the lattice coordinate: hash(-1) == -2)
+    __shared__ uint64_t s_t2[CX_T2_MAX];
+    const bool use_t2 = (P.flags & CX_DIAG_CPYTHON310) && P.n2 <= CX_T2_MAX && !(P.flags & CX_DBG_HASH64);
+    if (use_t2)
+        for (uint32_t x = threadIdx.x; x < P.n2; x += blockDim.x) {
+            const int32_t v = (int32_t)x + (int32_t)P.org2;
+            s_t2[x] = ((v == -1) ? ~1ULL : (uint64_t)(int64_t)v) * CX_PY_P2;
+        }
     for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
     __syncthreads();
     const uint32_t lane = cx_lane_id();
@@ -1450,7 +1523,7 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
         uint4 rec_d = record(nidx + 2u * stride);          // the record three steps ahead
         cx_triq_stage1(P, T, hash_xy, rec_c, Ac);           // queue words of the record two steps ahead
         cx_triq_stage2(P, T, hash_xy, Ab, Ib);              // info words (and hash prefixes) of the next record
-        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia, use_t2 ? s_t2 : nullptr);
         cx_triq_pin1(Ac, rec_d);                            // ... all back before the stores go out
         cx_triq_pin2(Ib);
         cx_tri_phase2(P, L, lane, wave, ttot);

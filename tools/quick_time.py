@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from contourist_amd import _ffi, synthetic
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+extra = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0   # debug flag bits added to both modes
 A = synthetic.smooth_noise_torch((size,) * 3, 1235, 1400, torch.device("cuda", 0))
 ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
 print(ctx.extract3d(0.0, 1))
-for fl, name in ((1, "full"), (1 | 0x10000 | 0x800000, "phaseA")):
+for fl, name in ((1 | extra, "full"), (1 | 0x10000 | 0x800000, "phaseA")):
     r = []
     for rnd in range(7):
         ctx.extract3d_async(0.0, fl)
