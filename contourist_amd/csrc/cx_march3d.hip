@@ -554,7 +554,10 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     __shared__ uint32_t s_br[4][CX_SBR][5];
     __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
     __shared__ uint32_t s_tot[4][6];
+    __shared__ uint8_t s_ntri[256];      // triangles of a voxel by its corner sign mask
     if (b >= T.nblocks) return;
+    s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
+    __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* q = s_q[wave];
@@ -616,6 +619,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         // cells that exist / whose k+1 / j+1 neighbour exists (bit layout of CX_CELL_MASK)
         const cx_lmasks LM = cx_lane_masks(P, k0, j0, lane);
         const uint32_t mr = LM.mr, mk = LM.mk, mj = LM.mj;
+        (void)mk; (void)mj;
 
         // one sample plane of this lane: RJ+1 rows x 4 consecutive k-samples, plus the sample right of the segment
         struct plane_raw {
@@ -698,8 +702,33 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                     // corners (k,k+1) of rows (r,r+1): bits (bit, bit+1, bit+6, bit+7) of the two plane words
                     q[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
                 }
+#ifndef CX_S1_COUNTS
+#define CX_S1_COUNTS 1   // 1: one lane per queued ENTRY; 0: bit-sliced over the lane's 16 cells (round 1, ~2.5 x the instructions)
+#endif
+#if CX_S1_COUNTS == 1
+                // counts of the cells just queued, one lane per ENTRY and with the vertex stage's own formulas (cx_vround_front):
+                // ~40 instructions for the step's ~30 cells.  (Round 1 counted all 16 cells of every lane at once on the packed
+                // sign words with bit-sliced adders over the 6 tetrahedra: ~150 instructions per step whatever is active --
+                // a quarter of this kernel's VALU work, and VALU issue is what bounds it next to the sample loads.)
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t o = lane; o < tot; o += 64u) {
+                    const uint32_t e = q[ql + o];
+                    uint32_t ci, cj, ck;
+                    cx_decode_entry(P, G, e, ci, cj, ck);
+                    const uint32_t vm = cx_corner_valid(P, ci, cj, ck);
+                    const uint32_t sm = cx_entry_signs(e);
+                    const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+                    const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
+                    const bool real = (vm == 0xFFu);
+                    const uint32_t nt = real ? (uint32_t)s_ntri[sm] : 0u;
+                    acc.v += nv;
+                    acc.t += nt;
+                    acc.c += (nv | nt) ? 1u : 0u;
+                    acc.b += real ? 1u : 0u;
+                }
                 ql += tot;
-#ifndef CX_S1_NO_COUNT   // timing experiments only
+#else
+                ql += tot;
                 // counts of this lane's 16 cells, all at once on the packed sign words: corner
                 // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
                 // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
