@@ -16,5 +16,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/traffic.py gpurun_out/pmc gpurun_out/prof > gpurun_out/prof/traffic.log
 timeout -k 10 300 python3 tools/bench_levels.py 512 > gpurun_out/prof/bench_levels_512.json 2> gpurun_out/prof/levels.err
+# config 4 (4-D): bench line without the profiler, then the kernel trace of the same command
+timeout -k 10 300 python3 tools/bench4d.py > gpurun_out/prof/bench4d.json 2> gpurun_out/prof/bench4d.err
+bash tools/prof4d.sh > /dev/null
 cat gpurun_out/prof/kernel_stats_512.csv
 cat gpurun_out/prof/traffic.json
