@@ -237,7 +237,8 @@ extern "C" int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* e
 }
 
 extern "C" int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3) {
-    if (!ctx || o0 < 0 || o1 < 0 || o2 < 0 || o3 < 0) return CX_ERR_INVALID;
+    // negative: the array starts before the reference's grid (a rim of extra samples)
+    if (!ctx || o0 < -1024 || o1 < -1024 || o2 < -1024 || o3 < -1024) return CX_ERR_INVALID;
     ctx->origin4[0] = o0; ctx->origin4[1] = o1; ctx->origin4[2] = o2; ctx->origin4[3] = o3;
     return CX_OK;
 }

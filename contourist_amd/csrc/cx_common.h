@@ -80,7 +80,9 @@ struct cx_params {
     uint32_t* chunksum;       // [ceil(nwaves / 256)][8] totals (v, t, c, b, nb, near) of every 256 streaming waves, added up by the stream kernel
     uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
 };
+#ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
+#endif
 
 struct cx_wsum {   // 32 bytes
     uint32_t nb;           // batches

@@ -418,8 +418,11 @@ __global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
 #define CX4_PY_P1 11400714785074694791ULL
 #define CX4_PY_P2 14029467366897019727ULL
 #define CX4_PY_P5 2870177450012600261ULL
+// x is a lattice coordinate as CPython sees it: it may be negative (an array with a rim of samples around the reference's grid has
+// its origin at -1); a small int hashes to itself, except hash(-1) == -2
 __device__ __forceinline__ uint64_t py_round4(uint64_t acc, uint32_t x) {
-    acc += (uint64_t)x * CX4_PY_P2;
+    const int32_t sx = (int32_t)x;
+    acc += ((sx == -1) ? ~1ULL : (uint64_t)(int64_t)sx) * CX4_PY_P2;
     acc = (acc << 31) | (acc >> 33);
     return acc * CX4_PY_P1;
 }

@@ -1178,7 +1178,7 @@ extern "C" int cx_surface_geometry(cx_ctx* ctx, double* points_xyz, int64_t* nv_
 // float64 4-D vertex coordinates exactly as the reference interpolates them, with t snapped to its bin
 __global__ void cxp_k_vertices4_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, uint32_t n3, cx_fdiv d3, cx_fdiv d2, cx_fdiv d1,
                                     double value, const uint32_t* __restrict__ vkeys, uint32_t nv, double min_interval, double* pts,
-                                    uint32_t* prio) {
+                                    uint32_t* prio, int o0, int o1, int o2, int o3) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     const uint32_t key = vkeys[v];
@@ -1198,11 +1198,13 @@ __global__ void cxp_k_vertices4_f64(const float* __restrict__ A, uint32_t n1, ui
     const double den = 1.0 * (fhigh - flow);
     if (!(fabs(den) <= 1e-8)) ratio = (value - flow) / den;
     const uint32_t db[4] = {(d >> 3) & 1u, (d >> 2) & 1u, (d >> 1) & 1u, d & 1u};
+    const int org[4] = {o0, o1, o2, o3};   // (negative) origin of the array in the reference's lattice: the points are interpolated there
     double x[4];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-        const double low = owner_low ? (double)q[a] : (double)q[a] + (double)db[a];
-        const double high = owner_low ? (double)q[a] + (double)db[a] : (double)q[a];
+        const double qa = (double)((int)q[a] + org[a]);
+        const double low = owner_low ? qa : qa + (double)db[a];
+        const double high = owner_low ? qa + (double)db[a] : qa;
         x[a] = low + ratio * (high - low);
     }
     // bin_times: bin = int(t / min_interval); t = bin * min_interval
@@ -1298,10 +1300,17 @@ extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts)
     uint32_t nt2 = 0;
     if (nv && nt) {
         const uint32_t n1 = (uint32_t)G->n[1], n2 = (uint32_t)G->n[2], n3 = (uint32_t)G->n[3];
-        const double corner[4] = {(double)(G->n[0] - 1), (double)(G->n[1] - 1), (double)(G->n[2] - 1), (double)(G->n[3] - 1)};
+        // an array with a rim of samples around the reference's grid (negative origin, cx_set_origin4d): the reference's own
+        // corner and lattice (scales of the tiny collapse, bin width, coordinates)
+        int org[4];
+        double corner[4];
+        for (int a = 0; a < 4; a++) {
+            org[a] = (G->origin[a] < 0) ? (int)G->origin[a] : 0;
+            corner[a] = (double)(G->n[a] - 1 + 2 * org[a]);
+        }
         const double min_interval = corner[3] * (1.0 / (double)nbins);
         hipLaunchKernelGGL(cxp_k_vertices4_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, G->grid, n1, n2, n3, cx_fdiv_make(n1 * n2 * n3),
-                           cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio);
+                           cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio, org[0], org[1], org[2], org[3]);
         hipLaunchKernelGGL(cxp_k_drop_instant, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1e-7);
         // cx_select_seeded4d: only the tetrahedra of the selected components exist
         if (G->keep_valid) hipLaunchKernelGGL(cxp_k_and_mask, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, (const uint8_t*)G->tet_keep, nt);

@@ -13,12 +13,15 @@
 // whose corner 0 is the componentwise minimum of the owners of its four edges (every tetrahedron touches all five
 // corners of its pentatope, every pentatope contains corner 0 of its hypercube).
 // Deviations: hyper-voxels whose corners only touch the isovalue (no strict sign change) do not bridge groups; seed
-// points whose hyper-voxel is not inside the array are skipped.
+// points whose hyper-voxel is not inside the ARRAY are skipped (the array may carry a rim of samples around the reference's
+// grid: cx_select_seeded4d_ex takes the grid's box, and seed voxels in the rim are kept as the reference keeps them).
 #include <algorithm>
 #include <cstring>
 #include <string>
 
 #include "cx_state4.h"
+
+extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
 
 #define CXS4_HIP(ctx, call)                                                                      \
     do {                                                                                         \
@@ -35,7 +38,13 @@ struct cxs4_grid {
     const float* A;
     uint32_t n[4];
     double value;
+    int lo[4], hi[4];   // in_range box of the breadth-first growth: lo <= hyper-voxel < hi (default 0 .. n-1)
 };
+__device__ __forceinline__ bool cxs4_in_range(const cxs4_grid& G, const int p[4]) {
+    for (int a = 0; a < 4; a++)
+        if (p[a] < G.lo[a] || p[a] >= G.hi[a]) return false;
+    return true;
+}
 __device__ __forceinline__ uint32_t cxs4_lin(const cxs4_grid& G, const int p[4]) {
     return (((uint32_t)p[0] * G.n[1] + (uint32_t)p[1]) * G.n[2] + (uint32_t)p[2]) * G.n[3] + (uint32_t)p[3];
 }
@@ -100,6 +109,7 @@ __global__ void cxs4_k_union(const uint4* cells, uint32_t ncells, const uint32_t
     if (!cxs4_is_voxel_record(G, c)) return;
     int p[4];
     cxs4_unravel(G, c.x, p);
+    if (!cxs4_in_range(G, p)) return;   // only in-range hyper-voxels grow (seed voxels outside the box: cxs4_k_mark)
     // the 40 "forward" neighbours (the other 40 are reached from the other side)
     for (int code = 41; code < 81; code++) {   // offsets in lexicographic order, (0,0,0,0) is code 40
         int o[4], x = code;
@@ -108,6 +118,7 @@ __global__ void cxs4_k_union(const uint4* cells, uint32_t ncells, const uint32_t
         o[1] = x % 3 - 1; x /= 3;
         o[0] = x - 1;
         const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
+        if (!cxs4_in_range(G, q)) continue;   // in_range (tetrahedral.py:465-469)
         const uint32_t other = cxs4_lookup(G, cells, ncells, vmap, q);
         if (other != CXS4_NONE) cxs4_union(parent, r, other);
     }
@@ -195,18 +206,37 @@ __global__ void cxs4_k_seeds(cxs4_grid G, const int32_t* ep, uint32_t n, unsigne
     out[0] = ns;
     out[1] = bad;
 }
+// flag[] = groups reached; seedkeep[] = seed voxels themselves: a seed voxel outside the in_range box (the reference does not
+// range-check the voxels it starts from, tetrahedral.py:396-441) is kept and grows one step into the box, as the reference's
+// first expand_voxels round does
 __global__ void cxs4_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint32_t* seeds,
-                            const uint32_t* nseeds, uint8_t* flag, cxs4_grid G) {
+                            const uint32_t* nseeds, uint8_t* flag, uint8_t* seedkeep, cxs4_grid G) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseeds[0]) return;
     int p[4];
     cxs4_unravel(G, seeds[s], p);
     const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, p);
-    if (r != CXS4_NONE) flag[parent[r]] = 1;   // (a border voxel without a strict sign change has no tetrahedra and does not grow here)
+    if (cxs4_in_range(G, p)) {
+        if (r != CXS4_NONE) flag[parent[r]] = 1;   // (a border voxel without a strict sign change has no tetrahedra and does not grow here)
+        return;
+    }
+    if (r != CXS4_NONE) seedkeep[r] = 1;
+    for (int code = 0; code < 81; code++) {
+        if (code == 40) continue;
+        int o[4], x = code;
+        o[3] = x % 3 - 1; x /= 3;
+        o[2] = x % 3 - 1; x /= 3;
+        o[1] = x % 3 - 1; x /= 3;
+        o[0] = x - 1;
+        const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
+        if (!cxs4_in_range(G, q)) continue;
+        const uint32_t r2 = cxs4_lookup(G, cells, ncells, vmap, q);
+        if (r2 != CXS4_NONE) flag[parent[r2]] = 1;
+    }
 }
 // keep[t] = 1 for the tetrahedra of the hyper-voxels in flagged groups; out[2] groups kept, out[3] tetrahedra kept
 __global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint8_t* flag,
-                            const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G) {
+                            const uint8_t* seedkeep, const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     int b[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
@@ -216,7 +246,7 @@ __global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t*
         for (int a = 0; a < 4; a++) b[a] = min(b[a], p[a]);
     }
     const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, b);
-    const uint8_t k = (r != CXS4_NONE && flag[parent[r]] != 0) ? 1 : 0;
+    const uint8_t k = (r != CXS4_NONE && ((cxs4_in_range(G, b) && flag[parent[r]] != 0) || seedkeep[r] != 0)) ? 1 : 0;
     keep[t] = k;
     if (k) atomicAdd(&out[3], 1u);
 }
@@ -226,6 +256,9 @@ __global__ void cxs4_k_count_groups(const uint32_t* parent, uint32_t ncells, con
 }
 
 extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, int64_t* out_counts) {
+    return cx_select_seeded4d_ex(ctx, endpoints_ijkl, n, nullptr, out_counts);
+}
+extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts) {
     if (!ctx || (n > 0 && !endpoints_ijkl) || n < 0) return CX_ERR_INVALID;
     cx_state4* S4 = ctx->s4;
     if (!S4 || !S4->extracted) { ctx->err = "cx_select_seeded4d: no valid 4-D extraction"; return CX_ERR_STATE; }
@@ -235,7 +268,11 @@ extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, in
     cxs4_grid G;
     G.A = S4->grid;
     size_t nsamples = 1;
-    for (int a = 0; a < 4; a++) { G.n[a] = (uint32_t)S4->n[a]; nsamples *= (size_t)S4->n[a]; }
+    for (int a = 0; a < 4; a++) {
+        G.n[a] = (uint32_t)S4->n[a]; nsamples *= (size_t)S4->n[a];
+        G.lo[a] = range_lo_hi ? std::max(range_lo_hi[a], 0) : 0;
+        G.hi[a] = range_lo_hi ? std::min(range_lo_hi[4 + a], (int)S4->n[a] - 1) : (int)S4->n[a] - 1;
+    }
     G.value = S4->value;
     if (S4->keep_cap < (size_t)nt + 64) {
         if (S4->tet_keep) (void)hipFree(S4->tet_keep);
@@ -257,12 +294,12 @@ extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, in
 #define CXS4_TRY(call) if ((e = (call)) != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP; break; }
         CXS4_TRY(hipMalloc(&vmap, (nsamples + 64) * sizeof(uint32_t)));
         CXS4_TRY(hipMalloc(&parent, ((size_t)ncells + 64) * sizeof(uint32_t)));
-        CXS4_TRY(hipMalloc(&flag, (size_t)ncells + 64));
+        CXS4_TRY(hipMalloc(&flag, 2 * ((size_t)ncells + 64)));   // flag | seedkeep
         CXS4_TRY(hipMalloc(&seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t)));
         CXS4_TRY(hipMalloc(&out, 16 * sizeof(uint32_t)));
         CXS4_TRY(hipMalloc(&ep, ((size_t)n * 8 + 8) * sizeof(int32_t)));
         CXS4_TRY(hipMalloc(&visited, vsize * sizeof(unsigned long long)));
-        CXS4_TRY(hipMemsetAsync(flag, 0, (size_t)ncells + 64, st));
+        CXS4_TRY(hipMemsetAsync(flag, 0, 2 * ((size_t)ncells + 64), st));
         CXS4_TRY(hipMemsetAsync(out, 0, 16 * sizeof(uint32_t), st));
         CXS4_TRY(hipMemsetAsync(visited, 0, vsize * sizeof(unsigned long long), st));
         CXS4_TRY(hipMemsetAsync(S4->tet_keep, 0, (size_t)nt + 64, st));
@@ -273,8 +310,8 @@ extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, in
             hipLaunchKernelGGL(cxs4_k_union, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs4_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
             hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
-            hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, G);
-            hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, S4->tets, S4->vkeys, nt,
+            hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
+            hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, flag + ncells + 64, S4->tets, S4->vkeys, nt,
                                S4->tet_keep, out, G);
             hipLaunchKernelGGL(cxs4_k_count_groups, dim3(blocks), dim3(256), 0, st, parent, ncells, flag, out);
         }
@@ -293,5 +330,16 @@ extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, in
     if (host_out[1]) { ctx->err = "cx_select_seeded4d: an end point pair does not straddle the isovalue (or lies outside the grid)"; return CX_ERR_INVALID; }
     S4->keep_valid = true;
     S4->post_valid = false;
+    return CX_OK;
+}
+
+extern "C" int cx_seeded4d_mask_download(cx_ctx* ctx, uint8_t* tet_keep) {
+    if (!ctx || !tet_keep) return CX_ERR_INVALID;
+    cx_state4* S4 = ctx->s4;
+    if (!S4 || !S4->extracted || !S4->keep_valid) { ctx->err = "cx_seeded4d_mask_download: run cx_select_seeded4d first"; return CX_ERR_STATE; }
+    CXS4_HIP(ctx, hipSetDevice(ctx->device));
+    if (S4->counts.n_triangles)
+        CXS4_HIP(ctx, hipMemcpyAsync(tet_keep, S4->tet_keep, (size_t)S4->counts.n_triangles, hipMemcpyDeviceToHost, ctx->stream));
+    CXS4_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CX_OK;
 }

@@ -58,13 +58,29 @@ class GridContour4D(object):
     pentatopes.py:32-39; on the device: cx_select_seeded4d).  march() always returns the whole Level-0 mesh."""
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
-                 device=None, diagonal="cpython310", context=None):
+                 device=None, diagonal="cpython310", context=None, voxel_range=None, origin=(0, 0, 0, 0)):
         self.corner = np.array(corner, dtype=int)
         assert self.corner.shape == (4,), "dimension should be 4 " + repr(self.corner.shape)
         if not linear_interpolate:
             raise NotImplementedError("linear_interpolate=False needs f off the grid")
         self.dimension = 4
         self.value = float(value)
+        if callable(samples):
+            # GridContour4D(corner, function, value, segment_endpoints): the reference's own signature (pentatopes.py:92-100;
+            # its test0 demo, :528-551).  f over lattice coordinates is sampled once -- with explicit end points one lattice
+            # step beyond the grid as well, where the reference puts seed voxels (tetrahedral.py:396-441)
+            gd = tuple(int(c) for c in self.corner)
+            g = grid_field.FunctionGrid([0.0] * 4, [c - 0.5 for c in gd], [1.0] * 4, samples)
+            assert tuple(int(n) for n in g.grid_dimensions) == gd
+            if segment_endpoints is not None and len(segment_endpoints):
+                m = 1
+                segment_endpoints = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in segment_endpoints]
+                samples = g.dense_samples(margin=m)
+                voxel_range = ((m,) * 4, tuple(n + m for n in gd))
+                origin = (-m,) * 4
+                self.corner = self.corner + 2 * m
+            else:
+                samples = g.dense_samples()
         self.end_points = segment_endpoints
         self.samples = samples
         self.shape = tuple(int(n) for n in samples.shape)
@@ -73,6 +89,10 @@ class GridContour4D(object):
         self.flags = {"cpython310": _ffi.CX_DIAG_CPYTHON310, "canonical": _ffi.CX_DIAG_CANONICAL}[diagonal]
         self._ctx = context
         self._counts = None
+        # an array with a rim of samples around the reference's grid (Delta4DContour.get_contour_maker): the lattice point of
+        # sample [0,0,0,0] (negative) and the in_range box of the seeded growth = the reference's grid, in array coordinates
+        self.origin = tuple(int(o) for o in origin)
+        self.voxel_range = voxel_range
 
     def context(self):
         if self._ctx is None:
@@ -83,6 +103,7 @@ class GridContour4D(object):
         """Level 0: the hyper-voxel march alone.  returns dict(xyzt (V,4) f32 grid coords, keys (V,) u32 edge ids,
         tetrahedra (T,4) i32, counts)"""
         ctx = self.context()
+        ctx.set_origin4d(*self.origin)
         s = self.samples
         if grid_field._is_torch(s):
             assert s.is_cuda and s.is_contiguous() and str(s.dtype) == "torch.float32"
@@ -91,6 +112,8 @@ class GridContour4D(object):
             ctx.upload_grid4d(s)
         self._counts = ctx.extract4d(self.value, self.flags)
         xyzt, keys, tets = ctx.download_level0_4d(self._counts)
+        if any(self.origin):        # array coordinates -> the reference's lattice (the edge ids stay those of the array)
+            xyzt = xyzt + np.asarray(self.origin, dtype=np.float32)
         return dict(xyzt=xyzt, keys=keys, tetrahedra=tets, counts=self._counts)
 
     def find_tetrahedra(self, nbins=100):
@@ -100,7 +123,7 @@ class GridContour4D(object):
         L = self.march()
         ctx = self.context()
         if self.end_points is not None and len(self.end_points):
-            self.seeded = ctx.select_seeded4d(self.end_points)
+            self.seeded = ctx.select_seeded4d(self.end_points, self.voxel_range)
         post = ctx.postprocess4d(nbins)
         pts, tets = ctx.download_level1_4d(post)
         self.post_counts = post
@@ -130,10 +153,20 @@ class GridContour4D(object):
 class Delta4DContour(tetrahedral.Delta3DContour):
     "world-coordinate facade (pentatopes.py:42-68)"
 
-    def get_contour_maker(self, grid_endpoints):
+    def get_contour_maker(self, grid_endpoints, rim=True):
         grid = self.grid
         self.grid_endpoints = grid_endpoints
-        return GridContour4D(tuple(int(n) for n in grid.grid_dimensions), grid.dense_samples(), self.value, grid_endpoints,
+        gd = tuple(int(n) for n in grid.grid_dimensions)
+        if grid_endpoints is not None and len(grid_endpoints) and rim and not getattr(grid, "array_backed", False):
+            # explicit end points on a callable field: the reference does not range-check its seed voxels and evaluates f one
+            # lattice step outside the grid (tetrahedral.py:396-441; its own test0 call, pentatopes.py:528-551, starts in two
+            # such hyper-voxels): sample that rim too, keep the breadth-first growth inside the reference's grid
+            m = 1
+            shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
+            return GridContour4D(tuple(n + 2 * m for n in gd), grid.dense_samples(margin=m), self.value, shifted,
+                                 linear_interpolate=self.linear_interpolate, device=self.device,
+                                 voxel_range=((m,) * 4, tuple(n + m for n in gd)), origin=(-m,) * 4)
+        return GridContour4D(gd, grid.dense_samples(), self.value, grid_endpoints,
                              linear_interpolate=self.linear_interpolate, device=self.device)
 
     def search_for_endpoints(self, skip=1):
@@ -143,7 +176,7 @@ class Delta4DContour(tetrahedral.Delta3DContour):
         if skip > 1:
             (maxf, minf, segments) = self.grid.find_contour_crossing_grid_segments(self.value, skip)
             self.grid_values = (minf, maxf)
-            self.contour_maker = self.get_contour_maker(segments if len(segments) else None)
+            self.contour_maker = self.get_contour_maker(segments if len(segments) else None, rim=False)   # coarse segments lie inside the grid
             self.grid_endpoints = segments
             return
         self.contour_maker = self.get_contour_maker(None)

@@ -246,22 +246,44 @@ def test_seeded_growth_4d():
 
 
 def test_reference_test0_call_on_device():
-    """the reference's own 4-D demo call (pentatopes.py:528-551) through the mirrored class: the device keeps the 26 004
-    tetrahedra the reference has inside the grid (its other 96 sit in two start voxels outside the grid)"""
+    """the reference's own 4-D demo call (pentatopes.py:528-551) through the mirrored class, with the CALLABLE: the device
+    returns the reference's 26 100 tetrahedra, the 96 included that sit in two start voxels one lattice step OUTSIDE the
+    grid (the reference does not range-check the voxels it starts from, tetrahedral.py:396-441): same edges, same
+    tetrahedra with the CPython-order splits"""
     from contourist_amd import pentatopes
     from oracle.make_goldens4d import test0_field, TEST0_END_POINTS
     G = np.load(os.path.join(G4, "reference_test0_seeded.npz"))
+    maker = pentatopes.GridContour4D((8, 8, 8, 8), test0_field, 2.0, [(tuple(a), tuple(b)) for a, b in TEST0_END_POINTS])
+    assert maker.origin == (-1, -1, -1, -1) and maker.shape == (11, 11, 11, 11)
+    L = maker.march()
+    ctx = maker.context()
+    assert ctx.select_seeded4d(maker.end_points, maker.voxel_range)["tetrahedra_kept"] == len(G["l0_tets"]) == 26100
+    keep = ctx.seeded4d_mask(L["counts"]).astype(bool)
+    lo, hi = pentatopes.unpack_edge_ids4(L["keys"], maker.shape)
+    lo, hi = lo - 1, hi - 1                                     # array lattice -> the reference's
+    code = lambda P: [tuple(int(x) for x in r) for r in P]
+    dev_pair = [(a, b) for a, b in zip(code(lo), code(hi))]
+    ref_pair = [tuple(sorted((tuple(int(x) for x in r[:4]), tuple(int(x) for x in r[4:])))) for r in G["l0_pairs"]]
+    dev_tets = set(frozenset(dev_pair[v] for v in t) for t in L["tetrahedra"][keep])
+    ref_tets = set(frozenset(ref_pair[v] for v in t) for t in G["l0_tets"])
+    assert len(dev_tets) == int(keep.sum()) == 26100 and dev_tets == ref_tets
+    P = G["l0_pairs"]
+    inside = (P.min(axis=1) >= 0) & (P.max(axis=1) <= 8)
+    assert int(inside[G["l0_tets"]].all(axis=1).sum()) == 26004       # the other 96 reach beyond the grid
+    used = np.unique(L["tetrahedra"][keep])
+    assert L["xyzt"][used].min() < 0.0 or L["xyzt"][used].max() > 8.0  # coordinates in the reference's lattice, rim included
+    R = maker.find_tetrahedra()
+    assert maker.seeded["tetrahedra_kept"] == 26100
+    assert R["counts"]["n_after_tiny"] > 0 and R["points4d"][np.unique(R["tetrahedra"])].min() >= -1.0
+    MT = maker.collect_morph_triangles()
+    assert len(MT.triangle_segment_indices) > 0
+    # the same field as an ARRAY cannot be evaluated outside itself: the growth keeps to the grid (26 004 tetrahedra)
     g = np.arange(9, dtype=np.float64)
     X, Y, Z, T = np.meshgrid(g, g, g, g, indexing="ij")
     A = test0_field(X, Y, Z, T).astype(np.float32)
-    maker = pentatopes.GridContour4D((8, 8, 8, 8), A, 2.0, [(tuple(a), tuple(b)) for a, b in TEST0_END_POINTS])
-    R = maker.find_tetrahedra()
-    P = G["l0_pairs"]
-    inside = (P.min(axis=1) >= 0) & (P.max(axis=1) <= 8)
-    assert maker.seeded["tetrahedra_kept"] == int(inside[G["l0_tets"]].all(axis=1).sum()) == 26004
-    assert maker.seeded["groups_kept"] >= 1 and R["counts"]["n_after_tiny"] > 0
-    MT = maker.collect_morph_triangles()
-    assert len(MT.triangle_segment_indices) > 0
+    maker2 = pentatopes.GridContour4D((8, 8, 8, 8), A, 2.0, [(tuple(a), tuple(b)) for a, b in TEST0_END_POINTS])
+    maker2.find_tetrahedra()
+    assert maker2.seeded["tetrahedra_kept"] == 26004
 
 
 def test_search_for_endpoints_with_skip_4d():
