@@ -123,7 +123,7 @@ def load():
         "cx_set_origin4d": [vp, i64, i64, i64, i64],
         "cx_extract4d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
         "cx_select_seeded4d": [vp, vp, i64, vp],
-        "cx_select_seeded4d_ex": [vp, vp, i64, vp, vp],
+        "cx_select_seeded4d_ex": [vp, vp, i64, vp, ctypes.c_uint32, vp],
         "cx_seeded4d_mask_download": [vp, vp],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
@@ -339,18 +339,19 @@ class Context(object):
         self._check(self.lib.cx_extract4d(self.handle, float(value), int(flags), ctypes.byref(c)))
         return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
 
-    def select_seeded4d(self, endpoints, voxel_range=None):
+    def select_seeded4d(self, endpoints, voxel_range=None, all_in_range=False):
         """restrict the 4-D post-pass to the components the reference's seeded search reaches from the lattice end
         point pairs [(i0,j0,k0,l0), (i1,j1,k1,l1)] -> dict(seed_voxels, groups_kept, tetrahedra_kept).
         voxel_range = (lo[4], hi[4]): in_range box of the growth in array coordinates (default: the whole array); seed
-        voxels outside it are kept and grow one step into it (an array with a rim around the reference's grid)."""
+        voxels outside it are kept and grow one step into it (an array with a rim around the reference's grid).
+        all_in_range: every hyper-voxel inside the box is kept, the end points only add seed voxels outside it."""
         ep = np.ascontiguousarray(np.asarray(endpoints, dtype=np.int64).reshape(-1, 8), dtype=np.int32)
         out = np.zeros(4, dtype=np.int64)
         box = None
         if voxel_range is not None:
             box = np.ascontiguousarray(np.asarray(voxel_range, dtype=np.int64).reshape(8), dtype=np.int32)
         self._check(self.lib.cx_select_seeded4d_ex(self.handle, ep.ctypes.data, int(len(ep)), box.ctypes.data if box is not None else None,
-                                                  out.ctypes.data))
+                                                  1 if all_in_range else 0, out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), tetrahedra_kept=int(out[2]))
 
     def seeded4d_mask(self, counts):

@@ -21,7 +21,7 @@
 
 #include "cx_state4.h"
 
-extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
+extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, uint32_t flags, int64_t* out_counts);
 
 #define CXS4_HIP(ctx, call)                                                                      \
     do {                                                                                         \
@@ -236,7 +236,7 @@ __global__ void cxs4_k_mark(const uint4* cells, uint32_t ncells, const uint32_t*
 }
 // keep[t] = 1 for the tetrahedra of the hyper-voxels in flagged groups; out[2] groups kept, out[3] tetrahedra kept
 __global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint8_t* flag,
-                            const uint8_t* seedkeep, const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G) {
+                            const uint8_t* seedkeep, const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G, int all_in_range) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     int b[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
@@ -246,7 +246,7 @@ __global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t*
         for (int a = 0; a < 4; a++) b[a] = min(b[a], p[a]);
     }
     const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, b);
-    const uint8_t k = (r != CXS4_NONE && ((cxs4_in_range(G, b) && flag[parent[r]] != 0) || seedkeep[r] != 0)) ? 1 : 0;
+    const uint8_t k = (r != CXS4_NONE && ((cxs4_in_range(G, b) && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0)) ? 1 : 0;
     keep[t] = k;
     if (k) atomicAdd(&out[3], 1u);
 }
@@ -256,9 +256,11 @@ __global__ void cxs4_k_count_groups(const uint32_t* parent, uint32_t ncells, con
 }
 
 extern "C" int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, int64_t* out_counts) {
-    return cx_select_seeded4d_ex(ctx, endpoints_ijkl, n, nullptr, out_counts);
+    return cx_select_seeded4d_ex(ctx, endpoints_ijkl, n, nullptr, 0u, out_counts);
 }
-extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts) {
+extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
+                                     int64_t* out_counts) {
+    const int all_in_range = (flags & CX_SEED_ALL_IN_RANGE) ? 1 : 0;
     if (!ctx || (n > 0 && !endpoints_ijkl) || n < 0) return CX_ERR_INVALID;
     cx_state4* S4 = ctx->s4;
     if (!S4 || !S4->extracted) { ctx->err = "cx_select_seeded4d: no valid 4-D extraction"; return CX_ERR_STATE; }
@@ -312,7 +314,7 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
             hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
             hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
             hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, flag + ncells + 64, S4->tets, S4->vkeys, nt,
-                               S4->tet_keep, out, G);
+                               S4->tet_keep, out, G, all_in_range);
             hipLaunchKernelGGL(cxs4_k_count_groups, dim3(blocks), dim3(256), 0, st, parent, ncells, flag, out);
         }
         CXS4_TRY(hipGetLastError());

@@ -93,6 +93,7 @@ class GridContour4D(object):
         # sample [0,0,0,0] (negative) and the in_range box of the seeded growth = the reference's grid, in array coordinates
         self.origin = tuple(int(o) for o in origin)
         self.voxel_range = voxel_range
+        self.keep_in_range = False        # True: every hyper-voxel of the box is kept, the end points only add seed voxels outside it
 
     def context(self):
         if self._ctx is None:
@@ -123,7 +124,7 @@ class GridContour4D(object):
         L = self.march()
         ctx = self.context()
         if self.end_points is not None and len(self.end_points):
-            self.seeded = ctx.select_seeded4d(self.end_points, self.voxel_range)
+            self.seeded = ctx.select_seeded4d(self.end_points, self.voxel_range, self.keep_in_range)
         post = ctx.postprocess4d(nbins)
         pts, tets = ctx.download_level1_4d(post)
         self.post_counts = post
@@ -178,6 +179,18 @@ class Delta4DContour(tetrahedral.Delta3DContour):
             self.grid_values = (minf, maxf)
             self.contour_maker = self.get_contour_maker(segments if len(segments) else None, rim=False)   # coarse segments lie inside the grid
             self.grid_endpoints = segments
+            return
+        rim = None
+        if not getattr(self.grid, "array_backed", False):
+            gd = [int(n) for n in self.grid.grid_dimensions]
+            rim = tetrahedral.rim_crossing_segments(np.asarray(self.grid.dense_samples_host(), dtype=np.float64), gd, float(self.value))
+        if rim is not None and len(rim):
+            # the surface reaches the rim of the grid: the reference starts from every crossing segment without range-checking
+            # the hyper-voxels it starts from (tetrahedral.py:396-441), so the ones one step OUTSIDE the grid next to the
+            # crossing segments on the rim get tetrahedra too.  One extra sample all around, every hyper-voxel of the grid
+            # kept, the rim segments as seeds (as Delta3DContour.search_for_endpoints does in 3-D)
+            self.contour_maker = self.get_contour_maker(rim, rim=True)
+            self.contour_maker.keep_in_range = True
             return
         self.contour_maker = self.get_contour_maker(None)
 

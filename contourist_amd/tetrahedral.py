@@ -429,31 +429,7 @@ class Delta3DContour(object):
         (tetrahedral.py:396-441), and which voxel next to the rim a point picks depends on what was visited before."""
         gd = np.array([int(n) for n in self.grid.grid_dimensions])
         S = np.asarray(self.grid.dense_samples_host(), dtype=np.float64)     # vertices 0 .. gd inclusive
-        v = float(self.value)
-        base = S[:gd[0], :gd[1], :gd[2]]
-        near = np.zeros(tuple(gd), dtype=bool)        # lower end within the shell
-        for a in range(3):
-            sl = [slice(None)] * 3
-            sl[a] = slice(0, shell + 1)
-            near[tuple(sl)] = True
-            sl[a] = slice(max(gd[a] - 1 - shell, 0), gd[a])
-            near[tuple(sl)] = True
-        rows, touches = [], False
-        for index in range(1, 8):
-            o = np.array([index & 1, (index >> 1) & 1, (index >> 2) & 1])          # first axis fastest (:58-61)
-            nb = S[o[0]:o[0] + gd[0], o[1]:o[1] + gd[1], o[2]:o[2] + gd[2]]
-            hit = np.argwhere(((base - v) * (nb - v) < 0) & near)
-            if len(hit) == 0:
-                continue
-            upper = hit + o
-            touches = touches or bool(np.any(hit == 0) or np.any(upper == gd))
-            lin = (hit[:, 0] * gd[1] + hit[:, 1]) * gd[2] + hit[:, 2]
-            rows.append(np.concatenate([lin[:, None], np.full((len(hit), 1), index), hit, upper], axis=1))
-        if not rows or not touches:
-            return None
-        R = np.concatenate(rows, axis=0)
-        R = R[np.lexsort((R[:, 1], R[:, 0]))]
-        return [(r[2:5].astype(int), r[5:8].astype(int)) for r in R]
+        return rim_crossing_segments(S, gd, float(self.value), shell)
 
     def get_points_and_triangles(self):
         (grid_points, triangles) = self.contour_maker.get_points_and_triangles()      # (the maker undoes its own shift)
@@ -558,3 +534,37 @@ class MultiLevelIsosurfaces(object):
             geometry = surface_geometry.SurfaceGeometry._from_device(grid_points, triangles, ctx)   # sorted rows, as the reference returns them
             points = self.grid.from_grid_coordinates(geometry.vertices) if len(grid_points) else np.zeros((0, 3))
             yield (v, points, geometry.oriented_triangles)
+
+
+def rim_crossing_segments(S, gd, v, shell=2):
+    """the crossing lattice segments of find_contour_crossing_grid_segments (grid_field.py:64-84: from every lattice point
+    0 <= p < grid_dimensions to its 2^d - 1 forward neighbours, strict sign change) that lie within `shell` lattice steps of
+    the rim of the grid, IN THE REFERENCE'S ORDER (points in index order, last axis fastest; neighbours in the order of
+    surrounding_vertices :52-62, first axis fastest).  Any dimension.  S: samples at the vertices 0 .. gd inclusive.
+    None if no segment touches the rim itself."""
+    gd = np.asarray(gd, dtype=int)
+    d = len(gd)
+    base = S[tuple(slice(0, int(n)) for n in gd)]
+    near = np.zeros(tuple(gd), dtype=bool)        # lower end within the shell
+    for a in range(d):
+        sl = [slice(None)] * d
+        sl[a] = slice(0, shell + 1)
+        near[tuple(sl)] = True
+        sl[a] = slice(max(int(gd[a]) - 1 - shell, 0), int(gd[a]))
+        near[tuple(sl)] = True
+    rows, touches = [], False
+    for index in range(1, 2 ** d):
+        o = np.array([(index >> a) & 1 for a in range(d)])          # first axis fastest (:58-61)
+        nb = S[tuple(slice(int(o[a]), int(o[a]) + int(gd[a])) for a in range(d))]
+        hit = np.argwhere(((base - v) * (nb - v) < 0) & near)
+        if len(hit) == 0:
+            continue
+        upper = hit + o
+        touches = touches or bool(np.any(hit == 0) or np.any(upper == gd))
+        lin = np.ravel_multi_index(tuple(hit.T), tuple(int(n) for n in gd))
+        rows.append(np.concatenate([lin[:, None], np.full((len(hit), 1), index), hit, upper], axis=1))
+    if not rows or not touches:
+        return None
+    R = np.concatenate(rows, axis=0)
+    R = R[np.lexsort((R[:, 1], R[:, 0]))]
+    return [(r[2:2 + d].astype(int), r[2 + d:2 + 2 * d].astype(int)) for r in R]

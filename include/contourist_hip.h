@@ -212,8 +212,9 @@ int cx_select_seeded4d(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, in
 /* The same with the reference's in_range box (tetrahedral.py:465-469) given explicitly: range_lo_hi = lo[4], hi[4] in array
  * coordinates, lo <= hyper-voxel < hi (NULL: the whole array).  For an array that carries a rim of samples around the reference's
  * grid (origin -1, cx_set_origin4d): the growth stays inside the grid, seed voxels in the rim are kept and grow one step into it
- * -- the reference does not range-check the voxels it starts from (tetrahedral.py:396-441, pentatopes.py:528-551). */
-int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
+ * -- the reference does not range-check the voxels it starts from (tetrahedral.py:396-441, pentatopes.py:528-551).
+ * flags: CX_SEED_ALL_IN_RANGE as for cx_select_seeded3d_ex (the exhaustive search on a surface that leaves the grid). */
+int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl, int64_t n, const int32_t* range_lo_hi, uint32_t flags, int64_t* out_counts);
 /* the selection as a mask over the Level-0 tetrahedra (n_tetrahedra bytes, 1 = kept) */
 int cx_seeded4d_mask_download(cx_ctx* ctx, uint8_t* tet_keep);
 int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, int32_t* tets);

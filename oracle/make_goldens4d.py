@@ -181,11 +181,54 @@ def make_test0():
     print("reference_test0_seeded: %d hyper-voxels, %d vertices, %d tetrahedra" % (len(sv), len(pairs), len(tets)))
 
 
+def open_rim_field(x, y, z, t):
+    "a ball that leaves the grid through three of its faces and moves in time; works on scalars and arrays"
+    return np.sqrt((x - 0.8) ** 2 + (y - 3.1) ** 2 + (z - 5.7) ** 2 + 0.6 * (t - 1.2) ** 2) - 2.55
+
+
+OPEN_RIM = dict(mins=[0.0] * 4, maxes=[5.5, 5.5, 6.5, 3.5], delta=[1.0] * 4, value=0.0)   # grid_dimensions (6, 6, 7, 4)
+
+
+def make_open_rim():
+    """MorphingIsoSurfaces(mins, maxes, delta, CALLABLE, value, []).search_for_endpoints() of the reference on a surface that
+    LEAVES the grid: the exhaustive search starts from every crossing lattice segment and does not range-check the voxels
+    it starts from, so hyper-voxels one lattice step outside the grid get tetrahedra too.  Level-0 snapshot only."""
+    import contextlib
+    import io
+    pentatopes = reference_modules4d()
+
+    def f(x, y, z, t):
+        return float(open_rim_field(float(x), float(y), float(z), float(t)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        M = pentatopes.MorphingIsoSurfaces(OPEN_RIM["mins"], OPEN_RIM["maxes"], OPEN_RIM["delta"], f, OPEN_RIM["value"], [])
+        M.search_for_endpoints()
+        G = M.contour_maker
+        G.find_initial_voxels()
+        while G.new_surface_voxels:
+            G.expand_voxels()
+        for q in G.surface_voxels:
+            G.enumerate_voxel_tetrahedra(q)
+    pair_list = list(G.interpolated_contour_pairs.keys())
+    pair_index = {p: n for n, p in enumerate(pair_list)}
+    pairs = np.array([list(p[0]) + list(p[1]) for p in pair_list], dtype=np.int32).reshape(-1, 8)
+    tets = np.array([[pair_index[p] for p in s] for s in G.simplex_sets], dtype=np.int64).reshape(-1, 4)
+    sv = np.array(sorted(tuple(int(x) for x in v) for v in G.surface_voxels), dtype=np.int32)
+    gd = np.array([int(n) for n in M.grid.grid_dimensions], dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "reference_open_rim_seeded.npz"), l0_pairs=pairs, l0_tets=tets, surface_voxels=sv,
+                        grid_dimensions=gd, value=np.float64(OPEN_RIM["value"]))
+    outside = int(((sv < 0) | (sv >= gd)).any(axis=1).sum())
+    print("reference_open_rim_seeded: grid %s, %d hyper-voxels (%d outside the grid), %d vertices, %d tetrahedra" % (
+        tuple(gd), len(sv), outside, len(pairs), len(tets)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     names = sys.argv[1:]
     if names == ["test0"]:
         make_test0()
+        sys.exit(0)
+    if names == ["open_rim"]:
+        make_open_rim()
         sys.exit(0)
     for name, spec in fields4d().items():
         if names and name not in names:

@@ -286,6 +286,36 @@ def test_reference_test0_call_on_device():
     assert maker2.seeded["tetrahedra_kept"] == 26004
 
 
+def test_open_surface_with_callable_reaches_the_rim_4d():
+    """MorphingIsoSurfaces(..., CALLABLE, ...).search_for_endpoints() on a surface that leaves the grid: the reference starts from
+    every crossing lattice segment and does not range-check the hyper-voxels it starts from (tetrahedral.py:396-441), so 109 of
+    its 352 hyper-voxels lie one lattice step OUTSIDE the grid.  Golden: the real reference (oracle/make_goldens4d.py open_rim)."""
+    from contourist_amd import pentatopes
+    from oracle.make_goldens4d import open_rim_field, OPEN_RIM
+    G = np.load(os.path.join(G4, "reference_open_rim_seeded.npz"))
+    M = pentatopes.MorphingIsoSurfaces(OPEN_RIM["mins"], OPEN_RIM["maxes"], OPEN_RIM["delta"], open_rim_field, OPEN_RIM["value"], [])
+    assert tuple(int(n) for n in M.grid.grid_dimensions) == tuple(int(n) for n in G["grid_dimensions"])
+    M.search_for_endpoints()
+    maker = M.contour_maker
+    assert maker.origin == (-1, -1, -1, -1) and maker.keep_in_range
+    L = maker.march()
+    ctx = maker.context()
+    assert ctx.select_seeded4d(maker.end_points, maker.voxel_range, True)["tetrahedra_kept"] == len(G["l0_tets"])
+    keep = ctx.seeded4d_mask(L["counts"]).astype(bool)
+    lo, hi = pentatopes.unpack_edge_ids4(L["keys"], maker.shape)
+    lo, hi = lo - 1, hi - 1
+    code = lambda P: [tuple(int(x) for x in r) for r in P]
+    dev_pair = [(a, b) for a, b in zip(code(lo), code(hi))]
+    ref_pair = [tuple(sorted((tuple(int(x) for x in r[:4]), tuple(int(x) for x in r[4:])))) for r in G["l0_pairs"]]
+    dev_tets = set(frozenset(dev_pair[v] for v in t) for t in L["tetrahedra"][keep])
+    ref_tets = set(frozenset(ref_pair[v] for v in t) for t in G["l0_tets"])
+    assert dev_tets == ref_tets and len(dev_tets) == int(keep.sum())
+    sv = G["surface_voxels"]
+    assert int(((sv < 0) | (sv >= G["grid_dimensions"])).any(axis=1).sum()) == 109
+    T = M.collect_morph_triangles()          # the whole path on the rimmed array, world coordinates
+    assert len(T.triangle_segment_indices) > 0
+
+
 def test_search_for_endpoints_with_skip_4d():
     """skip > 1 in 4-D: the coarse crossing search seeds the growth; a blob that fits between the coarse lattice points is
     not returned, the large one is (the reference's sparsity mode)"""
