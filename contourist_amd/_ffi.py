@@ -27,7 +27,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -125,6 +125,7 @@ def load():
         "cx_select_seeded4d": [vp, vp, i64, vp],
         "cx_select_seeded4d_ex": [vp, vp, i64, vp, ctypes.c_uint32, vp],
         "cx_seeded4d_mask_download": [vp, vp],
+        "cx_seeded_mode": [vp, vp],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
         "cx_level1_4d_download": [vp, vp, vp],
@@ -339,7 +340,7 @@ class Context(object):
         self._check(self.lib.cx_extract4d(self.handle, float(value), int(flags), ctypes.byref(c)))
         return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
 
-    def select_seeded4d(self, endpoints, voxel_range=None, all_in_range=False):
+    def select_seeded4d(self, endpoints, voxel_range=None, all_in_range=False, parallel=False):
         """restrict the 4-D post-pass to the components the reference's seeded search reaches from the lattice end
         point pairs [(i0,j0,k0,l0), (i1,j1,k1,l1)] -> dict(seed_voxels, groups_kept, tetrahedra_kept).
         voxel_range = (lo[4], hi[4]): in_range box of the growth in array coordinates (default: the whole array); seed
@@ -351,8 +352,14 @@ class Context(object):
         if voxel_range is not None:
             box = np.ascontiguousarray(np.asarray(voxel_range, dtype=np.int64).reshape(8), dtype=np.int32)
         self._check(self.lib.cx_select_seeded4d_ex(self.handle, ep.ctypes.data, int(len(ep)), box.ctypes.data if box is not None else None,
-                                                  1 if all_in_range else 0, out.ctypes.data))
+                                                  (1 if all_in_range else 0) | (2 if parallel else 0), out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), tetrahedra_kept=int(out[2]))
+
+    def seeded_mode(self):
+        "how the last seeded selection ran its end points: 'sequential' (the reference's shared visited set) or 'parallel'"
+        m = ctypes.c_int(0)
+        self._check(self.lib.cx_seeded_mode(self.handle, ctypes.byref(m)))
+        return "parallel" if m.value else "sequential"
 
     def seeded4d_mask(self, counts):
         "mask over the Level-0 tetrahedra left by select_seeded4d (uint8, 1 = kept)"

@@ -71,6 +71,7 @@ struct cx_ctx {
     // seeded selection (cx_select_seeded3d): triangle mask followed by vertex mask, valid until the next extraction
     uint8_t* tri_keep = nullptr;
     size_t keep_cap = 0;
+    int seed_mode = 0;      // how the last seeded selection (3-D or 4-D) ran its end points: 0 sequential (the reference's shared visited set), 1 one thread per pair
     bool keep_valid = false;
     // Level-1
     cx_post_state* post = nullptr;

@@ -313,6 +313,7 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     // beyond this many pairs (or on request): one thread per pair, no shared visited set
     const int64_t CXS_SEQUENTIAL_MAX = (flags & CX_SEED_PARALLEL) ? -1 : 65536;
     while (n <= CXS_SEQUENTIAL_MAX && vsize < (unsigned long long)n * 54ULL * 4ULL) vsize <<= 1;
+    ctx->seed_mode = (n <= CXS_SEQUENTIAL_MAX) ? 0 : 1;
     int rc = CX_OK;
     uint32_t host_out[4] = {0, 0, 0, 0};
     do {
@@ -375,5 +376,11 @@ extern "C" int cx_seeded_masks_download(cx_ctx* ctx, uint8_t* tri_keep, uint8_t*
     if (tri_keep && nt) CXS_HIP(ctx, hipMemcpyAsync(tri_keep, ctx->tri_keep, nt, hipMemcpyDeviceToHost, ctx->stream));
     if (vert_keep && nv) CXS_HIP(ctx, hipMemcpyAsync(vert_keep, ctx->tri_keep + nt, nv, hipMemcpyDeviceToHost, ctx->stream));
     CXS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+extern "C" int cx_seeded_mode(cx_ctx* ctx, int* mode) {
+    if (!ctx || !mode) return CX_ERR_INVALID;
+    *mode = ctx->seed_mode;
     return CX_OK;
 }

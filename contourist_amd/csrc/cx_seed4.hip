@@ -206,13 +206,62 @@ __global__ void cxs4_k_seeds(cxs4_grid G, const int32_t* ep, uint32_t n, unsigne
     out[0] = ns;
     out[1] = bad;
 }
+// many end point pairs (the exhaustive search on a large open surface, the coarse crossing search): one thread per pair, no
+// shared `visited` set -- each end point yields its own hyper-voxel or its first border neighbour (OFFSETS4D order).  (The
+// reference's shared set only changes which of several adjacent candidates gets picked when pairs collide.)
+// Slots 2s, 2s+1; CXS4_NONE = none.
+__global__ void cxs4_k_seeds_parallel(cxs4_grid G, const int32_t* ep, uint32_t n, uint32_t* seeds, uint32_t* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    seeds[2 * s] = seeds[2 * s + 1] = CXS4_NONE;
+    if (s == 0) out[0] = 2u * n;   // slots to look at
+    int lowp[4], highp[4];
+    for (int a = 0; a < 4; a++) {
+        lowp[a] = ep[s * 8 + a];
+        highp[a] = ep[s * 8 + 4 + a];
+        if (lowp[a] < 0 || highp[a] < 0 || lowp[a] >= (int)G.n[a] || highp[a] >= (int)G.n[a]) { atomicAdd(&out[1], 1u); return; }
+    }
+    double lowv = (double)G.A[cxs4_lin(G, lowp)], highv = (double)G.A[cxs4_lin(G, highp)];
+    if (lowv > G.value || highv < G.value) {
+        for (int a = 0; a < 4; a++) { const int t = lowp[a]; lowp[a] = highp[a]; highp[a] = t; }
+        const double t = lowv; lowv = highv; highv = t;
+    }
+    if (!(lowv <= G.value && highv >= G.value)) { atomicAdd(&out[1], 1u); return; }
+    for (;;) {
+        bool far = false;
+        for (int a = 0; a < 4; a++) far = far || abs(lowp[a] - highp[a]) > 1;
+        if (!far) break;
+        int mid[4];
+        for (int a = 0; a < 4; a++) mid[a] = (lowp[a] + highp[a]) / 2;
+        if ((double)G.A[cxs4_lin(G, mid)] < G.value) { for (int a = 0; a < 4; a++) lowp[a] = mid[a]; }
+        else { for (int a = 0; a < 4; a++) highp[a] = mid[a]; }
+    }
+    for (int which = 0; which < 2; which++) {
+        const int* p = which ? highp : lowp;
+        if (cxs4_border_voxel(G, p)) { seeds[2 * s + which] = cxs4_lin(G, p); continue; }
+        bool found = false;
+        for (int code = 0; code < 81 && !found; code++) {
+            if (code == 40) continue;
+            int o[4], x = code;
+            o[3] = x % 3 - 1; x /= 3;
+            o[2] = x % 3 - 1; x /= 3;
+            o[1] = x % 3 - 1; x /= 3;
+            o[0] = x - 1;
+            const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
+            bool neg = false;
+            for (int a = 0; a < 4; a++) neg = neg || q[a] < 0 || q[a] >= (int)G.n[a];
+            if (neg) continue;
+            if (cxs4_border_voxel(G, q)) { seeds[2 * s + which] = cxs4_lin(G, q); found = true; }
+        }
+    }
+}
 // flag[] = groups reached; seedkeep[] = seed voxels themselves: a seed voxel outside the in_range box (the reference does not
 // range-check the voxels it starts from, tetrahedral.py:396-441) is kept and grows one step into the box, as the reference's
 // first expand_voxels round does
 __global__ void cxs4_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint32_t* seeds,
                             const uint32_t* nseeds, uint8_t* flag, uint8_t* seedkeep, cxs4_grid G) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseeds[0]) return;
+    if (s >= nseeds[0] || seeds[s] == CXS4_NONE) return;
     int p[4];
     cxs4_unravel(G, seeds[s], p);
     const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, p);
@@ -288,7 +337,10 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
     int32_t* ep = nullptr;
     unsigned long long* visited = nullptr;
     unsigned long long vsize = 1024;
-    while (vsize < (unsigned long long)n * 164ULL * 4ULL) vsize <<= 1;
+    // beyond this many pairs (or on request): one thread per pair, no shared visited set (cx_seeded_mode tells which ran)
+    const int64_t sequential_max = (flags & CX_SEED_PARALLEL) ? -1 : 16384;
+    while (n <= sequential_max && vsize < (unsigned long long)n * 164ULL * 4ULL) vsize <<= 1;
+    ctx->seed_mode = (n <= sequential_max) ? 0 : 1;
     int rc = CX_OK;
     uint32_t host_out[4] = {0, 0, 0, 0};
     do {
@@ -311,7 +363,10 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
             hipLaunchKernelGGL(cxs4_k_map, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs4_k_union, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs4_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
-            hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
+            if (n <= sequential_max)   // sequential, with the reference's shared visited set
+                hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
+            else
+                hipLaunchKernelGGL(cxs4_k_seeds_parallel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, G, ep, (uint32_t)n, seeds, out);
             hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
             hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, flag + ncells + 64, S4->tets, S4->vkeys, nt,
                                S4->tet_keep, out, G, all_in_range);

@@ -153,6 +153,10 @@ int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, 
  * callers that refine the Level-0 mesh on the host before cx_postprocess3d_mesh -- linear_interpolate=False
  * re-evaluates the caller's function between the lattice points (tetrahedral.py:488-505) */
 int cx_seeded_masks_download(cx_ctx* ctx, uint8_t* tri_keep, uint8_t* vert_keep);
+/* how the last cx_select_seeded3d* / cx_select_seeded4d* call ran its end points: 0 = one after the other with the reference's
+ * shared `visited` set (tetrahedral.py:396-441; up to 65 536 pairs in 3-D, 16 384 in 4-D), 1 = one thread per pair
+ * (CX_SEED_PARALLEL, or more pairs than that): adjacent candidate voxels may then be picked differently where pairs collide */
+int cx_seeded_mode(cx_ctx* ctx, int* mode);
 /* Level 1 of a mesh assembled by the caller -- the way several GPUs share one volume: every rank marches its slab
  * (cx_extract3d), takes the float64 coordinates the reference would have interpolated (cx_level0_points_f64: nv*3
  * doubles in the order of cx_level0_download, in the grid coordinates of the whole volume = lattice point + origin of

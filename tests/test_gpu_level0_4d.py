@@ -312,6 +312,19 @@ def test_open_surface_with_callable_reaches_the_rim_4d():
     assert dev_tets == ref_tets and len(dev_tets) == int(keep.sum())
     sv = G["surface_voxels"]
     assert int(((sv < 0) | (sv >= G["grid_dimensions"])).any(axis=1).sum()) == 109
+    assert ctx.seeded_mode() == "sequential"
+    # one thread per end point pair (what more than 16 384 pairs get): no shared `visited` set.  The hyper-voxels of the GRID are
+    # the same (all kept); in the RIM each point then takes its own voxel or its first border neighbour, where the reference's
+    # later points move on to the next unvisited candidate -- fewer rim voxels; the caller can ask which mode ran
+    par = ctx.select_seeded4d(maker.end_points, maker.voxel_range, True, parallel=True)
+    assert ctx.seeded_mode() == "parallel"
+    keep_p = ctx.seeded4d_mask(L["counts"]).astype(bool)
+    lo4, _ = pentatopes.unpack_edge_ids4(L["keys"], maker.shape)
+    cell = lo4[L["tetrahedra"]].min(axis=1) - 1                       # hyper-voxel of a tetrahedron, the reference's lattice
+    in_grid = ((cell >= 0) & (cell < G["grid_dimensions"])).all(axis=1)
+    assert np.array_equal(keep_p[in_grid], keep[in_grid]) and keep[in_grid].all()
+    assert 0 < int(keep_p[~in_grid].sum()) <= int(keep[~in_grid].sum()) and par["tetrahedra_kept"] == int(keep_p.sum())
+    ctx.select_seeded4d(maker.end_points, maker.voxel_range, True)    # back to the reference's order for what follows
     T = M.collect_morph_triangles()          # the whole path on the rimmed array, world coordinates
     assert len(T.triangle_segment_indices) > 0
 
