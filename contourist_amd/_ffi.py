@@ -27,7 +27,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -128,6 +128,7 @@ def load():
         "cx_seeded_mode": [vp, vp],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
+        "cx_postprocess4d_points": [vp, ctypes.c_int32, vp, vp],
         "cx_level1_4d_download": [vp, vp, vp],
         "cx_morph_triangles": [vp, vp],
         "cx_morph_download": [vp, vp, vp, vp],
@@ -376,9 +377,15 @@ class Context(object):
         self._check(self.lib.cx_level0_4d_download(self.handle, verts.ctypes.data, keys.ctypes.data, tets.ctypes.data))
         return verts, keys, tets
 
-    def postprocess4d(self, nbins=100):
+    def postprocess4d(self, nbins=100, points=None):
+        """bin_times / drop_instant / tiny collapse on the device; points: (n_vertices, 4) float64 replacing the linearly
+        interpolated crossing points (linear_interpolate=False: refined on the host), in the reference's lattice"""
         out = np.zeros(8, dtype=np.int64)
-        self._check(self.lib.cx_postprocess4d(self.handle, int(nbins), out.ctypes.data))
+        if points is not None:
+            pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 4)
+            self._check(self.lib.cx_postprocess4d_points(self.handle, int(nbins), pts.ctypes.data, out.ctypes.data))
+        else:
+            self._check(self.lib.cx_postprocess4d(self.handle, int(nbins), out.ctypes.data))
         return dict(n_vertices=int(out[0]), n_tetrahedra=int(out[1]), n_after_drop=int(out[2]), n_after_tiny=int(out[3]))
 
     def download_level1_4d(self, counts):

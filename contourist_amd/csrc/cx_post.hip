@@ -1214,6 +1214,16 @@ __global__ void cxp_k_vertices4_f64(const float* __restrict__ A, uint32_t n1, ui
     prio[v] = key;
 }
 
+// the same for points handed over by the caller (linear_interpolate=False: refined on the host with the caller's function,
+// tetrahedral.py:488-505): only bin_times and the priority word
+__global__ void cxp_k_vertices4_given(const uint32_t* __restrict__ vkeys, uint32_t nv, double min_interval, double* pts, uint32_t* prio) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const double t = pts[(size_t)v * 4 + 3];
+    pts[(size_t)v * 4 + 3] = (double)(long long)(t / min_interval) * min_interval;
+    prio[v] = vkeys[v];
+}
+
 __global__ void cxp_k_and_mask(uint8_t* alive, const uint8_t* keep, uint32_t n) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n && !keep[t]) alive[t] = 0;
@@ -1273,7 +1283,11 @@ __global__ void cxp_k_compact_tets(const int32_t* tets, const uint8_t* alive, co
     for (int s = 0; s < 4; s++) out[(size_t)tnew[t] * 4 + s] = tets[(size_t)t * 4 + s];
 }
 
+extern "C" int cx_postprocess4d_points(cx_ctx* ctx, int32_t nbins, const double* points_xyzt, int64_t* out_counts);
 extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts) {
+    return cx_postprocess4d_points(ctx, nbins, nullptr, out_counts);
+}
+extern "C" int cx_postprocess4d_points(cx_ctx* ctx, int32_t nbins, const double* points_xyzt, int64_t* out_counts) {
     if (!ctx || nbins <= 0) return CX_ERR_INVALID;
     cx_state4* G = ctx->s4;
     if (!G || !G->extracted) { ctx->err = "cx_postprocess4d: no valid 4-D extraction"; return CX_ERR_STATE; }
@@ -1309,6 +1323,10 @@ extern "C" int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts)
             corner[a] = (double)(G->n[a] - 1 + 2 * org[a]);
         }
         const double min_interval = corner[3] * (1.0 / (double)nbins);
+        if (points_xyzt) {   // the caller's points (in the reference's lattice), one per Level-0 vertex
+            CXP_HIP(ctx, hipMemcpyAsync(pts, points_xyzt, (size_t)nv * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(cxp_k_vertices4_given, dim3(cxp_blocks(nv)), dim3(256), 0, st, G->vkeys, nv, min_interval, pts, prio);
+        } else
         hipLaunchKernelGGL(cxp_k_vertices4_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, G->grid, n1, n2, n3, cx_fdiv_make(n1 * n2 * n3),
                            cx_fdiv_make(n2 * n3), cx_fdiv_make(n3), G->value, G->vkeys, nv, min_interval, pts, prio, org[0], org[1], org[2], org[3]);
         hipLaunchKernelGGL(cxp_k_drop_instant, dim3(cxp_blocks(nt)), dim3(256), 0, st, G->tets, alive, nt, pts, 1e-7);

@@ -58,14 +58,16 @@ class GridContour4D(object):
     pentatopes.py:32-39; on the device: cx_select_seeded4d).  march() always returns the whole Level-0 mesh."""
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True, callback=None,
-                 device=None, diagonal="cpython310", context=None, voxel_range=None, origin=(0, 0, 0, 0)):
+                 device=None, diagonal="cpython310", context=None, voxel_range=None, origin=(0, 0, 0, 0), function=None):
         self.corner = np.array(corner, dtype=int)
         assert self.corner.shape == (4,), "dimension should be 4 " + repr(self.corner.shape)
-        if not linear_interpolate:
-            raise NotImplementedError("linear_interpolate=False needs f off the grid")
+        self.linear_interpolate = linear_interpolate
+        self.function = function              # f over the REFERENCE's lattice coordinates (linear_interpolate=False re-evaluates it)
+        self._f_broadcasts = None
         self.dimension = 4
         self.value = float(value)
         if callable(samples):
+            self.function = samples
             # GridContour4D(corner, function, value, segment_endpoints): the reference's own signature (pentatopes.py:92-100;
             # its test0 demo, :528-551).  f over lattice coordinates is sampled once -- with explicit end points one lattice
             # step beyond the grid as well, where the reference puts seed voxels (tetrahedral.py:396-441)
@@ -125,10 +127,42 @@ class GridContour4D(object):
         ctx = self.context()
         if self.end_points is not None and len(self.end_points):
             self.seeded = ctx.select_seeded4d(self.end_points, self.voxel_range, self.keep_in_range)
-        post = ctx.postprocess4d(nbins)
+        if self.linear_interpolate:
+            post = ctx.postprocess4d(nbins)
+        else:
+            post = ctx.postprocess4d(nbins, points=self._refined_points(L["keys"]))
         pts, tets = ctx.download_level1_4d(post)
         self.post_counts = post
         return dict(points4d=pts, keys=L["keys"], tetrahedra=tets, counts=post)
+
+    # -- linear_interpolate=False (tetrahedral.py:488-505) ------------------------------------------------------
+    def _feval(self, P):
+        "function at the rows of P (N,4), float64: one broadcast call if the function allows it, else one call per row"
+        P = np.asarray(P, dtype=np.float64).reshape(-1, 4)
+        if len(P) == 0:
+            return np.zeros(0)
+        if self._f_broadcasts is not False:
+            try:
+                out = np.asarray(self.function(P[:, 0], P[:, 1], P[:, 2], P[:, 3]), dtype=np.float64)
+                if out.shape != (len(P),):
+                    self._f_broadcasts = False
+                elif self._f_broadcasts is None:     # first time: spot-check the broadcast result against scalar calls
+                    probe = [0, len(P) // 2, len(P) - 1]
+                    self._f_broadcasts = all(abs(out[k] - float(self.function(*P[k]))) <= 1e-12 * max(1.0, abs(out[k])) for k in probe)
+                if self._f_broadcasts:
+                    return out
+            except Exception:
+                self._f_broadcasts = False
+        return np.array([float(self.function(*row)) for row in P], dtype=np.float64)
+
+    def _refined_points(self, keys):
+        """the reference's float64 crossing points with its regula-falsi refinement (contour_pair_interpolation,
+        tetrahedral.py:471-512, linear_interpolate == False), in the reference's lattice, one per Level-0 vertex"""
+        if self.function is None:
+            raise NotImplementedError("linear_interpolate=False needs the function itself (it is evaluated between the lattice points)")
+        lo, hi = unpack_edge_ids4(keys, self.shape)
+        shift = np.asarray(self.origin, dtype=np.int64)
+        return tetrahedral.refined_crossing_points(self._feval, self.value, lo + shift, hi + shift)
 
     def collect_morph_triangles(self, epsilon=1e-7):
         """slice the tetrahedra into morph triangles and orient them (pentatopes.py:314-368) on the device.
@@ -166,9 +200,20 @@ class Delta4DContour(tetrahedral.Delta3DContour):
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
             return GridContour4D(tuple(n + 2 * m for n in gd), grid.dense_samples(margin=m), self.value, shifted,
                                  linear_interpolate=self.linear_interpolate, device=self.device,
-                                 voxel_range=((m,) * 4, tuple(n + m for n in gd)), origin=(-m,) * 4)
+                                 voxel_range=((m,) * 4, tuple(n + m for n in gd)), origin=(-m,) * 4, function=self._lattice_function())
         return GridContour4D(gd, grid.dense_samples(), self.value, grid_endpoints,
-                             linear_interpolate=self.linear_interpolate, device=self.device)
+                             linear_interpolate=self.linear_interpolate, device=self.device, function=self._lattice_function())
+
+    def _lattice_function(self):
+        "f over the grid's lattice coordinates (grid_field.py:95-118: world = grid * delta + mins); None for a grid made from samples"
+        grid = self.grid
+        if getattr(grid, "array_backed", False):
+            return None
+        mins, delta, f = grid.mins, grid.delta, grid.f
+
+        def lattice_f(i, j, k, l):
+            return f(i * delta[0] + mins[0], j * delta[1] + mins[1], k * delta[2] + mins[2], l * delta[3] + mins[3])
+        return lattice_f
 
     def search_for_endpoints(self, skip=1):
         """skip == 1: every component (the dense march contains the exhaustive search).  skip > 1: the coarse crossing
@@ -218,7 +263,9 @@ class Delta4DContour(tetrahedral.Delta3DContour):
 
 
 class MorphingIsoSurfaces(Delta4DContour):
-    "MorphingIsoSurfaces(mins, maxes, delta, function, value, segment_endpoints, ...)  (pentatopes.py:71-89)"
+    """MorphingIsoSurfaces(mins, maxes, delta, function, value, segment_endpoints, ...)  (pentatopes.py:71-89).
+    linear_interpolate=False is honoured here; the reference's constructor loses the flag (the base constructor it calls last
+    resets it to True, pentatopes.py:82-83: there a caller has to set the attribute again before search_for_endpoints)."""
 
     def __init__(self, mins, maxes, delta, function, value, segment_endpoints, linear_interpolate=True, flatten=False,
                  minimum_ratio=None, minimum_extent=None, smooth=None, device=None):

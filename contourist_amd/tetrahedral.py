@@ -187,37 +187,8 @@ class GridContour3d(object):
     def _refined_points(self, keys):
         """the reference's float64 crossing points with its regula-falsi refinement: contour_pair_interpolation
         (tetrahedral.py:471-512) with linear_interpolate == False, iterations = 5, for every crossing edge at once"""
-        z = self.value
         lo, hi = unpack_edge_ids(keys, self.shape)
-        low_a, high_a = lo.astype(np.float64), hi.astype(np.float64)
-        flow, fhigh = self._feval(low_a), self._feval(high_a)
-        swap = flow > fhigh                                                  # :478-480
-        low_a[swap], high_a[swap] = hi[swap].astype(np.float64), lo[swap].astype(np.float64)
-        flow, fhigh = np.where(swap, fhigh, flow), np.where(swap, flow, fhigh)
-        crosses = (flow <= z) & (fhigh >= z)
-        den = 1.0 * (fhigh - flow)
-        flat = np.abs(den) <= 1e-8                                           # np.allclose(denominator, 0)
-        ratio = np.where(flat, 0.5, (z - flow) / np.where(flat, 1.0, den))
-        P = low_a + ratio[:, None] * (high_a - low_a)
-        P[~crosses] = low_a[~crosses]                                        # ":509 temporary hack": interpolated = low_a
-        active = crosses.copy()
-        fint = np.full(len(P), z, dtype=np.float64)
-        if active.any():
-            fint[active] = self._feval(P[active])
-        for _ in range(5):                                                   # iterations=5
-            close_f = np.abs(fint - z) <= 1e-8 + 1e-5 * abs(z)
-            close_p = np.all(np.abs(low_a - high_a) <= 1e-8 + 1e-5 * np.abs(high_a), axis=1)
-            active = active & ~close_f & ~close_p
-            if not active.any():
-                break
-            below = active & (fint < z)
-            above = active & ~(fint < z)
-            low_a[below], flow[below] = P[below], fint[below]
-            high_a[above], fhigh[above] = P[above], fint[above]
-            r = (z - flow[active]) * 1.0 / (fhigh[active] - flow[active])
-            P[active] = low_a[active] + r[:, None] * (high_a[active] - low_a[active])
-            fint[active] = self._feval(P[active])
-        return P
+        return refined_crossing_points(self._feval, self.value, lo, hi)
 
     def _postprocess_refined(self, ctx, clean):
         """Level 1 on refined points: the Level-0 mesh comes to the host, its points are replaced by the reference's
@@ -568,3 +539,39 @@ def rim_crossing_segments(S, gd, v, shell=2):
     R = np.concatenate(rows, axis=0)
     R = R[np.lexsort((R[:, 1], R[:, 0]))]
     return [(r[2:2 + d].astype(int), r[2 + d:2 + 2 * d].astype(int)) for r in R]
+
+
+def refined_crossing_points(feval, z, lo, hi):
+    """contour_pair_interpolation (tetrahedral.py:471-512) with linear_interpolate == False, iterations = 5, for many crossing
+    edges at once, any dimension.  feval(P (N,d) float64) -> f at the rows; lo, hi: (N,d) integer lattice points of the edges
+    (the coordinates f expects).  -> (N,d) float64 points in those coordinates."""
+    low_a, high_a = np.asarray(lo).astype(np.float64), np.asarray(hi).astype(np.float64)
+    lo_f, hi_f = low_a.copy(), high_a.copy()
+    flow, fhigh = feval(low_a), feval(high_a)
+    swap = flow > fhigh                                                  # :478-480
+    low_a[swap], high_a[swap] = hi_f[swap], lo_f[swap]
+    flow, fhigh = np.where(swap, fhigh, flow), np.where(swap, flow, fhigh)
+    crosses = (flow <= z) & (fhigh >= z)
+    den = 1.0 * (fhigh - flow)
+    flat = np.abs(den) <= 1e-8                                           # np.allclose(denominator, 0)
+    ratio = np.where(flat, 0.5, (z - flow) / np.where(flat, 1.0, den))
+    P = low_a + ratio[:, None] * (high_a - low_a)
+    P[~crosses] = low_a[~crosses]                                        # ":509 temporary hack": interpolated = low_a
+    active = crosses.copy()
+    fint = np.full(len(P), z, dtype=np.float64)
+    if active.any():
+        fint[active] = feval(P[active])
+    for _ in range(5):                                                   # iterations=5
+        close_f = np.abs(fint - z) <= 1e-8 + 1e-5 * abs(z)
+        close_p = np.all(np.abs(low_a - high_a) <= 1e-8 + 1e-5 * np.abs(high_a), axis=1)
+        active = active & ~close_f & ~close_p
+        if not active.any():
+            break
+        below = active & (fint < z)
+        above = active & ~(fint < z)
+        low_a[below], flow[below] = P[below], fint[below]
+        high_a[above], fhigh[above] = P[above], fint[above]
+        r = (z - flow[active]) * 1.0 / (fhigh[active] - flow[active])
+        P[active] = low_a[active] + r[:, None] * (high_a[active] - low_a[active])
+        fint[active] = feval(P[active])
+    return P

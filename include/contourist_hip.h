@@ -227,6 +227,10 @@ int cx_level0_4d_download(cx_ctx* ctx, float* verts_xyzt, uint32_t* edge_ids, in
  * out_counts (8 x int64): [0] vertices (unchanged numbering), [1] surviving tetrahedra,
  * [2] after drop_instant, [3] after the tiny collapse.  Download: points = nv*4 doubles, tets = nt*4 int32. */
 int cx_postprocess4d(cx_ctx* ctx, int32_t nbins, int64_t* out_counts);
+/* the same on points handed over by the caller: n_vertices * 4 doubles in the order of cx_level0_4d_download, in the reference's
+ * lattice -- linear_interpolate=False re-evaluates the caller's function between the lattice points (tetrahedral.py:488-505),
+ * which is Python; NULL = cx_postprocess4d */
+int cx_postprocess4d_points(cx_ctx* ctx, int32_t nbins, const double* points_xyzt, int64_t* out_counts);
 int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* tets);
 /* GridContour4D.collect_morph_triangles (pentatopes.py:314-368) + MorphTriangles.orient_triangles
  * (morph_geometry.py:49-89) on the tetrahedra left by cx_postprocess4d: every tetrahedron is sliced at the

@@ -221,9 +221,66 @@ def make_open_rim():
         tuple(gd), len(sv), outside, len(pairs), len(tets)))
 
 
+def refined_field(x, y, z, t):
+    "a closed blob well inside the grid, not linear along the lattice edges; works on scalars and arrays"
+    return (x - 3.4) ** 2 + 0.8 * (y - 3.1) ** 2 + 1.3 * (z - 2.8) ** 2 + 2.0 * (t - 2.2) ** 2 + 0.3 * np.sin(1.3 * x + 0.7 * t) - 3.9
+
+
+REFINED = dict(mins=[0.0] * 4, maxes=[6.5, 6.5, 5.5, 4.5], delta=[1.0] * 4, value=0.0)   # grid_dimensions (7, 7, 6, 5)
+
+
+def make_refined():
+    """MorphingIsoSurfaces(mins, maxes, delta, CALLABLE, value, [], linear_interpolate=False) of the reference: every crossing
+    point is refined with up to 5 regula-falsi steps on the callable (tetrahedral.py:488-505).  Level-0 snapshot with the refined
+    points, then bin_times / drop_instant / tiny collapse (pentatopes.py:107, 122-125)."""
+    import contextlib
+    import io
+    pentatopes = reference_modules4d()
+
+    def f(x, y, z, t):
+        return float(refined_field(float(x), float(y), float(z), float(t)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        M = pentatopes.MorphingIsoSurfaces(REFINED["mins"], REFINED["maxes"], REFINED["delta"], f, REFINED["value"], [],
+                                           linear_interpolate=False)
+        # (the reference's constructor loses the flag: the base constructor it calls last resets it to its default True,
+        # pentatopes.py:82-83 -- set it again, as a caller who wants the refinement has to)
+        M.linear_interpolate = False
+        M.search_for_endpoints()
+        G = M.contour_maker
+        assert not G.linear_interpolate
+        G.find_initial_voxels()
+        while G.new_surface_voxels:
+            G.expand_voxels()
+        for q in G.surface_voxels:
+            G.enumerate_voxel_tetrahedra(q)
+        pair_list = list(G.interpolated_contour_pairs.keys())
+        pair_index = {p: n for n, p in enumerate(pair_list)}
+        out = dict(l0_pairs=np.array([list(p[0]) + list(p[1]) for p in pair_list], dtype=np.int32).reshape(-1, 8),
+                   l0_xyzt=np.array([G.interpolated_contour_pairs[p] for p in pair_list], dtype=np.float64).reshape(-1, 4),
+                   l0_tets=np.array([[pair_index[p] for p in s] for s in G.simplex_sets], dtype=np.int64).reshape(-1, 4),
+                   surface_voxels=np.array(sorted(tuple(int(x) for x in v) for v in G.surface_voxels), dtype=np.int32))
+        G.bin_times()
+        out["b3_xyzt_binned"] = np.array([G.interpolated_contour_pairs[p] for p in pair_list], dtype=np.float64).reshape(-1, 4)
+        G.drop_instant_tetrahedra()
+        out["n_tets_after_drop"] = np.int64(len(G.simplex_sets))
+        G.remove_tiny_simplices(epsilon=1e-3)
+        out["n_tets_after_tiny"] = np.int64(len(G.simplex_sets))
+    gd = np.array([int(n) for n in M.grid.grid_dimensions], dtype=np.int32)
+    sv = out["surface_voxels"]
+    assert not ((sv < 0) | (sv >= gd)).any(), "the fixture is meant to stay inside the grid"
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "reference_refined_seeded.npz"), grid_dimensions=gd, value=np.float64(REFINED["value"]), **out)
+    lin = out["l0_pairs"][:, :4] + 0.5 * (out["l0_pairs"][:, 4:] - out["l0_pairs"][:, :4])
+    print("reference_refined_seeded: grid %s, %d hyper-voxels, %d vertices, %d tetrahedra (%d after drop, %d after tiny); refined points move up to %.3f from the edge midpoints" % (
+        tuple(int(n) for n in gd), len(sv), len(out["l0_pairs"]), len(out["l0_tets"]), out["n_tets_after_drop"], out["n_tets_after_tiny"],
+        float(np.abs(out["l0_xyzt"] - lin).max())))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     names = sys.argv[1:]
+    if names == ["refined"]:
+        make_refined()
+        sys.exit(0)
     if names == ["test0"]:
         make_test0()
         sys.exit(0)

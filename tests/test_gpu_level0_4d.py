@@ -329,6 +329,47 @@ def test_open_surface_with_callable_reaches_the_rim_4d():
     assert len(T.triangle_segment_indices) > 0
 
 
+def test_linear_interpolate_false_4d():
+    """linear_interpolate=False in 4-D: every crossing point is refined with the reference's regula falsi on the CALLABLE
+    (tetrahedral.py:488-505), then bin_times / drop_instant / tiny collapse run on the refined points.  Golden: the real
+    reference (oracle/make_goldens4d.py refined)."""
+    from contourist_amd import pentatopes
+    from oracle.make_goldens4d import refined_field, REFINED
+    G = np.load(os.path.join(G4, "reference_refined_seeded.npz"))
+    M = pentatopes.MorphingIsoSurfaces(REFINED["mins"], REFINED["maxes"], REFINED["delta"], refined_field, REFINED["value"], [],
+                                       linear_interpolate=False)
+    M.search_for_endpoints()
+    maker = M.contour_maker
+    assert not maker.linear_interpolate     # (the surface comes within a lattice step of the t = 0 face: the array carries a rim)
+    R = maker.find_tetrahedra()
+    assert R["counts"]["n_after_drop"] == int(G["n_tets_after_drop"]) and R["counts"]["n_after_tiny"] == int(G["n_tets_after_tiny"])
+    ctx = maker.context()
+    L0 = ctx.download_level0_4d(maker._counts)
+    keep = ctx.seeded4d_mask(maker._counts).astype(bool) if maker.end_points is not None and len(maker.end_points) else np.ones(len(L0[2]), bool)
+    lo, hi = pentatopes.unpack_edge_ids4(R["keys"], maker.shape)
+    lo, hi = lo + np.asarray(maker.origin), hi + np.asarray(maker.origin)
+    used = np.zeros(len(lo), bool)
+    used[L0[2][keep].ravel()] = True
+    dev = dict(((tuple(int(x) for x in a), tuple(int(x) for x in b)), n) for n, (a, b) in enumerate(zip(lo, hi)) if used[n])
+    ref_pair = [tuple(sorted((tuple(int(x) for x in r[:4]), tuple(int(x) for x in r[4:])))) for r in G["l0_pairs"]]
+    assert set(dev) == set(ref_pair)
+    idx = np.array([dev[p] for p in ref_pair])
+    # the refined points themselves, and after bin_times: the host restates the reference's float64 iteration exactly
+    refined = maker._refined_points(R["keys"])
+    assert np.abs(refined[idx] - G["l0_xyzt"]).max() <= 1e-12
+    assert np.abs(R["points4d"][idx] - G["b3_xyzt_binned"]).max() <= 1e-12
+    dev_tets = set(frozenset(int(v) for v in t) for t in L0[2][keep])
+    ref_tets = set(frozenset(int(idx[v]) for v in t) for t in G["l0_tets"])
+    assert dev_tets == ref_tets
+    # and it is not the linear interpolation
+    M2 = pentatopes.MorphingIsoSurfaces(REFINED["mins"], REFINED["maxes"], REFINED["delta"], refined_field, REFINED["value"], [])
+    M2.search_for_endpoints()
+    R2 = M2.contour_maker.find_tetrahedra()
+    assert np.array_equal(R2["keys"], R["keys"]) and np.abs(R2["points4d"] - R["points4d"]).max() > 1e-3
+    T = M.collect_morph_triangles()
+    assert len(T.triangle_segment_indices) > 0
+
+
 def test_search_for_endpoints_with_skip_4d():
     """skip > 1 in 4-D: the coarse crossing search seeds the growth; a blob that fits between the coarse lattice points is
     not returned, the large one is (the reference's sparsity mode)"""
