@@ -365,7 +365,8 @@ def test_linear_interpolate_false_4d():
     M2 = pentatopes.MorphingIsoSurfaces(REFINED["mins"], REFINED["maxes"], REFINED["delta"], refined_field, REFINED["value"], [])
     M2.search_for_endpoints()
     R2 = M2.contour_maker.find_tetrahedra()
-    assert np.array_equal(R2["keys"], R["keys"]) and np.abs(R2["points4d"] - R["points4d"]).max() > 1e-3
+    o1, o2 = np.argsort(R["keys"]), np.argsort(R2["keys"])      # (the vertex ORDER of the 4-D march varies from run to run)
+    assert np.array_equal(R2["keys"][o2], R["keys"][o1]) and np.abs(R2["points4d"][o2] - R["points4d"][o1]).max() > 1e-3
     T = M.collect_morph_triangles()
     assert len(T.triangle_segment_indices) > 0
 
