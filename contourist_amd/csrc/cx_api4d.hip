@@ -145,7 +145,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.vlo = (float)(value - (double)P.vhi);
         P.value = value;
         P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
-        P.flags = flags | (cx_debug_knob("CX4_ABL", 0) << 16);
+        P.flags = flags;
         for (int d = 0; d < 4; d++) P.org[d] = (uint32_t)S->origin[d];
         P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;

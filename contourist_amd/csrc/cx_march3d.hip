@@ -1485,7 +1485,11 @@ __device__ __forceinline__ void cx_triq_stage2(const cx_params& P, const cx_task
         if ((A.nbw >> (19u + c)) & 1u) {
             const uint32_t wY = cx_wave_of_neighbour(T, A.w, (A.nbw >> (3u * c)) & 7u);
             const uint32_t qa = A.qa[c];
+#ifdef CX_ABL_INFO   // timing experiment: no info-word gathers
+            const uint64_t e = ((uint64_t)0xFE << 32) | (uint64_t)(wY + qa);
+#else
             const uint64_t e = P.info64[(size_t)wY * T.wcap + (qa >> 16) + __popc(qa & 0xFFFFu)];
+#endif
             pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
         }
         I.nb[c] = pr;

@@ -621,7 +621,7 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
     }
     __builtin_amdgcn_wave_barrier();
     // ---- phase 2: one lane per tetrahedron
-#ifdef CX4_ABL_P2
+#ifdef CX4_ABL_P2   // timing experiments (tools/variants.sh + tools/ab4d.py): no phase 2 / CX4_ABL_STORE 1 no stores, 2 plain stores
     if (P.tcap != 12345u) return;
 #endif
     for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
