@@ -27,7 +27,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -126,6 +126,7 @@ def load():
         "cx_select_seeded4d_ex": [vp, vp, i64, vp, ctypes.c_uint32, vp],
         "cx_seeded4d_mask_download": [vp, vp],
         "cx_seeded_mode": [vp, vp],
+        "cx_halo_exchange": [vp, vp, ctypes.c_int, ctypes.c_int, vp, i64, i64],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
         "cx_postprocess4d_points": [vp, ctypes.c_int32, vp, vp],
@@ -355,6 +356,11 @@ class Context(object):
         self._check(self.lib.cx_select_seeded4d_ex(self.handle, ep.ctypes.data, int(len(ep)), box.ctypes.data if box is not None else None,
                                                   (1 if all_in_range else 0) | (2 if parallel else 0), out.ctypes.data))
         return dict(seed_voxels=int(out[0]), groups_kept=int(out[1]), tetrahedra_kept=int(out[2]))
+
+    def halo_exchange(self, rccl_comm, rank, world, local_ptr, n_own, plane_samples):
+        """send plane 0 of the device buffer to rank-1, receive plane n_own from rank+1 (RCCL, on the context's stream); rccl_comm:
+        the caller's ncclComm_t as an integer / ctypes pointer.  (contourist_amd.distributed does this step with torch.distributed.)"""
+        self._check(self.lib.cx_halo_exchange(self.handle, rccl_comm, int(rank), int(world), local_ptr, int(n_own), int(plane_samples)))
 
     def seeded_mode(self):
         "how the last seeded selection ran its end points: 'sequential' (the reference's shared visited set) or 'parallel'"

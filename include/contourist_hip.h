@@ -138,6 +138,13 @@ int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out
  * When the sample array carries a margin around the reference's grid, hand over the reference's own corner
  * (voxels per axis); 0 restores the default. */
 int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2);
+/* The one exchange step of a volume split into slabs along array axis 0 (no counterpart in the single-process reference; SURVEY
+ * section 8e): rank r owns n_own planes and marches them with ONE halo plane, the first plane of rank r+1.  local_planes: device
+ * buffer of (n_own + 1) * plane_samples floats (n_own on the last rank); sends plane 0 to rank-1 and receives plane n_own from
+ * rank+1 in one RCCL group on the context's stream, so extractions enqueued afterwards are ordered behind it.  rccl_comm: the
+ * caller's ncclComm_t; RCCL is not linked but looked up in the calling process (CX_ERR_UNSUPPORTED if there is none).
+ * world == 1: nothing to do.  (The Python host uses torch.distributed for the same step: contourist_amd/distributed.py.) */
+int cx_halo_exchange(cx_ctx* ctx, void* rccl_comm, int rank, int world, float* local_planes, int64_t n_own, int64_t plane_samples);
 int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
 /* flags CX_SEED_ALL_IN_RANGE: every voxel inside range_lo_hi is kept (the exhaustive search_for_endpoints() of the
  * reference, tetrahedral.py:74-81) and the end points only add the seed voxels OUTSIDE it: the reference does not

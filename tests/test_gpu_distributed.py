@@ -170,3 +170,20 @@ def test_postprocess_mesh_rejects_bad_indices():
     assert post["n_triangles"] == 1 and post["n_vertices"] == 3
     p1, t1 = ctx.download_level1(post)
     assert sorted(t1[0].tolist()) == [0, 1, 2]
+
+
+def test_halo_exchange_c_abi_single_rank_and_arguments():
+    """cx_halo_exchange: one rank has nothing to exchange; bad arguments are refused before RCCL is touched.  (Two ranks need two
+    GPUs -- RCCL refuses two ranks on one device -- so the send / receive pair itself is not exercised on this pool; the Python
+    host's torch.distributed exchange is what tests/test_distributed_gloo.py and the bench cover.)"""
+    import torch
+    from contourist_amd import _ffi
+    ctx = _ffi.Context(0)
+    buf = torch.zeros(3 * 16, dtype=torch.float32, device="cuda:0")
+    ctx.halo_exchange(None, 0, 1, buf.data_ptr(), 2, 16)                 # world 1: no-op, no communicator needed
+    for args in ((None, 0, 2, buf.data_ptr(), 2, 16),                    # no communicator
+                 (None, 2, 2, buf.data_ptr(), 2, 16),                    # rank out of range
+                 (None, 0, 0, buf.data_ptr(), 2, 16),                    # world 0
+                 (None, 0, 1, buf.data_ptr(), 0, 16)):                   # no owned plane
+        with pytest.raises(_ffi.CxError):
+            ctx.halo_exchange(*args)
