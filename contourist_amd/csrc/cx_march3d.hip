@@ -1464,7 +1464,11 @@ __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task
         if (ntri && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
             const uint32_t wsel = (dk ? kfl : 0u) | ((dj ? r3 : 0u) << 1) | ((di ? pl : 0u) << 2);
             const uint32_t wY = cx_wave_of_neighbour(T, A.w, wsel);
+#ifdef CX_ABL_QA     // timing experiment: no queue-word gathers
+            const uint32_t qa = (wY * 977u + pofs[di] + lane_k[dk]) & 0x00FFFFFFu;
+#else
             const uint32_t qa = P.qa[(size_t)wY * (CX_SWP * 64u) + pofs[di] + lane_k[dk]];
+#endif
             A.qa[c - 1u] = (qa & 0xFFFF0000u) | (qa & ((1u << (cr[dj] + cm[dk])) - 1u));
             A.nbw |= (wsel << (3u * (c - 1u))) | (1u << (18u + c));
         }
