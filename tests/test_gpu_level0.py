@@ -90,7 +90,8 @@ def test_random_fields_ragged_shapes(ctx, shape, seed):
 
 
 @pytest.mark.parametrize("shape,seed", [((6, 5, 4), 11), ((6, 5, 5), 12), ((6, 5, 6), 13), ((6, 5, 7), 14), ((9, 6, 257), 15),
-                                        ((5, 9, 258), 16), ((4, 5, 259), 17), ((3, 18, 513), 18), ((20, 20, 255), 19)])
+                                        ((5, 9, 258), 16), ((4, 5, 259), 17), ((3, 18, 513), 18), ((20, 20, 255), 19),
+                                        ((3, 6, 1024), 20), ((4, 5, 1030), 25)])   # (rows longer than the k * P2 table of the triangle kernels: 64-bit hashes)
 def test_rows_not_multiple_of_four(ctx, shape, seed):
     """rows whose length is not a multiple of 4 (16-byte loads only 4-byte aligned, the lane at the end of a row
     shifts its samples into place), one to three k-segments"""
