@@ -558,6 +558,77 @@ __global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab
         cxp_union(parent, nullptr, t, o, rel);
     }
 }
+// The same linking for the meshes of the march (coherent != 0: connectivity only) in two steps.  Triangle ids follow the march, so
+// most edges join two triangles a few hundred ids apart: a workgroup takes CXP_LINK_BLOCK consecutive triangles, unites those
+// whose partner lies in the same block in LDS (ds atomics instead of ~4 device-scope atomics per union, which are executed at
+// the memory side of the fabric and bound the one-step kernel), writes the block's forest into the global parent words with
+// plain stores -- nobody else touches them in this kernel -- and leaves the partners outside the block in `others` for the
+// second kernel, which unites them with the global routine as before.  The roots are the smallest ids either way.
+#define CXP_LINK_BLOCK 2048u
+#define CXP_LINK_PER_THREAD (CXP_LINK_BLOCK / 256u)
+__device__ __forceinline__ uint32_t cxp_lfind(uint32_t* lp, uint32_t x) {
+    for (;;) {
+        const uint32_t p = ((volatile uint32_t*)lp)[x];
+        if (p == x) return x;
+        const uint32_t g = ((volatile uint32_t*)lp)[p];
+        if (g != p) ((volatile uint32_t*)lp)[x] = g;   // path halving: only ever replaces a parent by an ancestor
+        x = p;
+    }
+}
+__global__ __launch_bounds__(256) void cxp_k_edges_link_local(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, u64* parent,
+                                                              uint32_t* others) {
+    __shared__ uint32_t lp[CXP_LINK_BLOCK];
+    const uint32_t b0 = blockIdx.x * CXP_LINK_BLOCK;
+    for (uint32_t x = threadIdx.x; x < CXP_LINK_BLOCK; x += 256u) lp[x] = x;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t i = 0; i < CXP_LINK_PER_THREAD; i++) {
+        const uint32_t t = b0 + i * 256u + threadIdx.x;
+        if (t >= nt) continue;
+        const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const uint32_t p = v[e], q = v[(e + 1) % 3];
+            const uint32_t lo = min(p, q), hi = max(p, q);
+            const u64 key = ((u64)lo << 32) | (u64)hi;
+            u64 slot = cxp_edge_slot(lo, hi, mask, mult);
+            while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every key was inserted by the claim kernel
+            const uint32_t o = (uint32_t)tab[2 * slot + 1];
+            uint32_t far = CXP_NONE;
+            if (o != t) {
+                if (o - b0 < CXP_LINK_BLOCK) {          // partner in this block (o >= b0 by unsigned wrap-around)
+                    uint32_t a = t - b0, b = o - b0;
+                    for (;;) {
+                        a = cxp_lfind(lp, a);
+                        b = cxp_lfind(lp, b);
+                        if (a == b) break;
+                        const uint32_t win = min(a, b), lose = max(a, b);
+                        if (atomicCAS(&lp[lose], lose, win) == lose) break;
+                    }
+                } else {
+                    far = o;
+                }
+            }
+            others[(size_t)t * 3 + e] = far;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < CXP_LINK_PER_THREAD; i++) {
+        const uint32_t x = i * 256u + threadIdx.x;
+        if (b0 + x >= nt) continue;
+        const uint32_t r = cxp_lfind(lp, x);
+        if (r != x) parent[b0 + x] = (u64)(b0 + r);      // parity 0
+    }
+}
+__global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const uint32_t o = others[(size_t)t * 3 + e];
+        if (o != CXP_NONE) cxp_union(parent, nullptr, t, o, 0u);
+    }
+}
 // per component (root triangle): largest x over its vertices
 __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -752,7 +823,13 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-        hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
+        if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
+            uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 24 bytes per triangle that the component tables take below
+            hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
+                               emult, parent, others);
+            hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
+        } else
+            hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
