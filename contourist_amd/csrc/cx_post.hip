@@ -319,8 +319,11 @@ __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_param
     rep[v] = (uint32_t)tvals[slot];
 }
 
-// remap triangles through `map` (optionally a union-find: map == nullptr), kill those with < 3 distinct vertices
-__global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uint32_t* map, const u64* parent) {
+// remap triangles through `map` (optionally a union-find: map == nullptr), kill those with < 3 distinct vertices.
+// involved (optional): flags the vertices something was merged INTO.  Two different triangles of the march can only become the
+// same vertex set through a merge, and then both contain such a vertex: the dedupe that follows only has to look at triangles
+// with a flagged vertex (a few per cent of a mesh) instead of putting all of them through its table of compare-and-swaps.
+__global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uint32_t* map, const u64* parent, uint8_t* involved = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
     uint32_t v[3];
@@ -330,6 +333,7 @@ __global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uin
         uint32_t par;
         v[s] = map ? map[x] : cxp_find(parent, x, par);
         tri[(size_t)t * 3 + s] = (int32_t)v[s];
+        if (involved && v[s] != x) involved[v[s]] = 1;
     }
     if (v[0] == v[1] || v[0] == v[2] || v[1] == v[2]) alive[t] = 0;
 }
@@ -353,9 +357,10 @@ __device__ __forceinline__ bool cxp_less3(const cxp_tri3& p, const cxp_tri3& q) 
 
 // dedupe triangles that are the same vertex set: table slot holds the id of the current winner
 __global__ void cxp_k_dedupe_insert(const int32_t* tri, const uint32_t* tprio3, const uint8_t* alive, uint32_t nt, u64* table,
-                                    u64 mask) {
+                                    u64 mask, const uint8_t* involved = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
+    if (involved && !(involved[tri[(size_t)t * 3]] | involved[tri[(size_t)t * 3 + 1]] | involved[tri[(size_t)t * 3 + 2]])) return;   // cannot have a twin
     const cxp_tri3 me = cxp_sorted3((uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]);
     const cxp_tri3 mp = {tprio3[(size_t)t * 3], tprio3[(size_t)t * 3 + 1], tprio3[(size_t)t * 3 + 2]};
     u64 slot = cxp_mix(((u64)me.a << 40) ^ ((u64)me.b << 20) ^ (u64)me.c ^ ((u64)me.c << 50)) & mask;
@@ -375,9 +380,10 @@ __global__ void cxp_k_dedupe_insert(const int32_t* tri, const uint32_t* tprio3, 
         slot = (slot + 1) & mask;
     }
 }
-__global__ void cxp_k_dedupe_resolve(const int32_t* tri, uint8_t* alive, uint32_t nt, const u64* table, u64 mask) {
+__global__ void cxp_k_dedupe_resolve(const int32_t* tri, uint8_t* alive, uint32_t nt, const u64* table, u64 mask, const uint8_t* involved = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
+    if (involved && !(involved[tri[(size_t)t * 3]] | involved[tri[(size_t)t * 3 + 1]] | involved[tri[(size_t)t * 3 + 2]])) return;   // was not inserted
     const cxp_tri3 me = cxp_sorted3((uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]);
     u64 slot = cxp_mix(((u64)me.a << 40) ^ ((u64)me.b << 20) ^ (u64)me.c ^ ((u64)me.c << 50)) & mask;
     for (;;) {
@@ -759,7 +765,7 @@ static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_d
 // Shared tail: clean (optional) + compaction + orientation (optional) on S->pts (nv x 3 doubles),
 // S->tri (nt x 3), S->alive.  prio = vertex priorities.  Results in S->pts_out / S->tri_out.
 static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, bool do_clean, bool do_orient,
-                            uint32_t* tprio3, int64_t* out_counts, bool coherent) {
+                            uint32_t* tprio3, int64_t* out_counts, bool coherent, uint8_t* involved = nullptr) {
     int rc;
     double* pts = (double*)S->pts.p;
     uint32_t* prio = (uint32_t*)S->prio.p;
@@ -771,12 +777,13 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         u64* parent2 = (u64*)S->parent2.p;
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent2, nv);
         hipLaunchKernelGGL(cxp_k_degenerate, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, pts, parent2, prio);
-        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2);
+        if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2, involved);
         const u64 tsz = cxp_table_size(nt);
         if ((rc = cxp_reserve(ctx, S->tkeys, tsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
-        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1);
-        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
+        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
     }
     // ---- compaction of used vertices and living triangles
     if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
@@ -941,11 +948,15 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, (u64)0);
         hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, vkeep);
         hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep, vkeep);
-        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr);
+        // meshes of the march hold no triangle twice: only triangles with a vertex something was welded into can have a twin
+        // (`moved` is free until the tiny collapse: it carries the flags)
+        uint8_t* involved = (coherent && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr;
+        if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr, involved);
         const u64 tsz = cxp_table_size(nt);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
-        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1);
-        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1);
+        hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
+        hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
         CXP_HIP(ctx, hipMemsetAsync(misc + 4, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(cxp_k_count_alive, dim3(std::min(cxp_blocks(nt), 1024u)), dim3(256), 0, st, alive, nt, misc + 4);
         if (smooth > 0.0) {
@@ -977,7 +988,9 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
         CXP_HIP(ctx, hipStreamSynchronize(st));
         counts[2] = h[0]; counts[3] = h[1];
     }
-    return cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, coherent);
+    // (`moved` is free again after cxp_k_move)
+    return cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, coherent,
+                            (coherent && nv && nt && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr);
 }
 
 extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {
