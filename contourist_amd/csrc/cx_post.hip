@@ -278,7 +278,21 @@ __global__ void cxp_k_iota_prio(uint32_t* prio, uint32_t n) {
 
 struct cxp_weld_params {
     double ex[3];
+    double thr;   // > 0: vertices are crossings of the march (priority = edge id); those further than thr from both ends of their
+                  // lattice edge cannot share a bucket with another crossing (see cxp_weld_alone)
 };
+// Crossings sit on edges of the Kuhn lattice (one per edge).  Two of them in one weld bucket are less than 1/ex apart in every
+// axis.  Edges without a common end point stay at least 1/3 apart (max-norm; checked over all pairs of edge directions), edges
+// with a common end point V run apart from it along some axis -- so one of the two crossings is within 1/ex of V and the other
+// within 2/ex.  A crossing at least 2/ex from both ends of its edge is therefore ALONE in its bucket (ex >= 16): it is its own
+// representative and does not have to go through the table (at 512^3: 4 of 5 vertices).
+__device__ __forceinline__ bool cxp_weld_alone(const double* p, uint32_t key, const cxp_weld_params& W) {
+    if (!(W.thr > 0.0)) return false;
+    const uint32_t d = key & 7u;
+    const double x = (d & 4u) ? p[0] : ((d & 2u) ? p[1] : p[2]);   // an axis the edge moves along
+    const double u = x - floor(x);
+    return u > W.thr && u < 1.0 - W.thr;
+}
 // weld bucket of a point: trunc(p * expander) per axis as the reference's astype(int) does it (tetrahedral.py:192-196),
 // i.e. TOWARDS ZERO: on an array with a rim around the reference's grid the coordinates are the reference's own and
 // may be negative, and (-1/ex, 0) shares bucket 0 with [0, 1/ex).  Biased by 2^20 per axis so the fields stay unsigned.
@@ -299,6 +313,7 @@ __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint3
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     if (vkeep && !vkeep[v]) return;   // seeded selection: vertices of dropped components do not exist
+    if (cxp_weld_alone(pts + (size_t)v * 3, prio[v], W)) return;
     const u64 key = cxp_weld_key(pts + (size_t)v * 3, W);
     u64 slot = cxp_mix(key) & mask;
     for (;;) {
@@ -309,10 +324,11 @@ __global__ void cxp_k_weld_insert(const double* pts, const uint32_t* prio, uint3
     atomicMax(&tvals[slot], ((u64)prio[v] << 32) | (u64)v);
 }
 __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_params W, const u64* tkeys, const u64* tvals, u64 mask,
-                                  uint32_t* rep, const uint8_t* vkeep) {
+                                  uint32_t* rep, const uint8_t* vkeep, const uint32_t* prio) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
     if (vkeep && !vkeep[v]) { rep[v] = v; return; }
+    if (cxp_weld_alone(pts + (size_t)v * 3, prio[v], W)) { rep[v] = v; return; }
     const u64 key = cxp_weld_key(pts + (size_t)v * 3, W);
     u64 slot = cxp_mix(key) & mask;
     while (tkeys[slot] != key) slot = (slot + 1) & mask;
@@ -924,8 +940,10 @@ static int cxp_reserve3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt
     return CX_OK;
 }
 // weld -> (smooth) -> tiny collapse -> clean -> orient on S->pts / S->prio / S->tri / S->alive (A6..A10)
+// edge_crossings: the vertices are the march's own crossings with their edge ids as priorities (cx_postprocess3d*), not points
+// handed over by a caller (cx_postprocess3d_mesh: refined points, slab meshes with global edge ids as ranks)
 static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, const double corner[3], const uint8_t* vkeep, bool do_clean,
-                     double smooth, bool coherent, int64_t* counts) {
+                     double smooth, bool coherent, int64_t* counts, bool edge_crossings = false) {
     int rc;
     hipStream_t st = ctx->stream;
     double* pts = (double*)S->pts.p;
@@ -941,13 +959,18 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
         // ---- weld (tetrahedral.py:190-215): expander = int(10000 / corner)
         cxp_weld_params W;
         for (int a = 0; a < 3; a++) W.ex[a] = std::trunc((10000 * 1.0) / corner[a]);
+        W.thr = 0.0;
+        if (edge_crossings && !cx_debug_knob("CX_WELD_ALL", 0)) {
+            const double exmin = std::min(W.ex[0], std::min(W.ex[1], W.ex[2]));
+            if (exmin >= 16.0) W.thr = 2.0 / exmin + 1e-9;
+        }
         const u64 wsz = cxp_table_size(nv);
         if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->tvals, wsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)wsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tvals.p, (size_t)wsz, (u64)0);
         hipLaunchKernelGGL(cxp_k_weld_insert, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, prio, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, vkeep);
-        hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep, vkeep);
+        hipLaunchKernelGGL(cxp_k_weld_lookup, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, W, (u64*)S->tkeys.p, (u64*)S->tvals.p, wsz - 1, rep, vkeep, prio);
         // meshes of the march hold no triangle twice: only triangles with a vertex something was welded into can have a twin
         // (`moved` is free until the tiny collapse: it carries the flags)
         uint8_t* involved = (coherent && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr;
@@ -1028,7 +1051,7 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
     for (int a = 0; a < 3; a++)
         if (ctx->corner_ref[a] > 0) corner[a] = (double)ctx->corner_ref[a];
-    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, vkeep, !(flags & 1u), smooth, true, counts))) return rc;   // the march winds every triangle low -> high
+    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, vkeep, !(flags & 1u), smooth, true, counts, true))) return rc;   // the march winds every triangle low -> high
     ctx->post_valid = true;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
     return CX_OK;
