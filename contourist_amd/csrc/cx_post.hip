@@ -1913,14 +1913,14 @@ __device__ __forceinline__ bool cxp_seg_inside(const double* P4, const int32_t* 
     const double lo = P4[(size_t)segs[(size_t)s * 2] * 4 + 3], hi = P4[(size_t)segs[(size_t)s * 2 + 1] * 4 + 3];
     return lo <= t && t <= hi;
 }
-__global__ void cxp_k_morph_visible(const double* P4, const int32_t* segs, const int32_t* tris, uint32_t nt, double t,
-                                    uint32_t* tflag, uint32_t* sused) {
+// (a triangle is visible while all three of its segments exist: lo <= t <= hi with the intersection of their ranges, which
+// cxp_k_tri_segments left per triangle -- 16 bytes read in order instead of 12 gathers through segments and points per triangle)
+__global__ void cxp_k_morph_visible(const double* ttime, const int32_t* tris, uint32_t nt, double t, uint32_t* tflag, uint32_t* sused) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nt) return;
-    const uint32_t s0 = tris[(size_t)q * 3], s1 = tris[(size_t)q * 3 + 1], s2 = tris[(size_t)q * 3 + 2];
-    const bool vis = cxp_seg_inside(P4, segs, s0, t) && cxp_seg_inside(P4, segs, s1, t) && cxp_seg_inside(P4, segs, s2, t);
+    const bool vis = ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1];
     tflag[q] = vis ? 1u : 0u;
-    if (vis) { sused[s0] = 1u; sused[s1] = 1u; sused[s2] = 1u; }
+    if (vis) { sused[tris[(size_t)q * 3]] = 1u; sused[tris[(size_t)q * 3 + 1]] = 1u; sused[tris[(size_t)q * 3 + 2]] = 1u; }
 }
 __global__ void cxp_k_morph_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint32_t* sused,
                                    const uint32_t* snew, double* out) {
@@ -1961,7 +1961,8 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     const int32_t* segs = (const int32_t*)S->msegs.p;
     const int32_t* tris = (const int32_t*)S->mtris.p;
     CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(cxp_k_morph_visible, dim3(cxp_blocks(nt)), dim3(256), 0, st, P4, segs, tris, nt, t, tflag, sused);
+    const double* ttime = (const double*)S->mtime.p + (size_t)(ns + 1) * 2;   // behind the segments' ranges (cx_morph_triangles)
+    hipLaunchKernelGGL(cxp_k_morph_visible, dim3(cxp_blocks(nt)), dim3(256), 0, st, ttime, tris, nt, t, tflag, sused);
     if ((rc = cxp_scan(ctx, S, sused, snew, ns, misc + 8))) return rc;
     if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 9))) return rc;
     uint32_t tot[2] = {0, 0};
