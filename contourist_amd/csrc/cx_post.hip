@@ -1684,11 +1684,13 @@ __global__ void cxp_k_morph_emit(const int32_t* tets, uint32_t nt, const double*
     cxp_morph_slices(tets, t, pts, prio, t_eps, [&](u64 p0, u64 p1, u64 p2) { out[0] = p0; out[1] = p1; out[2] = p2; out += 3; });
 }
 // segments = distinct vertex pairs
-__global__ void cxp_k_seg_insert(const u64* pairs, size_t n, u64* tkeys, u64 mask) {
+// (slots by the first vertex of the pair, as in the 3-D edge table: vertex ids follow the march, so the triangles of a wave
+// probe neighbouring lines; segment ids = slot order then follow the vertices too, which carries on into the edge table)
+__global__ void cxp_k_seg_insert(const u64* pairs, size_t n, u64* tkeys, u64 mask, u64 mult) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 key = pairs[i];
-    u64 slot = cxp_mix(key) & mask;
+    u64 slot = cxp_edge_slot((uint32_t)(key >> 32), (uint32_t)key, mask, mult);
     for (;;) {
         u64 cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see cxp_k_edge_lists)
         if (cur == CXP_EMPTY) cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key);
@@ -1713,7 +1715,7 @@ __global__ void cxp_k_seg_write(const u64* tkeys, const uint32_t* ids, size_t n,
     stime[(size_t)s * 2] = pts[(size_t)a * 4 + 3]; stime[(size_t)s * 2 + 1] = pts[(size_t)b * 4 + 3];
 }
 // triangles as segment-id triples + their time range (morph_geometry.py:69-89)
-__global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tkeys, const uint32_t* ids, u64 mask, const double* stime,
+__global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tkeys, const uint32_t* ids, u64 mask, u64 mult, const double* stime,
                                    const u64* mm, int32_t* tris, double* ttime) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -1721,7 +1723,7 @@ __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tke
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const u64 key = pairs[(size_t)t * 3 + e];
-        u64 slot = cxp_mix(key) & mask;
+        u64 slot = cxp_edge_slot((uint32_t)(key >> 32), (uint32_t)key, mask, mult);
         while (tkeys[slot] != key) slot = (slot + 1) & mask;
         const uint32_t s = ids[slot];
         tris[(size_t)t * 3 + e] = (int32_t)s;
@@ -1731,7 +1733,7 @@ __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tke
     ttime[(size_t)t * 2] = lo; ttime[(size_t)t * 2 + 1] = hi;
 }
 // edge table with a linked list of the triangles on each edge (an "edge" = pair of segment ids)
-__global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u64* eheads, u64 mask, uint32_t* next) {
+__global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u64* eheads, u64 mask, u64 mult, uint32_t* next) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
@@ -1739,7 +1741,7 @@ __global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u6
     for (int e = 0; e < 3; e++) {
         const uint32_t p = v[e], q = v[(e + 1) % 3];
         const u64 key = ((u64)min(p, q) << 32) | (u64)max(p, q);
-        u64 slot = cxp_mix(key) & mask;
+        u64 slot = cxp_edge_slot(min(p, q), max(p, q), mask, mult);
         for (;;) {
             // device-scope read first: every visitor of an edge but the first finds the key there and needs no read-modify-write
             // (they execute at the memory side of the fabric, ~21 G/s for the whole chip: what this stage is bound by)
@@ -1753,7 +1755,7 @@ __global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u6
     }
 }
 // link every pair of time-compatible triangles on a common edge (morph_geometry.py:61-67, surface_geometry.py:117-128)
-__global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u64* ekeys, const u64* eheads, u64 mask, const uint32_t* next,
+__global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u64* ekeys, const u64* eheads, u64 mask, u64 mult, const uint32_t* next,
                                         const double* ttime, u64* parent) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -1764,7 +1766,7 @@ __global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u
         const uint32_t p = v[e], q = v[(e + 1) % 3];
         const uint32_t elo = min(p, q), ehi = max(p, q);
         const u64 key = ((u64)elo << 32) | (u64)ehi;
-        u64 slot = cxp_mix(key) & mask;
+        u64 slot = cxp_edge_slot(elo, ehi, mask, mult);
         while (ekeys[slot] != key) slot = (slot + 1) & mask;
         for (uint32_t it = (uint32_t)eheads[slot]; it != CXP_NONE; it = next[it]) {
             const uint32_t o = it / 3u;
@@ -1827,7 +1829,8 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             uint32_t* sflag = (uint32_t*)S->flags.p;
             uint32_t* sid = (uint32_t*)S->scan.p;
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, skeys, (size_t)ssz, CXP_EMPTY);
-            hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np)), dim3(256), 0, st, pairs, np, skeys, ssz - 1);
+            const u64 smult = std::max<u64>(1, ssz / std::max<u64>(1, (u64)nv));
+            hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np)), dim3(256), 0, st, pairs, np, skeys, ssz - 1, smult);
             hipLaunchKernelGGL(cxp_k_slot_flags, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, (size_t)ssz, sflag);
             if ((rc = cxp_scan(ctx, S, sflag, sid, (uint32_t)ssz, misc + 2))) return rc;
             uint32_t nseg = 0;
@@ -1843,10 +1846,11 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             double* ttime = stime + (size_t)(nseg + 1) * 2;
             int32_t* tris = (int32_t*)S->mtris.p;
             hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
-            hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, stime, mm, tris, ttime);
+            hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, smult, stime, mm, tris, ttime);
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
             const u64 esz = cxp_table_size((size_t)ntri * 3);
+            const u64 emult4 = std::max<u64>(1, esz / std::max<u64>(1, (u64)nseg));
             if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->parent, (size_t)ntri * sizeof(u64)))) return rc;
@@ -1863,8 +1867,8 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, eheads, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(ntri)), dim3(256), 0, st, parent, ntri);
-            hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, next);
-            hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, next, ttime, parent);
+            hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next);
+            hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next, ttime, parent);
             if ((rc = cxp_flatten(ctx, parent, ntri, misc))) return rc;
             CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
             CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
