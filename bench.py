@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--generic", action="store_true", help="force the shape-agnostic classify kernel")
     ap.add_argument("--weak", action="store_true", help="one size^3 slab PER GPU instead of one volume split over the GPUs")
     ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the extra pass on one stream (unoverlapped kernel durations)")
+    ap.add_argument("--streams", type=int, default=2, help="extractions in flight: consecutive steps alternate between this many contexts / HIP streams")
     return ap.parse_args()
 
 
@@ -117,25 +119,37 @@ class Job(object):
         self.total_samples = n ** 3 if strong else world * n ** 3
 
 
-def run_job(args, torch, dist, ctx, job, flags, overlap_halo, timing=True):
-    """size buffers, warm up, time args.steps steps; -> (elapsed max over ranks, timing dict, counts)"""
+def run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=True):
+    """size buffers, warm up, time args.steps steps; -> (elapsed max over ranks, timing dict, counts).
+    ctxs / streams: consecutive steps alternate between these contexts (one HIP stream each): independent volumes, so
+    the extraction of step i+1 starts while step i is still in its emit stages -- each kernel alone leaves part of the
+    chip idle in its ramp and tail (thin slabs most of all)."""
     cxdist, rank, world = job.cxdist, job.rank, job.world
     distributed = world > 1
     nrot = len(job.slabs)
-    ctx.set_origin(job.origin0, 0, 0)
+    ns = len(ctxs)
+    for c in ctxs:
+        c.set_origin(job.origin0, 0, 0)
     pending = {}
 
     def step(i):
         buf = job.slabs[i % nrot]
+        ctx, st = ctxs[i % ns], streams[i % ns]
         if overlap_halo:
             # the only exchange of the path is the 1-plane halo.  The exchange for volume i+1 (another buffer) is
             # posted before volume i is extracted and runs on RCCL's stream meanwhile.
             if i not in pending:
-                pending[i] = cxdist.HaloExchange(buf, job.n_own, rank, world, dist)
-            pending.pop(i).finish()
-            pending[i + 1] = cxdist.HaloExchange(job.slabs[(i + 1) % nrot], job.n_own, rank, world, dist)
+                with torch.cuda.stream(st):
+                    pending[i] = cxdist.HaloExchange(buf, job.n_own, rank, world, dist)
+            with torch.cuda.stream(st):          # the stream that extracts volume i waits for its halo
+                pending.pop(i).finish()
+            # (posted on the stream that last read that buffer, volume i + 1 - nrot: RCCL orders itself behind the work queued there)
+            last_user = i + 1 - nrot
+            with torch.cuda.stream(streams[last_user % ns] if last_user >= 0 else streams[0]):
+                pending[i + 1] = cxdist.HaloExchange(job.slabs[(i + 1) % nrot], job.n_own, rank, world, dist)
         elif distributed:
-            cxdist.exchange_halo(buf, job.n_own, rank, world, dist)
+            with torch.cuda.stream(st):
+                cxdist.exchange_halo(buf, job.n_own, rank, world, dist)
         ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
         ctx.extract3d_async(args.value, flags)
 
@@ -144,14 +158,18 @@ def run_job(args, torch, dist, ctx, job, flags, overlap_halo, timing=True):
     for r in range(nrot):
         if distributed:
             cxdist.exchange_halo(job.slabs[r], job.n_own, rank, world, dist)
-        ctx.adopt_device_grid(job.slabs[r].data_ptr(), tuple(job.slabs[r].shape), keepalive=job.slabs[r])
-        c = ctx.extract3d(args.value, flags)
-        counts = c if counts is None else {k: max(counts[k], c[k]) for k in c}
-    ctx.reserve(int(counts["n_cells"] * 1.05) + 1024, int(counts["n_vertices"] * 1.05) + 1024,
-                int(counts["n_triangles"] * 1.05) + 1024)
+        torch.cuda.synchronize()
+        for ctx in ctxs[:1]:
+            ctx.adopt_device_grid(job.slabs[r].data_ptr(), tuple(job.slabs[r].shape), keepalive=job.slabs[r])
+            c = ctx.extract3d(args.value, flags)
+            counts = c if counts is None else {k: max(counts[k], c[k]) for k in c}
+    for ctx in ctxs:
+        ctx.reserve(int(counts["n_cells"] * 1.05) + 1024, int(counts["n_vertices"] * 1.05) + 1024,
+                    int(counts["n_triangles"] * 1.05) + 1024)
     for i in range(args.warmup):
         step(i)
-    ctx.timing_enable(timing)
+    for ctx in ctxs:
+        ctx.timing_enable(timing)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,9 +183,14 @@ def run_job(args, torch, dist, ctx, job, flags, overlap_halo, timing=True):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tm = ctx.timing_read()
-    ctx.timing_enable(False)
-    final = ctx.counts()           # also verifies that the last extract fitted its buffers
+    tm = None
+    for ctx in ctxs:
+        t = ctx.timing_read()
+        ctx.timing_enable(False)
+        tm = t if tm is None else {k: tm[k] + t[k] for k in tm}
+    final = None
+    for k in range(min(ns, args.steps + args.warmup)):
+        final = ctxs[k].counts()           # also verifies that the last extracts fitted their buffers
     if distributed:
         dev = job.slabs[0].device
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -228,14 +251,27 @@ def main():
     nrot = args.rotate or (2 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
     overlap_halo = distributed and os.environ.get("BENCH_SYNC_HALO", "0") != "1"
     if overlap_halo:
-        nrot = max(nrot, 2)      # the halo of the next volume is exchanged while the current one is extracted
+        # the halo of the next volume is exchanged while the current one is extracted, and with S extractions in flight the buffer
+        # it lands in must not be one that is still being read: S + 1 buffers
+        nrot = max(nrot, max(1, args.streams) + 1)
 
-    stream = torch.cuda.current_stream()
-    ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    ctxs = [_ffi.Context(device_index, stream=st.cuda_stream) for st in streams]
+    ctx = ctxs[0]
     flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
 
     job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, nrot)
-    elapsed, timing, final = run_job(args, torch, dist, ctx, job, flags, overlap_halo)
+    elapsed, timing, final = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo)
+    if os.environ.get("BENCH_NO_EVENTS") == "1":      # measurement of what the per-kernel events cost: the same region without them
+        el2, _, _ = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=False)
+        if rank == 0:
+            print("# without per-kernel events: %.4f ms/step (with: %.4f)" % (el2 / args.steps * 1e3, elapsed / args.steps * 1e3), file=sys.stderr, flush=True)
+    single = None
+    if nstreams > 1 and rank == 0 and not distributed and not args.no_single_stream:
+        # the same steps on ONE stream: per-kernel durations that do not overlap with another extraction's kernels
+        s_el, s_tm, _ = run_job(args, torch, dist, ctxs[:1], streams[:1], job, flags, overlap_halo)
+        single = (s_el, s_tm)
 
     weak_line = None
     if distributed and strong:
@@ -244,7 +280,7 @@ def main():
         del job.slabs[:]
         torch.cuda.empty_cache()
         wjob = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, False, nrot)
-        wel, _, _ = run_job(args, torch, dist, ctx, wjob, flags, overlap_halo, timing=False)
+        wel, _, _ = run_job(args, torch, dist, ctxs, streams, wjob, flags, overlap_halo, timing=False)
         weak_line = {"value": wjob.total_samples * args.steps / wel / 1e6, "unit": "Mvoxels/s", "ms_per_step": wel / args.steps * 1e3,
                      "workload": "one %d^3 slab per GPU (%d x %d x %d volume)" % (n, world * n, n, n)}
         del wjob.slabs[:]
@@ -252,32 +288,37 @@ def main():
         job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, 1)
 
     if rank == 0:
-        nt = max(timing["n"], 1)
-        k1_ms = timing["classify_ms"] / nt
-        k2_ms = timing["emit_ms"] / nt
-        level0_ms = k1_ms + k2_ms
         local_samples = job.slabs[0].numel()
         alg_bytes = 4.0 * local_samples             # 4 B per input sample, read once
-        # per-kernel durations (HIP events on the extraction stream, inside the timed region) with the algorithmic
-        # bytes of each: stream = 4 B per sample read; emit = 16 B per vertex record + 12 B per triangle written
-        names = ctx.kernel_names()
-        kernels = []
-        for key, name in names:
-            ms = timing[key] / nt
-            if key == "stream_ms":
-                ab = alg_bytes
-            elif key == "scan_ms":
-                ab = 0.0
-            elif key == "cells_ms":
-                ab = ctx.vertex_stage_bytes(final)
-            else:
-                ab = ctx.triangle_stage_bytes(final)
-            kernels.append({"name": name, "ms": ms, "alg_bytes": ab})
-        for kk in kernels:
-            kk["GBps"] = kk["alg_bytes"] / (kk["ms"] * 1e-3) / 1e9 if kk["ms"] > 0 else 0.0
-            kk["frac"] = kk["GBps"] / HBM_PEAK_GBS
-        kernels = [kk for kk in kernels if kk["ms"] > 0]
+
+        def kernel_table(tmg):
+            """per-kernel durations (HIP events on the extraction streams, inside a timed region) with the algorithmic bytes of
+            each: stream = 4 B per sample read; emit = 16 B per vertex record + 12 B per triangle written"""
+            nt_ = max(tmg["n"], 1)
+            rows = []
+            for key, name in ctx.kernel_names():
+                ms = tmg[key] / nt_
+                if key == "stream_ms":
+                    ab = alg_bytes
+                elif key == "scan_ms":
+                    ab = 0.0
+                elif key == "cells_ms":
+                    ab = ctx.vertex_stage_bytes(final)
+                else:
+                    ab = ctx.triangle_stage_bytes(final)
+                rows.append({"name": name, "ms": ms, "alg_bytes": ab})
+            for kk in rows:
+                kk["GBps"] = kk["alg_bytes"] / (kk["ms"] * 1e-3) / 1e9 if kk["ms"] > 0 else 0.0
+                kk["frac"] = kk["GBps"] / HBM_PEAK_GBS
+            rows = [kk for kk in rows if kk["ms"] > 0]
+            return rows, (tmg["classify_ms"] + tmg["emit_ms"]) / nt_
+        kernels, kernel_sum_ms = kernel_table(timing)
         dom = max(kernels, key=lambda kk: kk["ms"])
+        step_ms = elapsed / args.steps * 1e3
+        # SURVEY 8(d): 4 B x samples of one extraction / time of one extraction.  With ONE extraction in flight that time is the
+        # sum of its Level-0 kernel durations; with several in flight the kernels of different extractions overlap in time
+        # (their durations add up to MORE than the time an extraction takes), so the time is the step time of the timed region
+        level0_ms = kernel_sum_ms if nstreams == 1 else step_ms
         achieved = alg_bytes / (level0_ms * 1e-3) / 1e9 if level0_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -293,7 +334,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -308,21 +349,32 @@ def main():
                 "active_voxel_fraction": final["n_border_voxels"] / float(max((job.n_own - (0 if job.has_upper else 1)) * (n - 1) ** 2, 1)),
                 "vertices_rank0": final["n_vertices"], "triangles_rank0": final["n_triangles"],
                 "grids_rotated": nrot,
+                "extractions_in_flight": nstreams,
                 "classify_kernel": "generic" if args.generic else "auto",
             },
-            # achieved = 4 B x samples of one launch sequence / sum of ALL Level-0 kernel durations of one
-            # extraction (HIP events on the extraction stream, rank 0); per-kernel figures under `kernels`
+            # achieved = 4 B x samples of one extraction / time of one extraction (see above); per-kernel figures
+            # (HIP events on the extraction streams, rank 0, inside the timed region) under `kernels`
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "all Level-0 kernels of one extraction (%s)" % " + ".join(kk["name"] for kk in kernels),
+                "kernel": "all Level-0 kernels of one extraction (%s)%s" % (" + ".join(kk["name"] for kk in kernels),
+                          "" if nstreams == 1 else "; %d extractions in flight, time = step time" % nstreams),
                 "kernel_ms": level0_ms,
                 "dominant_kernel": dom["name"], "dominant_kernel_ms": dom["ms"],
                 "kernels": kernels,
+                "kernel_sum_ms": kernel_sum_ms,
                 "level0_ms": level0_ms,
                 "level0_frac": achieved / HBM_PEAK_GBS,
             },
         }
+        if single is not None:
+            # one extraction in flight: kernels that do not overlap with another extraction's, their sum = the extraction
+            s_kernels, s_sum = kernel_table(single[1])
+            s_ach = alg_bytes / (s_sum * 1e-3) / 1e9 if s_sum > 0 else 0.0
+            out["roofline"]["single_stream"] = {
+                "ms_per_step": single[0] / args.steps * 1e3, "value": job.total_samples * args.steps / single[0] / 1e6,
+                "level0_ms": s_sum, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "kernels": s_kernels,
+                "note": "the same steps on one stream: 4N / sum of the Level-0 kernel durations of one extraction"}
         if weak_line is not None:
             out["weak"] = weak_line
         if world == 1 and not args.no_api:

@@ -10,3 +10,5 @@ cp gpurun_out/prof/bench_levels_512.json profiles/${R}_bench_levels_512.json
 cp gpurun_out/prof/bench4d.json profiles/${R}_bench4d_128x128x128x64.json
 cp gpurun_out/prof/kernel_stats_4d.csv profiles/${R}_kernel_stats_4d.csv
 cp gpurun_out/prof/kernel_stats_level1_512.csv profiles/${R}_kernel_stats_level1_512.csv
+cp gpurun_out/prof/kernel_stats_512_one_stream.csv profiles/${R}_kernel_stats_512_one_stream.csv
+cp gpurun_out/prof/bench_one_stream_under_rocprof.json profiles/${R}_bench_line_512_one_stream_under_rocprof.json
