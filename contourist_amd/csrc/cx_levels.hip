@@ -59,6 +59,12 @@ struct cx_levels_state {
     size_t hcounters_cap = 0;
     cx_task T;
     uint32_t flags = 0;
+    // the emit stages of two levels run side by side (each kernel alone leaves part of the chip idle): a second stream, and a
+    // second set of info words for the levels that run on it
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint64_t* info64b = nullptr;
+    size_t info64b_cap = 0;
 };
 
 static void free_slot(cx_level_slot& S) {
@@ -82,6 +88,10 @@ void cx_levels_free(cx_ctx* ctx) {
     for (auto& S : L->slots) free_slot(S);
     if (L->dparams) (void)hipFree(L->dparams);
     if (L->hcounters) (void)hipHostFree(L->hcounters);
+    if (L->info64b) (void)hipFree(L->info64b);
+    if (L->stream2) (void)hipStreamDestroy(L->stream2);
+    if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
+    if (L->ev_join) (void)hipEventDestroy(L->ev_join);
     delete L;
     ctx->lv = nullptr;
 }
@@ -266,13 +276,32 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
             S.P.info64 = ctx->info64;
         }
-        // vertex and triangle stages, level by level (each fills the chip on its own)
+        // vertex and triangle stages, two levels side by side: even levels on the context's stream, odd ones on a second stream
+        // with their own info words (the staged kernels of one level hand over through them)
+        const bool two = nlevels > 1 && !cx_debug_knob("CX_LEVELS_ONE_STREAM", 0);
+        if (two) {
+            if (!L->stream2) {
+                CXL_HIP(ctx, hipStreamCreateWithFlags(&L->stream2, hipStreamNonBlocking));
+                CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
+                CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
+            }
+            if ((rc = grow(ctx, L->info64b, L->info64b_cap, ctx->info64_cap))) return rc;
+            CXL_HIP(ctx, hipEventRecord(L->ev_fork, ctx->stream));
+            CXL_HIP(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
+        }
         for (int l = 0; l < nlevels; l++) {
             cx_level_slot& S = L->slots[l];
-            cx_launch_emit_vertices(S.P, T, ctx->stream);
-            cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, ctx->stream);
+            const bool side = two && (l & 1);
+            hipStream_t st = side ? L->stream2 : ctx->stream;
+            S.P.info64 = side ? L->info64b : ctx->info64;
+            cx_launch_emit_vertices(S.P, T, st);
+            cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, st);
         }
         CXL_HIP(ctx, hipGetLastError());
+        if (two) {
+            CXL_HIP(ctx, hipEventRecord(L->ev_join, L->stream2));
+            CXL_HIP(ctx, hipStreamWaitEvent(ctx->stream, L->ev_join, 0));
+        }
         CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         break;
     }
