@@ -260,6 +260,8 @@ def main():
     ctxs = [_ffi.Context(device_index, stream=st.cuda_stream) for st in streams]
     ctx = ctxs[0]
     flags = _ffi.CX_DIAG_CPYTHON310 | (_ffi.CX_KERNEL_GENERIC if args.generic else 0)
+    if os.environ.get("CX_DEBUG") == "1" and os.environ.get("BENCH_EXTRA_FLAGS"):      # A/B of debug flag bits (tools)
+        flags |= int(os.environ["BENCH_EXTRA_FLAGS"], 0)
 
     job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, nrot)
     elapsed, timing, final = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo)
