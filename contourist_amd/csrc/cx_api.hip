@@ -48,6 +48,8 @@ extern "C" int cx_ctx_create(int device_id, cx_ctx** out) {
 
 static void free_outputs(cx_ctx* ctx) {
     if (ctx->verts) (void)hipFree(ctx->verts);
+    if (ctx->verts_xyz) (void)hipFree(ctx->verts_xyz);
+    ctx->verts_xyz = nullptr; ctx->verts_xyz_cap = 0;
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->tris) (void)hipFree(ctx->tris);
     ctx->verts = nullptr; ctx->cells = nullptr; ctx->tris = nullptr;
@@ -171,7 +173,7 @@ extern "C" int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, 
     if (max_vertices > (int64_t)ctx->vcap) {
         if (ctx->verts) (void)hipFree(ctx->verts);
         ctx->verts = nullptr; ctx->vcap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->verts, (size_t)max_vertices * sizeof(float4)));
+        CX_HIP(ctx, hipMalloc(&ctx->verts, (size_t)max_vertices * sizeof(cx_vrec)));
         ctx->vcap = (uint32_t)max_vertices;
     }
     if (max_triangles > (int64_t)ctx->tcap) {
@@ -480,13 +482,33 @@ extern "C" int cx_level0_path(cx_ctx* ctx, int* path) {
     return CX_OK;
 }
 
+// the vertex records of the current extraction expanded to float4 {x, y, z, bits(edge id)} in a buffer of the context
+int cx_level0_expanded(cx_ctx* ctx, float4** out) {
+    const size_t nv = (size_t)ctx->counts.n_vertices;
+    if (ctx->verts_xyz_cap < nv) {
+        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->verts_xyz) (void)hipFree(ctx->verts_xyz);
+        ctx->verts_xyz = nullptr; ctx->verts_xyz_cap = 0;
+        CX_HIP(ctx, hipMalloc(&ctx->verts_xyz, (nv + nv / 16 + 64) * sizeof(float4)));
+        ctx->verts_xyz_cap = nv + nv / 16 + 64;
+    }
+    cx_launch_expand_verts(ctx->verts, ctx->verts_xyz, (uint32_t)nv, (uint32_t)ctx->n1, (uint32_t)ctx->n2, ctx->stream);
+    CX_HIP(ctx, hipGetLastError());
+    *out = ctx->verts_xyz;
+    return CX_OK;
+}
+
 extern "C" int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris) {
     if (!ctx) return CX_ERR_INVALID;
     if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
     CX_HIP(ctx, hipSetDevice(ctx->device));
-    if (verts_xyzk && ctx->counts.n_vertices)
-        CX_HIP(ctx, hipMemcpyAsync(verts_xyzk, ctx->verts, (size_t)ctx->counts.n_vertices * sizeof(float4),
+    if (verts_xyzk && ctx->counts.n_vertices) {
+        float4* xyz = nullptr;
+        const int rc = cx_level0_expanded(ctx, &xyz);
+        if (rc) return rc;
+        CX_HIP(ctx, hipMemcpyAsync(verts_xyzk, xyz, (size_t)ctx->counts.n_vertices * sizeof(float4),
                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (tris && ctx->counts.n_triangles)
         CX_HIP(ctx, hipMemcpyAsync(tris, ctx->tris, (size_t)ctx->counts.n_triangles * 3 * sizeof(int32_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
@@ -497,7 +519,23 @@ extern "C" int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris)
 extern "C" int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris) {
     if (!ctx) return CX_ERR_INVALID;
     if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
-    if (verts_xyzk) *verts_xyzk = ctx->verts;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    if (verts_xyzk) {
+        cx_counts c;
+        int rc = cx_counts_get(ctx, &c);
+        if (rc) return rc;
+        float4* xyz = nullptr;
+        if ((rc = cx_level0_expanded(ctx, &xyz))) return rc;
+        *verts_xyzk = xyz;
+    }
+    if (tris) *tris = ctx->tris;
+    return CX_OK;
+}
+
+extern "C" int cx_level0_device_records(cx_ctx* ctx, void** vertex_records, void** tris) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
+    if (vertex_records) *vertex_records = ctx->verts;
     if (tris) *tris = ctx->tris;
     return CX_OK;
 }

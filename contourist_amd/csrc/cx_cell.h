@@ -197,7 +197,7 @@ __device__ __forceinline__ cx_cell_info cx_classify_cell(const cx_params& P, con
 template <typename Sink>
 __device__ __forceinline__ void cx_emit_vertices(const cx_params& P, const float f[8], uint32_t emask, uint32_t lin,
                                                  uint32_t i, uint32_t j, uint32_t k, Sink sink) {
-    const float fi = (float)i, fj = (float)j, fk = (float)k;
+    (void)i; (void)j; (void)k;
     // v - f(q) with the isovalue carried as two floats: exact to fp32 rounding of the result
     const float num = (P.vhi - f[0]) + P.vlo;
     uint32_t r = 0;
@@ -213,12 +213,7 @@ __device__ __forceinline__ void cx_emit_vertices(const cx_params& P, const float
                 const double dd = (double)f[d] - (double)f[0];
                 t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f[0]) / dd);
             }
-            float4 rec4;
-            rec4.x = (d & 4u) ? fi + t : fi;
-            rec4.y = (d & 2u) ? fj + t : fj;
-            rec4.z = (d & 1u) ? fk + t : fk;
-            rec4.w = __uint_as_float((lin << 3) | d);
-            sink(r++, rec4);
+            sink(r++, make_uint2((lin << 3) | d, __float_as_uint(t)));
         }
     }
 }

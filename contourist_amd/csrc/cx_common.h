@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t cx_div(uint32_t n, const cx_fdiv& f) {
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// Level-0 vertex record: 8 bytes.  x = edge id = (linear index of the owning lattice point q << 3) | direction d (1..7 = 4di+2dj+dk),
+// y = bits of the fp32 fraction t in (v - f(q)) / (f(q+d) - f(q)): the crossing sits at q + t*d.  Level 1 recomputes the point in
+// float64 from the grid and the id alone (cxp_k_vertices_f64, as the reference does: tetrahedral.py:471-512); callers that want
+// fp32 grid coordinates get them expanded on request (cx_k_expand_verts: cx_level0_download / cx_level0_device_ptrs).
+typedef uint2 cx_vrec;
+
 // ---- parameters of one extraction ---------------------------------------------------------------
 struct cx_params {
     const float* grid;     // n0*n1*n2 fp32 samples
@@ -56,7 +62,7 @@ struct cx_params {
     uint32_t org0, org1, org2;   // lattice offset of this array inside a larger volume (hash order only)
     // outputs
     uint64_t* celltab;     // [nsamples] per lattice cell that owns a vertex: (crossing mask << 32) | first vertex index
-    float4* verts;         // [vcap]  {x,y,z,bits(edge id)}
+    cx_vrec* verts;        // [vcap]  {edge id, bits(fp32 fraction t from the owning lattice point)}
     uint4* cells;          // [ccap]  {lin, sign|tetskip<<8|ntri<<16|emask<<24, tri base, first own vertex}
     int32_t* tris;         // [tcap*3]
     uint32_t vcap, ccap, tcap;
@@ -151,4 +157,5 @@ void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipSt
 void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_hash_bytes(uint8_t* table, const uint64_t* hash_xy, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t org2, hipStream_t s);
+void cx_launch_expand_verts(const cx_vrec* recs, float4* out, uint32_t n, uint32_t n1, uint32_t n2, hipStream_t s);
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

@@ -58,7 +58,9 @@ struct cx_ctx {
     cx_levels_state* lv = nullptr;
     int lv_current = -1;               // level of cx_extract3d_levels whose mesh the context's output buffers hold (-1: none)
     // Level-0 outputs
-    float4* verts = nullptr;
+    cx_vrec* verts = nullptr;          // 8-byte vertex records {edge id, fp32 fraction}
+    float4* verts_xyz = nullptr;       // {x, y, z, bits(edge id)} expanded from the records on request (cx_level0_expanded)
+    size_t verts_xyz_cap = 0;
     uint4* cells = nullptr;
     int32_t* tris = nullptr;
     uint32_t vcap = 0, ccap = 0, tcap = 0;
@@ -88,6 +90,7 @@ struct cx_ctx {
 // cx_api.hip
 int cx_ensure_cell_records(cx_ctx* ctx);
 int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags);
+int cx_level0_expanded(cx_ctx* ctx, float4** out);   // the records of the current extraction as float4 {x,y,z,id} (device, enqueued on the stream)
 void cx_fill_value_params(cx_params& P, double value);
 // cx_levels.hip
 void cx_levels_free(cx_ctx* ctx);

@@ -44,7 +44,7 @@ struct cx_level_slot {
     uint32_t* chunksum = nullptr;
     size_t chunksum_cap = 0;
     // Level-0 outputs of the level (swapped with the context's while the level is selected)
-    float4* verts = nullptr;
+    cx_vrec* verts = nullptr;
     uint4* cells = nullptr;
     int32_t* tris = nullptr;
     uint32_t vcap = 0, ccap = 0, tcap = 0;

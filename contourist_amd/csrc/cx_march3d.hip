@@ -51,7 +51,7 @@ struct cx_run {
 #define CX_VSTAGE_LDS 384u   // float4 slots per wave in the vertex stage's LDS (fast path: 2 x 448 slot words + 64 x 9 corner samples)
 template <bool RECORDS, typename LinOf>
 __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_of, uint32_t n, uint32_t lane,
-                                                 bool emit, cx_run& run, float4* vstage, uint64_t* info = nullptr) {
+                                                 bool emit, cx_run& run, cx_vrec* vstage, uint64_t* info = nullptr) {
     const uint32_t plane = P.n1 * P.n2;
     for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
         const uint32_t idx = b0 + lane;
@@ -89,11 +89,11 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_o
                 if (vtot <= CX_VSTAGE) {
                     // the wave's vertices of this batch are one contiguous run of the vertex array:
                     // stage them in LDS, then write full 16-byte-per-lane rows
-                    if (nv) cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const float4& rec4) { vstage[vpre + r2] = rec4; });
+                    if (nv) cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const cx_vrec& rec4) { vstage[vpre + r2] = rec4; });
                     if (!(P.flags & CX_DBG_NO_VERTS))
                         for (uint32_t o = lane; o < vtot; o += 64u) P.verts[run.v + o] = vstage[o];
                 } else if (nv && !(P.flags & CX_DBG_NO_VERTS)) {
-                    cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const float4& rec4) { P.verts[vfirst + r2] = rec4; });
+                    cx_emit_vertices(P, f, R.emask, lin, i, j, k, [&](uint32_t r2, const cx_vrec& rec4) { P.verts[vfirst + r2] = rec4; });
                 }
                 // (first vertex, crossing mask) of the cell for the triangle stage: per queue entry (staged pipeline), or in
                 // the table of one entry per sample (generic classify kernel)
@@ -167,8 +167,9 @@ __device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t
 #define CX_NT_GRID 0
 #endif
 typedef float cx_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t cx_v2u __attribute__((ext_vector_type(2)));
 #if CX_NT_VERTS
-#define CX_STORE_VERT(ptr, val) __builtin_nontemporal_store(cx_v4f{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<cx_v4f*>(ptr))
+#define CX_STORE_VERT(ptr, val) __builtin_nontemporal_store(cx_v2u{(val).x, (val).y}, reinterpret_cast<cx_v2u*>(ptr))
 #else
 #define CX_STORE_VERT(ptr, val) (*(ptr) = (val))
 #endif
@@ -228,19 +229,11 @@ __device__ __forceinline__ void cx_vround_pin(cx_vround& R) {
     for (uint32_t c = 0; c < 8; c++) asm volatile("" : "+v"(R.f[c]) :: "memory");
     asm volatile("" : "+v"(R.e_next) :: "memory");
 }
-__device__ __forceinline__ float4 cx_vertex_record(const cx_params& P, const cx_fast_geom& G, uint32_t e2, uint32_t d, float f0, float f1) {
-    uint32_t i2, j2, k2;
-    cx_decode_entry(P, G, e2, i2, j2, k2);
-    const uint32_t lin2 = (i2 * P.n1 + j2) * P.n2 + k2;
+__device__ __forceinline__ cx_vrec cx_vertex_record(const cx_params& P, const cx_fast_geom& G, uint32_t e2, uint32_t d, float f0, float f1) {
+    const uint32_t lin2 = cx_entry_lin(P, G, e2);
     // same arithmetic as cx_emit_vertices; |f1 - f0| > 1e-8 here (cx_k_stream keeps waves with flatter crossings off this path)
     const float t = __fdividef((P.vhi - f0) + P.vlo, f1 - f0);
-    const float fi = (float)i2, fj = (float)j2, fk = (float)k2;
-    float4 rec4;
-    rec4.x = (d & 4u) ? fi + t : fi;
-    rec4.y = (d & 2u) ? fj + t : fj;
-    rec4.z = (d & 1u) ? fk + t : fk;
-    rec4.w = __uint_as_float((lin2 << 3) | d);
-    return rec4;
+    return make_uint2((lin2 << 3) | d, __float_as_uint(t));
 }
 
 // vertex records, (first vertex, crossing mask) words and cell records of n queued cells, common case (no sample of
@@ -273,10 +266,10 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
         const bool vroom = Ra.base.v + Ra.vtot <= P.vcap;   // wave-uniform
         const uint32_t* slot = slot2 + par * 448u;
         // ... the first CX_VR x 64 vertices are interpolated before the next round's loads are waited for ...
-        float4 rec4[CX_VR];
+        cx_vrec rec4[CX_VR];
 #pragma unroll
         for (uint32_t r = 0; r < CX_VR; r++) {
-            rec4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rec4[r] = make_uint2(0u, 0u);
             if (64u * r >= Ra.vtot) continue;   // wave-uniform
             const uint32_t o = 64u * r + lane;
             const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
@@ -297,7 +290,7 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
                 const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
                 const uint32_t cell = sl >> 3, d = sl & 7u;
                 const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
-                const float4 r4 = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
+                const cx_vrec r4 = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
                 if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], r4);
             }
             // (first vertex, crossing mask) of every queued cell, one 8-byte word per queue entry: 512 contiguous bytes per round
@@ -409,7 +402,7 @@ __device__ __forceinline__ void cx_cross_words(uint32_t A, uint32_t B, const cx_
 // =================================================================================================
 __global__ __launch_bounds__(256) void cx_k_classify_generic(const cx_params P, const uint32_t cells_per_block) {
     __shared__ uint32_t s_queue[4][CX_QCAP];
-    __shared__ float4 s_vstage[4][CX_VSTAGE];
+    __shared__ cx_vrec s_vstage[4][CX_VSTAGE];
     __shared__ uint32_t s_tot[4][4];
     __shared__ uint32_t s_base[4];
     const uint32_t lane = cx_lane_id();
@@ -1027,7 +1020,7 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
         uint64_t* __restrict__ info = P.info64 + D.qofs;
         if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
-        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, s_vstage[wave], info);
+        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, reinterpret_cast<cx_vrec*>(s_vstage[wave]), info);
         if (fn >= nbatches) break;
         f = fn;
         D = Dn;
@@ -1916,7 +1909,7 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
             if (more1) cx_mesh_stage2(P, T, G, Sb, n, b0 + 64u, lane, Ra.vbase + Ra.vtot, Ra.tbase + Ra.ttot, L.vslot[wave][par ^ 1u],
                                       L.ntri, L.qbt[wave], Rb);
             // ---- stage 3 of round b0: what needs no store
-            float4 rec4[CX_VR];
+            cx_vrec rec4[CX_VR];
 #pragma unroll
             for (uint32_t r = 0; r < CX_VR; r++) rec4[r] = cx_vertex_record(P, G, Ra.e2[r], Ra.sl[r] & 7u, Ra.f0[r], Ra.f1[r]);
             const uint32_t ttot = cx_mesh_phase1(P, L.tri, lane, wave, Ra, L.vbt[wave]);
@@ -1938,7 +1931,7 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
                     const uint32_t lin2 = cx_entry_lin(P, G, e2);
                     const float f0 = A[lin2];
                     const float f1 = A[lin2 + ((d & 4u) ? plane : 0u) + ((d & 2u) ? P.n2 : 0u) + (d & 1u)];
-                    const float4 r4 = cx_vertex_record(P, G, e2, d, f0, f1);
+                    const cx_vrec r4 = cx_vertex_record(P, G, e2, d, f0, f1);
                     if (o < Ra.vtot) CX_STORE_VERT(&P.verts[Ra.vbase + o], r4);
                 }
             }
@@ -2056,6 +2049,32 @@ void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint
     if (g > most) g = most;
     if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_triangles_q<true>, dim3(g ? g : 1u), dim3(256), 0, s, P, T, hash_xy);
     else hipLaunchKernelGGL(cx_k_emit_triangles_q<false>, dim3(g ? g : 1u), dim3(256), 0, s, P, T, hash_xy);
+}
+
+// ---- fp32 grid coordinates of the vertex records, on request (cx_level0_download, cx_level0_device_ptrs): {x, y, z, bits(edge id)}
+// with the crossing at q + t*d, in the same fp32 arithmetic the vertex stage used while its records still carried xyz
+__global__ __launch_bounds__(256) void cx_k_expand_verts(const cx_vrec* __restrict__ recs, float4* __restrict__ out, uint32_t n, uint32_t n2, uint32_t plane,
+                                                         cx_fdiv dplane, cx_fdiv drow) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= n) return;
+    const cx_vrec r = recs[v];
+    const uint32_t lin = r.x >> 3, d = r.x & 7u;
+    const uint32_t i = cx_div(lin, dplane);
+    const uint32_t rem = lin - i * plane;
+    const uint32_t j = cx_div(rem, drow);
+    const uint32_t k = rem - j * n2;
+    const float t = __uint_as_float(r.y);
+    const float fi = (float)i, fj = (float)j, fk = (float)k;
+    float4 o;
+    o.x = (d & 4u) ? fi + t : fi;
+    o.y = (d & 2u) ? fj + t : fj;
+    o.z = (d & 1u) ? fk + t : fk;
+    o.w = __uint_as_float(r.x);
+    out[v] = o;
+}
+void cx_launch_expand_verts(const cx_vrec* recs, float4* out, uint32_t n, uint32_t n1, uint32_t n2, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(cx_k_expand_verts, dim3((n + 255u) / 256u), dim3(256), 0, s, recs, out, n, n2, n1 * n2, cx_fdiv_make(n1 * n2), cx_fdiv_make(n2));
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {

@@ -243,10 +243,10 @@ struct cxp_origin3 {
     double o[3];   // lattice coordinates of sample (0,0,0) in the whole volume (cx_set_origin), or zeros
 };
 __global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, cx_fdiv dplane, cx_fdiv drow,
-                                   double value, const float4* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio, cxp_origin3 org) {
+                                   double value, const cx_vrec* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio, cxp_origin3 org) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
-    const uint32_t key = __float_as_uint(verts[v].w);
+    const uint32_t key = verts[v].x;
     const uint32_t lin = key >> 3, d = key & 7u;
     const uint32_t plane = n1 * n2;
     const uint32_t i = cx_div(lin, dplane);

@@ -84,9 +84,12 @@ int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, int64_t max
  *   GridContour.find_initial_voxels/expand_voxels/border_voxel  tetrahedral.py:383-469 (active voxels)
  *   GridContour3d.enumerate_voxel_triangles / enumerate_tetrahedron_triangles  tetrahedral.py:554-595
  *   GridContour.add_simplex / interpolate_pair / contour_pair_interpolation    tetrahedral.py:176-188, 471-512
- * Result (device resident): vertex records float4 {x, y, z, bits(edge id)} in grid coordinates,
- * edge id = (linear index of the edge's lower lattice point << 3) | direction(1..7, = 4di+2dj+dk),
- * and triangles as int32 index triples wound so the normal points from f<value to f>=value.
+ * Result (device resident): 8-byte vertex records {uint32 edge id, fp32 t}: the crossing sits at q + t*d on the lattice edge
+ * q -> q+d, edge id = (linear index of the owning lattice point q << 3) | direction(1..7, = 4di+2dj+dk), t = (v - f(q)) /
+ * (f(q+d) - f(q)) -- what contour_pair_interpolation keeps per pair (tetrahedral.py:471-512: the pair and its ratio); and
+ * triangles as int32 index triples wound so the normal points from f<value to f>=value.  Level 1 recomputes every point in
+ * float64 from the grid and the id alone; fp32 grid coordinates {x, y, z, bits(edge id)} are expanded from the records on
+ * request (cx_level0_download, cx_level0_device_ptrs).
  * cx_extract3d enqueues the kernels and returns the counts (one device->host copy);
  * the _async form only enqueues.  Returns CX_ERR_CAPACITY (with valid counts) if a buffer was too
  * small: call cx_reserve with the counts and extract again. */
@@ -109,8 +112,12 @@ int cx_levels_select(cx_ctx* ctx, int32_t index);
 int cx_level0_path(cx_ctx* ctx, int* path);
 /* copy the Level-0 mesh to host: verts = n_vertices*4 floats, tris = n_triangles*3 int32 */
 int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris);
-/* device pointers of the Level-0 buffers (valid until the next extract / reserve / destroy) */
+/* device pointers of the Level-0 mesh (valid until the next extract / reserve / destroy / call of this function): the
+ * vertex records expanded to float4 {x, y, z, bits(edge id)} (enqueued on the context's stream) and the index triples */
 int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris);
+/* device pointers of the Level-0 buffers as the march leaves them: n_vertices x {uint32 edge id, fp32 t}, n_triangles x 3
+ * int32 (no copy, no kernel; valid until the next extract / reserve / destroy) */
+int cx_level0_device_records(cx_ctx* ctx, void** vertex_records, void** tris);
 
 /* ---- Level 1: mesh post-passes -------------------------------------------------------------------
  * Replaces GridContour.quantize_interpolations (tetrahedral.py:190-215), remove_tiny_simplices
