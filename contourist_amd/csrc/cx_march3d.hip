@@ -1047,6 +1047,11 @@ __device__ __forceinline__ uint64_t py_round_signed(uint64_t acc, int32_t x) {
     acc = (acc << 31) | (acc >> 33);
     return acc * CX_PY_P1;
 }
+// the second half of py_round: acc already holds accumulator + lane * P2
+__device__ __forceinline__ uint64_t py_round_tail(uint64_t acc) {
+    acc = (acc << 31) | (acc >> 33);
+    return acc * CX_PY_P1;
+}
 __device__ __forceinline__ uint64_t py_finish3(uint64_t acc) {
     acc += 3ULL ^ (CX_PY_P5 ^ 3527539ULL);
     return (acc == ~0ULL) ? 1546275796ULL : acc;
@@ -1107,13 +1112,71 @@ __device__ constexpr uint32_t CX_TRI_CD[6][16][2][2] = CX_TET_TRIS_CD_INIT;
 #ifndef CX_VE_ROW
 #define CX_VE_ROW 65
 #endif
-#define CX_T2_MAX 1024u
+// what depends on the corner sign mask of a voxel alone, as tables (built at compile time from the tetrahedron list)
+constexpr uint8_t CX_TCH[6][4] = CX_TET_CORNERS_INIT;
+struct cx_pats_tab {
+    uint32_t w[256][2];    // [sm]: x = 6 tetrahedron patterns x 4 bits (bit m: tet vertex m is low) | mask of the 2-2 tetrahedra << 24;
+                           //       y = mask of the 1-3 / 3-1 tetrahedra | neighbour cells 1..6 that own a crossing edge of the voxel << 8
+    uint16_t c22[6 * 16];  // [tet * 16 + pattern] of a 2-2 tetrahedron: cube corners of its low pair and of its high pair (tet
+                           // vertex order = the reference's set insertion order), 3 bits each
+};
+constexpr cx_pats_tab cx_make_pats() {
+    cx_pats_tab T{};
+    for (uint32_t sm = 0; sm < 256u; sm++) {
+        uint32_t pw = 0, m22 = 0, m1 = 0, want = 0;
+        for (uint32_t t = 0; t < 6u; t++) {
+            uint32_t pat = 0, np = 0;
+            for (uint32_t m = 0; m < 4u; m++) {
+                const uint32_t b = (sm >> CX_TCH[t][m]) & 1u;
+                pat |= b << m;
+                np += b;
+            }
+            pw |= pat << (4u * t);
+            if (np == 2u) m22 |= 1u << t;
+            if (np == 1u || np == 3u) m1 |= 1u << t;
+        }
+        for (uint32_t c = 1; c < 7u; c++) {
+            // does corner c own a crossing edge of this voxel?  (a strict superset corner on the other side)
+            const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
+            uint32_t sup = 0;
+            for (uint32_t c2 = 0; c2 < 8u; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
+            if (((sm ^ sc) & sup) != 0u) want |= 1u << c;
+        }
+        T.w[sm][0] = pw | (m22 << 24);
+        T.w[sm][1] = m1 | (want << 8);
+    }
+    for (uint32_t t = 0; t < 6u; t++)
+        for (uint32_t pat = 0; pat < 16u; pat++) {
+            uint32_t lo[2] = {0, 0}, hi[2] = {0, 0}, nl = 0, nh = 0;
+            for (uint32_t m = 0; m < 4u; m++) {
+                if ((pat >> m) & 1u) { if (nl < 2u) lo[nl] = CX_TCH[t][m]; nl++; }
+                else { if (nh < 2u) hi[nh] = CX_TCH[t][m]; nh++; }
+            }
+            T.c22[t * 16u + pat] = (uint16_t)((nl == 2u) ? (lo[0] | (lo[1] << 3) | (hi[0] << 6) | (hi[1] << 9)) : 0u);
+        }
+    return T;
+}
+__device__ constexpr cx_pats_tab CX_PATS = cx_make_pats();
 struct cx_tri_lds {
     uint2 ve[4][7][CX_VE_ROW];   // per wave: (first vertex, crossing mask) of corner c of each cell (rows padded: bank spread)
-    uint16_t slot[4][12 * 64];   // per wave: one word per triangle
-    uint32_t tfirst[4][64];      // per wave: first triangle index of each cell minus its rank in the wave
+    union {
+        struct {
+            uint16_t slot[12 * 64];  // one word per triangle
+            uint32_t tfirst[64];     // first triangle index of each cell minus its rank in the wave
+        } a;
+        uint32_t hs[8][64];          // low words of the 8 corner hashes of each cell (dead before the slot words are written)
+    } u[4];                      // per wave
+    uint16_t slot22[4][6 * 64];  // per wave: one word per 2-2 tetrahedron: cell lane | tet << 6 | pattern << 9
+    uint32_t var[4][64];         // per wave: quad diagonal variants of each cell (bit t)
     uint32_t lut[6 * 16 * 2 * 2];
+    uint2 pats[256];
+    uint16_t c22[6 * 16];
 };
+__device__ __forceinline__ void cx_tri_lds_init(cx_tri_lds& L) {
+    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    for (uint32_t x = threadIdx.x; x < 256u; x += blockDim.x) L.pats[x] = make_uint2(CX_PATS.w[x][0], CX_PATS.w[x][1]);
+    for (uint32_t x = threadIdx.x; x < 96u; x += blockDim.x) L.c22[x] = CX_PATS.c22[x];
+}
 // slot word: bits 0-5 cell lane, 6 second triangle of the entry, 7-14 LUT entry (tet*32 + pattern*2 + variant)
 
 // everything of one cell record that comes from memory.  The loads of record n+1 are issued before
@@ -1191,22 +1254,30 @@ __device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
 // phase 1 of one record per lane: LDS tables and slot words; returns the wave's triangle count
 // NEG_ORIGIN: the array starts at a negative lattice point (rim of extra samples): signed hash lanes.  A kernel of its
 // own, because the extra path costs the common one ~9 % when it is a run-time branch (registers, code size)
+//
+// The triangle kernels are bound by VALU issue, so everything that depends on the corner sign mask
+// alone comes from a table (CX_PATS: the 6 tetrahedron patterns, which tetrahedra split 2-2 / 1-3, which neighbour cells own an
+// edge of the voxel), and the CPython set order of the quad diagonals is decided one lane per 2-2 TETRAHEDRON instead of six
+// predicated tetrahedra per cell lane: a voxel has 1.7 of them on average, so two rounds of 64 lanes replace six unrolled
+// hash comparisons per lane.  The corner hashes (low words) of a round's cells go through LDS (hs), overlaying the slot
+// words, which are written afterwards.
 template <bool NEG_ORIGIN>
-__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I,
-                                                  const uint64_t* t2 = nullptr) {
+__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
     const uint32_t sm = I.rec.y & 0xFFu, tetskip = (I.rec.y >> 8) & 0x3Fu, ntri = (I.rec.y >> 16) & 0xFFu;
     L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
 #pragma unroll
     for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u];
+    const uint2 pw = L.pats[sm];                                  // x: 6 patterns x 4 bits | 2-2 mask << 24; y: 1-3 mask | wanted neighbours << 8
+    const uint32_t em6 = ntri ? (~tetskip & 0x3Fu) : 0u;          // tetrahedra that emit
+    const uint32_t m22 = (pw.x >> 24) & em6, m1 = pw.y & em6;
     // quad diagonal variants of the 2-2 tetrahedra (bit t of `variants`)
     uint32_t variants = 0;
     if (P.hbytes) {
         // code of corner c = byte (c & 1) of column c >> 1
 #pragma unroll
         for (int t = 0; t < 6; t++) {
-            const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                                 (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-            if (__popc(pat) != 2) continue;
+            const uint32_t pat = (pw.x >> (4 * t)) & 15u;
+            if (!((m22 >> t) & 1u)) continue;
             uint32_t l0 = 0, l1 = 0, h0 = 0, h1 = 0;
             int nl = 0, nh = 0;
 #pragma unroll
@@ -1218,69 +1289,66 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
             }
             if (cx_set2_swapped(l0, l1) != cx_set2_swapped(h0, h1)) variants |= 1u << t;
         }
-    } else if (P.flags & CX_DIAG_CPYTHON310) {
-        const uint32_t need = cx_need_hash(sm, tetskip, ntri);
-        if (__ballot(need != 0u) != 0ULL) {
+    } else if ((P.flags & CX_DIAG_CPYTHON310) && __ballot(m22 != 0u) != 0ULL) {
+        // (k + origin) * P2 of the tuple hash's last round for k and k + 1 (as CPython sees the lattice coordinate: hash(-1) == -2)
+        uint64_t kp0, kp1;
+        if (!NEG_ORIGIN) {
+            kp0 = (uint64_t)(I.ck + P.org2) * CX_PY_P2;
+            kp1 = kp0 + CX_PY_P2;
+        } else {
+            const int32_t v0 = (int32_t)I.ck + (int32_t)P.org2, v1 = v0 + 1;
+            kp0 = ((v0 == -1) ? ~1ULL : (uint64_t)(int64_t)v0) * CX_PY_P2;
+            kp1 = ((v1 == -1) ? ~1ULL : (uint64_t)(int64_t)v1) * CX_PY_P2;
+        }
+        bool exact = (P.flags & CX_DBG_HASH64) != 0u;
+        if (!exact) {
             // Fast form: only the LOW 32 bits of the corner hashes -- a probe step of the set order reads three bits five places
-            // further up, so five steps fit -- with k * P2 from a table in LDS (t2): one 32-bit multiplication per corner
-            // instead of seven (integer multiplications run at a quarter of the VALU rate, and this kernel is bound by VALU
-            // issue: DESIGN.md section 4).  A pair still on one slot after five steps, or a hash word of all ones (possibly
+            // further up, so five steps fit.  A pair still on one slot after five steps, or a hash word of all ones (possibly
             // the hash CPython replaces by a constant), sends the whole wave through the 64-bit form below.
-            bool exact = (t2 == nullptr);
-            if (!exact) {
-                uint32_t h[8];
-                bool bad = false;
+            bool bad = false;
+            uint32_t (*hs)[64] = L.u[wave].hs;
 #pragma unroll
-                for (uint32_t c = 0; c < 8; c++) {
-                    h[c] = 0;
-                    if ((need >> c) & 1u) {
-                        const uint64_t sacc = I.hxy[c >> 1] + t2[I.ck + (c & 1u)];
-                        const uint32_t rot = __builtin_amdgcn_alignbit((uint32_t)sacc, (uint32_t)(sacc >> 32), 1);   // low word of rotl64(s, 31)
-                        h[c] = rot * (uint32_t)CX_PY_P1 + (uint32_t)(3ULL ^ (CX_PY_P5 ^ 3527539ULL));
-                        bad = bad || (h[c] == 0xFFFFFFFFu);
-                    }
-                }
-                uint32_t var32 = 0;
-#pragma unroll
-                for (int t = 0; t < 6; t++) {
-                    const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                                         (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-                    if (__popc(pat) != 2) continue;
-                    uint32_t hl0 = 0, hl1 = 0, hh0 = 0, hh1 = 0;
-                    int nl = 0, nh = 0;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const uint32_t hm = h[CX_TC[t][m]];
-                        if ((pat >> m) & 1u) { if (nl == 0) hl0 = hm; else hl1 = hm; nl++; }
-                        else { if (nh == 0) hh0 = hm; else hh1 = hm; nh++; }
-                    }
-                    bool u1, u2;
-                    if (py_set2_swapped_lo(hl0, hl1, u1) != py_set2_swapped_lo(hh0, hh1, u2)) var32 |= 1u << t;
-                    bad = bad || u1 || u2;
-                }
-                variants = var32;
-                exact = __ballot(bad && need != 0u) != 0ULL;
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint64_t sacc = I.hxy[c >> 1] + ((c & 1u) ? kp1 : kp0);
+                const uint32_t rot = __builtin_amdgcn_alignbit((uint32_t)sacc, (uint32_t)(sacc >> 32), 1);   // low word of rotl64(s, 31)
+                const uint32_t h = rot * (uint32_t)CX_PY_P1 + (uint32_t)(3ULL ^ (CX_PY_P5 ^ 3527539ULL));
+                bad = bad || (h == 0xFFFFFFFFu);
+                hs[c][lane] = h;
             }
-            if (exact) {
+            bad = bad && m22 != 0u;
+            L.var[wave][lane] = 0u;
+            uint32_t tot22;
+            const uint32_t pre22 = cx_wave_prefix_small<3>(__popc(m22), tot22);
+#pragma unroll
+            for (uint32_t t = 0; t < 6; t++)
+                if ((m22 >> t) & 1u)
+                    L.slot22[wave][pre22 + __popc(m22 & ((1u << t) - 1u))] = (uint16_t)(lane | (t << 6) | (((pw.x >> (4u * t)) & 15u) << 9));
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j0 = 0; j0 < tot22; j0 += 64u) {   // wave-uniform: one lane per 2-2 tetrahedron
+                const uint32_t j = j0 + lane;
+                const bool ok = j < tot22;
+                const uint32_t w = L.slot22[wave][ok ? j : 0u];
+                const uint32_t cell = w & 63u, t = (w >> 6) & 7u;
+                const uint32_t cc = L.c22[(t << 4) | (w >> 9)];   // corners of the low pair and of the high pair, 3 bits each
+                bool u1, u2;
+                const bool a = py_set2_swapped_lo(hs[cc & 7u][cell], hs[(cc >> 3) & 7u][cell], u1);
+                const bool b = py_set2_swapped_lo(hs[(cc >> 6) & 7u][cell], hs[(cc >> 9) & 7u][cell], u2);
+                if (ok && a != b) atomicOr(&L.var[wave][cell], 1u << t);
+                bad = bad || (ok && (u1 || u2));
+            }
+            __builtin_amdgcn_wave_barrier();
+            variants = L.var[wave][lane];
+            exact = __ballot(bad) != 0ULL;
+        }
+        if (exact) {
             variants = 0;
-            uint64_t h[8];            if (!NEG_ORIGIN) {
+            uint64_t h[8];
 #pragma unroll
-                for (uint32_t c = 0; c < 8; c++) {
-                    h[c] = 0;
-                    if ((need >> c) & 1u) h[c] = py_finish3(py_round(I.hxy[c >> 1], I.ck + (c & 1u) + P.org2));
-                }
-            } else {   // signed lanes
-#pragma unroll
-                for (uint32_t c = 0; c < 8; c++) {
-                    h[c] = 0;
-                    if ((need >> c) & 1u) h[c] = py_finish3(py_round_signed(I.hxy[c >> 1], (int32_t)(I.ck + (c & 1u)) + (int32_t)P.org2));
-                }
-            }
+            for (uint32_t c = 0; c < 8; c++) h[c] = py_finish3(py_round_tail(I.hxy[c >> 1] + ((c & 1u) ? kp1 : kp0)));
 #pragma unroll
             for (int t = 0; t < 6; t++) {
-                const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                                     (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-                if (__popc(pat) != 2) continue;
+                if (!((m22 >> t) & 1u)) continue;
+                const uint32_t pat = (pw.x >> (4 * t)) & 15u;
                 // low set and high set, each in insertion (tet vertex) order
                 uint64_t hl0 = 0, hl1 = 0, hh0 = 0, hh1 = 0;
                 int nl = 0, nh = 0;
@@ -1292,24 +1360,22 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
                 }
                 if (py_set2_swapped(hl0, hl1) != py_set2_swapped(hh0, hh1)) variants |= 1u << t;
             }
-            }
         }
+        __builtin_amdgcn_wave_barrier();   // hs is dead: the slot words below overlay it
     }
     // slot words of this cell's triangles, in tetrahedron order
     uint32_t ttot;
     const uint32_t tpre = cx_wave_prefix_small<4>(ntri, ttot);
-    L.tfirst[wave][lane] = I.rec.z - tpre;   // triangle j of the wave goes to tfirst[cell] + j
+    L.u[wave].a.tfirst[lane] = I.rec.z - tpre;   // triangle j of the wave goes to tfirst[cell] + j
     uint32_t pos = tpre;
+    uint16_t* slot = L.u[wave].a.slot;
 #pragma unroll
-    for (int t = 0; t < 6; t++) {
-        const uint32_t pat = ((sm >> CX_TC[t][0]) & 1u) | (((sm >> CX_TC[t][1]) & 1u) << 1) |
-                             (((sm >> CX_TC[t][2]) & 1u) << 2) | (((sm >> CX_TC[t][3]) & 1u) << 3);
-        const uint32_t np = __popc(pat);
-        const uint32_t nt = (ntri == 0u || ((tetskip >> t) & 1u)) ? 0u : ((np == 2u) ? 2u : (np & 1u));
-        const uint32_t word = lane | (((uint32_t)t * 32u + pat * 2u + ((variants >> t) & 1u)) << 7);
-        if (nt >= 1u) L.slot[wave][pos] = (uint16_t)word;
-        if (nt == 2u) L.slot[wave][pos + 1u] = (uint16_t)(word | (1u << 6));
-        pos += nt;
+    for (uint32_t t = 0; t < 6; t++) {
+        const uint32_t two = (m22 >> t) & 1u, one = (m1 >> t) & 1u;
+        const uint32_t word = lane | (t << 12) | (((pw.x >> (4u * t)) & 15u) << 8) | (((variants >> t) & 1u) << 7);
+        if (two | one) slot[pos] = (uint16_t)word;
+        if (two) slot[pos + 1u] = (uint16_t)(word | (1u << 6));
+        pos += 2u * two + one;
     }
     __builtin_amdgcn_wave_barrier();
     return ttot;
@@ -1319,7 +1385,7 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
     for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
         const uint32_t j = j0 + lane;
         const bool ok = j < ttot;
-        const uint32_t w = L.slot[wave][ok ? j : 0u];
+        const uint32_t w = L.u[wave].a.slot[ok ? j : 0u];
         const uint32_t cell = w & 63u;
         const uint32_t tw = L.lut[((w >> 7) & 0xFFu) * 2u + ((w >> 6) & 1u)];
         int32_t vi[3];
@@ -1332,7 +1398,7 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
         if (ok && !(P.flags & CX_DBG_NO_TRIS)) {
             // 32-bit wrap-around on purpose: tfirst = first - rank may be "negative" when the wave's cells come from
             // different reservations (generic path); the sum is the triangle index again
-            int32_t* out = P.tris + (size_t)(uint32_t)(L.tfirst[wave][cell] + j) * 3u;
+            int32_t* out = P.tris + (size_t)(uint32_t)(L.u[wave].a.tfirst[cell] + j) * 3u;
 #if CX_NT_TRIS
             typedef int32_t cx_v3i __attribute__((ext_vector_type(3)));
             __builtin_nontemporal_store(cx_v3i{vi[0], vi[1], vi[2]}, reinterpret_cast<cx_v3i*>(out));
@@ -1366,15 +1432,7 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
-    // k -> (k + origin) * P2 of the tuple hash's last round (as CPython sees the lattice coordinate: hash(-1) == -2)
-    __shared__ uint64_t s_t2[CX_T2_MAX];
-    const bool use_t2 = (P.flags & CX_DIAG_CPYTHON310) && P.n2 <= CX_T2_MAX && !(P.flags & CX_DBG_HASH64);
-    if (use_t2)
-        for (uint32_t x = threadIdx.x; x < P.n2; x += blockDim.x) {
-            const int32_t v = (int32_t)x + (int32_t)P.org2;
-            s_t2[x] = ((v == -1) ? ~1ULL : (uint64_t)(int64_t)v) * CX_PY_P2;
-        }
-    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    cx_tri_lds_init(L);
     __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1389,7 +1447,7 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
         const uint32_t nidx = idx + stride;
         cx_tri_fetch(P, hash_xy, rec_b, Ib);                                    // loads of the next record ...
         uint4 rec_c = (nidx + stride < ncells) ? cx_load_record(P.cells + nidx + stride) : zero;   // ... and the record after it
-        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia, use_t2 ? s_t2 : nullptr);
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
         cx_tri_pin(Ib, rec_c);                                                  // ... are back before the stores go out
         cx_tri_phase2(P, L, lane, wave, ttot);
         Ia = Ib;
@@ -1424,7 +1482,7 @@ __device__ __forceinline__ uint32_t cx_wave_of_neighbour(const cx_task& T, uint3
     if (wsel & 4u) wY += 4u * T.nks * T.njg;                              // next chunk of planes
     return wY;
 }
-__device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const uint64_t* __restrict__ hash_xy, const uint4& rec,
+__device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const cx_tri_lds& L, const uint4& rec,
                                                cx_tri_qa& A) {
     const uint32_t plane = P.n1 * P.n2;
     A.rec = rec;
@@ -1446,15 +1504,13 @@ __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task
     const uint32_t cr[2] = {4u * rr, 4u * ((rr + 1u) & 3u)};
     const uint32_t pofs[2] = {ps << 6, pl ? 0u : ((ps + 1u) << 6)};
     A.nbw = 0;
+    // neighbour cells that own a crossing edge of this voxel (bit c), from the table
+    const uint32_t want = (ntri && !(P.flags & CX_DBG_NO_LOOKUP)) ? (L.pats[sm].y >> 8) : 0u;
 #pragma unroll
     for (uint32_t c = 1; c < 7; c++) {
         const uint32_t dk = c & 1u, dj = (c >> 1) & 1u, di = c >> 2;
-        const uint32_t sc = ((sm >> c) & 1u) ? 0xFFu : 0u;
-        uint32_t sup = 0;
-#pragma unroll
-        for (uint32_t c2 = 0; c2 < 8; c2++) sup |= ((c2 & c) == c && c2 != c) ? (1u << c2) : 0u;
         A.qa[c - 1u] = 0;
-        if (ntri && ((sm ^ sc) & sup) != 0u && !(P.flags & CX_DBG_NO_LOOKUP)) {
+        if ((want >> c) & 1u) {
             const uint32_t wsel = (dk ? kfl : 0u) | ((dj ? r3 : 0u) << 1) | ((di ? pl : 0u) << 2);
             const uint32_t wY = cx_wave_of_neighbour(T, A.w, wsel);
 #ifdef CX_ABL_QA     // timing experiment: no queue-word gathers
@@ -1467,7 +1523,7 @@ __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task
         }
     }
     A.ci = ci; A.cj = cj; A.ck = ck;
-    (void)hash_xy; (void)tetskip;
+    (void)tetskip;
 }
 __device__ __forceinline__ void cx_triq_pin1(cx_tri_qa& A, uint4& nxt) {
     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) :: "memory");
@@ -1518,15 +1574,7 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
     if (blockIdx.x * blockDim.x >= ncells) return;                 // whole block idle
-    // k -> (k + origin) * P2 of the tuple hash's last round (as CPython sees the lattice coordinate: hash(-1) == -2)
-    __shared__ uint64_t s_t2[CX_T2_MAX];
-    const bool use_t2 = (P.flags & CX_DIAG_CPYTHON310) && P.n2 <= CX_T2_MAX && !(P.flags & CX_DBG_HASH64);
-    if (use_t2)
-        for (uint32_t x = threadIdx.x; x < P.n2; x += blockDim.x) {
-            const int32_t v = (int32_t)x + (int32_t)P.org2;
-            s_t2[x] = ((v == -1) ? ~1ULL : (uint64_t)(int64_t)v) * CX_PY_P2;
-        }
-    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    cx_tri_lds_init(L);
     __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1541,8 +1589,8 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     {
         uint4 r0 = record(idx), r1 = record(idx + stride);
         asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w) :: "memory");
-        cx_triq_stage1(P, T, hash_xy, r0, Ac);
-        cx_triq_stage1(P, T, hash_xy, r1, Ab);
+        cx_triq_stage1(P, T, L, r0, Ac);
+        cx_triq_stage1(P, T, L, r1, Ab);
         cx_triq_pin1(Ac, rec_c);
         cx_triq_pin1(Ab, rec_c);
         cx_triq_stage2(P, T, hash_xy, Ac, Ia);
@@ -1551,9 +1599,9 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     while (idx - lane < ncells) {   // wave-uniform
         const uint32_t nidx = idx + stride;
         uint4 rec_d = record(nidx + 2u * stride);          // the record three steps ahead
-        cx_triq_stage1(P, T, hash_xy, rec_c, Ac);           // queue words of the record two steps ahead
+        cx_triq_stage1(P, T, L, rec_c, Ac);           // queue words of the record two steps ahead
         cx_triq_stage2(P, T, hash_xy, Ab, Ib);              // info words (and hash prefixes) of the next record
-        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia, use_t2 ? s_t2 : nullptr);
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
         cx_triq_pin1(Ac, rec_d);                            // ... all back before the stores go out
         cx_triq_pin2(Ib);
         cx_tri_phase2(P, L, lane, wave, ttot);
@@ -1834,7 +1882,7 @@ __device__ __forceinline__ uint32_t cx_mesh_phase1(const cx_params& P, cx_tri_ld
             if (cx_set2_swapped(l0, l1) != cx_set2_swapped(h0, h1)) variants |= 1u << t;
         }
     }
-    L.tfirst[wave][lane] = R.tbase;   // triangle j of the round goes to tbase + j
+    L.u[wave].a.tfirst[lane] = R.tbase;   // triangle j of the round goes to tbase + j
     uint32_t pos = R.tpre;
 #pragma unroll
     for (int t = 0; t < 6; t++) {
@@ -1843,8 +1891,8 @@ __device__ __forceinline__ uint32_t cx_mesh_phase1(const cx_params& P, cx_tri_ld
         const uint32_t np = __popc(pat);
         const uint32_t nt = (ntri == 0u) ? 0u : ((np == 2u) ? 2u : (np & 1u));
         const uint32_t word = lane | (((uint32_t)t * 32u + pat * 2u + ((variants >> t) & 1u)) << 7);
-        if (nt >= 1u) L.slot[wave][pos] = (uint16_t)word;
-        if (nt == 2u) L.slot[wave][pos + 1u] = (uint16_t)(word | (1u << 6));
+        if (nt >= 1u) L.u[wave].a.slot[pos] = (uint16_t)word;
+        if (nt == 2u) L.u[wave].a.slot[pos + 1u] = (uint16_t)(word | (1u << 6));
         pos += nt;
     }
     __builtin_amdgcn_wave_barrier();
@@ -1860,7 +1908,7 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;   // host re-runs with more room
     const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
     if (blockIdx.x * 4u >= nbatches) return;
-    for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.tri.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
+    cx_tri_lds_init(L.tri);
     L.ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
     __syncthreads();
     const float* __restrict__ A = P.grid;
