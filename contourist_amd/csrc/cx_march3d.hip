@@ -1471,22 +1471,22 @@ __global__ __launch_bounds__(256, CX_K2_MIN_WAVES) void cx_k_emit_triangles(cons
 static_assert(CX_RJ == 4, "the wave / row arithmetic below assumes 4 rows per streaming wave");
 struct cx_tri_qa {          // a record between its first stage (queue words requested) and its second
     uint4 rec;
-    uint32_t qa[6];         // per neighbour: (queue position of the lane's first cell << 16) | active cells below the neighbour
-    uint32_t nbw, w;        // 3 bits per neighbour (next k | next j << 1 | next chunk << 2), bit 18 + c: wanted; streaming wave of the cell
-    uint32_t ci, cj, ck;    // lattice point of the cell
+    uint32_t qa[6];         // per neighbour cell X + c, c = 1..6: the queue word of its streaming lane and plane step, as loaded
+    uint32_t geo;           // bits 0-5: neighbour c is wanted (bit c-1); 6: X + dk is in the next k block; 7: X + dj in the next wave;
+                            // 8: X + di in the next chunk of planes; 9-10: row of X in its wave; 11-12: sample of X in its lane
+    uint32_t w;             // streaming wave of the cell
+    uint32_t ij, ck;        // (i * n1 + j) and k of the cell's lattice point
 };
-__device__ __forceinline__ uint32_t cx_wave_of_neighbour(const cx_task& T, uint32_t w, uint32_t wsel) {
-    uint32_t wY = w;
-    if (wsel & 1u) wY += 4u;                                              // next block in k
-    if (wsel & 2u) wY += ((w & 3u) == 3u) ? (4u * T.nks - 3u) : 1u;       // next wave / next block in j
-    if (wsel & 4u) wY += 4u * T.nks * T.njg;                              // next chunk of planes
-    return wY;
+// byte-offset loads with a 32-bit offset from a uniform base (global_load with an SGPR base and a VGPR offset: no 64-bit
+// address arithmetic per lane); the tables they read are smaller than 4 GiB
+__device__ __forceinline__ uint32_t cx_ld_u32_at(const uint32_t* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const cx_tri_lds& L, const uint4& rec,
                                                cx_tri_qa& A) {
     const uint32_t plane = P.n1 * P.n2;
     A.rec = rec;
-    const uint32_t lin = rec.x, sm = rec.y & 0xFFu, tetskip = (rec.y >> 8) & 0x3Fu, ntri = (rec.y >> 16) & 0xFFu;
+    const uint32_t lin = rec.x, sm = rec.y & 0xFFu, ntri = (rec.y >> 16) & 0xFFu;
     const uint32_t ci = cx_div(lin, P.div_plane);
     const uint32_t rem = lin - ci * plane;
     const uint32_t cj = cx_div(rem, P.div_row);
@@ -1496,34 +1496,33 @@ __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task
     const uint32_t ps = ci - ic * T.ci;
     const uint32_t nsteps = min(T.ci, P.n0 - ic * T.ci);
     const uint32_t rr = cj & 3u, ls = (ck >> 2) & 63u, mm = ck & 3u;
-    A.w = 4u * ((ck >> 8) + T.nks * ((cj >> 4) + T.njg * ic)) + ((cj >> 2) & 3u);
-    const uint32_t m3 = (mm == 3u) ? 1u : 0u, r3 = (rr == 3u) ? 1u : 0u, pl = (ps + 1u == nsteps) ? 1u : 0u;
-    const uint32_t kfl = m3 & ((ls == 63u) ? 1u : 0u);
-    const uint32_t lane_k[2] = {ls, m3 ? ((ls + 1u) & 63u) : ls};
-    const uint32_t cm[2] = {mm, (mm + 1u) & 3u};
-    const uint32_t cr[2] = {4u * rr, 4u * ((rr + 1u) & 3u)};
-    const uint32_t pofs[2] = {ps << 6, pl ? 0u : ((ps + 1u) << 6)};
-    A.nbw = 0;
+    const uint32_t wv = (cj >> 2) & 3u;
+    A.w = 4u * ((ck >> 8) + T.nks * ((cj >> 4) + T.njg * ic)) + wv;
+    const bool m3 = (mm == 3u), r3 = (rr == 3u), pl = (ps + 1u == nsteps);
+    const bool kfl = m3 && ls == 63u;
     // neighbour cells that own a crossing edge of this voxel (bit c), from the table
-    const uint32_t want = (ntri && !(P.flags & CX_DBG_NO_LOOKUP)) ? (L.pats[sm].y >> 8) : 0u;
+    const uint32_t want = (ntri && !(P.flags & CX_DBG_NO_LOOKUP)) ? ((L.pats[sm].y >> 9) & 0x3Fu) : 0u;
+    A.geo = want | (kfl ? 64u : 0u) | (r3 ? 128u : 0u) | (pl ? 256u : 0u) | (rr << 9) | (mm << 11);
+    A.ij = ci * P.n1 + cj; A.ck = ck;
+    // word index of the queue word of X + c in P.qa = [wave][plane step][lane]: a sum of one term per axis.  The neighbour
+    // is in the same lane word unless X is in the last sample column (next lane, or lane 0 of the next k block), the last
+    // row (next wave, or the first wave of the next block in j) or the last plane step (the next chunk of planes)
+    constexpr uint32_t WQ = CX_SWP * 64u;
+    const uint32_t bk1 = kfl ? 4u * WQ : (m3 ? ls + 1u : ls);
+    const uint32_t bj1 = r3 ? ((wv == 3u) ? (4u * T.nks - 3u) * WQ : WQ) : 0u;
+    const uint32_t bp0 = ps << 6, bp1 = pl ? 4u * T.nks * T.njg * WQ : ((ps + 1u) << 6);
+    const uint32_t base = A.w * WQ;
+    const uint32_t B0 = base + bp0, B1 = base + bp1, B0j = B0 + bj1, B1j = B1 + bj1;
+    const uint32_t idx[6] = {B0 + bk1, B0j + ls, B0j + bk1, B1 + ls, B1 + bk1, B1j + ls};
 #pragma unroll
-    for (uint32_t c = 1; c < 7; c++) {
-        const uint32_t dk = c & 1u, dj = (c >> 1) & 1u, di = c >> 2;
-        A.qa[c - 1u] = 0;
-        if ((want >> c) & 1u) {
-            const uint32_t wsel = (dk ? kfl : 0u) | ((dj ? r3 : 0u) << 1) | ((di ? pl : 0u) << 2);
-            const uint32_t wY = cx_wave_of_neighbour(T, A.w, wsel);
+    for (uint32_t c = 0; c < 6; c++) {
+        A.qa[c] = 0;
 #ifdef CX_ABL_QA     // timing experiment: no queue-word gathers
-            const uint32_t qa = (wY * 977u + pofs[di] + lane_k[dk]) & 0x00FFFFFFu;
+        if ((want >> c) & 1u) A.qa[c] = (idx[c] * 977u) & 0x00FFFFFFu;
 #else
-            const uint32_t qa = P.qa[(size_t)wY * (CX_SWP * 64u) + pofs[di] + lane_k[dk]];
+        if ((want >> c) & 1u) A.qa[c] = cx_ld_u32_at(P.qa, idx[c] << 2);
 #endif
-            A.qa[c - 1u] = (qa & 0xFFFF0000u) | (qa & ((1u << (cr[dj] + cm[dk])) - 1u));
-            A.nbw |= (wsel << (3u * (c - 1u))) | (1u << (18u + c));
-        }
     }
-    A.ci = ci; A.cj = cj; A.ck = ck;
-    (void)tetskip;
 }
 __device__ __forceinline__ void cx_triq_pin1(cx_tri_qa& A, uint4& nxt) {
     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) :: "memory");
@@ -1532,16 +1531,28 @@ __device__ __forceinline__ void cx_triq_pin1(cx_tri_qa& A, uint4& nxt) {
 __device__ __forceinline__ void cx_triq_stage2(const cx_params& P, const cx_task& T, const uint64_t* __restrict__ hash_xy, const cx_tri_qa& A,
                                                cx_tri_in& I) {
     I.rec = A.rec;
+    // queue entry of X + c = first entry of its wave + (queue position of its lane's first cell) + active cells of the lane below it
+    const bool kfl = (A.geo >> 6) & 1u, r3 = (A.geo >> 7) & 1u, pl = (A.geo >> 8) & 1u;
+    const uint32_t rr = (A.geo >> 9) & 3u, mm = (A.geo >> 11) & 3u;
+    const uint32_t qk1 = kfl ? 4u * T.wcap : 0u;
+    const uint32_t qj1 = r3 ? (((A.w & 3u) == 3u) ? (4u * T.nks - 3u) * T.wcap : T.wcap) : 0u;
+    const uint32_t qp1 = pl ? 4u * T.nks * T.njg * T.wcap : 0u;
+    const uint32_t Q0 = A.w * T.wcap, Q1 = Q0 + qp1, Q0j = Q0 + qj1, Q1j = Q1 + qj1;
+    const uint32_t qb[6] = {Q0 + qk1, Q0j, Q0j + qk1, Q1, Q1 + qk1, Q1j};
+    // bit of X + c in its lane's 16-bit set of active cells (bit 4r + m)
+    const uint32_t b00 = 4u * rr + mm, b01 = 4u * rr + ((mm + 1u) & 3u), b10 = 4u * ((rr + 1u) & 3u) + mm, b11 = 4u * ((rr + 1u) & 3u) + ((mm + 1u) & 3u);
+    const uint32_t bit[6] = {b01, b10, b11, b00, b01, b10};
 #pragma unroll
     for (uint32_t c = 0; c < 6; c++) {
         uint2 pr = make_uint2(0u, 0u);
-        if ((A.nbw >> (19u + c)) & 1u) {
-            const uint32_t wY = cx_wave_of_neighbour(T, A.w, (A.nbw >> (3u * c)) & 7u);
+        if ((A.geo >> c) & 1u) {
             const uint32_t qa = A.qa[c];
+            const uint32_t below = qa & ((1u << bit[c]) - 1u);     // bit[c] <= 15: only bits of the 16-bit set
+            const uint32_t at = qb[c] + (qa >> 16) + __popc(below);
 #ifdef CX_ABL_INFO   // timing experiment: no info-word gathers
-            const uint64_t e = ((uint64_t)0xFE << 32) | (uint64_t)(wY + qa);
+            const uint64_t e = ((uint64_t)0xFE << 32) | (uint64_t)at;
 #else
-            const uint64_t e = P.info64[(size_t)wY * T.wcap + (qa >> 16) + __popc(qa & 0xFFFFu)];
+            const uint64_t e = P.info64[at];
 #endif
             pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
         }
@@ -1555,8 +1566,8 @@ __device__ __forceinline__ void cx_triq_stage2(const cx_params& P, const cx_task
         // only voxels get here (cj + 1 < n1, ci + 1 < n0): the prefixes of columns (i, j), (i, j+1) are neighbours in the
         // table, ONE 16-byte load per plane (8-byte aligned)
         struct __attribute__((packed, aligned(8))) u64x2 { uint64_t a, b; };
-        const u64x2 p0 = *reinterpret_cast<const u64x2*>(hash_xy + (A.ci * P.n1 + A.cj));
-        const u64x2 p1 = *reinterpret_cast<const u64x2*>(hash_xy + ((A.ci + 1u) * P.n1 + A.cj));
+        const u64x2 p0 = *reinterpret_cast<const u64x2*>(hash_xy + A.ij);
+        const u64x2 p1 = *reinterpret_cast<const u64x2*>(hash_xy + (A.ij + P.n1));
         I.hxy[0] = p0.a; I.hxy[1] = p0.b; I.hxy[2] = p1.a; I.hxy[3] = p1.b;
     }
 }
