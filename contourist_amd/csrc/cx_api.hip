@@ -37,8 +37,10 @@ extern "C" int cx_ctx_create(int device_id, cx_ctx** out) {
         return CX_ERR_HIP;
     }
     ctx->own_stream = ctx->stream;
-    if (hipMalloc(&ctx->counters, CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc(&ctx->counters_host, CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess) {
+    // two counter blocks: [0, CX_CNT_WORDS) the 3-D march, [CX_CNT_WORDS, 2 CX_CNT_WORDS) the 4-D march -- a 4-D extraction on the
+    // same context must not disturb what a later relaunch of the 3-D vertex stage (cx_ensure_cell_records) reads on the device
+    if (hipMalloc(&ctx->counters, 2 * CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&ctx->counters_host, 2 * CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess) {
         cx_ctx_destroy(ctx);
         return CX_ERR_NOMEM;
     }

@@ -150,7 +150,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
         P.queue = S->queue; P.qcap = S->qcap; P.rounds = S->rounds;
-        P.counters = ctx->counters;
+        P.counters = ctx->counters + CX_CNT_WORDS;   // the 4-D march's own block (cx_ctx_create)
         P.lut = cx_pent_lut_device();
         if (!P.lut) { ctx->err = "pentatope table symbol not found"; return CX_ERR_HIP; }
         if (flags & CX_DIAG_CPYTHON310) {
@@ -187,21 +187,21 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         // the counter block is shared with the 3-D march: an enqueued 3-D extraction whose counts were never fetched
         // (cx_extract3d_async without cx_counts_get) loses them here and has to be run again
         if (ctx->extracted && !ctx->counts_fetched) ctx->extracted = false;
-        CX4_HIP(ctx, hipMemsetAsync(ctx->counters, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
+        CX4_HIP(ctx, hipMemsetAsync(ctx->counters + CX_CNT_WORDS, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
         cx_launch_signbits4d(P, ctx->stream);
         cx_launch_classify4d(P, ctx->stream);
         cx_launch_emit_tets(P, ctx->stream);
         CX4_HIP(ctx, hipGetLastError());
-        CX4_HIP(ctx, hipMemcpyAsync(ctx->counters_host, ctx->counters, CX_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CX4_HIP(ctx, hipMemcpyAsync(ctx->counters_host + CX_CNT_WORDS, ctx->counters + CX_CNT_WORDS, CX_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
         cx_counts c;
-        c.n_cells = ctx->counters_host[CX_CNT_CELLS];
-        c.n_vertices = ctx->counters_host[CX_CNT_VERTS];
-        c.n_triangles = ctx->counters_host[CX_CNT_TRIS];   // tetrahedra
-        c.n_border_voxels = ctx->counters_host[CX_CNT_BORDER];
+        c.n_cells = ctx->counters_host[CX_CNT_WORDS + CX_CNT_CELLS];
+        c.n_vertices = ctx->counters_host[CX_CNT_WORDS + CX_CNT_VERTS];
+        c.n_triangles = ctx->counters_host[CX_CNT_WORDS + CX_CNT_TRIS];   // tetrahedra
+        c.n_border_voxels = ctx->counters_host[CX_CNT_WORDS + CX_CNT_BORDER];
         S->counts = c;
         if (out) *out = c;
-        const uint32_t nq = ctx->counters_host[CX4_CNT_QUEUE];
+        const uint32_t nq = ctx->counters_host[CX_CNT_WORDS + CX4_CNT_QUEUE];
         if (nq > S->qcap) {   // nothing was classified: only the queue length is known
             if ((rc = reserve4(ctx, S, 0, 0, 0, (int64_t)nq + nq / 20 + 1024))) return rc;
             continue;

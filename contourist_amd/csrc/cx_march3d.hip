@@ -176,7 +176,7 @@ typedef uint32_t cx_v2u __attribute__((ext_vector_type(2)));
 // one round of 64 queued cells, as the vertex stage carries it from its front half (decode, prefix
 // sums, slot table, corner loads issued) to its back half (interpolation, stores)
 struct cx_vround {
-    uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, ctot, real_voxel;
+    uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, ctot, real_voxel, vk;
     uint64_t recm;
     cx_run base;                       // first vertex / triangle / record of the round
     float f[8];                        // the 8 corner samples of the lane's cell
@@ -198,14 +198,28 @@ __device__ __forceinline__ void cx_vround_front(const cx_params& P, const cx_fas
     // the voxel = 4 loads per lane whose addresses follow the queue order (runs along k inside a few rows).  One lane per
     // VERTEX loading its own two samples, as this stage did first, touched 2.7 x the cache lines: the vector L1 takes
     // about one line per 3-4 cycles per CU, and that -- not bytes -- bounds these kernels.
-    uint32_t vm;
+    // The loaded pairs stay untouched until the back half (cx_vround_corners): any arithmetic on them here would make the
+    // wave wait for the gathers right where it issues them (`s_waitcnt vmcnt` in front of the first use) instead of
+    // interpolating the previous round's vertices meanwhile.
+    uint32_t vm = cx_corner_valid(P, i, j, k);
+    R.vk = (vm >> 1) & 1u;
     if (P.flags & CX_DBG_NO_VLOADS) {
-        vm = cx_corner_valid(P, i, j, k);
 #pragma unroll
         for (int c = 0; c < 8; c++) R.f[c] = (float)(c + 1);
+        R.vk = 1u;
     } else {
-        vm = cx_load_corners(P, have ? R.lin : 0u, have ? i : 0u, have ? j : 0u, have ? k : 0u, R.f);
-        if (!have) vm = 0;
+        const float* __restrict__ A = P.grid;
+        const uint32_t lin = have ? R.lin : 0u;
+        const uint32_t oi = (have && (vm & 0x10u)) ? P.n1 * P.n2 : 0u, oj = (have && (vm & 4u)) ? P.n2 : 0u;
+        // at the array edge in k read the pair (k-1, k) instead and repeat k (as cx_load_corners does)
+        const uint32_t base = (R.vk || !have) ? lin : lin - 1u;
+        const cx_f2 p0 = *reinterpret_cast<const cx_f2*>(A + base);
+        const cx_f2 p1 = *reinterpret_cast<const cx_f2*>(A + base + oj);
+        const cx_f2 p2 = *reinterpret_cast<const cx_f2*>(A + base + oi);
+        const cx_f2 p3 = *reinterpret_cast<const cx_f2*>(A + base + oi + oj);
+        R.f[0] = p0.x; R.f[1] = p0.y; R.f[2] = p1.x; R.f[3] = p1.y;
+        R.f[4] = p2.x; R.f[5] = p2.y; R.f[6] = p3.x; R.f[7] = p3.y;
+        if (!have) { vm = 0; R.vk = 1u; }
     }
     R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
     const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
@@ -261,7 +275,7 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
         }
         // back half of round b0: the corner samples of the 64 cells go to LDS ...
 #pragma unroll
-        for (uint32_t c = 0; c < 8; c++) corners[lane * CX_CORNER_ROW + c] = Ra.f[c];
+        for (uint32_t c = 0; c < 8; c++) corners[lane * CX_CORNER_ROW + c] = ((c & 1u) || Ra.vk) ? Ra.f[c] : Ra.f[c + 1u];   // no k+1: the pair is (k-1, k)
         __builtin_amdgcn_wave_barrier();
         const bool vroom = Ra.base.v + Ra.vtot <= P.vcap;   // wave-uniform
         const uint32_t* slot = slot2 + par * 448u;
@@ -1004,6 +1018,8 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
+    // (Handing the batches out by a ticket counter instead -- one atomicAdd per wave and batch -- was 3 x slower: 25 k
+    // same-address atomics at the ~88 / us this chip sustains are 0.28 ms by themselves.)
     const uint32_t stride = gridDim.x * 4u;
     uint32_t f = blockIdx.x * 4u + wave;
     if (f >= nbatches) return;
