@@ -80,6 +80,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (ctx->info) (void)hipFree(ctx->info);
     if (ctx->info64) (void)hipFree(ctx->info64);
     if (ctx->chunksum) (void)hipFree(ctx->chunksum);
+    if (ctx->rstart) (void)hipFree(ctx->rstart);
     if (ctx->hbytes) (void)hipFree(ctx->hbytes);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
@@ -365,6 +366,15 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
         P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
+        P.nvw = cx_vertex_stage_waves(P);
+        if (ctx->rstart_cap < (size_t)P.nvw + 1u) {
+            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->rstart) (void)hipFree(ctx->rstart);
+            ctx->rstart = nullptr; ctx->rstart_cap = 0;
+            CX_HIP(ctx, hipMalloc(&ctx->rstart, ((size_t)P.nvw + 1u) * sizeof(uint32_t)));
+            ctx->rstart_cap = (size_t)P.nvw + 1u;
+        }
+        P.rstart = ctx->rstart;
         ctx->last = P;
     }
     ctx->last_task = T;

@@ -85,6 +85,8 @@ struct cx_params {
     cx_fdiv div_ci;           // / (cell planes per task)
     uint32_t* chunksum;       // [ceil(nwaves / 256)][8] totals (v, t, c, b, nb, near) of every 256 streaming waves, added up by the stream kernel
     uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
+    uint32_t* rstart;         // [nvw] vertex stage: the batch in which wave m's share of the rounds starts (written by the scan kernel)
+    uint32_t nvw;             // waves of the vertex stage (4 x its grid)
 };
 #ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
@@ -95,7 +97,7 @@ struct cx_wsum {   // 32 bytes
     uint32_t v, t, c, b;   // vertices, triangles, cell records, border voxels of the wave's cells
     uint32_t nq;           // queued cells
     uint32_t near;         // a sample of the wave's region lies inside the tolerance screen: per-cell path
-    uint32_t pad;
+    uint32_t nr;           // rounds of 64 queued cells, batch by batch (sum of ceil(n / 64))
 };
 struct cx_wbase {  // 16 bytes
     uint32_t v, t, c, boff;
@@ -108,7 +110,8 @@ struct cx_bdesc {  // 32 bytes: one batch as the emit kernel needs it
     uint32_t w;            // streaming wave (-> tile geometry)
     uint32_t qofs, n;      // its cells: queue[qofs .. qofs+n)
     uint32_t vbase, tbase, cbase;   // first vertex / triangle / cell record
-    uint32_t near, pad;
+    uint32_t near;
+    uint32_t rbase;        // rounds of 64 cells in the batches before this one
 };
 
 // launch geometry of the staged pipeline: workgroup -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
@@ -136,6 +139,7 @@ struct cx_task {
 
 enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4,
        CX_CNT_NEAR = 5,   // streaming waves that met a sample inside the tolerance screen (their cells take the per-cell path)
+       CX_CNT_ROUNDS = 6, // rounds of 64 queued cells over all batches (what the vertex stage divides among its waves)
        CX_CNT_WORDS = 8 };
 
 // device tables (defined in cx_march3d.hip)
@@ -153,6 +157,7 @@ void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_stream_levels(const cx_params* device_params, const cx_params& P0, const cx_task& T, uint32_t nlevels, hipStream_t s);
 void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uint32_t nlevels, hipStream_t s);
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
+uint32_t cx_vertex_stage_waves(const cx_params& P);   // -> cx_params::nvw (the scan kernel needs it before the vertex stage runs)
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s);

@@ -39,6 +39,8 @@ struct cx_ctx {
     size_t info64_cap = 0;
     uint32_t* chunksum = nullptr;      // totals of every 256 streaming waves (cx_params::chunksum)
     size_t chunksum_cap = 0;
+    uint32_t* rstart = nullptr;        // vertex stage: first batch of every wave's share of the rounds (cx_params::rstart)
+    size_t rstart_cap = 0;
     uint8_t* hbytes = nullptr;         // fused emit: CPython set-order code per lattice point (valid for hash_xy's shape and origin)
     size_t hbytes_cap = 0;
     bool hbytes_valid = false;

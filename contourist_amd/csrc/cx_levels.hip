@@ -43,6 +43,8 @@ struct cx_level_slot {
     uint32_t* counters = nullptr;
     uint32_t* chunksum = nullptr;
     size_t chunksum_cap = 0;
+    uint32_t* rstart = nullptr;        // vertex stage: first batch of every wave's share of the rounds
+    size_t rstart_cap = 0;
     // Level-0 outputs of the level (swapped with the context's while the level is selected)
     cx_vrec* verts = nullptr;
     uint4* cells = nullptr;
@@ -68,7 +70,7 @@ struct cx_levels_state {
 };
 
 static void free_slot(cx_level_slot& S) {
-    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.verts, S.cells, S.tris};
+    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.rstart, S.verts, S.cells, S.tris};
     for (void* p : all)
         if (p) (void)hipFree(p);
     S = cx_level_slot();
@@ -207,6 +209,9 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         P.queue = S.queue; P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
         P.qa = S.qa;
         P.chunksum = S.chunksum;
+        P.nvw = cx_vertex_stage_waves(P);
+        if ((rc = grow(ctx, S.rstart, S.rstart_cap, (size_t)P.nvw + 1u))) return rc;
+        P.rstart = S.rstart;
         P.verts = S.verts; P.cells = S.cells; P.tris = S.tris;
         P.vcap = S.vcap; P.ccap = S.ccap; P.tcap = S.tcap;
     }

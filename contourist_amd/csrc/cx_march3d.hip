@@ -257,22 +257,31 @@ __device__ __forceinline__ cx_vrec cx_vertex_record(const cx_params& P, const cx
 // are software-pipelined: the corner loads of round s+1 are issued, and waited for, before the stores of round s go
 // out (`s_waitcnt vmcnt` retires loads and stores in issue order: a load behind a store waits for it).
 // LDS per wave: two slot tables of 448 words (double buffered) and the corner table of 64 x CX_CORNER_ROW words.
-__device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n,
-                                                   uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut, uint64_t* info) {
+// `first`: the cell the walk starts at (a multiple of 64; `run` holds what precedes it), `n`: where it ends -- a wave takes a
+// range of a batch's rounds (cx_k_emit_vertices)
+__device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t first, uint32_t n,
+                                                   uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut, uint64_t* info, unsigned long long* tacc = nullptr) {
     float* corners = reinterpret_cast<float*>(slot2 + 2u * 448u);
     cx_vround Ra, Rb;
-    uint32_t e0 = (lane < n) ? q[lane] : 0u;
+    uint32_t e0 = (first + lane < n) ? q[first + lane] : 0u;
     asm volatile("" : "+v"(e0) :: "memory");
-    cx_vround_front(P, G, q, n, 0u, lane, e0, run, slot2, ntri_lut, Ra);
+    cx_vround_front(P, G, q, n, first, lane, e0, run, slot2, ntri_lut, Ra);
     cx_vround_pin(Ra);
     uint32_t par = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+#ifdef CX_S3_STAMPS
+#define CX_S3_T(k) { const unsigned long long tn = __builtin_amdgcn_s_memrealtime(); tacc[k] += tn - tprev; tprev = tn; }
+    unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+#else
+#define CX_S3_T(k)
+#endif
+    for (uint32_t b0 = first; b0 < n; b0 += 64u) {
         const bool more = b0 + 64u < n;   // wave-uniform
         if (more) {
             cx_run nb = Ra.base;
             nb.v += Ra.vtot; nb.t += Ra.ttot; nb.c += Ra.ctot;
             cx_vround_front(P, G, q, n, b0 + 64u, lane, Ra.e_next, nb, slot2 + (par ^ 1u) * 448u, ntri_lut, Rb);
         }
+        CX_S3_T(0)
         // back half of round b0: the corner samples of the 64 cells go to LDS ...
 #pragma unroll
         for (uint32_t c = 0; c < 8; c++) corners[lane * CX_CORNER_ROW + c] = ((c & 1u) || Ra.vk) ? Ra.f[c] : Ra.f[c + 1u];   // no k+1: the pair is (k-1, k)
@@ -291,7 +300,9 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
             rec4[r] = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
         }
+        CX_S3_T(1)
         if (more) cx_vround_pin(Rb);
+        CX_S3_T(2)
         // ... then the stores
         if (vroom) {
 #pragma unroll
@@ -320,6 +331,7 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             P.cells[Ra.base.c + cx_mbcnt(Ra.recm)] = c4;
         }
         __builtin_amdgcn_wave_barrier();
+        CX_S3_T(3)
         if (more) Ra = Rb;
         par ^= 1u;
     }
@@ -560,7 +572,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
     __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
-    __shared__ uint32_t s_tot[4][6];
+    __shared__ uint32_t s_tot[4][7];
     __shared__ uint8_t s_ntri[256];      // triangles of a voxel by its corner sign mask
     if (b >= T.nblocks) return;
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
@@ -572,7 +584,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     uint32_t nbl = 0, nbflushed = 0;    // the same for batch records
     const uint32_t w = b * 4u + wave;
     unsigned long long* stamp = P.stamps ? P.stamps + (size_t)w * 4u : nullptr;
+#ifndef CX_S3_STAMPS
     if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+#endif
     const cx_tile tile = cx_tile_of(P, T, b, wave);
     const uint32_t k0 = tile.k0, j0 = tile.j0, ib = tile.ib, nrows = tile.nrows;
     uint32_t p = tile.p;
@@ -582,6 +596,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     cx_cnt acc = {0, 0, 0, 0};   // per-lane counts of the cells queued since the last batch record (b: all)
     uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
     uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
+    uint32_t nr = 0;                       // wave-uniform: rounds of 64 cells of the closed batches
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
@@ -612,6 +627,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             s_br[wave][nbl][3] = rt; s_br[wave][nbl][4] = rc;
         }
         nbl++; nb++; rv += bv; rt += bt; rc += bc;
+        nr += (qn - qstart + 63u) >> 6;
         qstart = qn;
         acc.v = acc.t = acc.c = 0;
     };
@@ -788,7 +804,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         __builtin_amdgcn_wave_barrier();
         for (uint32_t sidx = 0; sidx < nsteps; sidx++) gqa[sidx * 64u + lane] = s_qa[wave][sidx][lane];
     }
+#ifndef CX_S3_STAMPS
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
     cx_run run;
     run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
     const bool near = __ballot(dnear <= P.near_abs) != 0ULL && !(P.flags & CX_DBG_NO_NEAR);   // wave-uniform
@@ -808,6 +826,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         if (really_near) {
             run.v = ex.v; run.t = ex.t; run.c = ex.c;
             nb = 1;
+            nr = (qn + 63u) >> 6;
             if (lane == 0) {
                 cx_brec R;
                 R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
@@ -817,19 +836,20 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     }
     if (lane == 0) {
         cx_wsum S;
-        S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = really_near ? 1u : 0u; S.pad = 0;
+        S.nb = nb; S.v = run.v; S.t = run.t; S.c = run.c; S.b = run.b; S.nq = qn; S.near = really_near ? 1u : 0u; S.nr = nr;
         P.wsum[w] = S;
         s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b; s_tot[wave][4] = nb;
         s_tot[wave][5] = (really_near && qn != 0u) ? 1u : 0u;
+        s_tot[wave][6] = nr;
     }
     // totals of every 256 waves (64 workgroups), so that the scan needs ONE round of loads for everything before its chunk
     // (the per-wave totals were just written by CUs all over the chip: each dependent round of loads from them costs ~2 us).
     // One atomic per workgroup and counter.
     __syncthreads();
-    if (threadIdx.x < 6u) {
+    if (threadIdx.x < 7u) {
         const uint32_t sum = s_tot[0][threadIdx.x] + s_tot[1][threadIdx.x] + s_tot[2][threadIdx.x] + s_tot[3][threadIdx.x];
         uint32_t* cs = P.chunksum + (size_t)(b >> 6) * 8u;
-        if (sum) atomicAdd(cs + threadIdx.x, sum);      // (slot 5: number of waves on the tolerance path; non-zero = flag)
+        if (sum) atomicAdd(cs + threadIdx.x, sum);      // (slot 5: number of waves on the tolerance path; non-zero = flag; slot 6: rounds)
     }
 }
 template <bool ALIGNED>
@@ -848,154 +868,77 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream_levels(const
     cx_stream_tile<ALIGNED>(P, T, (blockIdx.x & 7u) * T.chunk + tile_seq);
 }
 
-// ---- S2: exclusive scan of the per-wave totals (one workgroup of 16 waves; coalesced loads of
-// CX_SC chunks of 1024 waves at a time), output offsets per wave, the flat batch list, the counters.
-#define CX_SC 12
-__global__ __launch_bounds__(1024) void cx_k_scan_waves(const cx_params P, const uint32_t nw) {
-    __shared__ uint32_t s_part[5][CX_SC * 16];   // per (chunk, wave) totals, then their exclusive prefixes
-    __shared__ uint32_t s_total[5];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = cx_lane_id();
-    const uint32_t wave = tid >> 6;
-    uint32_t carry[5] = {0, 0, 0, 0, 0};   // v, t, c, b, nb of everything before this super-chunk
-    int near_any = 0;                      // this thread saw a wave whose cells take the per-cell (tolerance) path
-    for (uint32_t base = 0; base < nw; base += 1024u * CX_SC) {
-        uint32_t x[CX_SC][5], inc[CX_SC][5];
-#pragma unroll
-        for (int k = 0; k < CX_SC; k++) {
-            const uint32_t w = base + (uint32_t)k * 1024u + tid;
-            cx_wsum S;
-            S.nb = S.v = S.t = S.c = S.b = S.nq = S.near = 0;
-            if (w < nw) S = P.wsum[w];
-            near_any |= (S.near != 0u && S.nq != 0u) ? 1 : 0;
-            x[k][0] = S.v; x[k][1] = S.t; x[k][2] = S.c; x[k][3] = S.b; x[k][4] = S.nb;
-        }
-#pragma unroll
-        for (int k = 0; k < CX_SC; k++)
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                inc[k][m] = cx_wave_incl_scan(x[k][m], lane);
-                if (lane == 63u) s_part[m][k * 16 + wave] = inc[k][m];
-            }
-        __syncthreads();
-        if (wave == 0) {   // exclusive scan of the CX_SC*16 partial totals: CX_SC*16/64 consecutive items per lane
-            constexpr int PER = CX_SC * 16 / 64;
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                uint32_t loc[PER], sum = 0;
-#pragma unroll
-                for (int q = 0; q < PER; q++) { loc[q] = s_part[m][lane * PER + q]; sum += loc[q]; }
-                const uint32_t incl = cx_wave_incl_scan(sum, lane);
-                uint32_t run = incl - sum;
-#pragma unroll
-                for (int q = 0; q < PER; q++) { s_part[m][lane * PER + q] = run; run += loc[q]; }
-                if (lane == 63u) s_total[m] = incl;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < CX_SC; k++) {
-            const uint32_t w = base + (uint32_t)k * 1024u + tid;
-            if (w < nw) {
-                uint32_t ex[5];
-#pragma unroll
-                for (int m = 0; m < 5; m++) ex[m] = carry[m] + s_part[m][k * 16 + wave] + inc[k][m] - x[k][m];
-                cx_wbase B;
-                B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
-                P.wbase[w] = B;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 5; m++) carry[m] += s_total[m];
-        __syncthreads();
-    }
-    near_any = __syncthreads_or(near_any);
-    if (tid == 0) {
-        P.counters[CX_CNT_NEAR] = near_any ? 1u : 0u;
-        P.counters[CX_CNT_VERTS] = carry[0]; P.counters[CX_CNT_TRIS] = carry[1];
-        P.counters[CX_CNT_CELLS] = carry[2]; P.counters[CX_CNT_BORDER] = carry[3];
-        P.counters[CX_CNT_BATCHES] = carry[4];
-    }
-}
-
-// the flat batch list: self-contained descriptors (one thread per streaming wave; spread over many CUs --
-// the scattered stores of a single workgroup would take longer than the scan)
-__global__ __launch_bounds__(256) void cx_k_list_batches(const cx_params P, const cx_task T, const uint32_t nw) {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    if (w >= nw) return;
-    const uint32_t nb = P.wsum[w].nb;
-    if (nb == 0u) return;
-    const cx_wbase B = P.wbase[w];
-    for (uint32_t i = 0; i < nb; i++) {
-        if (B.boff + i >= P.fcap) break;
-        const cx_brec R = P.brec[(size_t)w * T.bcap + i];
-        cx_bdesc D;
-        D.w = w; D.qofs = w * T.wcap + R.qoff; D.n = R.n; D.near = R.near;
-        D.vbase = B.v + R.vpre; D.tbase = B.t + R.tpre; D.cbase = B.c + R.cpre; D.pad = 0;
-        P.flat[B.boff + i] = D;
-    }
-}
-
 // ---- S2 in one launch: workgroup g owns the streaming waves [256 g, 256 g + 256).  It sums the totals of ALL waves before its
 // chunk itself (every thread reads one wave of each earlier chunk: g x 8 KB per workgroup out of L2 -- no partial sums to
 // wait for, no second kernel, no atomics), scans its own 256 waves, and writes their output offsets and batch descriptors;
 // the last workgroup, which has seen every wave, writes the counters.  (One workgroup scanning all 12 k waves of a 512^3
 // grid was bound by what a single CU can pull: 22 us + 5 us for the list kernel.)
 __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_task& T, const uint32_t nw, const uint32_t g, const uint32_t nchunks) {
-    __shared__ uint32_t s_part[4][6];    // per wave of the workgroup: totals of the earlier chunks (5) + near flag
-    __shared__ uint32_t s_own[4][5];     // per wave: inclusive totals of its 64 streaming waves
+    __shared__ uint32_t s_part[4][8];    // per wave of the workgroup: totals of the earlier chunks (6), near flag, rounds of ALL chunks
+    __shared__ uint32_t s_own[4][6];     // per wave: inclusive totals of its 64 streaming waves
     const uint32_t tid = threadIdx.x, lane = cx_lane_id(), wave = tid >> 6;
-    uint32_t acc[5] = {0, 0, 0, 0, 0}, near_any = 0;   // v, t, c, b, nb
-    for (uint32_t c = tid; c < nchunks; c += 256u) {     // thread c: the totals of chunk c (the last workgroup looks at all of them for the near flag)
+    uint32_t acc[6] = {0, 0, 0, 0, 0, 0}, near_any = 0, rall = 0;   // v, t, c, b, nb, nr
+    for (uint32_t c = tid; c < nchunks; c += 256u) {     // thread c: the totals of chunk c (every workgroup looks at all of them: near flag, total rounds)
         const uint4 lo = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u);
         const uint4 hi = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u + 4u);
-        if (c < g) { acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w; acc[4] += hi.x; }
+        if (c < g) { acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w; acc[4] += hi.x; acc[5] += hi.z; }
         near_any |= hi.y;
+        rall += hi.z;
     }
     const uint32_t w = g * 256u + tid;
     cx_wsum S;
-    S.nb = S.v = S.t = S.c = S.b = S.nq = S.near = 0;
+    S.nb = S.v = S.t = S.c = S.b = S.nq = S.near = S.nr = 0;
     if (w < nw) S = P.wsum[w];
     near_any |= (S.near != 0u && S.nq != 0u) ? 1u : 0u;
-    const uint32_t x[5] = {S.v, S.t, S.c, S.b, S.nb};
-    uint32_t inc[5];
+    const uint32_t x[6] = {S.v, S.t, S.c, S.b, S.nb, S.nr};
+    uint32_t inc[6];
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
+    for (int m = 0; m < 6; m++) {
         inc[m] = cx_wave_incl_scan(x[m], lane);
         const uint32_t before = cx_wave_sum(acc[m]);
         if (lane == 63u) { s_own[wave][m] = inc[m]; s_part[wave][m] = before; }
     }
     {
         const uint32_t nr = (__ballot(near_any != 0u) != 0ULL) ? 1u : 0u;
-        if (lane == 63u) s_part[wave][5] = nr;
+        const uint32_t ra = cx_wave_sum(rall);
+        if (lane == 63u) { s_part[wave][6] = nr; s_part[wave][7] = ra; }
     }
     __syncthreads();
-    uint32_t ex[5];
+    uint32_t ex[6];
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
+    for (int m = 0; m < 6; m++) {
         uint32_t base = s_part[0][m] + s_part[1][m] + s_part[2][m] + s_part[3][m];
         for (uint32_t ww = 0; ww < wave; ww++) base += s_own[ww][m];
         ex[m] = base + inc[m] - x[m];
     }
+    // the vertex stage divides the rounds of 64 queued cells evenly among its P.nvw waves: wave m takes rounds [m q, m q + q)
+    const uint32_t rounds = s_part[0][7] + s_part[1][7] + s_part[2][7] + s_part[3][7];
+    const uint32_t q = max((rounds + P.nvw - 1u) / P.nvw, 1u);
     if (w < nw) {
         cx_wbase B;
         B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
         P.wbase[w] = B;
         // the flat batch list: self-contained descriptors
+        uint32_t rb = ex[5];
         for (uint32_t i = 0; i < S.nb; i++) {
             if (ex[4] + i >= P.fcap) break;
             const cx_brec R = P.brec[(size_t)w * T.bcap + i];
             cx_bdesc D;
             D.w = w; D.qofs = w * T.wcap + R.qoff; D.n = R.n; D.near = R.near;
-            D.vbase = ex[0] + R.vpre; D.tbase = ex[1] + R.tpre; D.cbase = ex[2] + R.cpre; D.pad = 0;
+            D.vbase = ex[0] + R.vpre; D.tbase = ex[1] + R.tpre; D.cbase = ex[2] + R.cpre; D.rbase = rb;
             P.flat[ex[4] + i] = D;
+            // the waves whose share starts inside this batch
+            const uint32_t nrb = (R.n + 63u) >> 6;
+            for (uint32_t m = (rb + q - 1u) / q; m * q < rb + nrb; m++) P.rstart[m] = ex[4] + i;
+            rb += nrb;
         }
     }
     if (g == nchunks - 1u && tid == 255u) {   // this thread's inclusive totals are the grand totals
         P.counters[CX_CNT_VERTS] = ex[0] + x[0]; P.counters[CX_CNT_TRIS] = ex[1] + x[1];
         P.counters[CX_CNT_CELLS] = ex[2] + x[2]; P.counters[CX_CNT_BORDER] = ex[3] + x[3];
         P.counters[CX_CNT_BATCHES] = ex[4] + x[4];
-        P.counters[CX_CNT_NEAR] = (s_part[0][5] | s_part[1][5] | s_part[2][5] | s_part[3][5]) ? 1u : 0u;
+        P.counters[CX_CNT_ROUNDS] = rounds;
+        P.counters[CX_CNT_NEAR] = (s_part[0][6] | s_part[1][6] | s_part[2][6] | s_part[3][6]) ? 1u : 0u;
     }
 }
 __global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {
@@ -1006,7 +949,32 @@ __global__ __launch_bounds__(256) void cx_k_scan_list_levels(const cx_params* __
     cx_scan_list_chunk(P, T, nw, blockIdx.x, gridDim.x);
 }
 
-// ---- S3: vertex records, per-cell table entries and cell records; one wave per batch, grid-stride
+// what `rounds` full rounds of 64 queued cells at the front of a batch hold (vertices, triangles, records), from the queue
+// entries alone -- the same formulas as cx_vround_front.  A wave that starts inside a batch (below) adds this to the batch's bases.
+__device__ __forceinline__ void cx_skip_rounds(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t rounds, uint32_t lane,
+                                               const uint8_t* ntri_lut, cx_run& run) {
+    uint32_t v = 0, t = 0, c = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t e = q[r * 64u + lane];
+        uint32_t i, j, k;
+        cx_decode_entry(P, G, e, i, j, k);
+        const uint32_t vm = cx_corner_valid(P, i, j, k);
+        const uint32_t sm = cx_entry_signs(e);
+        const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+        const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
+        const uint32_t nt = (vm == 0xFFu) ? (uint32_t)ntri_lut[sm] : 0u;
+        v += nv; t += nt; c += (nv | nt) ? 1u : 0u;
+    }
+    run.v += cx_wave_sum(v); run.t += cx_wave_sum(t); run.c += cx_wave_sum(c);
+}
+
+// ---- S3: vertex records, (first vertex, crossing mask) words and cell records.  The ROUNDS of 64 queued cells of all batches
+// are divided evenly among the waves of the grid (wave m: rounds [m q, m q + q) of the flat batch list; the scan kernel left the
+// batch each share starts in, P.rstart): batches hold 1 to 24 rounds, and with whole batches dealt out to waves -- as this
+// kernel did first -- it lasted as long as its unluckiest wave (25 rounds against a mean of 7) while the chip stood half empty
+// for the last third of its time.  A wave that starts inside a batch counts what the rounds before hold (cx_skip_rounds).
+// A batch on the tolerance path (per-cell path, counts not derivable from the signs) goes as a whole to the wave in whose
+// share its first round falls.
 #ifndef CX_S3_MIN_WAVES
 #define CX_S3_MIN_WAVES 1
 #endif
@@ -1018,16 +986,25 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
-    // (Handing the batches out by a ticket counter instead -- one atomicAdd per wave and batch -- was 3 x slower: 25 k
-    // same-address atomics at the ~88 / us this chip sustains are 0.28 ms by themselves.)
-    const uint32_t stride = gridDim.x * 4u;
-    uint32_t f = blockIdx.x * 4u + wave;
+    const uint32_t rounds = P.counters[CX_CNT_ROUNDS];
+    const uint32_t nvw = gridDim.x * 4u;     // == P.nvw
+    const uint32_t share = max((rounds + nvw - 1u) / nvw, 1u);
+    const uint32_t lo = (blockIdx.x * 4u + wave) * share;
+    if (lo >= rounds || nbatches == 0u) return;
+    const uint32_t hi = min(rounds, lo + share);
+    uint32_t f = P.rstart[blockIdx.x * 4u + wave];
     if (f >= nbatches) return;
     cx_bdesc D = P.flat[f];
+#ifdef CX_S3_STAMPS
+    unsigned long long tacc[4] = {0, 0, 0, 0}, nrounds = 0;
+    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {   // waves are independent
-        const uint32_t fn = f + stride;
+        const uint32_t fn = f + 1u;
         cx_bdesc Dn = D;
         if (fn < nbatches) Dn = P.flat[fn];   // next descriptor in flight while this batch is processed
+        const uint32_t nrb = (D.n + 63u) >> 6;
+        const uint32_t r0 = max(lo, D.rbase) - D.rbase, r1 = min(hi, D.rbase + nrb) - D.rbase;   // this wave's rounds of the batch
         const cx_tile tile = cx_tile_of(P, T, D.w >> 2, D.w & 3u);
         cx_fast_geom G;
         G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
@@ -1035,12 +1012,28 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
         cx_run run;
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
         uint64_t* __restrict__ info = P.info64 + D.qofs;
-        if (!D.near) cx_emit_queue_fast(P, G, q, D.n, lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
-        else cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, reinterpret_cast<cx_vrec*>(s_vstage[wave]), info);
-        if (fn >= nbatches) break;
+        if (!D.near) {
+            if (r0) cx_skip_rounds(P, G, q, r0, lane, s_ntri, run);
+#ifdef CX_S3_STAMPS
+            nrounds += r1 - r0;
+            cx_emit_queue_fast(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info, tacc);
+#else
+            cx_emit_queue_fast(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
+#endif
+        } else if (r0 == 0u) {
+            cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, reinterpret_cast<cx_vrec*>(s_vstage[wave]), info);
+        }
+        if (D.rbase + nrb >= hi || fn >= nbatches) break;
         f = fn;
         D = Dn;
     }
+#ifdef CX_S3_STAMPS
+    if (P.stamps && lane == 0) {   // per wave: start, end, time in the 4 parts of a round, rounds
+        unsigned long long* st = P.stamps + (size_t)(blockIdx.x * 4u + wave) * 8u;
+        st[0] = tstart; st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = tacc[0]; st[3] = tacc[1]; st[4] = tacc[2]; st[5] = tacc[3]; st[6] = nrounds;
+    }
+#endif
 }
 
 // ---- CPython 3.10 tuple hash + 8-slot set order, used only with
@@ -2070,11 +2063,6 @@ void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uin
 
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s) {
     const uint32_t nw = T.nblocks * 4u;
-    if (cx_debug_knob("CX_SCAN2", 0u)) {   // A/B: the two-kernel scan
-        hipLaunchKernelGGL(cx_k_scan_waves, dim3(1), dim3(1024), 0, s, P, nw);
-        hipLaunchKernelGGL(cx_k_list_batches, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
-        return;
-    }
     hipLaunchKernelGGL(cx_k_scan_list, dim3((nw + 255u) / 256u), dim3(256), 0, s, P, T, nw);
 }
 
@@ -2085,8 +2073,16 @@ static uint32_t cx_batch_grid(const cx_params& P, uint32_t per_cu) {
     const uint32_t most = (P.fcap + 3u) / 4u;
     return g < most ? g : most;
 }
+// the vertex stage launches what is resident at once (24.8 KB of LDS per workgroup: 6 per CU) and gives every wave the same
+// number of rounds; small grids: no more waves than batches could be
+static uint32_t cx_vertex_grid(const cx_params& P) {
+    const uint32_t g = cx_debug_knob("CX_BGRID", 256u * 6u);
+    const uint32_t most = (P.fcap + 3u) / 4u;
+    return g < most ? g : most;
+}
+uint32_t cx_vertex_stage_waves(const cx_params& P) { return 4u * cx_vertex_grid(P); }
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s) {
-    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(cx_batch_grid(P, 10u)), dim3(256), 0, s, P, T);
+    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(P.nvw / 4u), dim3(256), 0, s, P, T);
 }
 
 
