@@ -119,6 +119,14 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_o
 //   bits 10-14  position of the cell inside its lane's packed word (6*row + m)
 //   bits 15-20  streaming lane (k = k0 + 4*lane + m)
 //   bits 21-27  plane offset inside the task
+// Where a wave waits for the loads it issued at the top of an iteration: before the iteration's stores (1: rounds 1 and 2 --
+// a wait issued behind stores retires them too, `s_waitcnt vmcnt` counts loads and stores in issue order) or after them (0).
+// tools/micro/mix_rate.hip settles it: 4 scattered gathers + 6 coalesced stores per iteration cost 1011 cycles per CU when the
+// wave waits for the gathers before it stores and 662 when it stores first -- the stores of one iteration and the gathers of
+// the next then travel together instead of one after the other.
+#ifndef CX_PIN_BEFORE_STORES
+#define CX_PIN_BEFORE_STORES 0
+#endif
 #ifndef CX_VR
 #define CX_VR 4u          // rounds of 64 vertices whose loads are issued together
 #endif
@@ -301,7 +309,9 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             rec4[r] = cx_vertex_record(P, G, e2, d, corners[cell * CX_CORNER_ROW], corners[cell * CX_CORNER_ROW + d]);
         }
         CX_S3_T(1)
+#if CX_PIN_BEFORE_STORES
         if (more) cx_vround_pin(Rb);
+#endif
         CX_S3_T(2)
         // ... then the stores
         if (vroom) {
@@ -331,6 +341,9 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             P.cells[Ra.base.c + cx_mbcnt(Ra.recm)] = c4;
         }
         __builtin_amdgcn_wave_barrier();
+#if !CX_PIN_BEFORE_STORES
+        if (more) cx_vround_pin(Rb);   // the next round's samples are waited for AFTER this round's stores went out (see CX_PIN_BEFORE_STORES)
+#endif
         CX_S3_T(3)
         if (more) Ra = Rb;
         par ^= 1u;
@@ -1622,9 +1635,15 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
         cx_triq_stage1(P, T, L, rec_c, Ac);           // queue words of the record two steps ahead
         cx_triq_stage2(P, T, hash_xy, Ab, Ib);              // info words (and hash prefixes) of the next record
         const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
+#if CX_PIN_BEFORE_STORES
         cx_triq_pin1(Ac, rec_d);                            // ... all back before the stores go out
         cx_triq_pin2(Ib);
         cx_tri_phase2(P, L, lane, wave, ttot);
+#else
+        cx_tri_phase2(P, L, lane, wave, ttot);
+        cx_triq_pin1(Ac, rec_d);                            // ... waited for after the stores went out
+        cx_triq_pin2(Ib);
+#endif
         Ia = Ib;
         Ab = Ac;
         rec_c = rec_d;
@@ -2076,7 +2095,16 @@ static uint32_t cx_batch_grid(const cx_params& P, uint32_t per_cu) {
 // the vertex stage launches what is resident at once (24.8 KB of LDS per workgroup: 6 per CU) and gives every wave the same
 // number of rounds; small grids: no more waves than batches could be
 static uint32_t cx_vertex_grid(const cx_params& P) {
-    const uint32_t g = cx_debug_knob("CX_BGRID", 256u * 6u);
+    // workgroups of the vertex stage the device holds at once, asked of the runtime (a grid beyond that starts a second
+    // generation of waves when the first is two thirds through: measured +40 % kernel time with 6 per CU launched, 5 resident)
+    static const uint32_t resident = [] {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cx_k_emit_vertices, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256u * (uint32_t)per_cu;
+        return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }();
+    const uint32_t g = cx_debug_knob("CX_BGRID", resident);
     const uint32_t most = (P.fcap + 3u) / 4u;
     return g < most ? g : most;
 }
