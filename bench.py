@@ -383,6 +383,12 @@ def main():
             # what the reference's API returns: Level 0 + Level 1 (weld, tiny collapse, clean, orient) + download
             buf = job.slabs[0]
             ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
+            # one untimed pass first: the Level-1 state is allocated, the post-pass kernels and the pinned staging buffers of the
+            # download exist (a fresh process pays ~0.1 s for those once; a caller streaming volumes pays it once, too)
+            ctx.extract3d(args.value, flags)
+            warm = ctx.postprocess3d()
+            _w = ctx.download_level1(warm)
+            del _w
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             c0 = ctx.extract3d(args.value, flags)
@@ -396,7 +402,7 @@ def main():
             out["api"] = {"extract_sync_ms": (t1 - t0) * 1e3, "level1_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3,
                           "level1_vertices": int(post["n_vertices"]), "level1_triangles": int(post["n_triangles"]),
                           "Mvoxels_per_s_through_api": n ** 3 / (t3 - t0) / 1e6,
-                          "note": "get_points_and_triangles() equivalent: extract + post-pass + download of float64 points / int32 triangles"}
+                          "note": "get_points_and_triangles() equivalent: extract + post-pass + download of float64 points / int32 triangles (second call on the context: allocations exist)"}
             del pts, tris
         if world == 1 and not args.no_cpu_baseline:
             host = job.slabs[0].cpu().numpy()

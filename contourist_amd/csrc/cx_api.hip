@@ -63,6 +63,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     cx_levels_free(ctx);
+    cx_xfer_free(ctx);
     cx_post_free(ctx);
     cx_state4_free(ctx);
     cx_state2_free(ctx);
@@ -514,18 +515,15 @@ extern "C" int cx_level0_download(cx_ctx* ctx, float* verts_xyzk, int32_t* tris)
     if (!ctx) return CX_ERR_INVALID;
     if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
     CX_HIP(ctx, hipSetDevice(ctx->device));
+    float4* xyz = nullptr;
     if (verts_xyzk && ctx->counts.n_vertices) {
-        float4* xyz = nullptr;
         const int rc = cx_level0_expanded(ctx, &xyz);
         if (rc) return rc;
-        CX_HIP(ctx, hipMemcpyAsync(verts_xyzk, xyz, (size_t)ctx->counts.n_vertices * sizeof(float4),
-                                   hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (tris && ctx->counts.n_triangles)
-        CX_HIP(ctx, hipMemcpyAsync(tris, ctx->tris, (size_t)ctx->counts.n_triangles * 3 * sizeof(int32_t),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CX_OK;
+    void* d[2] = {xyz ? (void*)verts_xyzk : nullptr, (tris && ctx->counts.n_triangles) ? (void*)tris : nullptr};
+    const void* sp[2] = {xyz, ctx->tris};
+    const size_t nb[2] = {(size_t)ctx->counts.n_vertices * sizeof(float4), (size_t)ctx->counts.n_triangles * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
 }
 
 extern "C" int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris) {

@@ -82,6 +82,9 @@ struct cx_ctx {
     bool post_valid = false;
     unsigned long long* stamps = nullptr;   // diagnostic stamps (cx_debug_stamps)
     size_t stamps_words = 0;
+    // device -> host copies of mesh-sized buffers (cx_xfer.hip): two pinned staging buffers and their events
+    void* xfer_stage[2] = {nullptr, nullptr};
+    hipEvent_t xfer_ev[2] = {nullptr, nullptr};
     // timing
     struct evset { hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     bool timing = false;
@@ -94,6 +97,10 @@ int cx_ensure_cell_records(cx_ctx* ctx);
 int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags);
 int cx_level0_expanded(cx_ctx* ctx, float4** out);   // the records of the current extraction as float4 {x,y,z,id} (device, enqueued on the stream)
 void cx_fill_value_params(cx_params& P, double value);
+// cx_xfer.hip
+int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const* src, const size_t* bytes);
+int cx_copy_to_host1(cx_ctx* ctx, void* dst, const void* src, size_t bytes);
+void cx_xfer_free(cx_ctx* ctx);
 // cx_levels.hip
 void cx_levels_free(cx_ctx* ctx);
 void cx_levels_invalidate(cx_ctx* ctx);

@@ -1075,8 +1075,7 @@ extern "C" int cx_level0_points_f64(cx_ctx* ctx, double* points_xyz) {
     const cxp_origin3 org{{(double)ctx->origin[0], (double)ctx->origin[1], (double)ctx->origin[2]}};
     hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, ctx->stream, P.grid, P.n1, P.n2, P.div_plane, P.div_row, P.value,
                        ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
-    CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts.p, (size_t)nv * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = cx_copy_to_host1(ctx, points_xyz, S->pts.p, (size_t)nv * 3 * sizeof(double)))) return rc;
     ctx->post_valid = false;   // the post-pass buffers no longer hold a Level-1 mesh
     return CX_OK;
 }
@@ -1119,12 +1118,10 @@ extern "C" int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris
     if (!ctx->post || !ctx->post_valid) { ctx->err = "cx_level1_download: run cx_postprocess3d first"; return CX_ERR_STATE; }
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     cx_post_state* S = ctx->post;
-    if (points_xyz && S->nv_out)
-        CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->nv_out * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (tris && S->nt_out)
-        CXP_HIP(ctx, hipMemcpyAsync(tris, S->tri_out.p, (size_t)S->nt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CX_OK;
+    void* d[2] = {(points_xyz && S->nv_out) ? (void*)points_xyz : nullptr, (tris && S->nt_out) ? (void*)tris : nullptr};
+    const void* sp[2] = {S->pts_out.p, S->tri_out.p};
+    const size_t nb[2] = {(size_t)S->nv_out * 3 * sizeof(double), (size_t)S->nt_out * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);   // pinned, double-buffered, several host threads (cx_xfer.hip)
 }
 
 // ---- binary mesh files straight from the Level-1 device buffers (what every caller of the reference does next,
@@ -1481,12 +1478,10 @@ extern "C" int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* 
     if (!G || !G->post_valid || !ctx->post) { ctx->err = "cx_level1_4d_download: run cx_postprocess4d first"; return CX_ERR_STATE; }
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     cx_post_state* S = ctx->post;
-    if (points_xyzt && S->nv_out)
-        CXP_HIP(ctx, hipMemcpyAsync(points_xyzt, S->pts.p, (size_t)S->nv_out * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (tets && S->nt_out)
-        CXP_HIP(ctx, hipMemcpyAsync(tets, S->tri_out.p, (size_t)S->nt_out * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CX_OK;
+    void* d[2] = {(points_xyzt && S->nv_out) ? (void*)points_xyzt : nullptr, (tets && S->nt_out) ? (void*)tets : nullptr};
+    const void* sp[2] = {S->pts.p, S->tri_out.p};
+    const size_t nb[2] = {(size_t)S->nv_out * 4 * sizeof(double), (size_t)S->nt_out * 4 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
 }
 
 
@@ -1899,14 +1894,11 @@ extern "C" int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segm
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     cx_post_state* S = ctx->post;
-    if (points_xyzt && S->nv_out)
-        CXP_HIP(ctx, hipMemcpyAsync(points_xyzt, S->pts.p, (size_t)S->nv_out * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (segments && S->ms_out)
-        CXP_HIP(ctx, hipMemcpyAsync(segments, S->msegs.p, (size_t)S->ms_out * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (triangles && S->mt_out)
-        CXP_HIP(ctx, hipMemcpyAsync(triangles, S->mtris.p, (size_t)S->mt_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CX_OK;
+    void* d[3] = {(points_xyzt && S->nv_out) ? (void*)points_xyzt : nullptr, (segments && S->ms_out) ? (void*)segments : nullptr,
+                  (triangles && S->mt_out) ? (void*)triangles : nullptr};
+    const void* sp[3] = {S->pts.p, S->msegs.p, S->mtris.p};
+    const size_t nb[3] = {(size_t)S->nv_out * 4 * sizeof(double), (size_t)S->ms_out * 2 * sizeof(int32_t), (size_t)S->mt_out * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 3, d, sp, nb);
 }
 
 // ---- B6: the surface at time t from the morph triangles (misc/morph_triangles.js:26-140; MorphTriangles.triangles_at):
@@ -1985,10 +1977,8 @@ extern "C" int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* 
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
     cx_post_state* S = ctx->post;
     CXP_HIP(ctx, hipSetDevice(ctx->device));
-    if (points_xyz && S->me_points)
-        CXP_HIP(ctx, hipMemcpyAsync(points_xyz, S->pts_out.p, (size_t)S->me_points * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (triangles && S->me_tris)
-        CXP_HIP(ctx, hipMemcpyAsync(triangles, S->tri_out.p, (size_t)S->me_tris * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CX_OK;
+    void* d[2] = {(points_xyz && S->me_points) ? (void*)points_xyz : nullptr, (triangles && S->me_tris) ? (void*)triangles : nullptr};
+    const void* sp[2] = {S->pts_out.p, S->tri_out.p};
+    const size_t nb[2] = {(size_t)S->me_points * 3 * sizeof(double), (size_t)S->me_tris * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
 }
