@@ -49,13 +49,10 @@ extern "C" int cx_ctx_create(int device_id, cx_ctx** out) {
 }
 
 static void free_outputs(cx_ctx* ctx) {
-    if (ctx->verts) (void)hipFree(ctx->verts);
-    if (ctx->verts_xyz) (void)hipFree(ctx->verts_xyz);
-    ctx->verts_xyz = nullptr; ctx->verts_xyz_cap = 0;
-    if (ctx->cells) (void)hipFree(ctx->cells);
-    if (ctx->tris) (void)hipFree(ctx->tris);
-    ctx->verts = nullptr; ctx->cells = nullptr; ctx->tris = nullptr;
-    ctx->vcap = ctx->ccap = ctx->tcap = 0;
+    cx_release(ctx->verts, ctx->vcap);
+    cx_release(ctx->verts_xyz, ctx->verts_xyz_cap);
+    cx_release(ctx->cells, ctx->ccap);
+    cx_release(ctx->tris, ctx->tcap);
 }
 
 extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
@@ -68,21 +65,21 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_state4_free(ctx);
     cx_state2_free(ctx);
     free_outputs(ctx);
-    if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
-    if (ctx->celltab) (void)hipFree(ctx->celltab);
-    if (ctx->queue) (void)hipFree(ctx->queue);
-    if (ctx->wsum) (void)hipFree(ctx->wsum);
-    if (ctx->wbase) (void)hipFree(ctx->wbase);
-    if (ctx->tri_keep) (void)hipFree(ctx->tri_keep);
-    if (ctx->brec) (void)hipFree(ctx->brec);
-    if (ctx->flat) (void)hipFree(ctx->flat);
-    if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
-    if (ctx->qa) (void)hipFree(ctx->qa);
-    if (ctx->info) (void)hipFree(ctx->info);
-    if (ctx->info64) (void)hipFree(ctx->info64);
-    if (ctx->chunksum) (void)hipFree(ctx->chunksum);
-    if (ctx->rstart) (void)hipFree(ctx->rstart);
-    if (ctx->hbytes) (void)hipFree(ctx->hbytes);
+    cx_release(ctx->grid_owned, ctx->grid_owned_bytes);
+    cx_release(ctx->celltab, ctx->tables_for);
+    cx_release(ctx->queue, ctx->queue_cap);
+    cx_release(ctx->wsum, ctx->wsum_cap);
+    cx_release(ctx->wbase, ctx->wbase_cap);
+    cx_release(ctx->tri_keep, ctx->keep_cap);
+    cx_release(ctx->brec, ctx->brec_cap);
+    cx_release(ctx->flat, ctx->flat_cap);
+    cx_release(ctx->hash_xy, ctx->hash_xy_cap);
+    cx_release(ctx->qa, ctx->qa_cap);
+    cx_release(ctx->info, ctx->info_cap);
+    cx_release(ctx->info64, ctx->info64_cap);
+    cx_release(ctx->chunksum, ctx->chunksum_cap);
+    cx_release(ctx->rstart, ctx->rstart_cap);
+    cx_release(ctx->hbytes, ctx->hbytes_cap);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -125,11 +122,11 @@ extern "C" int cx_grid_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_
     int rc = set_grid_dims(ctx, n0, n1, n2);
     if (rc) return rc;
     const size_t bytes = (size_t)(n0 * n1 * n2) * sizeof(float);
-    if (ctx->grid_owned_bytes < bytes) {
-        if (ctx->grid_owned) (void)hipFree(ctx->grid_owned);
-        ctx->grid_owned = nullptr; ctx->grid_owned_bytes = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->grid_owned, bytes));
-        ctx->grid_owned_bytes = bytes;
+    {
+        size_t have = ctx->grid_owned_bytes / sizeof(float);
+        rc = cx_grow(ctx, ctx->grid_owned, have, (size_t)(n0 * n1 * n2));
+        ctx->grid_owned_bytes = have * sizeof(float);
+        if (rc) return rc;
     }
     CX_HIP(ctx, hipMemcpyAsync(ctx->grid_owned, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -167,24 +164,13 @@ extern "C" int cx_reserve(cx_ctx* ctx, int64_t max_cells, int64_t max_vertices, 
     if (max_cells > 0xFFFFFFF0LL || max_vertices > 0xFFFFFFF0LL || max_triangles > 0x7FFFFFF0LL)
         return fail(ctx, CX_ERR_UNSUPPORTED, "capacity beyond 32-bit indices");
     CX_HIP(ctx, hipSetDevice(ctx->device));
-    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (max_cells > (int64_t)ctx->ccap) {
-        if (ctx->cells) (void)hipFree(ctx->cells);
-        ctx->cells = nullptr; ctx->ccap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->cells, (size_t)max_cells * sizeof(uint4)));
-        ctx->ccap = (uint32_t)max_cells;
-    }
-    if (max_vertices > (int64_t)ctx->vcap) {
-        if (ctx->verts) (void)hipFree(ctx->verts);
-        ctx->verts = nullptr; ctx->vcap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->verts, (size_t)max_vertices * sizeof(cx_vrec)));
-        ctx->vcap = (uint32_t)max_vertices;
-    }
-    if (max_triangles > (int64_t)ctx->tcap) {
-        if (ctx->tris) (void)hipFree(ctx->tris);
-        ctx->tris = nullptr; ctx->tcap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->tris, (size_t)max_triangles * 3 * sizeof(int32_t)));
-        ctx->tcap = (uint32_t)max_triangles;
+    int rc;
+    if ((rc = cx_grow(ctx, ctx->cells, ctx->ccap, (size_t)max_cells))) return rc;
+    if ((rc = cx_grow(ctx, ctx->verts, ctx->vcap, (size_t)max_vertices))) return rc;
+    {
+        size_t t3 = (size_t)ctx->tcap * 3u;
+        if ((rc = cx_grow(ctx, ctx->tris, t3, (size_t)max_triangles * 3u))) { ctx->tcap = 0; return rc; }
+        ctx->tcap = (uint32_t)(t3 / 3u);
     }
     ctx->extracted = false;
     ctx->post_valid = false;
@@ -204,12 +190,9 @@ int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags) {
     if (ctx->hash_xy_n0 == ctx->n0 && ctx->hash_xy_n1 == ctx->n1 && ctx->hash_xy_o0 == ctx->origin[0] && ctx->hash_xy_o1 == ctx->origin[1])
         return CX_OK;
     const size_t need = (size_t)(ctx->n0 * ctx->n1);
-    if (ctx->hash_xy_cap < need) {
-        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->hash_xy) (void)hipFree(ctx->hash_xy);
-        ctx->hash_xy = nullptr; ctx->hash_xy_cap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->hash_xy, need * sizeof(uint64_t)));
-        ctx->hash_xy_cap = need;
+    {
+        const int rc = cx_grow(ctx, ctx->hash_xy, ctx->hash_xy_cap, need);
+        if (rc) return rc;
     }
     cx_launch_hash_xy(ctx->hash_xy, (uint32_t)ctx->n0, (uint32_t)ctx->n1, (uint32_t)ctx->origin[0], (uint32_t)ctx->origin[1], ctx->stream);
     ctx->hash_xy_n0 = ctx->n0; ctx->hash_xy_n1 = ctx->n1;
@@ -254,13 +237,10 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     // fused emit kernel (no per-cell table, no cell records) only on request: measured slower than the staged kernels
     // (DESIGN.md section 4); an extraction that meets the tolerance path is sent through the staged kernels by cx_counts_get
     const bool fused = staged && (flags & CX_KERNEL_FUSED) && !(flags & CX_KERNEL_STAGED);
-    if (!staged && ctx->tables_for < (size_t)N) {
-        // the per-cell table of the staged / generic emit path (one 8-byte entry per sample): only when that path runs
-        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->celltab) (void)hipFree(ctx->celltab);
-        ctx->celltab = nullptr; ctx->tables_for = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
-        ctx->tables_for = (size_t)N;
+    if (!staged) {
+        // the per-cell table of the generic emit path (one 8-byte entry per sample): only when that path runs
+        const int rc = cx_grow(ctx, ctx->celltab, ctx->tables_for, (size_t)N + 64u);
+        if (rc) return rc;
     }
     P.celltab = ctx->celltab;
     P.fused = fused ? 1u : 0u;
@@ -279,12 +259,9 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if ((flags & CX_DIAG_CPYTHON310) && (fused || cx_debug_knob("CX_HBYTES", 0u))) {   // staged kernels: measured slower than the hash arithmetic (byte gathers from a table of one byte per sample)
         // one byte per lattice point: its slot (and alternative slot) in CPython's 8-slot set, built once per shape / origin
         if (!ctx->hbytes_valid || ctx->hbytes_n2 != ctx->n2 || ctx->hbytes_o2 != ctx->origin[2]) {
-            if (ctx->hbytes_cap < (size_t)N + 64u) {
-                CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->hbytes) (void)hipFree(ctx->hbytes);
-                ctx->hbytes = nullptr; ctx->hbytes_cap = 0;
-                CX_HIP(ctx, hipMalloc(&ctx->hbytes, (size_t)N + 64u));
-                ctx->hbytes_cap = (size_t)N + 64u;
+            {
+                const int rc = cx_grow(ctx, ctx->hbytes, ctx->hbytes_cap, (size_t)N + 64u);
+                if (rc) return rc;
             }
             cx_launch_hash_bytes(ctx->hbytes, ctx->hash_xy, P.n0, P.n1, P.n2, P.org2, ctx->stream);
             ctx->hbytes_valid = true; ctx->hbytes_n2 = ctx->n2; ctx->hbytes_o2 = ctx->origin[2];
@@ -296,85 +273,29 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (staged) {
         T = cx_fast_task(P.n0, P.n1, P.n2);
         const size_t nw = (size_t)T.nblocks * 4u, need = nw * T.wcap;
-        if (ctx->queue_cap < need) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->queue) (void)hipFree(ctx->queue);
-            ctx->queue = nullptr; ctx->queue_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->queue, need * sizeof(uint32_t)));
-            ctx->queue_cap = need;
-        }
-        if (ctx->waves_cap < nw) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->wsum) (void)hipFree(ctx->wsum);
-            if (ctx->wbase) (void)hipFree(ctx->wbase);
-            ctx->wsum = nullptr; ctx->wbase = nullptr; ctx->waves_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->wsum, nw * sizeof(cx_wsum)));
-            CX_HIP(ctx, hipMalloc(&ctx->wbase, nw * sizeof(cx_wbase)));
-            ctx->waves_cap = nw;
-        }
-        const size_t nbrec = nw * T.bcap;
-        if (ctx->brec_cap < nbrec) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->brec) (void)hipFree(ctx->brec);
-            ctx->brec = nullptr; ctx->brec_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->brec, nbrec * sizeof(cx_brec)));
-            ctx->brec_cap = nbrec;
-        }
+        int rc;
+        if ((rc = cx_grow(ctx, ctx->queue, ctx->queue_cap, need))) return rc;
+        if ((rc = cx_grow(ctx, ctx->wsum, ctx->wsum_cap, nw))) return rc;
+        if ((rc = cx_grow(ctx, ctx->wbase, ctx->wbase_cap, nw))) return rc;
+        if ((rc = cx_grow(ctx, ctx->brec, ctx->brec_cap, nw * T.bcap))) return rc;
         // batches: at most one short batch per streaming wave plus one per CX_BATCH_MIN (>= 128) queued cells; queued
         // cells = cell records + array-boundary cells without vertices.  Sized from the cell capacity, so a
         // surface that fits the cell capacity fits here (cx_counts_get reports CX_ERR_CAPACITY otherwise).
         const size_t boundary = (size_t)(ctx->n0 * ctx->n1 + ctx->n0 * ctx->n2 + ctx->n1 * ctx->n2);
         const size_t nflat = nw + (size_t)ctx->ccap / 64u + boundary / 128u + 4096u;
-        if (ctx->flat_cap < nflat) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->flat) (void)hipFree(ctx->flat);
-            ctx->flat = nullptr; ctx->flat_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->flat, nflat * sizeof(cx_bdesc)));
-            ctx->flat_cap = nflat;
-        }
-        const size_t nqa = nw * CX_SWP * 64u + 64u;
-        if (ctx->qa_cap < nqa) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->qa) (void)hipFree(ctx->qa);
-            ctx->qa = nullptr; ctx->qa_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->qa, nqa * sizeof(uint32_t)));
-            ctx->qa_cap = nqa;
-        }
+        if ((rc = cx_grow(ctx, ctx->flat, ctx->flat_cap, nflat))) return rc;
+        if ((rc = cx_grow(ctx, ctx->qa, ctx->qa_cap, nw * CX_SWP * 64u + 64u))) return rc;
         const size_t nchunk_words = ((nw + 255u) / 256u) * 8u;
-        if (ctx->chunksum_cap < nchunk_words) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->chunksum) (void)hipFree(ctx->chunksum);
-            ctx->chunksum = nullptr; ctx->chunksum_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->chunksum, nchunk_words * sizeof(uint32_t)));
-            ctx->chunksum_cap = nchunk_words;
-        }
+        if ((rc = cx_grow(ctx, ctx->chunksum, ctx->chunksum_cap, nchunk_words))) return rc;
         CX_HIP(ctx, hipMemsetAsync(ctx->chunksum, 0, nchunk_words * sizeof(uint32_t), ctx->stream));
-        if (!fused && ctx->info64_cap < need) {   // staged kernels: (first vertex, crossing mask) per queue entry
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->info64) (void)hipFree(ctx->info64);
-            ctx->info64 = nullptr; ctx->info64_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->info64, need * sizeof(uint64_t)));
-            ctx->info64_cap = need;
-        }
-        if (fused && ctx->info_cap < need) {   // one word per queue entry (only the front of each wave's region is touched)
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->info) (void)hipFree(ctx->info);
-            ctx->info = nullptr; ctx->info_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->info, need * sizeof(uint32_t)));
-            ctx->info_cap = need;
-        }
+        if (!fused && (rc = cx_grow(ctx, ctx->info64, ctx->info64_cap, need))) return rc;   // staged kernels: (first vertex, crossing mask) per queue entry
+        if (fused && (rc = cx_grow(ctx, ctx->info, ctx->info_cap, need))) return rc;        // fused kernel: one word per queue entry
         P.queue = ctx->queue; P.wsum = ctx->wsum; P.wbase = ctx->wbase; P.brec = ctx->brec;
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
         P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
         P.nvw = cx_vertex_stage_waves(P);
-        if (ctx->rstart_cap < (size_t)P.nvw + 1u) {
-            CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->rstart) (void)hipFree(ctx->rstart);
-            ctx->rstart = nullptr; ctx->rstart_cap = 0;
-            CX_HIP(ctx, hipMalloc(&ctx->rstart, ((size_t)P.nvw + 1u) * sizeof(uint32_t)));
-            ctx->rstart_cap = (size_t)P.nvw + 1u;
-        }
+        if ((rc = cx_grow(ctx, ctx->rstart, ctx->rstart_cap, (size_t)P.nvw + 1u))) return rc;
         P.rstart = ctx->rstart;
         ctx->last = P;
     }
@@ -499,11 +420,8 @@ extern "C" int cx_level0_path(cx_ctx* ctx, int* path) {
 int cx_level0_expanded(cx_ctx* ctx, float4** out) {
     const size_t nv = (size_t)ctx->counts.n_vertices;
     if (ctx->verts_xyz_cap < nv) {
-        CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->verts_xyz) (void)hipFree(ctx->verts_xyz);
-        ctx->verts_xyz = nullptr; ctx->verts_xyz_cap = 0;
-        CX_HIP(ctx, hipMalloc(&ctx->verts_xyz, (nv + nv / 16 + 64) * sizeof(float4)));
-        ctx->verts_xyz_cap = nv + nv / 16 + 64;
+        const int rc = cx_grow(ctx, ctx->verts_xyz, ctx->verts_xyz_cap, nv + nv / 16 + 64);
+        if (rc) return rc;
     }
     cx_launch_expand_verts(ctx->verts, ctx->verts_xyz, (uint32_t)nv, (uint32_t)ctx->n1, (uint32_t)ctx->n2, ctx->stream);
     CX_HIP(ctx, hipGetLastError());

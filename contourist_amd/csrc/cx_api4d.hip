@@ -20,9 +20,10 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    void* all[] = {S->grid_owned, S->celltab, S->verts, S->vkeys, S->cells, S->tets, S->hash_xyz, S->signbits, S->tet_keep, S->queue, S->rounds};
-    for (void* p : all)
-        if (p) (void)hipFree(p);
+    cx_release(S->grid_owned, S->grid_owned_bytes); cx_release(S->celltab, S->celltab_for);
+    cx_release(S->verts, S->vcap); cx_release(S->vkeys, S->vkeys_cap); cx_release(S->cells, S->ccap); cx_release(S->tets, S->tcap);
+    cx_release(S->hash_xyz, S->hash_cap); cx_release(S->signbits, S->signbits_cap); cx_release(S->tet_keep, S->keep_cap);
+    cx_release(S->queue, S->qcap); cx_release(S->rounds, S->rounds_cap);
     delete S;
     ctx->s4 = nullptr;
 }
@@ -38,11 +39,9 @@ static int set_dims4(cx_ctx* ctx, cx_state4* S, int64_t n0, int64_t n1, int64_t 
     if (n0 < 2 || n1 < 2 || n2 < 2 || n3 < 2) { ctx->err = "4-D grid needs at least 2 samples per axis"; return CX_ERR_INVALID; }
     const int64_t N = n0 * n1 * n2 * n3;
     if (N > (1LL << 28)) { ctx->err = "more than 2^28 samples in one 4-D grid: partition into slabs"; return CX_ERR_UNSUPPORTED; }
-    if (S->celltab_for < (size_t)N) {
-        if (S->celltab) (void)hipFree(S->celltab);
-        S->celltab = nullptr; S->celltab_for = 0;
-        CX4_HIP(ctx, hipMalloc(&S->celltab, ((size_t)N + 64) * sizeof(uint64_t)));
-        S->celltab_for = (size_t)N;
+    {
+        const int rc = cx_grow(ctx, S->celltab, S->celltab_for, (size_t)N + 64u);
+        if (rc) return rc;
     }
     S->n[0] = n0; S->n[1] = n1; S->n[2] = n2; S->n[3] = n3;
     S->extracted = false;
@@ -58,11 +57,11 @@ extern "C" int cx_grid4d_upload(cx_ctx* ctx, const float* host, int64_t n0, int6
     if (rc) return rc;
     if ((rc = set_dims4(ctx, S, n0, n1, n2, n3))) return rc;
     const size_t bytes = (size_t)(n0 * n1 * n2 * n3) * sizeof(float);
-    if (S->grid_owned_bytes < bytes) {
-        if (S->grid_owned) (void)hipFree(S->grid_owned);
-        S->grid_owned = nullptr; S->grid_owned_bytes = 0;
-        CX4_HIP(ctx, hipMalloc(&S->grid_owned, bytes));
-        S->grid_owned_bytes = bytes;
+    {
+        size_t have = S->grid_owned_bytes / sizeof(float);
+        rc = cx_grow(ctx, S->grid_owned, have, bytes / sizeof(float));
+        S->grid_owned_bytes = have * sizeof(float);
+        if (rc) return rc;
     }
     CX4_HIP(ctx, hipMemcpyAsync(S->grid_owned, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -83,34 +82,16 @@ extern "C" int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64
 
 static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t nt, int64_t nq) {
     if (nq > 0xFFFFFFF0LL || nc > 0xFFFFFFF0LL || nv > 0xFFFFFFF0LL || nt > 0x7FFFFFF0LL) { ctx->err = "capacity beyond 32-bit indices"; return CX_ERR_UNSUPPORTED; }
-    CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (nq > (int64_t)S->qcap) {
-        if (S->queue) (void)hipFree(S->queue);
-        if (S->rounds) (void)hipFree(S->rounds);
-        S->queue = nullptr; S->rounds = nullptr; S->qcap = 0;
-        CX4_HIP(ctx, hipMalloc(&S->queue, (size_t)nq * sizeof(uint32_t)));
-        CX4_HIP(ctx, hipMalloc(&S->rounds, ((size_t)nq / 64 + 8) * sizeof(uint4)));
-        S->qcap = (uint32_t)nq;
-    }
-    if (nc > (int64_t)S->ccap) {
-        if (S->cells) (void)hipFree(S->cells);
-        S->cells = nullptr; S->ccap = 0;
-        CX4_HIP(ctx, hipMalloc(&S->cells, (size_t)nc * sizeof(uint4)));
-        S->ccap = (uint32_t)nc;
-    }
-    if (nv > (int64_t)S->vcap) {
-        if (S->verts) (void)hipFree(S->verts);
-        if (S->vkeys) (void)hipFree(S->vkeys);
-        S->verts = nullptr; S->vkeys = nullptr; S->vcap = 0;
-        CX4_HIP(ctx, hipMalloc(&S->verts, (size_t)nv * sizeof(float4)));
-        CX4_HIP(ctx, hipMalloc(&S->vkeys, (size_t)nv * sizeof(uint32_t)));
-        S->vcap = (uint32_t)nv;
-    }
-    if (nt > (int64_t)S->tcap) {
-        if (S->tets) (void)hipFree(S->tets);
-        S->tets = nullptr; S->tcap = 0;
-        CX4_HIP(ctx, hipMalloc(&S->tets, (size_t)nt * 4 * sizeof(int32_t)));
-        S->tcap = (uint32_t)nt;
+    int rc;
+    if ((rc = cx_grow(ctx, S->queue, S->qcap, (size_t)nq))) return rc;
+    if ((rc = cx_grow(ctx, S->rounds, S->rounds_cap, (size_t)S->qcap / 64 + 8))) return rc;
+    if ((rc = cx_grow(ctx, S->cells, S->ccap, (size_t)nc))) return rc;
+    if ((rc = cx_grow(ctx, S->verts, S->vcap, (size_t)nv))) return rc;
+    if ((rc = cx_grow(ctx, S->vkeys, S->vkeys_cap, (size_t)S->vcap))) return rc;
+    {
+        size_t t4 = (size_t)S->tcap * 4u;
+        if ((rc = cx_grow(ctx, S->tets, t4, (size_t)nt * 4u))) { S->tcap = 0; return rc; }
+        S->tcap = (uint32_t)(t4 / 4u);
     }
     return CX_OK;
 }
@@ -157,12 +138,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
             const int64_t key[7] = {S->n[0], S->n[1], S->n[2], S->origin[0], S->origin[1], S->origin[2], 1};
             if (memcmp(key, S->hash_key, sizeof(key)) != 0) {
                 const size_t need = (size_t)(S->n[0] * S->n[1] * S->n[2]);
-                if (S->hash_cap < need) {
-                    if (S->hash_xyz) (void)hipFree(S->hash_xyz);
-                    S->hash_xyz = nullptr; S->hash_cap = 0;
-                    CX4_HIP(ctx, hipMalloc(&S->hash_xyz, need * sizeof(uint64_t)));
-                    S->hash_cap = need;
-                }
+                if ((rc = cx_grow(ctx, S->hash_xyz, S->hash_cap, need))) return rc;
                 cx_launch_hash_xyz(S->hash_xyz, P.n0, P.n1, P.n2, P.org, ctx->stream);
                 memcpy(S->hash_key, key, sizeof(key));
             }
@@ -175,18 +151,9 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.div_r1 = cx_fdiv_make(P.n2);
         {
             const size_t need = (size_t)P.nrows * P.nw3 + 64u;
-            if (S->signbits_cap < need) {
-                CX4_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (S->signbits) (void)hipFree(S->signbits);
-                S->signbits = nullptr; S->signbits_cap = 0;
-                CX4_HIP(ctx, hipMalloc(&S->signbits, need * sizeof(uint32_t)));
-                S->signbits_cap = need;
-            }
+            if ((rc = cx_grow(ctx, S->signbits, S->signbits_cap, need))) return rc;
             P.signbits = S->signbits;
         }
-        // the counter block is shared with the 3-D march: an enqueued 3-D extraction whose counts were never fetched
-        // (cx_extract3d_async without cx_counts_get) loses them here and has to be run again
-        if (ctx->extracted && !ctx->counts_fetched) ctx->extracted = false;
         CX4_HIP(ctx, hipMemsetAsync(ctx->counters + CX_CNT_WORDS, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
         cx_launch_signbits4d(P, ctx->stream);
         cx_launch_classify4d(P, ctx->stream);

@@ -25,8 +25,9 @@ struct cx_ctx {
     uint32_t* queue = nullptr;         // staged pipeline: per-wave queues, totals and offsets
     size_t queue_cap = 0;
     cx_wsum* wsum = nullptr;
+    size_t wsum_cap = 0;
     cx_wbase* wbase = nullptr;
-    size_t waves_cap = 0;
+    size_t wbase_cap = 0;
     cx_brec* brec = nullptr;
     size_t brec_cap = 0;
     cx_bdesc* flat = nullptr;
@@ -91,6 +92,33 @@ struct cx_ctx {
     int nevents = 0;
     evset events[256];
 };
+
+// THE place where a device buffer of a context is freed and allocated again.  A buffer is a (pointer, capacity) pair that always
+// travels together through this function: a regrow branch cannot free a neighbour's pointer or leave a capacity describing a
+// buffer that is gone (rounds 1 and 2 each had a stray hipFree in a hand-written regrow block).  Waits for the context's stream
+// first (kernels enqueued on it may still use the old buffer).  `need` in elements; grows to exactly `need`.
+template <typename T, typename C>
+int cx_grow(cx_ctx* ctx, T*& ptr, C& cap, size_t need) {
+    if ((size_t)cap >= need && ptr) return CX_OK;
+    if (need == 0) return CX_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && ptr) e = hipFree(ptr);
+    ptr = nullptr; cap = 0;
+    void* fresh = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&fresh, need * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("device buffer (") + std::to_string(need * sizeof(T)) + " bytes): " + hipGetErrorString(e);
+        return (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;
+    }
+    ptr = static_cast<T*>(fresh);
+    cap = (C)need;
+    return CX_OK;
+}
+template <typename T, typename C>
+void cx_release(T*& ptr, C& cap) {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; cap = 0;
+}
 
 // cx_api.hip
 int cx_ensure_cell_records(cx_ctx* ctx);

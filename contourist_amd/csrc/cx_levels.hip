@@ -32,8 +32,9 @@ struct cx_level_slot {
     uint32_t* queue = nullptr;
     size_t queue_cap = 0;
     cx_wsum* wsum = nullptr;
+    size_t wsum_cap = 0;
     cx_wbase* wbase = nullptr;
-    size_t waves_cap = 0;
+    size_t wbase_cap = 0;
     cx_brec* brec = nullptr;
     size_t brec_cap = 0;
     cx_bdesc* flat = nullptr;
@@ -88,9 +89,9 @@ void cx_levels_free(cx_ctx* ctx) {
         ctx->lv_current = -1;
     }
     for (auto& S : L->slots) free_slot(S);
-    if (L->dparams) (void)hipFree(L->dparams);
+    cx_release(L->dparams, L->dparams_cap);
     if (L->hcounters) (void)hipHostFree(L->hcounters);
-    if (L->info64b) (void)hipFree(L->info64b);
+    cx_release(L->info64b, L->info64b_cap);
     if (L->stream2) (void)hipStreamDestroy(L->stream2);
     if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
     if (L->ev_join) (void)hipEventDestroy(L->ev_join);
@@ -98,16 +99,8 @@ void cx_levels_free(cx_ctx* ctx) {
     ctx->lv = nullptr;
 }
 
-template <typename Tp>
-static int grow(cx_ctx* ctx, Tp*& ptr, size_t& cap, size_t need) {
-    if (cap >= need) return CX_OK;
-    CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr; cap = 0;
-    CXL_HIP(ctx, hipMalloc(&ptr, need * sizeof(Tp)));
-    cap = need;
-    return CX_OK;
-}
+template <typename Tp, typename C>
+static int grow(cx_ctx* ctx, Tp*& ptr, C& cap, size_t need) { return cx_grow(ctx, ptr, cap, need); }
 
 // a single-level extraction is about to overwrite the context's output buffers: the levels are gone
 void cx_levels_invalidate(cx_ctx* ctx) {
@@ -179,15 +172,8 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         cx_level_slot& S = L->slots[l];
         S.value = values[l];
         if ((rc = grow(ctx, S.queue, S.queue_cap, need))) return rc;
-        if (S.waves_cap < nw) {
-            CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (S.wsum) (void)hipFree(S.wsum);
-            if (S.wbase) (void)hipFree(S.wbase);
-            S.wsum = nullptr; S.wbase = nullptr; S.waves_cap = 0;
-            CXL_HIP(ctx, hipMalloc(&S.wsum, nw * sizeof(cx_wsum)));
-            CXL_HIP(ctx, hipMalloc(&S.wbase, nw * sizeof(cx_wbase)));
-            S.waves_cap = nw;
-        }
+        if ((rc = grow(ctx, S.wsum, S.wsum_cap, nw))) return rc;
+        if ((rc = grow(ctx, S.wbase, S.wbase_cap, nw))) return rc;
         if ((rc = grow(ctx, S.brec, S.brec_cap, nw * T.bcap))) return rc;
         if ((rc = grow(ctx, S.flat, S.flat_cap, nflat))) return rc;
         if ((rc = grow(ctx, S.qa, S.qa_cap, nw * CX_SWP * 64u + 64u))) return rc;
@@ -216,20 +202,8 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         P.vcap = S.vcap; P.ccap = S.ccap; P.tcap = S.tcap;
     }
     // the staged kernels' word per queue entry is shared: the levels' vertex and triangle stages run one level after the other
-    if (ctx->info64_cap < need) {
-        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->info64) (void)hipFree(ctx->info64);
-        ctx->info64 = nullptr; ctx->info64_cap = 0;
-        CXL_HIP(ctx, hipMalloc(&ctx->info64, need * sizeof(uint64_t)));
-        ctx->info64_cap = need;
-    }
-    if (L->dparams_cap < (size_t)nlevels) {
-        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (L->dparams) (void)hipFree(L->dparams);
-        L->dparams = nullptr; L->dparams_cap = 0;
-        CXL_HIP(ctx, hipMalloc(&L->dparams, (size_t)nlevels * sizeof(cx_params)));
-        L->dparams_cap = (size_t)nlevels;
-    }
+    if ((rc = grow(ctx, ctx->info64, ctx->info64_cap, need))) return rc;
+    if ((rc = grow(ctx, L->dparams, L->dparams_cap, (size_t)nlevels))) return rc;
     if (L->hcounters_cap < (size_t)nlevels) {
         if (L->hcounters) (void)hipHostFree(L->hcounters);
         L->hcounters = nullptr; L->hcounters_cap = 0;

@@ -576,7 +576,8 @@ __device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task&
 // loads, stores and atomics in issue order, so a store issued between two plane loads would make the
 // second wait for the store's round trip (measured: +45 % kernel time with one store per active step).
 #define CX_SQ 1024u     // queue entries a wave stages (one step adds at most 1024)
-#define CX_SBR 32u      // batch records a wave stages
+#define CX_SBR 32u      // batch records a wave stages: all a wave can close (at most one per CX_BATCH_MIN cells of its (CX_SWP - 1) x 1024)
+static_assert((CX_SWP - 1u) * 1024u / CX_BATCH_MIN + 1u <= CX_SBR, "a streaming wave can close more batches than its LDS stage holds");
 // ALIGNED: n2 % 4 == 0 and a 16-byte aligned grid (rows start on 16-byte boundaries, every lane holds 4 samples
 // of one row).  Otherwise the 16-byte loads are only 4-byte aligned and the lane that holds the end of a row
 // loads the row's last 4 samples and shifts them into place, repeating the last one (a clamped corner).
@@ -634,7 +635,6 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     };
     auto close_batch = [&]() {
         const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
-        if (nbl == CX_SBR) flush_brec();
         if (lane == 0) {
             s_br[wave][nbl][0] = qstart; s_br[wave][nbl][1] = qn - qstart; s_br[wave][nbl][2] = rv;
             s_br[wave][nbl][3] = rt; s_br[wave][nbl][4] = rc;

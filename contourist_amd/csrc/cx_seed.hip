@@ -295,11 +295,9 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
         G.hi[a] = range_lo_hi ? std::min(range_lo_hi[3 + a], dims[a] - 1) : dims[a] - 1;
     }
     // persistent masks
-    if (ctx->keep_cap < (size_t)nt + (size_t)nv + 64) {
-        if (ctx->tri_keep) (void)hipFree(ctx->tri_keep);
-        ctx->tri_keep = nullptr; ctx->keep_cap = 0;
-        CXS_HIP(ctx, hipMalloc(&ctx->tri_keep, (size_t)nt + (size_t)nv + 64));
-        ctx->keep_cap = (size_t)nt + (size_t)nv + 64;
+    {
+        const int rcg = cx_grow(ctx, ctx->tri_keep, ctx->keep_cap, (size_t)nt + (size_t)nv + 64);
+        if (rcg) return rcg;
     }
     uint8_t* tri_keep = ctx->tri_keep;
     uint8_t* vkeep = ctx->tri_keep + nt;

@@ -325,11 +325,9 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
         G.hi[a] = range_lo_hi ? std::min(range_lo_hi[4 + a], (int)S4->n[a] - 1) : (int)S4->n[a] - 1;
     }
     G.value = S4->value;
-    if (S4->keep_cap < (size_t)nt + 64) {
-        if (S4->tet_keep) (void)hipFree(S4->tet_keep);
-        S4->tet_keep = nullptr; S4->keep_cap = 0;
-        CXS4_HIP(ctx, hipMalloc(&S4->tet_keep, (size_t)nt + 64));
-        S4->keep_cap = (size_t)nt + 64;
+    {
+        const int rcg = cx_grow(ctx, S4->tet_keep, S4->keep_cap, (size_t)nt + 64);
+        if (rcg) return rcg;
     }
     S4->keep_valid = false;
     uint32_t *vmap = nullptr, *parent = nullptr, *seeds = nullptr, *out = nullptr;

@@ -44,6 +44,7 @@ struct cx_state4 {
     size_t celltab_for = 0;
     float4* verts = nullptr;
     uint32_t* vkeys = nullptr;
+    size_t vkeys_cap = 0;
     uint4* cells = nullptr;
     int32_t* tets = nullptr;
     uint32_t vcap = 0, ccap = 0, tcap = 0;
@@ -51,6 +52,7 @@ struct cx_state4 {
     size_t hash_cap = 0;
     uint32_t* queue = nullptr;
     uint4* rounds = nullptr;
+    size_t rounds_cap = 0;
     uint32_t qcap = 0;
     uint32_t* signbits = nullptr;
     size_t signbits_cap = 0;

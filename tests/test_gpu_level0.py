@@ -122,14 +122,39 @@ def test_generic_kernel_many_reservations(ctx):
         check_against_oracle(ctx, A, 0.8, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_GENERIC, 1)
 
 
-def test_long_tasks_flush_queue_and_batch_records(ctx, monkeypatch):
-    """a dense surface with very long streaming tasks (CX_TASKS tuning knob): every wave queues ~65 k cells,
-    so the LDS-staged queue entries AND the LDS-staged batch records are flushed many times per task"""
-    from contourist_amd import _ffi
-    monkeypatch.setenv("CX_TASKS", "2")
-    rng = np.random.RandomState(41)
-    A = rng.standard_normal((128, 32, 256)).astype(np.float32)
-    check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+_LONG_TASKS_CHILD = """
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+from contourist_amd import _ffi
+import test_gpu_level0 as T
+ctx = _ffi.Context(0)
+rng = np.random.RandomState(41)
+A = rng.standard_normal((128, 32, 256)).astype(np.float32)
+c = T.check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+T.check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CANONICAL, 0)
+ctx.close()
+print("LONG_TASKS_OK", c["n_cells"], c["n_vertices"], c["n_triangles"])
+"""
+
+
+def test_long_tasks_flush_queue_and_batch_records():
+    """A dense surface with the longest streaming tasks the kernel supports: the tuning knob CX_TASKS=2 (honoured only in a
+    process STARTED with CX_DEBUG=1, hence the child process) makes every streaming wave cover 15 planes of 4 x 256 cells of
+    white noise, i.e. queue ~15 000 cells: the LDS-staged queue (1024 entries) is flushed about fifteen times per wave, the
+    wave closes ~30 batches, and the vertex stage's waves start inside batches (cx_skip_rounds).  Checked against the oracle
+    exactly like every other case (both diagonal modes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CX_DEBUG="1", CX_TASKS="2")
+    r = subprocess.run([sys.executable, "-c", _LONG_TASKS_CHILD.format(root=root, tests=os.path.join(root, "tests"))],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("LONG_TASKS_OK")]
+    assert line, r.stdout[-2000:]
+    n_cells = int(line[0].split()[1])
+    assert n_cells > 900000      # ~all 127 x 31 x 255 voxels (+ boundary cells) are active: the queues were long
 
 
 def test_empty_and_full(ctx):
