@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="one size^3 slab PER GPU instead of one volume split over the GPUs")
     ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the extra pass on one stream (unoverlapped kernel durations)")
+    ap.add_argument("--levels", type=int, default=8, help="BASELINE config 5 after the timed region: this many isovalues (20..90th percentiles) of the same volume in ONE call per rank (0 = skip)")
     ap.add_argument("--streams", type=int, default=2, help="extractions in flight: consecutive steps alternate between this many contexts / HIP streams")
     return ap.parse_args()
 
@@ -199,6 +200,65 @@ def run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=T
     return elapsed, tm, final
 
 
+def run_levels(args, torch, dist, _ffi, job, stream, device_index, flags, distributed):
+    """BASELINE config 5: `args.levels` isovalues (20..90th percentiles of the field) of the resident volume, every rank its slab
+    x ALL levels in one cx_extract3d_levels call (the slab is streamed once for all levels; the halo plane exchanged for the
+    single-level steps serves every level).  -> dict for the line (rank 0), timed like the main region (barrier, max over ranks)."""
+    import numpy as np
+    L = int(args.levels)
+    buf = job.slabs[0]
+    dev = buf.device
+    if job.rank == 0:
+        sample = buf[:job.n_own].flatten()[:: max(1, buf[:job.n_own].numel() // (1 << 22))].float()
+        q = torch.tensor([float(x) / 100.0 for x in np.linspace(20.0, 90.0, L)], dtype=torch.float32, device=dev)
+        vals = torch.quantile(sample, q).double()
+    else:
+        vals = torch.zeros(L, dtype=torch.float64, device=dev)
+    if distributed:
+        if dist.get_backend() == "nccl":
+            dist.broadcast(vals, src=0)
+        else:
+            v = vals.cpu()
+            dist.broadcast(v, src=0)
+            vals = v
+    values = [float(x) for x in vals.cpu()]
+    if distributed:
+        job.cxdist.exchange_halo(buf, job.n_own, job.rank, job.world, dist)
+    ctx = _ffi.Context(device_index, stream=stream.cuda_stream)
+    try:
+        ctx.set_origin(job.origin0, 0, 0)
+        ctx.adopt_device_grid(buf.data_ptr(), tuple(buf.shape), keepalive=buf)
+        with torch.cuda.stream(stream):
+            counts = ctx.extract3d_levels(values, flags & 1)        # sizes every level's buffers
+            ctx.extract3d_levels(values, flags & 1)
+            reps = max(1, min(5, args.steps))
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.extract3d_levels(values, flags & 1)
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+    finally:
+        ctx.close()
+    torch.cuda.empty_cache()
+    return {"levels": values, "ms_all_levels": el * 1e3,
+            "Mvoxel_levels_per_s": L * job.total_samples / el / 1e6,
+            "Mvoxels_per_s_grid_once": job.total_samples / el / 1e6,
+            "triangles_per_level_rank0": [int(c["n_triangles"]) for c in counts],
+            "calls_timed": reps,
+            "note": "BASELINE config 5: every rank marches its slab for ALL isovalues in one cx_extract3d_levels call (one pass over the "
+                    "samples for all levels, then vertex + triangle stages per level); synchronous per call (counts come back to size the buffers); "
+                    "whole-job figures, max over ranks"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -288,6 +348,10 @@ def main():
         del wjob.slabs[:]
         torch.cuda.empty_cache()
         job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, 1)
+
+    multi = None
+    if args.levels > 0:
+        multi = run_levels(args, torch, dist, _ffi, job, streams[0], device_index, flags, distributed)
 
     if rank == 0:
         local_samples = job.slabs[0].numel()
@@ -379,6 +443,11 @@ def main():
                 "note": "the same steps on one stream: 4N / sum of the Level-0 kernel durations of one extraction"}
         if weak_line is not None:
             out["weak"] = weak_line
+        if multi is not None:
+            out["multi_level"] = multi
+            out["levels"] = len(multi["levels"])
+            out["ms_all_levels"] = multi["ms_all_levels"]
+            out["Mvoxel_levels_per_s"] = multi["Mvoxel_levels_per_s"]
         if world == 1 and not args.no_api:
             # what the reference's API returns: Level 0 + Level 1 (weld, tiny collapse, clean, orient) + download
             buf = job.slabs[0]

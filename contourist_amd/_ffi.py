@@ -466,10 +466,10 @@ class Context(object):
         return [("stream_ms", "cx_k_classify_generic"), ("emit_ms", "cx_k_emit_triangles")]
 
     def vertex_stage_bytes(self, counts):
-        if self.level0_path() == 2:     # fused emit: 16 B per vertex record + 12 B per triangle written
-            return 16.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
-        # vertex records + cell records + one 8-byte word per queue entry written
-        return 16.0 * counts["n_vertices"] + 24.0 * counts["n_cells"]
+        if self.level0_path() == 2:     # fused emit: 8 B per vertex record + 12 B per triangle written
+            return 8.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
+        # 8-byte vertex records + 16-byte cell records + one 8-byte word per queue entry written
+        return 8.0 * counts["n_vertices"] + 24.0 * counts["n_cells"]
 
     @staticmethod
     def triangle_stage_bytes(counts):

@@ -165,6 +165,64 @@ def extract_slabs(own_planes, value, rank, world, extract_fn, global_shape, dist
     return None
 
 
+def hip_extract_levels(device=0, diagonal_flags=1, context=None):
+    """local extractor for several isovalues of one slab in ONE call (cx_extract3d_levels: the samples are streamed once for
+    all levels): f(local_array_or_tensor, values, origin) -> list of (xyz, keys, tris), one per value.  run.context is the
+    context used."""
+    from . import _ffi
+    ctx = context or _ffi.Context(device)
+
+    def run(local, values, origin=(0, 0, 0)):
+        ctx.set_origin(*origin)
+        if type(local).__module__.split(".")[0] == "torch":
+            ctx.adopt_device_grid(local.data_ptr(), tuple(local.shape), keepalive=local)
+        else:
+            ctx.upload_grid(local)
+        counts = ctx.extract3d_levels(values, diagonal_flags)
+        out = []
+        for l, c in enumerate(counts):
+            ctx.select_level(l)
+            out.append(ctx.download_level0(c))
+        return out
+    run.context = ctx
+    run.global_points = False
+    return run
+
+
+def extract_slabs_levels(own_planes, values, rank, world, extract_levels_fn, global_shape, dist=None, gather=True):
+    """BASELINE config 5 across ranks: every rank marches ITS slab (own planes + one halo plane) for ALL isovalues in one
+    call -- the slab is streamed once however many levels there are (multiple_2d_contour.py:17-30, 48-59 classifies a value
+    against all sorted levels at once; here in 3-D) -- and the levels' meshes are assembled level by level exactly as
+    extract_slabs does for one.  extract_levels_fn(local, values, origin) -> [(xyz, keys, tris)] per value
+    (hip_extract_levels; tests pass the oracle).  gather=True: rank 0 returns [(keys, xyz, triangles)] per value, others None;
+    gather=False: every rank returns its parts [(gkeys, gxyz, tri_gkeys)] per value."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    n0 = int(global_shape[0])
+    i0, i1 = slab_bounds(n0, world, rank)
+    n_own = i1 - i0
+    has_halo = rank + 1 < world
+    t = own_planes if isinstance(own_planes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(own_planes, dtype=np.float32))
+    assert t.shape[0] == n_own, (t.shape, n_own)
+    local = torch.empty((n_own + (1 if has_halo else 0),) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+    local[:n_own] = t
+    exchange_halo(local, n_own, rank, world, dist)                     # ONE halo plane serves every level
+    arg = local if local.is_cuda else local.numpy()
+    meshes = extract_levels_fn(arg, [float(v) for v in values], (i0, 0, 0))
+    glob = getattr(extract_levels_fn, "global_points", False)
+    parts = [local_to_global(xyz, keys, tris, tuple(local.shape), i0, n_own, has_halo, glob) for xyz, keys, tris in meshes]
+    if not gather:
+        return parts
+    if world == 1:
+        return [assemble([p]) for p in parts]
+    out = []
+    for p in parts:
+        g = gather_parts(p, rank, world, dist, local.device if local.is_cuda else None)
+        out.append(assemble(g) if rank == 0 else None)
+    return out if rank == 0 else None
+
+
 def gather_parts(part, rank, world, dist, device=None):
     """(gkeys (V,) int64, gxyz (V,3) float64, tri_gkeys (T,3) int64) of every rank -> list of them on rank 0 (None elsewhere).
     Tensors, not pickles: the sizes go round with one all_gather, then every rank sends ONE flat 8-byte-word buffer

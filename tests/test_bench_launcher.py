@@ -39,5 +39,7 @@ def test_two_ranks_on_one_gpu_strong_scaling():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
     assert line["weak"]["value"] > 0
+    assert line["levels"] == 8 and line["ms_all_levels"] > 0 and line["Mvoxel_levels_per_s"] > 0      # config 5: every rank its slab x 8 levels
     one = run_bench({}, "--gpus", "1", "--size", "64", "--steps", "3", "--warmup", "1", "--passes", "40", "--no-cpu-baseline")
     assert one["n_gpus"] == 1 and one["api_ms"] > 0 and one["level1_ms"] > 0
+    assert one["levels"] == 8 and len(one["multi_level"]["triangles_per_level_rank0"]) == 8 and one["ms_all_levels"] > 0

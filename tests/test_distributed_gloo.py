@@ -173,3 +173,47 @@ def test_level1_input_of_slabs_is_the_undivided_volume(tmp_path):
     assert a["n_after_weld"] == b["n_after_weld"] and a["n_after_tiny"] == b["n_after_tiny"]
     assert np.array_equal(postpass.canonical_level1(a["grid_points"], a["triangles"], corner),
                           postpass.canonical_level1(b["grid_points"], b["triangles"], corner))
+
+
+LEVELS = (-0.6, 0.1, 0.45, 1.1)
+
+
+def oracle_extract_levels(local, values, origin=(0, 0, 0)):
+    return [oracle_extract(local, v, origin) for v in values]
+
+
+def levels_worker(rank, world, port, outdir):
+    """BASELINE config 5 over ranks: each rank its slab x ALL isovalues, ONE halo exchange for all of them"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    A = field()
+    i0, i1 = cd.slab_bounds(A.shape[0], world, rank)
+    res = cd.extract_slabs_levels(A[i0:i1], LEVELS, rank, world, oracle_extract_levels, A.shape, dist=dist)
+    if rank == 0:
+        assert len(res) == len(LEVELS)
+        np.savez(os.path.join(outdir, "levels.npz"), **{"%s%d" % (k, l): a for l, m in enumerate(res) for k, a in zip(("keys", "xyz", "tris"), m)})
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_levels_reproduce_single_volume(world, tmp_path):
+    """every level of the slab-partitioned multi-level extraction == the single-volume extraction of that isovalue"""
+    import torch.multiprocessing as mp
+    from oracle import level0
+    port = free_port()
+    mp.spawn(levels_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "levels.npz"))
+    A = field()
+    for l, v in enumerate(LEVELS):
+        xyz, keys, tris = oracle_extract(A, v)
+        ref = level0.canonical_level0(keys, xyz, tris)
+        out = level0.canonical_level0(got["keys%d" % l], got["xyz%d" % l], got["tris%d" % l])
+        assert len(ref[0]) > 50
+        assert np.array_equal(ref[0], out[0])
+        assert np.allclose(ref[1], out[1], rtol=0, atol=1e-12)
+        assert np.array_equal(ref[2], out[2])

@@ -81,6 +81,113 @@ def test_bench_field_against_oracle_slab_and_properties(size, passes):
         torch.cuda.empty_cache()
 
 
+def _slab_equals_oracle(sub, value, size, keys, xyz, tris):
+    """the mesh of the first PLANES - 1 voxel planes (device: whole volume; oracle: the slab alone) is the same: crossing edges
+    and triangles exactly, coordinates within 1e-6"""
+    from oracle import level0
+    plane = size * size
+    keys = keys.astype(np.int64)
+    lin = keys >> 3
+    in_slab_v = (lin // plane) < (PLANES - 1)
+    O = level0.march3d(sub, value, diag_mode=1)
+    ko = level0.edge_keys_from_pairs(O["pairs"], sub.shape)
+    own_o = ((ko >> 3) // plane) < (PLANES - 1)
+    assert np.array_equal(np.sort(keys[in_slab_v]), np.sort(ko[own_o])), "crossing edges of the first 32 voxel planes differ from the oracle"
+    tk = keys[tris.astype(np.int64)]
+    owner_plane = ((tk >> 3) // plane).min(axis=1)
+    ok_o = ((ko[O["tris"]] >> 3) // plane).min(axis=1) < (PLANES - 1)
+    dev_tr = np.sort(tk[owner_plane < (PLANES - 1)], axis=1)
+    ora_tr = np.sort(ko[O["tris"]][ok_o], axis=1)
+    dev_tr = dev_tr[np.lexsort((dev_tr[:, 2], dev_tr[:, 1], dev_tr[:, 0]))]
+    ora_tr = ora_tr[np.lexsort((ora_tr[:, 2], ora_tr[:, 1], ora_tr[:, 0]))]
+    assert np.array_equal(dev_tr, ora_tr), "triangles of the first 32 voxel planes differ from the oracle"
+    order_d = np.argsort(keys[in_slab_v]); order_o = np.argsort(ko[own_o])
+    xd, xo = xyz[in_slab_v][order_d].astype(np.float64), O["xyz"][own_o][order_o]
+    assert np.all(np.abs(xd - xo) <= 1e-6 * np.abs(xo) + 1e-6)
+    return len(ko)
+
+
+def test_config5_eight_levels_at_full_size():
+    """BASELINE config 5 at its full size: the 512^3 bench field, 8 isovalues (20..90th percentiles) in ONE cx_extract3d_levels
+    call.  Per level: the first 32 voxel planes equal the C oracle exactly, edge ids unique, indices in range; the call is
+    deterministic (a second call gives the same bits for every level) and every level has the counts of a single extraction."""
+    torch = pytest.importorskip("torch")
+    import zlib
+    from contourist_amd import _ffi, synthetic
+    size = 512
+    dev = torch.device("cuda", 0)
+    A = synthetic.smooth_noise_torch((size,) * 3, 1235, 1400, dev)
+    sample = A.flatten()[:: max(1, A.numel() // (1 << 22))].float()
+    values = [float(torch.quantile(sample, q / 100.0)) for q in range(20, 100, 10)]
+    sub = np.ascontiguousarray(A[:PLANES].cpu().numpy())
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    one = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        one.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        counts = ctx.extract3d_levels(values, _ffi.CX_DIAG_CPYTHON310)
+        assert len(counts) == 8
+        sums = []
+        for l, v in enumerate(values):
+            ctx.select_level(l)
+            xyz, keys, tris = ctx.download_level0(counts[l])
+            assert counts[l]["n_triangles"] > 5e6
+            k = keys.astype(np.int64)
+            assert len(np.unique(k)) == len(k)
+            assert tris.min() >= 0 and tris.max() < len(k)
+            assert _slab_equals_oracle(sub, v, size, keys, xyz, tris) > 10000
+            sums.append((zlib.crc32(keys.tobytes()), zlib.crc32(tris.tobytes()), zlib.crc32(xyz.tobytes())))
+            if l in (0, 5):      # the same level as a single extraction: same counts, same bits
+                c1 = one.extract3d(v, _ffi.CX_DIAG_CPYTHON310)
+                x1, k1, t1 = one.download_level0(c1)
+                assert c1 == counts[l]
+                assert np.array_equal(k1, keys) and np.array_equal(t1, tris) and np.array_equal(x1.view(np.uint32), xyz.view(np.uint32))
+            del xyz, keys, tris, k
+        counts2 = ctx.extract3d_levels(values, _ffi.CX_DIAG_CPYTHON310)
+        assert counts2 == counts
+        for l in (7, 2, 4):
+            ctx.select_level(l)
+            xyz, keys, tris = ctx.download_level0(counts2[l])
+            assert (zlib.crc32(keys.tobytes()), zlib.crc32(tris.tobytes()), zlib.crc32(xyz.tobytes())) == sums[l]
+    finally:
+        ctx.close()
+        one.close()
+        del A
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nlevels", [5, 4])
+def test_levels_many_tiles_odd_and_even_counts(nlevels):
+    """128^3 (hundreds of tiles per XCD, T.chunk >> 1), an odd and an even number of levels: the (XCD, tile, level) workgroup
+    numbering of the stream kernel and the two-stream emit with the second set of info words, level by level against single
+    extractions -- counts and the bits of vertex records and triangles"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi, synthetic
+    dev = torch.device("cuda", 0)
+    A = synthetic.smooth_noise_torch((128,) * 3, 77, 300, dev)
+    sample = A.flatten().float()
+    values = [float(torch.quantile(sample[::7], q)) for q in np.linspace(0.15, 0.9, nlevels)]
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    one = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        one.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        for diag in (1, 0):
+            counts = ctx.extract3d_levels(values, diag)
+            for l in list(range(nlevels))[::-1]:
+                ctx.select_level(l)
+                xyz, keys, tris = ctx.download_level0(counts[l])
+                c1 = one.extract3d(values[l], diag)
+                x1, k1, t1 = one.download_level0(c1)
+                assert c1 == counts[l] and c1["n_triangles"] > 10000
+                assert np.array_equal(k1, keys) and np.array_equal(t1, tris) and np.array_equal(x1.view(np.uint32), xyz.view(np.uint32))
+    finally:
+        ctx.close()
+        one.close()
+        del A
+        torch.cuda.empty_cache()
+
+
 def test_config4_field_4d_properties():
     """128^3 x 64 (BASELINE config 4: two moving blobs + noise): ids unique, indices in range, every tetrahedron has four
     distinct vertices inside one hyper-voxel neighbourhood, counts repeat, and a slab of hyper-voxel planes equals the C oracle"""

@@ -84,6 +84,40 @@ def test_two_ranks_gloo_hip(tmp_path):
     assert np.allclose(ref[1], out[1], rtol=1e-6, atol=1e-6)
 
 
+LEVELS = (-0.5, 0.2, 0.9)
+
+
+def _levels_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    A = field()
+    i0, i1 = cd.slab_bounds(A.shape[0], world, rank)
+    res = cd.extract_slabs_levels(A[i0:i1], LEVELS, rank, world, cd.hip_extract_levels(0), A.shape, dist=dist)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "levels.npz"), **{"%s%d" % (k, l): a for l, m in enumerate(res) for k, a in zip(("keys", "xyz", "tris"), m)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_hip_levels(tmp_path):
+    """BASELINE config 5 over ranks with the HIP extractor: every rank marches its slab for ALL isovalues in one
+    cx_extract3d_levels call; each assembled level == the undivided volume at that isovalue (CPython-order diagonals hash
+    global lattice coordinates: cx_set_origin)"""
+    import torch.multiprocessing as mp
+    from oracle import level0
+    A = field()
+    mp.spawn(_levels_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "levels.npz"))
+    for l, v in enumerate(LEVELS):
+        ref = whole(A, v)
+        out = level0.canonical_level0(got["keys%d" % l], got["xyz%d" % l], got["tris%d" % l])
+        assert len(ref[0]) > 100
+        assert np.array_equal(ref[0], out[0]) and np.array_equal(ref[2], out[2])
+        assert np.allclose(ref[1], out[1], rtol=1e-6, atol=1e-6)
+
+
 def same_level1(A, pts0, tris0, pts1, tris1):
     """two Level-1 meshes are the same surface: the same multiset of float64 points, and the same oriented triangles
     written as triples of weld-bucket ids (the vertex numbering differs: march order on a single GPU, edge-id order
