@@ -248,6 +248,36 @@ def unpack_edge_ids(keys, shape):
     return lo, hi
 
 
+def bisect_endpoints(lattice_function, value, pairs, lo, hi):
+    """The bisection of GridContour.find_initial_voxels (tetrahedral.py:408-423) on the host, for end points that lie OUTSIDE the
+    sampled array: the reference evaluates its callable wherever the end points are (its own demos pass (20,20,20) on a 12^3
+    grid and (100,100,100) in world coordinates, html_demo.py:147-161, 277-282) and halves the lattice segment until the two
+    points are neighbours.  Same swaps, same assert, same integer midpoints, the callable in float64.  A pair inside the box
+    [lo, hi] per axis is handed on untouched (the device bisects it on the samples, as before); a pair that leaves the box is
+    replaced by the neighbouring pair its bisection ends at.  -> list of (low_point, high_point) int arrays"""
+    out = []
+    lo, hi = np.asarray(lo), np.asarray(hi)
+    for a, b in pairs:
+        a, b = np.array(a, dtype=np.int64), np.array(b, dtype=np.int64)
+        inside = np.all(a >= lo) and np.all(a <= hi) and np.all(b >= lo) and np.all(b <= hi)
+        if inside:
+            out.append((a, b))
+            continue
+        low_point, high_point = a, b
+        low_value, high_value = float(lattice_function(*low_point)), float(lattice_function(*high_point))
+        if low_value > value or high_value < value:
+            low_point, low_value, high_point, high_value = high_point, high_value, low_point, low_value
+        assert low_value <= value and high_value >= value, "Bad end points " + repr((low_point, low_value, high_point, high_value, value))
+        while np.any(np.abs(low_point - high_point) > 1):
+            mid_point = (low_point + high_point) // 2
+            if float(lattice_function(*mid_point)) < value:
+                low_point = mid_point
+            else:
+                high_point = mid_point
+        out.append((low_point, high_point))
+    return out
+
+
 def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_endpoints,
                   linear_interpolate=True, callback=None, device=None):
     """Grid3DContour(n, m, l, function, value, segment_endpoints, ...)  (tetrahedral.py:104-107).
@@ -261,6 +291,7 @@ def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_
             # explicit end points: the reference does not range-check the voxels it starts from and evaluates the function
             # one lattice step outside the grid (tetrahedral.py:396-441): sample that rim too, grow inside the grid only
             m = 1
+            segment_endpoints = bisect_endpoints(function, float(value), segment_endpoints, [-m] * 3, [c + m for c in corner])
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in segment_endpoints]
             maker = GridContour3d(tuple(c + 2 * m for c in corner), g.dense_samples(margin=m), value, shifted, linear_interpolate, callback,
                                   device, voxel_range=((m, m, m), tuple(c + m for c in corner)),
@@ -328,6 +359,7 @@ class Delta3DContour(object):
             # evaluates f one lattice step outside the grid (tetrahedral.py:396-441); sample that rim too and
             # keep the breadth-first growth inside the reference's grid
             m = 1
+            grid_endpoints = bisect_endpoints(self._lattice_function(0), float(self.value), grid_endpoints, [-m] * 3, list(gd + m))
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
             result = GridContour3d(tuple(gd + 2 * m), grid.dense_samples(margin=m), self.value, shifted,
                                    linear_interpolate=self.linear_interpolate, device=self.device,

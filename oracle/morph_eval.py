@@ -15,8 +15,11 @@ viewer builds it (misc/morph_triangles.js).  Plain Python loops over the fixture
                                                            epsilon = 1e-7 * (max_value - min_value)  (:49-50)
   geometry                :179-204                        one vertex per segment of an active triangle, numbered by first use
 The viewer evaluates at the start `min_t` of each transition interval; `surface_at` takes that time as `t`.
-Parity pin: none of the reference's tests covers the viewer; this restatement is pinned by reading only.  It is what
-tests/test_gpu_level0_4d.py compares cx_morph_eval with (so the device is no longer compared with the package's own numpy)."""
+Parity pin: none of the reference's tests covers the viewer, so the reference ITSELF is run: oracle/make_goldens_viewer.py cuts
+the arithmetic lines out of misc/morph_triangles.js (the ranges above) and runs them unchanged under node on the bytes
+MorphTriangles.to_json wrote; tests/test_oracle_viewer.py holds this restatement to those results bit for bit (intervals, order,
+active sets, first-use numbering, interpolated points at both ends of the interval).  It is what tests/test_gpu_level0_4d.py
+compares cx_morph_eval with (so the device is no longer compared with the package's own numpy)."""
 import numpy as np
 
 
