@@ -120,7 +120,7 @@ class Job(object):
         self.total_samples = n ** 3 if strong else world * n ** 3
 
 
-def run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=True):
+def run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=True, c_halo=False):
     """size buffers, warm up, time args.steps steps; -> (elapsed max over ranks, timing dict, counts).
     ctxs / streams: consecutive steps alternate between these contexts (one HIP stream each): independent volumes, so
     the extraction of step i+1 starts while step i is still in its emit stages -- each kernel alone leaves part of the
@@ -136,6 +136,11 @@ def run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=T
     def step(i):
         buf = job.slabs[i % nrot]
         ctx, st = ctxs[i % ns], streams[i % ns]
+        if c_halo:
+            # the whole step of this rank as ONE C call: adopt, halo exchange on the extraction stream with the context's own
+            # communicator (context k of every rank shares communicator k; volume i goes to context i % ns on every rank), extract
+            ctx.slab_step(buf.data_ptr(), job.n_own, job.n, job.n, rank, world, args.value, flags, keepalive=buf)
+            return
         if overlap_halo:
             # the only exchange of the path is the 1-plane halo.  The exchange for volume i+1 (another buffer) is
             # posted before volume i is extracted and runs on RCCL's stream meanwhile.
@@ -323,16 +328,40 @@ def main():
     if os.environ.get("CX_DEBUG") == "1" and os.environ.get("BENCH_EXTRA_FLAGS"):      # A/B of debug flag bits (tools)
         flags |= int(os.environ["BENCH_EXTRA_FLAGS"], 0)
 
+    c_halo = False
+    if distributed and os.environ.get("BENCH_TORCH_HALO", "0") != "1" and dist.get_backend() == "nccl":
+        # the halo exchange inside the C call of a step (own RCCL communicators, one per context); a buffer is always used by the
+        # same context: the number of rotating buffers becomes a multiple of the number of contexts
+        c_halo = cxdist.own_communicators(ctxs, rank, world, dist)
+        if c_halo:
+            nrot = ((nrot + nstreams - 1) // nstreams) * nstreams
     job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, nrot)
-    elapsed, timing, final = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo)
+    if c_halo:
+        # self-check before anything is timed: the plane the C call receives is the plane torch.distributed delivers
+        probe = job.slabs[0].clone()
+        if job.has_upper:
+            probe[job.n_own].fill_(float("nan"))
+        torch.cuda.synchronize()
+        ctxs[0].halo_exchange(None, rank, world, probe.data_ptr(), job.n_own, n * n)
+        ctxs[0].synchronize()
+        want = job.slabs[0].clone()
+        cxdist.exchange_halo(want, job.n_own, rank, world, dist)
+        torch.cuda.synchronize()
+        same = torch.tensor([1 if torch.equal(probe, want) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        c_halo = bool(int(same.item()))
+        del probe, want
+        if not c_halo and rank == 0:
+            print("# C-side halo exchange disagrees with torch.distributed: staying on torch.distributed", file=sys.stderr, flush=True)
+    elapsed, timing, final = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, c_halo=c_halo)
     if os.environ.get("BENCH_NO_EVENTS") == "1":      # measurement of what the per-kernel events cost: the same region without them
-        el2, _, _ = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=False)
+        el2, _, _ = run_job(args, torch, dist, ctxs, streams, job, flags, overlap_halo, timing=False, c_halo=c_halo)
         if rank == 0:
             print("# without per-kernel events: %.4f ms/step (with: %.4f)" % (el2 / args.steps * 1e3, elapsed / args.steps * 1e3), file=sys.stderr, flush=True)
     single = None
     if nstreams > 1 and rank == 0 and not distributed and not args.no_single_stream:
         # the same steps on ONE stream: per-kernel durations that do not overlap with another extraction's kernels
-        s_el, s_tm, _ = run_job(args, torch, dist, ctxs[:1], streams[:1], job, flags, overlap_halo)
+        s_el, s_tm, _ = run_job(args, torch, dist, ctxs[:1], streams[:1], job, flags, overlap_halo, c_halo=c_halo)
         single = (s_el, s_tm)
 
     weak_line = None
@@ -342,7 +371,7 @@ def main():
         del job.slabs[:]
         torch.cuda.empty_cache()
         wjob = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, False, nrot)
-        wel, _, _ = run_job(args, torch, dist, ctxs, streams, wjob, flags, overlap_halo, timing=False)
+        wel, _, _ = run_job(args, torch, dist, ctxs, streams, wjob, flags, overlap_halo, timing=False, c_halo=c_halo)
         weak_line = {"value": wjob.total_samples * args.steps / wel / 1e6, "unit": "Mvoxels/s", "ms_per_step": wel / args.steps * 1e3,
                      "workload": "one %d^3 slab per GPU (%d x %d x %d volume)" % (n, world * n, n, n)}
         del wjob.slabs[:]
@@ -411,7 +440,8 @@ def main():
                             % (n, n, n, ("volume split over %d GPUs" % world if distributed else "volume") if strong else "slab per GPU", args.passes, args.value),
                 "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if strong else
                               "one slab per GPU (axis 0), 1-plane halo over RCCL") if distributed else "single GPU",
-                "halo_exchange": ("overlapped with the previous volume's extraction" if overlap_halo else "in line") if distributed else None,
+                "halo_exchange": ("one C call per step: RCCL send / receive on the extraction stream (the context's own communicator), then the extraction" if c_halo else
+                                  ("torch.distributed, overlapped with the previous volume's extraction" if overlap_halo else "torch.distributed, in line")) if distributed else None,
                 "active_voxel_fraction": final["n_border_voxels"] / float(max((job.n_own - (0 if job.has_upper else 1)) * (n - 1) ** 2, 1)),
                 "vertices_rank0": final["n_vertices"], "triangles_rank0": final["n_triangles"],
                 "grids_rotated": nrot,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
 ]
@@ -128,6 +128,10 @@ def load():
         "cx_seeded4d_mask_download": [vp, vp],
         "cx_seeded_mode": [vp, vp],
         "cx_halo_exchange": [vp, vp, ctypes.c_int, ctypes.c_int, vp, i64, i64],
+        "cx_rccl_unique_id": [vp],
+        "cx_rccl_comm_init": [vp, vp, ctypes.c_int, ctypes.c_int],
+        "cx_rccl_comm_destroy": [vp],
+        "cx_slab_step": [vp, vp, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_uint32],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
         "cx_postprocess4d_points": [vp, ctypes.c_int32, vp, vp],
@@ -362,6 +366,26 @@ class Context(object):
         """send plane 0 of the device buffer to rank-1, receive plane n_own from rank+1 (RCCL, on the context's stream); rccl_comm:
         the caller's ncclComm_t as an integer / ctypes pointer.  (contourist_amd.distributed does this step with torch.distributed.)"""
         self._check(self.lib.cx_halo_exchange(self.handle, rccl_comm, int(rank), int(world), local_ptr, int(n_own), int(plane_samples)))
+
+    def rccl_unique_id(self):
+        "128 bytes of a fresh ncclUniqueId (one rank calls this; the bytes go to every rank, e.g. by torch.distributed.broadcast)"
+        buf = np.zeros(128, dtype=np.uint8)
+        self._check(self.lib.cx_rccl_unique_id(buf.ctypes.data))
+        return buf
+
+    def rccl_comm_init(self, id128, rank, world):
+        "collective over the ranks: a communicator owned by this context (cx_halo_exchange / slab_step with rccl_comm == NULL)"
+        buf = np.ascontiguousarray(id128, dtype=np.uint8)
+        assert buf.size == 128
+        self._check(self.lib.cx_rccl_comm_init(self.handle, buf.ctypes.data, int(rank), int(world)))
+
+    def slab_step(self, local_ptr, n_own, n1, n2, rank, world, value, flags=CX_DIAG_CPYTHON310, keepalive=None):
+        """one rank's whole step for one volume in ONE call: adopt the device buffer (n_own planes + room for the halo plane unless
+        this is the last rank), halo exchange on this context's stream with its own communicator, extraction enqueued behind it"""
+        self._check(self.lib.cx_slab_step(self.handle, ctypes.c_void_p(int(local_ptr)), int(n_own), int(n1), int(n2), int(rank), int(world),
+                                          float(value), int(flags)))
+        self.shape = (int(n_own) + (1 if rank + 1 < world else 0), int(n1), int(n2))
+        self._keep = keepalive
 
     def seeded_mode(self):
         "how the last seeded selection ran its end points: 'sequential' (the reference's shared visited set) or 'parallel'"

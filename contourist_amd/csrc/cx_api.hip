@@ -59,6 +59,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     if (!ctx) return CX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    cx_rccl_comm_free(ctx);
     cx_levels_free(ctx);
     cx_xfer_free(ctx);
     cx_post_free(ctx);

@@ -83,6 +83,9 @@ struct cx_ctx {
     bool post_valid = false;
     unsigned long long* stamps = nullptr;   // diagnostic stamps (cx_debug_stamps)
     size_t stamps_words = 0;
+    // the context's own RCCL communicator (cx_rccl_comm_init, cx_halo.hip), or null
+    void* rccl_comm = nullptr;
+    int rccl_rank = 0, rccl_world = 1;
     // device -> host copies of mesh-sized buffers (cx_xfer.hip): two pinned staging buffers and their events
     void* xfer_stage[2] = {nullptr, nullptr};
     hipEvent_t xfer_ev[2] = {nullptr, nullptr};
@@ -125,6 +128,8 @@ int cx_ensure_cell_records(cx_ctx* ctx);
 int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags);
 int cx_level0_expanded(cx_ctx* ctx, float4** out);   // the records of the current extraction as float4 {x,y,z,id} (device, enqueued on the stream)
 void cx_fill_value_params(cx_params& P, double value);
+// cx_halo.hip
+void cx_rccl_comm_free(cx_ctx* ctx);
 // cx_xfer.hip
 int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const* src, const size_t* bytes);
 int cx_copy_to_host1(cx_ctx* ctx, void* dst, const void* src, size_t bytes);

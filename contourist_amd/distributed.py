@@ -80,6 +80,43 @@ class HaloExchange(object):
             self.staged_recv = None
 
 
+def own_communicators(ctxs, rank, world, dist=None):
+    """Give every context of this rank its own RCCL communicator (cx_rccl_comm_init), so that the halo exchange of a step is
+    part of ONE C call (Context.slab_step) instead of a Python batch_isend_irecv: context k of every rank joins communicator k.
+    The 128-byte ids travel by torch.distributed (whatever backend it runs).  Collective; returns True on EVERY rank only if
+    every rank succeeded with every context (otherwise the callers stay on exchange_halo / HaloExchange)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    if world == 1:
+        return True
+    ok = 1
+    on_device = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    for k, ctx in enumerate(ctxs):
+        uid = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            try:
+                uid = ctx.rccl_unique_id()
+            except Exception:
+                ok = 0
+        t = torch.from_numpy(uid.copy()).to(dev)
+        dist.broadcast(t, src=0)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:          # rank 0 has no RCCL to ask: nobody calls the collective init
+            return False
+        try:
+            ctx.rccl_comm_init(t.cpu().numpy(), rank, world)
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return False
+    return True
+
+
 def hip_extract(device=0, diagonal_flags=1, float64_points=False, context=None):
     """default local extractor: the HIP Level-0 march. returns f(local_array_or_tensor, value, origin) -> (xyz, keys, tris).
     float64_points: xyz are the float64 coordinates the reference interpolates (what the Level-1 post-pass works on)

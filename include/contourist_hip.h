@@ -152,6 +152,18 @@ int cx_set_reference_corner(cx_ctx* ctx, int64_t c0, int64_t c1, int64_t c2);
  * caller's ncclComm_t; RCCL is not linked but looked up in the calling process (CX_ERR_UNSUPPORTED if there is none).
  * world == 1: nothing to do.  (The Python host uses torch.distributed for the same step: contourist_amd/distributed.py.) */
 int cx_halo_exchange(cx_ctx* ctx, void* rccl_comm, int rank, int world, float* local_planes, int64_t n_own, int64_t plane_samples);
+/* A communicator owned by the context, for hosts that have none to hand over: cx_rccl_unique_id on ONE rank (128 bytes,
+ * ncclGetUniqueId), the bytes carried to every rank by the host's own means, cx_rccl_comm_init (ncclCommInitRank, collective)
+ * on every rank; cx_halo_exchange with rccl_comm == NULL then uses it.  Only an RCCL copy ALREADY loaded in the process is
+ * used (CX_ERR_UNSUPPORTED otherwise): a PyTorch host carries its own. */
+int cx_rccl_unique_id(uint8_t* out128);
+int cx_rccl_comm_init(cx_ctx* ctx, const uint8_t* id128, int rank, int world);
+int cx_rccl_comm_destroy(cx_ctx* ctx);
+/* One rank's whole step for one volume of a slab-partitioned stream of volumes, as ONE call: adopt the device buffer
+ * (n_own planes of n1 x n2 samples, followed by room for the halo plane unless rank == world - 1), exchange the halo on the
+ * context's stream with the context's own communicator, enqueue cx_extract3d_async behind it.  (A 64-plane slab of a 512^3
+ * volume is ~50 us of GPU time: the host side of a step has to be cheaper than that.) */
+int cx_slab_step(cx_ctx* ctx, float* local_planes, int64_t n_own, int64_t n1, int64_t n2, int rank, int world, double value, uint32_t flags);
 int cx_select_seeded3d(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, int64_t* out_counts);
 /* flags CX_SEED_ALL_IN_RANGE: every voxel inside range_lo_hi is kept (the exhaustive search_for_endpoints() of the
  * reference, tetrahedral.py:74-81) and the end points only add the seed voxels OUTSIDE it: the reference does not

