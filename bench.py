@@ -378,6 +378,34 @@ def main():
         torch.cuda.empty_cache()
         job = Job(args, torch, dist, cxdist, synthetic, dev, rank, world, strong, 1)
 
+    projection = None
+    if not distributed and n >= 256 and not args.no_single_stream:
+        # what one rank of an N-way strong run does, measured on THIS GPU: Level 0 of a slab of n / N planes (+ its halo plane) of
+        # the same field, extractions in flight as in the timed region.  A projection -- no halo exchange, no second GPU.
+        projection = {"note": "PROJECTION from one GPU: ms per extraction of a slab of n/N planes (+1 halo plane) of the bench field, %d in flight, no halo "
+                              "exchange; speedup bound = ms(full) / ms(slab)" % nstreams, "ms": {}}
+        for parts in (1, 2, 4, 8):
+            planes = n // parts
+            lo = (n - planes) // 2
+            subs = [job.slabs[k % len(job.slabs)][lo:lo + planes + (1 if lo + planes < n else 0)] for k in range(nstreams)]
+            for c, sv in zip(ctxs, subs):
+                c.set_origin(lo, 0, 0)
+                c.adopt_device_grid(sv.data_ptr(), tuple(sv.shape), keepalive=sv)
+                c.extract3d(args.value, flags)
+            torch.cuda.synchronize()
+            best = None
+            for rnd in range(3):
+                t0 = time.perf_counter()
+                for i in range(40):
+                    ctxs[i % nstreams].extract3d_async(args.value, flags)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 40 * 1e3
+                best = dt if best is None else min(best, dt)
+            projection["ms"][str(planes)] = best
+        full = projection["ms"][str(n)]
+        projection["speedup_bound"] = {str(p): full / projection["ms"][str(n // p)] for p in (2, 4, 8)}
+        for c in ctxs:
+            c.set_origin(job.origin0, 0, 0)
     multi = None
     if args.levels > 0:
         multi = run_levels(args, torch, dist, _ffi, job, streams[0], device_index, flags, distributed)
@@ -473,6 +501,8 @@ def main():
                 "note": "the same steps on one stream: 4N / sum of the Level-0 kernel durations of one extraction"}
         if weak_line is not None:
             out["weak"] = weak_line
+        if projection is not None:
+            out["slab_projection"] = projection
         if multi is not None:
             out["multi_level"] = multi
             out["levels"] = len(multi["levels"])

@@ -156,6 +156,8 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
     cx_levels_state* L = ctx->lv;
     unselect(ctx);
     L->nvalid = 0;
+    // nothing is selected from here on: an error return below must not leave the context describing a level that is gone
+    ctx->extracted = false; ctx->counts_fetched = false; ctx->post_valid = false; ctx->keep_valid = false;
     if ((int)L->slots.size() < nlevels) L->slots.resize(nlevels);
     const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
     int rc = cx_ensure_hash_xy(ctx, flags);
@@ -210,7 +212,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         CXL_HIP(ctx, hipHostMalloc(&L->hcounters, (size_t)nlevels * CX_CNT_WORDS * sizeof(uint32_t)));
         L->hcounters_cap = (size_t)nlevels;
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
+    {
         std::vector<cx_params> hp(nlevels);
         for (int l = 0; l < nlevels; l++) {
             cx_level_slot& S = L->slots[l];
@@ -276,13 +278,19 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             cx_launch_emit_vertices(S.P, T, st);
             cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, st);
         }
-        CXL_HIP(ctx, hipGetLastError());
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                if (two) (void)hipStreamSynchronize(L->stream2);   // the forked stream is not left running behind an error return
+                ctx->err = std::string("cx_extract3d_levels: ") + hipGetErrorString(le);
+                return CX_ERR_HIP;
+            }
+        }
         if (two) {
             CXL_HIP(ctx, hipEventRecord(L->ev_join, L->stream2));
             CXL_HIP(ctx, hipStreamWaitEvent(ctx->stream, L->ev_join, 0));
         }
         CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        break;
     }
     L->nvalid = nlevels;
     if (out_counts)

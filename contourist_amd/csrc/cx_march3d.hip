@@ -34,6 +34,9 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #ifndef CX_RJ
 #define CX_RJ 4             // cell rows per wave in the stream kernel (a workgroup covers 4*CX_RJ rows)
 #endif
+#ifndef CX_S3_MIN_SHARE
+#define CX_S3_MIN_SHARE 4u   // rounds a vertex-stage wave takes at least (small surfaces: fewer waves rather than waves that only start up)
+#endif
 #ifndef CX_BATCH_MIN
 #define CX_BATCH_MIN 512u   // a streaming wave closes a batch once it holds this many cells (128..1024 measured: 512 best)
 #endif
@@ -926,7 +929,7 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
     }
     // the vertex stage divides the rounds of 64 queued cells evenly among its P.nvw waves: wave m takes rounds [m q, m q + q)
     const uint32_t rounds = s_part[0][7] + s_part[1][7] + s_part[2][7] + s_part[3][7];
-    const uint32_t q = max((rounds + P.nvw - 1u) / P.nvw, 1u);
+    const uint32_t q = max((rounds + P.nvw - 1u) / P.nvw, CX_S3_MIN_SHARE);
     if (w < nw) {
         cx_wbase B;
         B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
     const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
     const uint32_t rounds = P.counters[CX_CNT_ROUNDS];
     const uint32_t nvw = gridDim.x * 4u;     // == P.nvw
-    const uint32_t share = max((rounds + nvw - 1u) / nvw, 1u);
+    const uint32_t share = max((rounds + nvw - 1u) / nvw, CX_S3_MIN_SHARE);
     const uint32_t lo = (blockIdx.x * 4u + wave) * share;
     if (lo >= rounds || nbatches == 0u) return;
     const uint32_t hi = min(rounds, lo + share);

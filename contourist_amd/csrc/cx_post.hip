@@ -1217,10 +1217,16 @@ extern "C" int cx_level1_write(cx_ctx* ctx, int format, const char* path, const 
                 if (!more) break;
                 e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { ctx->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = CX_ERR_HIP; break; }
-                if (section == 0 && format != CX_FILE_PLY) {   // glTF wants the bounds of the positions
-                    const float* q = reinterpret_cast<const float*>(hstage[half]);
-                    for (uint32_t i = 0; i < n; i++)
-                        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)q[3 * i + a]); hi[a] = std::max(hi[a], (double)q[3 * i + a]); }
+                if (section == 0) {   // bounds of the positions (glTF needs them in its JSON; reported for both formats)
+                    if (format != CX_FILE_PLY) {
+                        const float* q = reinterpret_cast<const float*>(hstage[half]);
+                        for (uint32_t i = 0; i < n; i++)
+                            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)q[3 * i + a]); hi[a] = std::max(hi[a], (double)q[3 * i + a]); }
+                    } else {
+                        const double* q = reinterpret_cast<const double*>(hstage[half]);
+                        for (uint32_t i = 0; i < n; i++)
+                            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], q[3 * i + a]); hi[a] = std::max(hi[a], q[3 * i + a]); }
+                    }
                 }
                 pending = half;
                 pending_bytes = (size_t)n * rec;
@@ -1228,11 +1234,13 @@ extern "C" int cx_level1_write(cx_ctx* ctx, int format, const char* path, const 
         }
 #undef CXW_TRY
     } while (0);
-    fclose(f);
+    // a short write may only surface when the buffered bytes are flushed (disk full): check both, and leave no partial file
+    if (fflush(f) != 0 && rc == CX_OK) { rc = CX_ERR_INVALID; ctx->err = "cx_level1_write: write failed (flush)"; }
+    if (fclose(f) != 0 && rc == CX_OK) { rc = CX_ERR_INVALID; ctx->err = "cx_level1_write: write failed (close)"; }
     if (dstage) (void)hipFree(dstage);
     for (int k = 0; k < 2; k++)
         if (hstage[k]) (void)hipHostFree(hstage[k]);
-    if (rc) return rc;
+    if (rc) { (void)remove(path); return rc; }
     if (out_info) {
         out_info[0] = (double)nv; out_info[1] = (double)nt; out_info[2] = (double)written;
         for (int a = 0; a < 3; a++) { out_info[3 + a] = nv ? lo[a] : 0.0; out_info[6 + a] = nv ? hi[a] : 0.0; }

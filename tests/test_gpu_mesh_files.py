@@ -19,7 +19,7 @@ def test_device_fed_ply_and_gltf(name, tmp_path):
     S = tetrahedral.TriangulatedIsosurfaces(G["mins"], None, G["delta"], G["A"], float(G["value"]), [])
     S.search_for_endpoints()
     p_dev = str(tmp_path / "device.ply")
-    mesh_io.write_ply_device(S, p_dev)
+    info = mesh_io.write_ply_device(S, p_dev)
     # the same mesh through the array API, faces as the device holds them
     ctx = S.contour_maker.context()
     pts_grid, tris_dev = ctx.download_level1(S.contour_maker._post)
@@ -27,6 +27,15 @@ def test_device_fed_ply_and_gltf(name, tmp_path):
     p_host = str(tmp_path / "host.ply")
     mesh_io.write_ply(p_host, world, tris_dev)
     assert open(p_dev, "rb").read() == open(p_host, "rb").read()
+    # what the writer reports: counts, bytes and the bounds of the positions (both formats)
+    assert info["n_vertices"] == len(world) and info["n_triangles"] == len(tris_dev) and info["bytes"] == os.path.getsize(p_dev)
+    assert np.array_equal(info["min"], world.min(axis=0)) and np.array_equal(info["max"], world.max(axis=0))
+    # a path that cannot be written: an error, and no partial file left behind
+    from contourist_amd import _ffi
+    bad = str(tmp_path / "no_such_dir" / "x.ply")
+    with pytest.raises(_ffi.CxError):
+        ctx.write_level1(bad, "ply", S.grid.mins, S.grid.delta)
+    assert not os.path.exists(bad)
     P, T = mesh_io.read_ply(p_dev)
     pts_api, tris_api = S.get_points_and_triangles()
     assert np.array_equal(P, np.asarray(pts_api)) and len(T) == len(tris_api)

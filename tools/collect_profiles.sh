@@ -1,6 +1,6 @@
 #!/bin/bash
 # after `gpurun -- bash tools/profile_round.sh`: copy the summaries that came back under gpurun_out/prof/ into profiles/ (tracked)
-R=${1:-r02}
+R=${1:-r03}
 cp gpurun_out/prof/bench_line.json profiles/${R}_bench_line_512.json
 cp gpurun_out/prof/bench_under_rocprof.json profiles/${R}_bench_line_512_under_rocprof.json
 cp gpurun_out/prof/kernel_stats_512.csv profiles/${R}_kernel_stats_512.csv

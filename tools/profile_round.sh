@@ -8,10 +8,10 @@ mkdir -p gpurun_out/prof gpurun_out/pmc
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/prof/bench_line.json 2> gpurun_out/prof/bench.err
 # the kernel trace of the SAME command (two extractions in flight: kernels of consecutive extractions overlap, their durations are
 # longer than alone) and of the same steps on one stream (--streams 1: durations that add up to the extraction)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-api --no-single-stream > gpurun_out/prof/bench_under_rocprof.json 2> gpurun_out/prof/kt.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-api --no-single-stream --levels 0 > gpurun_out/prof/bench_under_rocprof.json 2> gpurun_out/prof/kt.err
 f=$(find gpurun_out/prof/kt -name "*kernel_stats.csv" | head -1)
 grep -E "^\"Name\"|cx_k" "$f" > gpurun_out/prof/kernel_stats_512.csv
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt1 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-api --streams 1 > gpurun_out/prof/bench_one_stream_under_rocprof.json 2> gpurun_out/prof/kt1.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt1 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-api --no-single-stream --levels 0 --streams 1 > gpurun_out/prof/bench_one_stream_under_rocprof.json 2> gpurun_out/prof/kt1.err
 f=$(find gpurun_out/prof/kt1 -name "*kernel_stats.csv" | head -1)
 grep -E "^\"Name\"|cx_k" "$f" > gpurun_out/prof/kernel_stats_512_one_stream.csv
 for c in FETCH_SIZE WRITE_SIZE; do
