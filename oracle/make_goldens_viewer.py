@@ -14,7 +14,7 @@ and runs those lines UNCHANGED under node inside a small driver (written to a te
 that feeds them the JSON of the wire fixtures (tests/golden_wire/*.to_json.*.txt.gz: bytes written by the real reference),
 sets the viewer's clock to a list of times and prints what the lines computed.  The driver's own part is the loop over the
 active triangles' segments in order of first use (the reference does that inside THREE.Geometry calls, :179-204).
-Output: tests/golden4d/viewer_<fixture>.npz -- numbers only."""
+Output: tests/golden_viewer/viewer_<fixture>.npz -- numbers only."""
 import gzip
 import json
 import os
@@ -27,7 +27,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/misc/morph_triangles.js"
 WIRE = os.path.normpath(os.path.join(HERE, "..", "tests", "golden_wire"))
-OUT = os.path.normpath(os.path.join(HERE, "..", "tests", "golden4d"))
+OUT = os.path.normpath(os.path.join(HERE, "..", "tests", "golden_viewer"))
 
 SLICES = {   # name: (first line, last line, text the first line must contain, text the last line must contain)
     "A": (6, 12, 'var max_value = morph_triangle_data["max_value"]', "var ticking = false"),

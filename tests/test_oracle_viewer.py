@@ -1,7 +1,7 @@
 """CPU: oracle/morph_eval.py (the oracle cx_morph_eval is compared with on the GPU) against what the
 reference's OWN viewer code computed -- misc/morph_triangles.js, lines cut out and run unchanged under node by
 oracle/make_goldens_viewer.py on the bytes MorphTriangles.to_json wrote (tests/golden_wire), results in
-tests/golden4d/viewer_*.npz.  Which lines of the viewer each assertion covers is stated at the assertion."""
+tests/golden_viewer/viewer_*.npz.  Which lines of the viewer each assertion covers is stated at the assertion."""
 import glob
 import gzip
 import json
@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIX = sorted(glob.glob(os.path.join(ROOT, "tests", "golden4d", "viewer_*.npz")))
+FIX = sorted(glob.glob(os.path.join(ROOT, "tests", "golden_viewer", "viewer_*.npz")))
 
 
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[7:-4] for p in FIX])
