@@ -31,6 +31,9 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #ifndef CX_K1_MIN_WAVES
 #define CX_K1_MIN_WAVES 3   // stream kernel: two sample planes in flight per wave
 #endif
+#ifndef CX_S1_DEPTH
+#define CX_S1_DEPTH 1        // sample planes in flight ahead of the one the stream kernel works on (1 or 2; 2 measured slower: 0.131 vs 0.125 ms, 168 registers)
+#endif
 #ifndef CX_RJ
 #define CX_RJ 4             // cell rows per wave in the stream kernel (a workgroup covers 4*CX_RJ rows)
 #endif
@@ -665,8 +668,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             float4 v[CX_RJ + 1];
             float hv[CX_RJ + 1];
         };
+        const uint32_t plane_last = min(ib, P.n0 - 1u);
         auto load_plane = [&](uint32_t pp, plane_raw& R) {
-            const uint32_t pc = min(pp, P.n0 - 1u);
+            const uint32_t pc = min(pp, plane_last);   // never beyond the last plane this task needs: a request past it re-reads that plane (a cache hit)
 #pragma unroll
             for (int r = 0; r <= CX_RJ; r++) {
                 const uint32_t jr = min(j0 + (uint32_t)r, P.n1 - 1u);   // rows beyond the array repeat the last row
@@ -711,6 +715,22 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             return own | (nbr << 4);
         };
 
+        // Sample planes p .. ib are needed (cell plane ib - 1 reads sample plane ib).  The prefetch runs past ib; those requests are
+        // issued all the same -- a branch around them makes the compiler wait for ALL outstanding loads at the next use, which undoes
+        // the prefetch (measured: 0.126 -> 0.138 ms) -- but re-read plane ib, a cache hit, instead of the neighbour task's plane ib + 1
+        // (rounds 1 and 2: one plane in ci + 2, 6 % of the kernel's HBM reads).
+        // CX_S1_DEPTH planes are in flight ahead of the one being worked on (a second one was tried in round 3: no gain, the kernel
+        // is not starved for samples).
+#if CX_S1_DEPTH == 2
+        plane_raw rawA, rawB, rawC;
+        load_plane(p, rawB);
+        load_plane(p + 1u, rawA);
+        load_plane(p + 2u, rawC);
+        uint32_t wprev = plane_bits(rawB);
+        // one step: plane p+1 is in `cur`, plane p+2 is on its way, plane p+3 is requested into `nxt` (whose plane is used up)
+        auto step = [&](const plane_raw& cur, plane_raw& nxt) {
+            load_plane(p + 3u, nxt);
+#else
         plane_raw rawA, rawB;
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
@@ -718,6 +738,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 2u, nxt);
+#endif
             const uint32_t wcur = plane_bits(cur);
             // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
             const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
@@ -804,11 +825,21 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             wprev = wcur;
             p++;
         };
+#if CX_S1_DEPTH == 2
+        while (p < ib) {
+            step(rawA, rawB);
+            if (p >= ib) break;
+            step(rawC, rawA);
+            if (p >= ib) break;
+            step(rawB, rawC);
+        }
+#else
         while (p < ib) {
             step(rawA, rawB);
             if (p >= ib) break;
             step(rawB, rawA);
         }
+#endif
     }
     if (qn > qstart) close_batch();
     flush_queue();
