@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the extra pass on one stream (unoverlapped kernel durations)")
     ap.add_argument("--levels", type=int, default=8, help="BASELINE config 5 after the timed region: this many isovalues (20..90th percentiles) of the same volume in ONE call per rank (0 = skip)")
-    ap.add_argument("--streams", type=int, default=2, help="extractions in flight: consecutive steps alternate between this many contexts / HIP streams")
+    ap.add_argument("--streams", type=int, default=0, help="extractions in flight: consecutive steps alternate between this many contexts / HIP streams "
+                                                           "(0 = auto: 2; 3 from 4 ranks on, where a rank's slab is thin and every step waits for a halo plane)")
     return ap.parse_args()
 
 
@@ -311,6 +312,8 @@ def main():
         rank = dist.get_rank()
     n = args.size
     strong = not args.weak
+    if args.streams <= 0:
+        args.streams = 3 if world >= 4 else 2
     # distinct volumes cycled through: a 512^3 grid (537 MB) is twice the Infinity Cache, but half of it could stay
     # resident from step to step, so at least two are rotated; small grids need enough to exceed 256 MB several times
     nrot = args.rotate or (2 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
