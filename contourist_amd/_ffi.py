@@ -25,7 +25,7 @@ CX_KERNEL_FUSED = 0x400
 SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
-    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records",
+    "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
@@ -107,6 +107,7 @@ def load():
         "cx_level0_download": [vp, vp, vp],
         "cx_level0_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "cx_level0_device_records": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)],
+        "cx_level0_download_records": [vp, vp, vp],
         "cx_postprocess3d": [vp, u32, vp],
         "cx_postprocess3d_ex": [vp, u32, dbl, vp],
         "cx_level0_points_f64": [vp, vp],
@@ -253,6 +254,15 @@ class Context(object):
         self._check(self.lib.cx_level0_download(self.handle, verts.ctypes.data, tris.ctypes.data))
         keys = verts[:, 3].copy().view(np.uint32)
         return verts[:, :3].copy(), keys, tris
+
+    def download_level0_records(self, counts):
+        """-> (edge ids (V,) uint32, t (V,) float32: the crossing sits at q + t d on the lattice edge the id names, triangles (T,3) int32):
+        the 8-byte records as the march leaves them (no expansion to coordinates)"""
+        nv, nt = int(counts["n_vertices"]), int(counts["n_triangles"])
+        recs = np.empty((nv, 2), dtype=np.uint32)
+        tris = np.empty((nt, 3), dtype=np.int32)
+        self._check(self.lib.cx_level0_download_records(self.handle, recs.ctypes.data, tris.ctypes.data))
+        return recs[:, 0].copy(), recs[:, 1].copy().view(np.float32), tris
 
     def set_reference_corner(self, corner=(0, 0, 0)):
         self._check(self.lib.cx_set_reference_corner(self.handle, *[int(c) for c in corner]))

@@ -295,6 +295,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         P.flat = ctx->flat; P.fcap = (uint32_t)nflat;
         P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
+        P.qlimit = T.wcap;
         P.nvw = cx_vertex_stage_waves(P);
         if ((rc = cx_grow(ctx, ctx->rstart, ctx->rstart_cap, (size_t)P.nvw + 1u))) return rc;
         P.rstart = ctx->rstart;
@@ -459,6 +460,19 @@ extern "C" int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris
     }
     if (tris) *tris = ctx->tris;
     return CX_OK;
+}
+
+extern "C" int cx_level0_download_records(cx_ctx* ctx, uint32_t* vertex_records, int32_t* tris) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->extracted) return fail(ctx, CX_ERR_STATE, "no valid extraction");
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    cx_counts c;
+    const int rc = cx_counts_get(ctx, &c);
+    if (rc) return rc;
+    void* d[2] = {(vertex_records && c.n_vertices) ? (void*)vertex_records : nullptr, (tris && c.n_triangles) ? (void*)tris : nullptr};
+    const void* sp[2] = {ctx->verts, ctx->tris};
+    const size_t nb[2] = {(size_t)c.n_vertices * sizeof(cx_vrec), (size_t)c.n_triangles * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
 }
 
 extern "C" int cx_level0_device_records(cx_ctx* ctx, void** vertex_records, void** tris) {

@@ -87,6 +87,7 @@ struct cx_params {
     uint32_t fused;           // 1: the fused emit kernel follows (no per-cell table, no cell records)
     uint32_t* rstart;         // [nvw] vertex stage: the batch in which wave m's share of the rounds starts (written by the scan kernel)
     uint32_t nvw;             // waves of the vertex stage (4 x its grid)
+    uint32_t qlimit;          // queue entries a streaming wave may store (T.wcap; less when levels share a pool)
 };
 #ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
@@ -140,6 +141,7 @@ struct cx_task {
 enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, CX_CNT_BATCHES = 4,
        CX_CNT_NEAR = 5,   // streaming waves that met a sample inside the tolerance screen (their cells take the per-cell path)
        CX_CNT_ROUNDS = 6, // rounds of 64 queued cells over all batches (what the vertex stage divides among its waves)
+       CX_CNT_OVERFLOW = 7, // a streaming wave found more cells than its slice of a shared queue pool holds (cx_extract3d_levels)
        CX_CNT_WORDS = 8 };
 
 // device tables (defined in cx_march3d.hip)

@@ -68,6 +68,12 @@ struct cx_levels_state {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint64_t* info64b = nullptr;
     size_t info64b_cap = 0;
+    // ONE pool of queue entries for all levels (every level a slice of every streaming wave's region); false after a call
+    // whose surface overflowed a slice: that grid then gets full-size regions per level, as in round 2
+    bool pooled = true;
+    uint32_t* qpool = nullptr;
+    size_t qpool_cap = 0;
+    int64_t pooled_off_for[3] = {0, 0, 0};   // the grid shape `pooled == false` was decided for
 };
 
 static void free_slot(cx_level_slot& S) {
@@ -92,6 +98,7 @@ void cx_levels_free(cx_ctx* ctx) {
     cx_release(L->dparams, L->dparams_cap);
     if (L->hcounters) (void)hipHostFree(L->hcounters);
     cx_release(L->info64b, L->info64b_cap);
+    cx_release(L->qpool, L->qpool_cap);
     if (L->stream2) (void)hipStreamDestroy(L->stream2);
     if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
     if (L->ev_join) (void)hipEventDestroy(L->ev_join);
@@ -170,10 +177,25 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
     // batches: one short batch per streaming wave + one per CX_BATCH_MIN queued cells; the cell count is not known yet, so
     // room for a surface through a quarter of all cells (more: CX_ERR_CAPACITY, extract such levels one by one)
     const size_t nflat = nw + (size_t)N / 4u / 512u + boundary / 128u + 4096u;
+    // Queue entries: worst case one per sample and level.  Pooled (the default): the levels share ONE region of `need` entries,
+    // level l owning entries [l sub, l sub + sub) of every streaming wave's stretch of T.wcap -- 0.54 GB + 1.07 GB of info words at
+    // 512^3 whatever the number of levels (round 2: 0.6 GB per level + 2 x 1.07 GB).  A wave whose cells do not fit its slice
+    // raises the overflow flag; the call is then repeated with full-size regions per level, and that stays so for this grid shape.
+    if (!L->pooled && (L->pooled_off_for[0] != ctx->n0 || L->pooled_off_for[1] != ctx->n1 || L->pooled_off_for[2] != ctx->n2)) L->pooled = true;
+    uint32_t sub = (T.wcap / (uint32_t)nlevels) & ~63u;
+    if (cx_debug_knob("CX_LEVELS_SLICE", 0u)) sub = cx_debug_knob("CX_LEVELS_SLICE", 0u) & ~63u;   // tests: force small slices
+    bool pooled = L->pooled && sub >= 64u && !cx_debug_knob("CX_LEVELS_NO_POOL", 0u);
+    if (pooled) {
+        if ((rc = grow(ctx, L->qpool, L->qpool_cap, need))) return rc;
+        for (auto& S : L->slots) cx_release(S.queue, S.queue_cap);      // full-size regions of an earlier call
+        cx_release(L->info64b, L->info64b_cap);
+    } else {
+        cx_release(L->qpool, L->qpool_cap);
+    }
     for (int l = 0; l < nlevels; l++) {
         cx_level_slot& S = L->slots[l];
         S.value = values[l];
-        if ((rc = grow(ctx, S.queue, S.queue_cap, need))) return rc;
+        if (!pooled && (rc = grow(ctx, S.queue, S.queue_cap, need))) return rc;
         if ((rc = grow(ctx, S.wsum, S.wsum_cap, nw))) return rc;
         if ((rc = grow(ctx, S.wbase, S.wbase_cap, nw))) return rc;
         if ((rc = grow(ctx, S.brec, S.brec_cap, nw * T.bcap))) return rc;
@@ -194,7 +216,9 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         P.flags = flags;
         P.org0 = (uint32_t)ctx->origin[0]; P.org1 = (uint32_t)ctx->origin[1]; P.org2 = (uint32_t)ctx->origin[2];
         P.counters = S.counters;
-        P.queue = S.queue; P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
+        P.queue = pooled ? L->qpool + (size_t)l * sub : S.queue;
+        P.qlimit = pooled ? sub : T.wcap;
+        P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
         P.qa = S.qa;
         P.chunksum = S.chunksum;
         P.nvw = cx_vertex_stage_waves(P);
@@ -218,7 +242,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             cx_level_slot& S = L->slots[l];
             S.P.verts = S.verts; S.P.cells = S.cells; S.P.tris = S.tris;
             S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
-            S.P.info64 = ctx->info64;
+            S.P.info64 = pooled ? ctx->info64 + (size_t)l * sub : ctx->info64;
             hp[l] = S.P;
         }
         CXL_HIP(ctx, hipMemcpyAsync(L->dparams, hp.data(), (size_t)nlevels * sizeof(cx_params), hipMemcpyHostToDevice, ctx->stream));
@@ -236,6 +260,12 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             const uint32_t* hc = L->hcounters + (size_t)l * CX_CNT_WORDS;
             S.counts.n_cells = hc[CX_CNT_CELLS]; S.counts.n_vertices = hc[CX_CNT_VERTS];
             S.counts.n_triangles = hc[CX_CNT_TRIS]; S.counts.n_border_voxels = hc[CX_CNT_BORDER];
+            if (pooled && hc[CX_CNT_OVERFLOW]) {
+                // a level's surface is denser than a slice of the pool holds somewhere: the same call with full-size regions
+                L->pooled = false;
+                L->pooled_off_for[0] = ctx->n0; L->pooled_off_for[1] = ctx->n1; L->pooled_off_for[2] = ctx->n2;
+                return cx_extract3d_levels(ctx, values, nlevels, flags, out_counts);
+            }
             if (hc[CX_CNT_BATCHES] > nflat) {
                 ctx->err = "cx_extract3d_levels: a level's surface passes through too many cells for the batch list: extract it with cx_extract3d";
                 return CX_ERR_CAPACITY;
@@ -255,7 +285,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             S.ccap = (uint32_t)c; S.vcap = (uint32_t)v; S.tcap = (uint32_t)t;
             S.P.verts = S.verts; S.P.cells = S.cells; S.P.tris = S.tris;
             S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
-            S.P.info64 = ctx->info64;
+            S.P.info64 = pooled ? ctx->info64 + (size_t)l * sub : ctx->info64;
         }
         // vertex and triangle stages, two levels side by side: even levels on the context's stream, odd ones on a second stream
         // with their own info words (the staged kernels of one level hand over through them)
@@ -266,7 +296,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
                 CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
                 CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
             }
-            if ((rc = grow(ctx, L->info64b, L->info64b_cap, ctx->info64_cap))) return rc;
+            if (!pooled && (rc = grow(ctx, L->info64b, L->info64b_cap, ctx->info64_cap))) return rc;   // pooled: every level has its own slice of the info words
             CXL_HIP(ctx, hipEventRecord(L->ev_fork, ctx->stream));
             CXL_HIP(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
         }
@@ -274,7 +304,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             cx_level_slot& S = L->slots[l];
             const bool side = two && (l & 1);
             hipStream_t st = side ? L->stream2 : ctx->stream;
-            S.P.info64 = side ? L->info64b : ctx->info64;
+            if (!pooled) S.P.info64 = side ? L->info64b : ctx->info64;
             cx_launch_emit_vertices(S.P, T, st);
             cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, st);
         }

@@ -592,7 +592,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
     __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
-    __shared__ uint32_t s_tot[4][7];
+    __shared__ uint32_t s_tot[4][8];
     __shared__ uint8_t s_ntri[256];      // triangles of a voxel by its corner sign mask
     if (b >= T.nblocks) return;
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
@@ -620,11 +620,19 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
+    // P.qlimit: entries this wave's region holds.  A single extraction gives every wave room for all its cells (T.wcap); the levels of
+    // cx_extract3d_levels share ONE pool, each with a slice of every wave's region -- a wave that finds more cells than its slice
+    // holds stops storing them and raises the overflow flag (chunk slot 7): the host then gives that call full-size regions.
+    bool overflow = false;
     auto flush_queue = [&]() {
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t o = lane; o < ql; o += 64u) gq[qflushed + o] = q[o];
+        if (qflushed + ql <= P.qlimit) {
+            for (uint32_t o = lane; o < ql; o += 64u) gq[qflushed + o] = q[o];
+            qflushed += ql;
+        } else {
+            overflow = true;
+        }
         __builtin_amdgcn_wave_barrier();
-        qflushed += ql;
         ql = 0;
     };
     auto flush_brec = [&]() {
@@ -858,7 +866,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     run.v = rv; run.t = rt; run.c = rc; run.b = cx_wave_sum(acc.b);
     const bool near = __ballot(dnear <= P.near_abs) != 0ULL && !(P.flags & CX_DBG_NO_NEAR);   // wave-uniform
     bool really_near = false;
-    if (near && qn != 0u) {
+    if (near && qn != 0u && !overflow) {
         // a sample inside the screen: the reference's tolerance rules may drop tetrahedra or vertices.
         // Count exactly (per-cell path over the wave's own queue; its stores are complete after the
         // fence) and hand the whole queue over as ONE batch that takes the per-cell path downstream.
@@ -888,15 +896,16 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         s_tot[wave][0] = run.v; s_tot[wave][1] = run.t; s_tot[wave][2] = run.c; s_tot[wave][3] = run.b; s_tot[wave][4] = nb;
         s_tot[wave][5] = (really_near && qn != 0u) ? 1u : 0u;
         s_tot[wave][6] = nr;
+        s_tot[wave][7] = overflow ? 1u : 0u;
     }
     // totals of every 256 waves (64 workgroups), so that the scan needs ONE round of loads for everything before its chunk
     // (the per-wave totals were just written by CUs all over the chip: each dependent round of loads from them costs ~2 us).
     // One atomic per workgroup and counter.
     __syncthreads();
-    if (threadIdx.x < 7u) {
+    if (threadIdx.x < 8u) {
         const uint32_t sum = s_tot[0][threadIdx.x] + s_tot[1][threadIdx.x] + s_tot[2][threadIdx.x] + s_tot[3][threadIdx.x];
         uint32_t* cs = P.chunksum + (size_t)(b >> 6) * 8u;
-        if (sum) atomicAdd(cs + threadIdx.x, sum);      // (slot 5: number of waves on the tolerance path; non-zero = flag; slot 6: rounds)
+        if (sum) atomicAdd(cs + threadIdx.x, sum);      // (slot 5: number of waves on the tolerance path; non-zero = flag; slot 6: rounds; slot 7: waves whose queue slice overflowed)
     }
 }
 template <bool ALIGNED>
@@ -921,16 +930,17 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream_levels(const
 // the last workgroup, which has seen every wave, writes the counters.  (One workgroup scanning all 12 k waves of a 512^3
 // grid was bound by what a single CU can pull: 22 us + 5 us for the list kernel.)
 __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_task& T, const uint32_t nw, const uint32_t g, const uint32_t nchunks) {
-    __shared__ uint32_t s_part[4][8];    // per wave of the workgroup: totals of the earlier chunks (6), near flag, rounds of ALL chunks
+    __shared__ uint32_t s_part[4][8];    // per wave of the workgroup: totals of the earlier chunks (6), near | overflow << 1, rounds of ALL chunks
     __shared__ uint32_t s_own[4][6];     // per wave: inclusive totals of its 64 streaming waves
     const uint32_t tid = threadIdx.x, lane = cx_lane_id(), wave = tid >> 6;
-    uint32_t acc[6] = {0, 0, 0, 0, 0, 0}, near_any = 0, rall = 0;   // v, t, c, b, nb, nr
+    uint32_t acc[6] = {0, 0, 0, 0, 0, 0}, near_any = 0, rall = 0, over_any = 0;   // v, t, c, b, nb, nr
     for (uint32_t c = tid; c < nchunks; c += 256u) {     // thread c: the totals of chunk c (every workgroup looks at all of them: near flag, total rounds)
         const uint4 lo = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u);
         const uint4 hi = *reinterpret_cast<const uint4*>(P.chunksum + (size_t)c * 8u + 4u);
         if (c < g) { acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w; acc[4] += hi.x; acc[5] += hi.z; }
         near_any |= hi.y;
         rall += hi.z;
+        over_any |= hi.w;
     }
     const uint32_t w = g * 256u + tid;
     cx_wsum S;
@@ -948,7 +958,8 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
     {
         const uint32_t nr = (__ballot(near_any != 0u) != 0ULL) ? 1u : 0u;
         const uint32_t ra = cx_wave_sum(rall);
-        if (lane == 63u) { s_part[wave][6] = nr; s_part[wave][7] = ra; }
+        const uint32_t ov = (__ballot(over_any != 0u) != 0ULL) ? 1u : 0u;
+        if (lane == 63u) { s_part[wave][6] = nr | (ov << 1); s_part[wave][7] = ra; }
     }
     __syncthreads();
     uint32_t ex[6];
@@ -985,7 +996,9 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
         P.counters[CX_CNT_CELLS] = ex[2] + x[2]; P.counters[CX_CNT_BORDER] = ex[3] + x[3];
         P.counters[CX_CNT_BATCHES] = ex[4] + x[4];
         P.counters[CX_CNT_ROUNDS] = rounds;
-        P.counters[CX_CNT_NEAR] = (s_part[0][6] | s_part[1][6] | s_part[2][6] | s_part[3][6]) ? 1u : 0u;
+        const uint32_t fl = s_part[0][6] | s_part[1][6] | s_part[2][6] | s_part[3][6];
+        P.counters[CX_CNT_NEAR] = fl & 1u;
+        P.counters[CX_CNT_OVERFLOW] = (fl >> 1) & 1u;
     }
 }
 __global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {

@@ -118,6 +118,9 @@ int cx_level0_device_ptrs(cx_ctx* ctx, void** verts_xyzk, void** tris);
 /* device pointers of the Level-0 buffers as the march leaves them: n_vertices x {uint32 edge id, fp32 t}, n_triangles x 3
  * int32 (no copy, no kernel; valid until the next extract / reserve / destroy) */
 int cx_level0_device_records(cx_ctx* ctx, void** vertex_records, void** tris);
+/* the same to host memory: vertex_records = n_vertices x 2 uint32 {edge id, bits of the fp32 fraction t}, tris as above -- half the
+ * bytes of cx_level0_download for a host that keeps (pair, ratio) as the reference does (tetrahedral.py:471-512) */
+int cx_level0_download_records(cx_ctx* ctx, uint32_t* vertex_records, int32_t* tris);
 
 /* ---- Level 1: mesh post-passes -------------------------------------------------------------------
  * Replaces GridContour.quantize_interpolations (tetrahedral.py:190-215), remove_tiny_simplices

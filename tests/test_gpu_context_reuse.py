@@ -128,3 +128,49 @@ def test_exact_capacities(shape, generic):
             ctx2.close()
     finally:
         ctx.close()
+
+
+def test_vertex_records_and_expanded_coordinates_agree():
+    """the march's 8-byte vertex records {edge id, fp32 t} against the float4 {x, y, z, id} cx_level0_download expands them to:
+    same ids, same order, and q + t d reproduces the coordinates bit for bit (the expansion is that sum in fp32)"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(77)
+    A = rng.standard_normal((21, 18, 37)).astype(np.float32)
+    ctx = _ffi.Context(0)
+    try:
+        ctx.upload_grid(A)
+        c = ctx.extract3d(0.25, _ffi.CX_DIAG_CPYTHON310)
+        xyz, keys, tris = ctx.download_level0(c)
+        ids, t, tris2 = ctx.download_level0_records(c)
+        assert np.array_equal(ids, keys) and np.array_equal(tris, tris2)
+        assert np.all((t >= 0) & (t <= 1))
+        lin, d = ids.astype(np.int64) >> 3, ids.astype(np.int64) & 7
+        q = np.stack(np.unravel_index(lin, A.shape), axis=1).astype(np.float32)
+        step = np.stack([(d >> 2) & 1, (d >> 1) & 1, d & 1], axis=1).astype(bool)
+        want = np.where(step, q + t[:, None], q).astype(np.float32)
+        assert np.array_equal(want.view(np.uint32), xyz.view(np.uint32))
+    finally:
+        ctx.close()
+
+
+def test_slab_step_of_a_single_rank_is_adopt_plus_extract():
+    "cx_slab_step with world == 1 (no exchange): the same mesh as adopt + extract, and a communicator is only asked for when world > 1"
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(5)
+    A = torch.from_numpy(rng.standard_normal((19, 16, 24)).astype(np.float32)).cuda()
+    ctx = _ffi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.adopt_device_grid(A.data_ptr(), tuple(A.shape), keepalive=A)
+        c0 = ctx.extract3d(0.1, 1)
+        a = ctx.download_level0(c0)
+        ctx.slab_step(A.data_ptr(), A.shape[0], A.shape[1], A.shape[2], 0, 1, 0.1, 1, keepalive=A)
+        c1 = ctx.counts()
+        b = ctx.download_level0(c1)
+        assert c0 == c1 and all(np.array_equal(x, y) for x, y in zip(a, b))
+        with pytest.raises(_ffi.CxError):        # two ranks without a communicator: refused before anything is enqueued
+            ctx.slab_step(A.data_ptr(), A.shape[0] - 1, A.shape[1], A.shape[2], 0, 2, 0.1, 1, keepalive=A)
+        with pytest.raises(_ffi.CxError):
+            ctx.halo_exchange(None, 0, 2, A.data_ptr(), A.shape[0] - 1, A.shape[1] * A.shape[2])
+    finally:
+        ctx.close()

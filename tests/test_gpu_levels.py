@@ -111,3 +111,38 @@ def test_levels_then_single_extraction_and_reuse():
         assert all(np.array_equal(x, y) for x, y in zip(a2, b))
     finally:
         ctx.close()
+
+
+def test_levels_pool_overflow_falls_back_to_full_regions():
+    """the levels share one pool of queue entries, a slice of every streaming wave's region each; white noise crosses nearly every
+    voxel at every level, so the slices overflow, the flag comes back with the counts and the call repeats itself with full-size
+    regions -- the meshes must be the single extractions' bit for bit, and a smooth field afterwards goes through the pool again"""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(123)
+    A = rng.standard_normal((40, 36, 64)).astype(np.float32)
+    values = [-0.4, -0.1, 0.2, 0.5]
+    ctx = _ffi.Context(0)
+    try:
+        ctx.upload_grid(A)
+        counts = ctx.extract3d_levels(values, 1)
+        assert sum(c["n_cells"] for c in counts) > 2.5 * A.size        # every level through most cells: more than the pool holds
+        for n in (2, 0, 3, 1):
+            ctx.select_level(n)
+            xyz, keys, tris = ctx.download_level0(counts[n])
+            c1, x1, k1, t1 = single(A, values[n], 1)
+            assert counts[n] == c1
+            assert np.array_equal(keys, k1) and np.array_equal(tris, t1) and np.array_equal(xyz.view(np.uint32), x1.view(np.uint32))
+        # another shape on the same context: pooled again
+        g = np.linspace(-1, 1, 44)
+        X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+        B = (X * X + 0.8 * Y * Y + 1.2 * Z * Z).astype(np.float32)
+        ctx.upload_grid(B)
+        vb = [0.3, 0.6, 0.9]
+        cb = ctx.extract3d_levels(vb, 1)
+        for n in range(3):
+            ctx.select_level(n)
+            xyz, keys, tris = ctx.download_level0(cb[n])
+            c1, x1, k1, t1 = single(B, vb[n], 1)
+            assert cb[n] == c1 and np.array_equal(keys, k1) and np.array_equal(tris, t1) and np.array_equal(xyz.view(np.uint32), x1.view(np.uint32))
+    finally:
+        ctx.close()
