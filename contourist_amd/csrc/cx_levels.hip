@@ -184,7 +184,10 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
     if (!L->pooled && (L->pooled_off_for[0] != ctx->n0 || L->pooled_off_for[1] != ctx->n1 || L->pooled_off_for[2] != ctx->n2)) L->pooled = true;
     uint32_t sub = (T.wcap / (uint32_t)nlevels) & ~63u;
     if (cx_debug_knob("CX_LEVELS_SLICE", 0u)) sub = cx_debug_knob("CX_LEVELS_SLICE", 0u) & ~63u;   // tests: force small slices
-    bool pooled = L->pooled && sub >= 64u && !cx_debug_knob("CX_LEVELS_NO_POOL", 0u);
+    // Measured on the bench field (512^3, smooth): a sheet that runs along a wave's 4-row tile passes through up to half of the
+    // wave's cells, so slices of a quarter (4 levels) or an eighth (8 levels) of the region overflow and the call falls back --
+    // the pool is only tried with up to 3 levels (2 levels: 2.5 GB held instead of 3.7), more levels take full-size regions at once.
+    bool pooled = L->pooled && sub >= 64u && (nlevels <= 3 || cx_debug_knob("CX_LEVELS_SLICE", 0u)) && !cx_debug_knob("CX_LEVELS_NO_POOL", 0u);
     if (pooled) {
         if ((rc = grow(ctx, L->qpool, L->qpool_cap, need))) return rc;
         for (auto& S : L->slots) cx_release(S.queue, S.queue_cap);      // full-size regions of an earlier call

@@ -120,13 +120,13 @@ def test_levels_pool_overflow_falls_back_to_full_regions():
     from contourist_amd import _ffi
     rng = np.random.RandomState(123)
     A = rng.standard_normal((40, 36, 64)).astype(np.float32)
-    values = [-0.4, -0.1, 0.2, 0.5]
+    values = [-0.4, 0.0, 0.5]
     ctx = _ffi.Context(0)
     try:
         ctx.upload_grid(A)
         counts = ctx.extract3d_levels(values, 1)
-        assert sum(c["n_cells"] for c in counts) > 2.5 * A.size        # every level through most cells: more than the pool holds
-        for n in (2, 0, 3, 1):
+        assert sum(c["n_cells"] for c in counts) > 2.0 * A.size        # every level through most cells: more than the pool holds
+        for n in (2, 0, 1):
             ctx.select_level(n)
             xyz, keys, tris = ctx.download_level0(counts[n])
             c1, x1, k1, t1 = single(A, values[n], 1)
