@@ -70,7 +70,7 @@ int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const
         for (size_t off = 0; off < bytes[p]; off += CX_XFER_CHUNK)
             pieces.push_back({(char*)dst[p] + off, (const char*)src[p] + off, std::min(CX_XFER_CHUNK, bytes[p] - off)});
     }
-    const int nt = xfer_threads();
+    int nt = xfer_threads();
     const size_t np = pieces.size();
     std::atomic<long> ready{-1};                    // pieces 0..ready sit in their staging buffers
     std::atomic<bool> abort_flag{false};
@@ -85,18 +85,29 @@ int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const
         if (off < pc.n) memcpy(pc.dst + off, (const char*)((k & 1) ? stage1 : stage0) + off, std::min(per, pc.n - off));
         done[k].fetch_add(1, std::memory_order_release);
     };
+    // the workers wait for `go` before they look at nt: if the system refuses a thread, the copy runs with those it granted
+    std::atomic<bool> go{false};
     std::vector<std::thread> workers;
     workers.reserve((size_t)nt);
-    for (int t = 1; t < nt; t++)
-        workers.emplace_back([&, t] {
-            for (size_t k = 0; k < np; k++) {
-                while (ready.load(std::memory_order_acquire) < (long)k) {
+    try {
+        for (int t = 1; t < nt; t++)
+            workers.emplace_back([&, t] {
+                while (!go.load(std::memory_order_acquire)) {
                     if (abort_flag.load(std::memory_order_relaxed)) return;
                     std::this_thread::yield();
                 }
-                slice(k, t);
-            }
-        });
+                for (size_t k = 0; k < np; k++) {
+                    while (ready.load(std::memory_order_acquire) < (long)k) {
+                        if (abort_flag.load(std::memory_order_relaxed)) return;
+                        std::this_thread::yield();
+                    }
+                    slice(k, t);
+                }
+            });
+    } catch (...) {
+    }
+    nt = (int)workers.size() + 1;      // slices are cut for the threads that exist (read by slice() only after `go`)
+    go.store(true, std::memory_order_release);
     int rc = CX_OK;
     // piece i travels through staging buffer i & 1: its DMA is enqueued before piece i-1 is copied out on the host
     for (size_t i = 0; i <= np && rc == CX_OK; i++) {
