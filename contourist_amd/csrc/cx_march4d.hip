@@ -696,21 +696,27 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
         if (!real_voxel) pskip = 0xFFFFFFu;
         // first-vertex index and crossing mask of the 15 corners that can own an edge of this hyper-voxel
         const uint32_t st[4] = {P.n1 * P.n2 * P.n3, P.n2 * P.n3, P.n3, 1u};
+        // all (up to) 15 table words are requested before the first one is used: written as one loop -- load, then store to LDS --
+        // the compiler put an `s_waitcnt vmcnt(0)` behind every load, fifteen HBM round trips one after the other per round
+        uint64_t ew[15];
 #pragma unroll
         for (uint32_t c = 0; c < 15; c++) {
-            uint32_t vf = 0, em = 0;
             const uint32_t sc = ((sm >> c) & 1u) ? 0xFFFFu : 0u;
             uint32_t sup = 0;
 #pragma unroll
             for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
+            ew[c] = 0;
             if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
                 const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
-                const uint64_t e = P.celltab[lc];
-                vf = (uint32_t)e;
-                em = (uint32_t)(e >> 32);
+                ew[c] = P.celltab[lc];
             }
-            L.vf[wave][c][lane] = vf;
-            L.em[wave][c][lane] = (uint16_t)em;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 15; c++) asm volatile("" : "+v"(ew[c]) :: "memory");
+#pragma unroll
+        for (uint32_t c = 0; c < 15; c++) {
+            L.vf[wave][c][lane] = (uint32_t)ew[c];
+            L.em[wave][c][lane] = (uint16_t)(ew[c] >> 32);
         }
         // probe codes of the corner hashes (absolute lattice coordinates) for the set-order emulation
         uint32_t S[16];
