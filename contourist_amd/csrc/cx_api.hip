@@ -80,6 +80,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_release(ctx->info64, ctx->info64_cap);
     cx_release(ctx->chunksum, ctx->chunksum_cap);
     cx_release(ctx->rstart, ctx->rstart_cap);
+    cx_release(ctx->kstart, ctx->kstart_cap);
     cx_release(ctx->hbytes, ctx->hbytes_cap);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
@@ -296,15 +297,22 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
         P.qlimit = T.wcap;
+        // the triangle stage walks the vertex stage's cell records.  The kernel that walks queue entries instead (no records: 80 MB
+        // less HBM traffic per 512^3 extraction) is built and bit-identical, and measured no faster at 512^3 and slower on thin slabs
+        // (DESIGN.md section 4): it runs on request (CX_DEBUG=1 CX_K2_ENTRIES=1)
+        P.write_records = (!fused && !cx_debug_knob("CX_K2_ENTRIES", 0u)) ? 1u : 0u;
         P.nvw = cx_vertex_stage_waves(P);
         if ((rc = cx_grow(ctx, ctx->rstart, ctx->rstart_cap, (size_t)P.nvw + 1u))) return rc;
         P.rstart = ctx->rstart;
+        P.nkw = cx_triangle_stage_waves(P);
+        if ((rc = cx_grow(ctx, ctx->kstart, ctx->kstart_cap, (size_t)P.nkw + 1u))) return rc;
+        P.kstart = ctx->kstart;
         ctx->last = P;
     }
     ctx->last_task = T;
     ctx->last_flags = flags;
     ctx->path = staged ? (fused ? 2 : 1) : 0;
-    ctx->records_valid = !fused;
+    ctx->records_valid = staged ? (P.write_records != 0u) : true;   // the generic path always writes them
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {
         if (ctx->nevents < (int)(sizeof(ctx->events) / sizeof(ctx->events[0]))) {
@@ -331,7 +339,8 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[3], ctx->stream));
     if (!fused && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) {
-        if (staged) cx_launch_emit_triangles_q(P, T, ctx->hash_xy, ctx->stream);
+        if (staged && P.write_records) cx_launch_emit_triangles_q(P, T, ctx->hash_xy, ctx->stream);
+        else if (staged) cx_launch_emit_triangles_e(P, T, ctx->hash_xy, ctx->stream);   // (A/B: CX_K2_ENTRIES)
         else cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
     }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[4], ctx->stream));
@@ -405,6 +414,7 @@ int cx_ensure_cell_records(cx_ctx* ctx) {
     if (ctx->records_valid) return CX_OK;
     cx_params P = ctx->last;
     P.flags |= CX_DBG_NO_VERTS | CX_DBG_NO_CELLTAB;
+    P.write_records = 1u;
     P.ccap = ctx->ccap; P.cells = ctx->cells;
     cx_launch_emit_vertices(P, ctx->last_task, ctx->stream);
     CX_HIP(ctx, hipGetLastError());

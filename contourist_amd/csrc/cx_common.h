@@ -88,6 +88,9 @@ struct cx_params {
     uint32_t* rstart;         // [nvw] vertex stage: the batch in which wave m's share of the rounds starts (written by the scan kernel)
     uint32_t nvw;             // waves of the vertex stage (4 x its grid)
     uint32_t qlimit;          // queue entries a streaming wave may store (T.wcap; less when levels share a pool)
+    uint32_t* kstart;         // [nkw] triangle stage: the batch in which wave m's share of the rounds starts (as rstart for the vertex stage)
+    uint32_t nkw;             // waves of the triangle stage (4 x its grid)
+    uint32_t write_records;   // 1: the vertex stage also writes the 16-byte cell records (seeded selection, the record-walking triangle kernel)
 };
 #ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
@@ -107,12 +110,14 @@ struct cx_brec {   // 32 bytes: cells [qoff, qoff+n) of the wave's queue and wha
     uint32_t qoff, n, vpre, tpre, cpre, near, pad0, pad1;
 };
 
-struct cx_bdesc {  // 32 bytes: one batch as the emit kernel needs it
-    uint32_t w;            // streaming wave (-> tile geometry)
+struct cx_bdesc {  // 48 bytes: one batch as the emit kernels need it
+    uint32_t w;            // streaming wave
     uint32_t qofs, n;      // its cells: queue[qofs .. qofs+n)
     uint32_t vbase, tbase, cbase;   // first vertex / triangle / cell record
     uint32_t near;
     uint32_t rbase;        // rounds of 64 cells in the batches before this one
+    uint32_t p, j0, k0;    // the streaming wave's tile: first plane, first row, first sample (what cx_tile_of computes from w)
+    uint32_t nsteps;       // planes of cells in the tile
 };
 
 // launch geometry of the staged pipeline: workgroup -> (k segment of 256 samples, group of 16 rows, chunk of ci planes)
@@ -123,6 +128,7 @@ struct cx_task {
     uint32_t chunk;        // tasks per XCD (grid = 8 * chunk workgroups)
     uint32_t wcap;         // queue entries per wave (every cell of its task)
     uint32_t bcap;         // batch records per wave
+    cx_fdiv div_nks, div_njg;   // / nks, / njg: a streaming wave's tile from its number (triangle stage)
 };
 
 // debug / ablation flags (timing experiments only; results are wrong when set)
@@ -159,9 +165,11 @@ void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_stream_levels(const cx_params* device_params, const cx_params& P0, const cx_task& T, uint32_t nlevels, hipStream_t s);
 void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uint32_t nlevels, hipStream_t s);
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
-uint32_t cx_vertex_stage_waves(const cx_params& P);   // -> cx_params::nvw (the scan kernel needs it before the vertex stage runs)
+uint32_t cx_vertex_stage_waves(const cx_params& P);
+uint32_t cx_triangle_stage_waves(const cx_params& P);   // -> cx_params::nvw (the scan kernel needs it before the vertex stage runs)
 void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
+void cx_launch_emit_triangles_e(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_hash_bytes(uint8_t* table, const uint64_t* hash_xy, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t org2, hipStream_t s);
 void cx_launch_expand_verts(const cx_vrec* recs, float4* out, uint32_t n, uint32_t n1, uint32_t n2, hipStream_t s);

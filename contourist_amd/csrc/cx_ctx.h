@@ -42,11 +42,13 @@ struct cx_ctx {
     size_t chunksum_cap = 0;
     uint32_t* rstart = nullptr;        // vertex stage: first batch of every wave's share of the rounds (cx_params::rstart)
     size_t rstart_cap = 0;
+    uint32_t* kstart = nullptr;        // the same for the triangle stage (cx_params::kstart)
+    size_t kstart_cap = 0;
     uint8_t* hbytes = nullptr;         // fused emit: CPython set-order code per lattice point (valid for hash_xy's shape and origin)
     size_t hbytes_cap = 0;
     bool hbytes_valid = false;
     int64_t hbytes_n2 = 0, hbytes_o2 = 0;
-    cx_task last_task = {0, 0, 0, 0, 0, 0, 0, 0};
+    cx_task last_task = {};
     uint32_t last_flags = 0;
     int path = 0;                      // kernels of the last extraction: 0 generic, 1 staged, 2 fused
     bool records_valid = false;        // ctx->cells holds the cell records of the last extraction

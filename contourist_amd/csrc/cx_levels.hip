@@ -46,6 +46,8 @@ struct cx_level_slot {
     size_t chunksum_cap = 0;
     uint32_t* rstart = nullptr;        // vertex stage: first batch of every wave's share of the rounds
     size_t rstart_cap = 0;
+    uint32_t* kstart = nullptr;        // triangle stage: the same
+    size_t kstart_cap = 0;
     // Level-0 outputs of the level (swapped with the context's while the level is selected)
     cx_vrec* verts = nullptr;
     uint4* cells = nullptr;
@@ -77,7 +79,7 @@ struct cx_levels_state {
 };
 
 static void free_slot(cx_level_slot& S) {
-    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.rstart, S.verts, S.cells, S.tris};
+    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.rstart, S.kstart, S.verts, S.cells, S.tris};
     for (void* p : all)
         if (p) (void)hipFree(p);
     S = cx_level_slot();
@@ -221,12 +223,16 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         P.counters = S.counters;
         P.queue = pooled ? L->qpool + (size_t)l * sub : S.queue;
         P.qlimit = pooled ? sub : T.wcap;
+        P.write_records = 1u;
         P.wsum = S.wsum; P.wbase = S.wbase; P.brec = S.brec; P.flat = S.flat; P.fcap = (uint32_t)nflat;
         P.qa = S.qa;
         P.chunksum = S.chunksum;
         P.nvw = cx_vertex_stage_waves(P);
         if ((rc = grow(ctx, S.rstart, S.rstart_cap, (size_t)P.nvw + 1u))) return rc;
         P.rstart = S.rstart;
+        P.nkw = cx_triangle_stage_waves(P);
+        if ((rc = grow(ctx, S.kstart, S.kstart_cap, (size_t)P.nkw + 1u))) return rc;
+        P.kstart = S.kstart;
         P.verts = S.verts; P.cells = S.cells; P.tris = S.tris;
         P.vcap = S.vcap; P.ccap = S.ccap; P.tcap = S.tcap;
     }

@@ -44,6 +44,14 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #define CX_BATCH_MIN 512u   // a streaming wave closes a batch once it holds this many cells (128..1024 measured: 512 best)
 #endif
 
+// the word the vertex stage leaves per queue entry (staged pipeline): bits 0-31 first vertex of the cell, 32-39 crossing mask
+// (bit d: the cell owns a crossing on its edge in direction d), 40-43 triangles of its voxel, 44-49 tetrahedra that emit nothing
+// (the reference's tolerance skips; all six for a cell that is no voxel).  Everything the triangle stage needs about a cell besides
+// its queue entry: it walks queue entries, not cell records (cx_k_emit_triangles_e).
+__device__ __forceinline__ uint64_t cx_info_word(uint32_t vfirst, uint32_t emask, uint32_t ntri, uint32_t tetskip) {
+    return (uint64_t)vfirst | ((uint64_t)((emask & 0xFFu) | ((ntri & 0xFu) << 8) | ((tetskip & 0x3Fu) << 12)) << 32);
+}
+
 // ---- per-cell path ------------------------------------------------------------------------------
 struct cx_run {
     uint32_t v, t, c, b;   // running vertex / triangle / cell-record / border-voxel counts
@@ -103,10 +111,10 @@ __device__ __forceinline__ void cx_process_queue(const cx_params& P, LinOf lin_o
                 }
                 // (first vertex, crossing mask) of the cell for the triangle stage: per queue entry (staged pipeline), or in
                 // the table of one entry per sample (generic classify kernel)
-                if (info) { if (have && !(P.flags & CX_DBG_NO_CELLTAB)) info[idx] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst; }
+                if (info) { if (have && !(P.flags & CX_DBG_NO_CELLTAB)) info[idx] = cx_info_word(vfirst, R.emask, R.ntri, R.tetskip); }
                 else if (nv && !(P.flags & CX_DBG_NO_CELLTAB)) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
             }
-            if (RECORDS && rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            if (RECORDS && (P.write_records || !info) && rec && run.c + ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
                 uint4 c4;
                 c4.x = lin;
                 c4.y = sm | (R.tetskip << 8) | (R.ntri << 16) | (R.emask << 24);
@@ -336,9 +344,10 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
             }
             // (first vertex, crossing mask) of every queued cell, one 8-byte word per queue entry: 512 contiguous bytes per round
             // (was: scattered into a table of one entry per sample -- a cache line per cell, written and later gathered)
-            if (b0 + lane < n && !(P.flags & CX_DBG_NO_CELLTAB)) info[b0 + lane] = ((uint64_t)Ra.emask << 32) | (uint64_t)(Ra.base.v + Ra.vpre);
+            if (b0 + lane < n && !(P.flags & CX_DBG_NO_CELLTAB))
+                info[b0 + lane] = cx_info_word(Ra.base.v + Ra.vpre, Ra.emask, Ra.ntri, Ra.real_voxel ? 0u : 0x3Fu);
         }
-        if ((Ra.emask | Ra.ntri) != 0u && Ra.base.c + Ra.ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+        if (P.write_records && (Ra.emask | Ra.ntri) != 0u && Ra.base.c + Ra.ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
             uint4 c4;
             c4.x = Ra.lin;
             c4.y = Ra.sm | ((Ra.real_voxel ? 0u : 0x3Fu) << 8) | (Ra.ntri << 16) | (Ra.emask << 24);
@@ -972,11 +981,13 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
     // the vertex stage divides the rounds of 64 queued cells evenly among its P.nvw waves: wave m takes rounds [m q, m q + q)
     const uint32_t rounds = s_part[0][7] + s_part[1][7] + s_part[2][7] + s_part[3][7];
     const uint32_t q = max((rounds + P.nvw - 1u) / P.nvw, CX_S3_MIN_SHARE);
+    const uint32_t qk = max((rounds + P.nkw - 1u) / P.nkw, CX_S3_MIN_SHARE);
     if (w < nw) {
         cx_wbase B;
         B.v = ex[0]; B.t = ex[1]; B.c = ex[2]; B.boff = ex[4];
         P.wbase[w] = B;
         // the flat batch list: self-contained descriptors
+        const cx_tile tile = cx_tile_of(P, T, w >> 2, w & 3u);
         uint32_t rb = ex[5];
         for (uint32_t i = 0; i < S.nb; i++) {
             if (ex[4] + i >= P.fcap) break;
@@ -984,10 +995,12 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
             cx_bdesc D;
             D.w = w; D.qofs = w * T.wcap + R.qoff; D.n = R.n; D.near = R.near;
             D.vbase = ex[0] + R.vpre; D.tbase = ex[1] + R.tpre; D.cbase = ex[2] + R.cpre; D.rbase = rb;
+            D.p = tile.p; D.j0 = tile.j0; D.k0 = tile.k0; D.nsteps = tile.ib - tile.p;
             P.flat[ex[4] + i] = D;
             // the waves whose share starts inside this batch
             const uint32_t nrb = (R.n + 63u) >> 6;
             for (uint32_t m = (rb + q - 1u) / q; m * q < rb + nrb; m++) P.rstart[m] = ex[4] + i;
+            for (uint32_t m = (rb + qk - 1u) / qk; m * qk < rb + nrb; m++) P.kstart[m] = ex[4] + i;   // the same for the triangle stage's waves
             rb += nrb;
         }
     }
@@ -1065,9 +1078,8 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
         if (fn < nbatches) Dn = P.flat[fn];   // next descriptor in flight while this batch is processed
         const uint32_t nrb = (D.n + 63u) >> 6;
         const uint32_t r0 = max(lo, D.rbase) - D.rbase, r1 = min(hi, D.rbase + nrb) - D.rbase;   // this wave's rounds of the batch
-        const cx_tile tile = cx_tile_of(P, T, D.w >> 2, D.w & 3u);
         cx_fast_geom G;
-        G.pstart = tile.p; G.j0 = tile.j0; G.k0 = tile.k0;
+        G.pstart = D.p; G.j0 = D.j0; G.k0 = D.k0;
         const uint32_t* __restrict__ q = P.queue + D.qofs;
         cx_run run;
         run.v = D.vbase; run.t = D.tbase; run.c = D.cbase; run.b = 0;
@@ -1551,22 +1563,15 @@ struct cx_tri_qa {          // a record between its first stage (queue words req
 __device__ __forceinline__ uint32_t cx_ld_u32_at(const uint32_t* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-__device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const cx_tri_lds& L, const uint4& rec,
-                                               cx_tri_qa& A) {
-    const uint32_t plane = P.n1 * P.n2;
+// a cell at lattice point (ci, cj, ck) = plane step ps of streaming wave w (row rr of its 4, lane ls, sample mm): request the queue
+// words of the neighbour cells that own an edge of its voxel
+__device__ __forceinline__ void cx_triq_issue(const cx_params& P, const cx_task& T, const cx_tri_lds& L, const uint4& rec, uint32_t w, uint32_t ci,
+                                              uint32_t cj, uint32_t ck, uint32_t ps, uint32_t nsteps, cx_tri_qa& A) {
     A.rec = rec;
-    const uint32_t lin = rec.x, sm = rec.y & 0xFFu, ntri = (rec.y >> 16) & 0xFFu;
-    const uint32_t ci = cx_div(lin, P.div_plane);
-    const uint32_t rem = lin - ci * plane;
-    const uint32_t cj = cx_div(rem, P.div_row);
-    const uint32_t ck = rem - cj * P.n2;
-    // where the cell sits in the streaming layout
-    const uint32_t ic = cx_div(ci, P.div_ci);
-    const uint32_t ps = ci - ic * T.ci;
-    const uint32_t nsteps = min(T.ci, P.n0 - ic * T.ci);
+    const uint32_t sm = rec.y & 0xFFu, ntri = (rec.y >> 16) & 0xFFu;
     const uint32_t rr = cj & 3u, ls = (ck >> 2) & 63u, mm = ck & 3u;
-    const uint32_t wv = (cj >> 2) & 3u;
-    A.w = 4u * ((ck >> 8) + T.nks * ((cj >> 4) + T.njg * ic)) + wv;
+    const uint32_t wv = w & 3u;
+    A.w = w;
     const bool m3 = (mm == 3u), r3 = (rr == 3u), pl = (ps + 1u == nsteps);
     const bool kfl = m3 && ls == 63u;
     // neighbour cells that own a crossing edge of this voxel (bit c), from the table
@@ -1592,6 +1597,41 @@ __device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task
         if ((want >> c) & 1u) A.qa[c] = cx_ld_u32_at(P.qa, idx[c] << 2);
 #endif
     }
+}
+// ... of a cell record (the record-walking kernel): the lattice point from its linear index
+__device__ __forceinline__ void cx_triq_stage1(const cx_params& P, const cx_task& T, const cx_tri_lds& L, const uint4& rec,
+                                               cx_tri_qa& A) {
+    const uint32_t plane = P.n1 * P.n2;
+    const uint32_t lin = rec.x;
+    const uint32_t ci = cx_div(lin, P.div_plane);
+    const uint32_t rem = lin - ci * plane;
+    const uint32_t cj = cx_div(rem, P.div_row);
+    const uint32_t ck = rem - cj * P.n2;
+    // where the cell sits in the streaming layout
+    const uint32_t ic = cx_div(ci, P.div_ci);
+    const uint32_t ps = ci - ic * T.ci;
+    const uint32_t nsteps = min(T.ci, P.n0 - ic * T.ci);
+    const uint32_t w = 4u * ((ck >> 8) + T.nks * ((cj >> 4) + T.njg * ic)) + ((cj >> 2) & 3u);
+    cx_triq_issue(P, T, L, rec, w, ci, cj, ck, ps, nsteps, A);
+}
+// ... of a queue entry e of streaming wave w with its info word iw (the entry-walking kernel): the tile from the wave's number,
+// the position in the tile from the entry; tfirst = number of the cell's first triangle
+__device__ __forceinline__ void cx_trie_stage1(const cx_params& P, const cx_task& T, const cx_tri_lds& L, uint32_t e, uint64_t iw, uint32_t w,
+                                               uint32_t tfirst, cx_tri_qa& A) {
+    const uint32_t b = w >> 2;
+    const uint32_t t1 = cx_div(b, T.div_nks);
+    const uint32_t ks = b - t1 * T.nks;
+    const uint32_t ic = cx_div(t1, T.div_njg);
+    const uint32_t jg = t1 - ic * T.njg;
+    const uint32_t p = ic * T.ci;
+    const uint32_t bit = (e >> 10) & 31u;
+    const uint32_t rr = (bit * 11u) >> 6;
+    const uint32_t ps = (e >> 21) & 127u;
+    const uint32_t ci = p + ps, cj = jg * (4u * CX_RJ) + (w & 3u) * CX_RJ + rr, ck = ks * 256u + 4u * ((e >> 15) & 63u) + (bit - 6u * rr);
+    const uint32_t hi = (uint32_t)(iw >> 32);
+    // the cell's record as the later stages read it: {-, signs | tetskip << 8 | triangles << 16 | crossing mask << 24, first triangle, first vertex}
+    const uint4 rec = make_uint4(0u, cx_entry_signs(e) | (((hi >> 12) & 0x3Fu) << 8) | (((hi >> 8) & 0xFu) << 16) | ((hi & 0xFFu) << 24), tfirst, (uint32_t)iw);
+    cx_triq_issue(P, T, L, rec, w, ci, cj, ck, ps, min(T.ci, P.n0 - p), A);
 }
 __device__ __forceinline__ void cx_triq_pin1(cx_tri_qa& A, uint4& nxt) {
     asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w) :: "memory");
@@ -1623,7 +1663,7 @@ __device__ __forceinline__ void cx_triq_stage2(const cx_params& P, const cx_task
 #else
             const uint64_t e = P.info64[at];
 #endif
-            pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+            pr = make_uint2((uint32_t)e, (uint32_t)(e >> 32));   // (bits above the crossing mask ride along: phase 2 only looks below bit 8.  No arithmetic on the loaded word here -- it would put a wait behind every gather)
         }
         I.nb[c] = pr;
     }
@@ -1695,6 +1735,182 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
         Ab = Ac;
         rec_c = rec_d;
         idx = nidx;
+    }
+}
+
+// =================================================================================================
+// K2 walking QUEUE ENTRIES (cx_k_emit_triangles_e, the default of the staged pipeline from round 3 on).  The vertex stage no longer
+// writes a 16-byte record per cell for this kernel to read back (128 MB of round trip at 512^3): everything a record held is in
+// the cell's queue entry (signs, position in its streaming wave's tile) and in the word the vertex stage leaves per entry (first
+// vertex, crossing mask, triangles, tolerance skips), and the number of a cell's first triangle follows from a running count --
+// triangles are numbered along the flat batch list, cell after cell.
+// Work division as in the vertex stage: wave m takes rounds [m q, m q + q) of the flat batch list (P.rstart: the batch its share
+// starts in) and, where that is inside a batch, counts the triangles of the rounds before (info words; a batch on the tolerance
+// path is not divided).  Unlike the vertex stage it PACKS its cells: a round of 64 lanes is filled across batch boundaries
+// (up to four pieces), so only the last round of a wave's share is partial -- this kernel is bound by VALU issue per round.
+// Three rounds are in flight per wave, as in the record-walking kernel: round s+3 has its entries and info words requested,
+// round s+2 its queue words, round s+1 the neighbours' info words (and hash prefixes), round s is expanded and stored.
+// =================================================================================================
+// a descriptor of the flat batch list, its fields made wave-uniform for the compiler (the address is)
+__device__ __forceinline__ cx_bdesc cx_desc_uniform(const cx_bdesc& D) {
+    cx_bdesc U;
+    U.w = __builtin_amdgcn_readfirstlane(D.w); U.qofs = __builtin_amdgcn_readfirstlane(D.qofs); U.n = __builtin_amdgcn_readfirstlane(D.n);
+    U.vbase = 0; U.cbase = 0; U.p = 0; U.j0 = 0; U.k0 = 0; U.nsteps = 0;      // (not used by the triangle stage)
+    U.tbase = __builtin_amdgcn_readfirstlane(D.tbase);
+    U.near = __builtin_amdgcn_readfirstlane(D.near); U.rbase = __builtin_amdgcn_readfirstlane(D.rbase);
+    return U;
+}
+struct cx_esrc {              // wave-uniform: where the next round's cells come from
+    uint32_t f, nbatches, lo, hi; // current batch, batches in the list, the wave's share (rounds)
+    uint32_t at, bend;        // entries [at, bend) of the current batch are still to be handed out
+    uint32_t qofs, w;         // of the current batch
+    uint32_t bend_round;      // round behind the current batch
+    uint32_t tbase;           // first triangle of the current batch
+    cx_bdesc next;            // descriptor f + 1, requested when batch f was entered (as loaded: made uniform when it is entered)
+    bool done;
+};
+// entries [r0 * 64, end) of batch D belong to the wave whose share of rounds is [lo, hi): a batch on the tolerance path goes as a
+// whole to the wave in whose share its first round falls.  Requests the descriptor after it.
+__device__ __forceinline__ void cx_esrc_enter(const cx_params& P, cx_esrc& S, const cx_bdesc& Draw) {
+    const cx_bdesc D = cx_desc_uniform(Draw);
+    const uint32_t nrb = (D.n + 63u) >> 6;
+    const uint32_t r0 = max(S.lo, D.rbase) - D.rbase, r1 = min(S.hi, D.rbase + nrb) - D.rbase;
+    S.qofs = D.qofs; S.w = D.w; S.bend_round = D.rbase + nrb; S.tbase = D.tbase;
+    if (D.near) { S.at = 0u; S.bend = (r0 == 0u) ? D.n : 0u; }
+    else { S.at = r0 * 64u; S.bend = min(D.n, r1 * 64u); }
+    if (S.f + 1u < S.nbatches) S.next = P.flat[S.f + 1u];
+}
+// the batch in hand is used up (or was not ours): on to the next one of the share, if any
+__device__ __forceinline__ void cx_esrc_advance(const cx_params& P, cx_esrc& S) {
+    while (S.at >= S.bend && !S.done) {
+        if (S.bend_round >= S.hi || S.f + 1u >= S.nbatches) { S.done = true; break; }
+        S.f++;
+        cx_esrc_enter(P, S, S.next);
+    }
+}
+struct cx_eraw {              // per lane: a cell of a round as it comes from memory
+    uint32_t e, w;            // queue entry, streaming wave (0xFFFFFFFF: no cell in this lane)
+    uint64_t iw;              // the vertex stage's word
+};
+// hand out the next (up to) 64 cells and request their entries and info words.  Four rounds in five come whole out of the batch
+// in hand; the others take its tail and the head of the next batch (a next batch shorter than the gap leaves lanes empty).
+__device__ __forceinline__ void cx_esrc_fetch(const cx_params& P, cx_esrc& S, uint32_t lane, cx_eraw& R) {
+    R.w = 0xFFFFFFFFu; R.e = 0; R.iw = 0;
+    if (S.done) return;                            // wave-uniform
+    uint32_t at, w;
+    bool have;
+    if (S.at + 64u <= S.bend) {                    // wave-uniform
+        at = S.qofs + S.at + lane; w = S.w; have = true;
+        S.at += 64u;
+    } else {
+        const uint32_t c0 = S.bend - S.at, pos0 = S.qofs + S.at, w0 = S.w;
+        S.at = S.bend;
+        cx_esrc_advance(P, S);
+        uint32_t c1 = 0, pos1 = 0, w1 = 0;
+        if (!S.done) {
+            c1 = min(S.bend - S.at, 64u - c0); pos1 = S.qofs + S.at; w1 = S.w;
+            S.at += c1;
+        }
+        have = lane < c0 + c1;
+        at = (lane < c0) ? pos0 + lane : pos1 + (lane - c0);
+        w = (lane < c0) ? w0 : w1;
+    }
+    if (have) { R.w = w; R.e = P.queue[at]; R.iw = P.info64[at]; }
+}
+__device__ __forceinline__ void cx_eraw_pin(cx_eraw& R) { asm volatile("" : "+v"(R.e), "+v"(R.iw) :: "memory"); }
+
+#ifndef CX_K2E_MIN_WAVES
+#define CX_K2E_MIN_WAVES 4
+#endif
+template <bool NEG_ORIGIN>
+__global__ __launch_bounds__(256, CX_K2E_MIN_WAVES) void cx_k_emit_triangles_e(const cx_params P, const cx_task T, const uint64_t* __restrict__ hash_xy) {
+    __shared__ cx_tri_lds L;
+    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room
+    const uint32_t nbatches = min(P.counters[CX_CNT_BATCHES], P.fcap);
+    const uint32_t rounds = P.counters[CX_CNT_ROUNDS];
+    cx_tri_lds_init(L);
+    __syncthreads();
+    const uint32_t lane = cx_lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nkw = gridDim.x * 4u;     // == P.nkw
+    const uint32_t share = max((rounds + nkw - 1u) / nkw, CX_S3_MIN_SHARE);
+    const uint32_t lo = (blockIdx.x * 4u + wave) * share;
+    if (lo >= rounds || nbatches == 0u) return;
+    cx_esrc S;
+    S.lo = lo; S.hi = min(rounds, lo + share); S.nbatches = nbatches; S.done = false;
+    S.f = __builtin_amdgcn_readfirstlane(P.kstart[blockIdx.x * 4u + wave]);
+    if (S.f >= nbatches) return;
+    uint32_t run_t;      // number of the first triangle of the next round's first cell (wave-uniform)
+    {
+        const cx_bdesc D = P.flat[S.f];
+        cx_esrc_enter(P, S, D);
+        run_t = S.tbase;
+        if (S.at) {   // the share starts inside this batch (never one on the tolerance path): the triangles of the cells before
+            const uint64_t* __restrict__ iw = P.info64 + S.qofs;
+            uint32_t t = 0;
+            for (uint32_t x = lane; x < S.at; x += 64u) t += (uint32_t)(iw[x] >> 40) & 0xFu;
+            run_t += cx_wave_sum(t);
+        }
+        if (S.at >= S.bend) {
+            // the first batch of the share is on the tolerance path and belongs to the wave before: numbering is contiguous along
+            // the list, so the first batch actually taken sets the count (it is taken from its first cell)
+            cx_esrc_advance(P, S);
+            if (S.done) return;
+            run_t = S.tbase;
+        }
+    }
+    // a round between its request and its first stage
+    auto first_triangles = [&](const cx_eraw& R, uint32_t& tfirst) {
+        // triangles are numbered cell after cell along the flat batch list
+        const uint32_t nt = (R.w != 0xFFFFFFFFu) ? ((uint32_t)(R.iw >> 40) & 0xFu) : 0u;
+        uint32_t ttot;
+        const uint32_t tpre = cx_wave_prefix_small<4>(nt, ttot);
+        tfirst = run_t + tpre;
+        run_t += ttot;
+    };
+    cx_tri_qa Ab, Ac;
+    cx_tri_in Ia, Ib;
+    cx_eraw Rc, Rd;
+    uint4 dummy = make_uint4(0, 0, 0, 0);
+    auto stage1 = [&](const cx_eraw& R, cx_tri_qa& A) {
+        uint32_t tfirst;
+        first_triangles(R, tfirst);
+        if (R.w != 0xFFFFFFFFu) cx_trie_stage1(P, T, L, R.e, R.iw, R.w, tfirst, A);
+        else { A.rec = make_uint4(0, 0, 0, 0); A.geo = 0; A.w = 0; A.ij = 0; A.ck = 0; for (int c = 0; c < 6; c++) A.qa[c] = 0; }
+    };
+    // prologue: round 0 through both stages, round 1 through the first, round 2 requested
+    {
+        cx_eraw R0, R1;
+        cx_esrc_fetch(P, S, lane, R0);
+        cx_esrc_fetch(P, S, lane, R1);
+        cx_esrc_fetch(P, S, lane, Rc);
+        cx_eraw_pin(R0); cx_eraw_pin(R1);
+        stage1(R0, Ac);
+        stage1(R1, Ab);
+        cx_triq_pin1(Ac, dummy);
+        cx_triq_pin1(Ab, dummy);
+        cx_triq_stage2(P, T, hash_xy, Ac, Ia);
+        cx_triq_pin2(Ia);
+        cx_eraw_pin(Rc);
+    }
+    // the loop ends when the round being expanded holds no cell: the source hands out full rounds until it is exhausted (only the
+    // last one may be partial), then empty ones
+    for (;;) {
+        if (__ballot(Ia.rec.y != 0u) == 0ULL) break;         // (every queued cell has a sign change: its sign word is not 0)
+        cx_esrc_fetch(P, S, lane, Rd);                   // entries and info words of the round three steps ahead
+        stage1(Rc, Ac);                                      // queue words of the round two steps ahead
+        cx_triq_stage2(P, T, hash_xy, Ab, Ib);               // info words (and hash prefixes) of the next round
+        const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
+#if CX_PIN_BEFORE_STORES
+        cx_triq_pin1(Ac, dummy); cx_triq_pin2(Ib); cx_eraw_pin(Rd);
+        cx_tri_phase2(P, L, lane, wave, ttot);
+#else
+        cx_tri_phase2(P, L, lane, wave, ttot);
+        cx_triq_pin1(Ac, dummy); cx_triq_pin2(Ib); cx_eraw_pin(Rd);
+#endif
+        Ia = Ib;
+        Ab = Ac;
+        Rc = Rd;
     }
 }
 
@@ -2111,6 +2327,8 @@ cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
     T.chunk = (T.nblocks + 7u) / 8u;
     T.wcap = CX_RJ * 256u * ci;
     T.bcap = T.wcap / CX_BATCH_MIN + 1u;
+    T.div_nks = cx_fdiv_make(T.nks);
+    T.div_njg = cx_fdiv_make(T.njg);
     return T;
 }
 
@@ -2224,6 +2442,25 @@ __global__ __launch_bounds__(256) void cx_k_expand_verts(const cx_vrec* __restri
 void cx_launch_expand_verts(const cx_vrec* recs, float4* out, uint32_t n, uint32_t n1, uint32_t n2, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(cx_k_expand_verts, dim3((n + 255u) / 256u), dim3(256), 0, s, recs, out, n, n2, n1 * n2, cx_fdiv_make(n1 * n2), cx_fdiv_make(n2));
+}
+
+// the triangle stage's grid: what is resident at once, as for the vertex stage (its own count: it runs fewer waves per SIMD)
+static uint32_t cx_triangle_grid(const cx_params& P) {
+    static const uint32_t resident = [] {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cx_k_emit_triangles_e<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256u * (uint32_t)per_cu;
+        return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }();
+    const uint32_t g = cx_debug_knob("CX_TGRID_E", resident);
+    const uint32_t most = (P.fcap + 3u) / 4u;
+    return g < most ? g : most;
+}
+uint32_t cx_triangle_stage_waves(const cx_params& P) { return 4u * cx_triangle_grid(P); }
+void cx_launch_emit_triangles_e(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s) {
+    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_emit_triangles_e<true>, dim3(P.nkw / 4u), dim3(256), 0, s, P, T, hash_xy);
+    else hipLaunchKernelGGL(cx_k_emit_triangles_e<false>, dim3(P.nkw / 4u), dim3(256), 0, s, P, T, hash_xy);
 }
 
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s) {

@@ -157,6 +157,51 @@ def test_long_tasks_flush_queue_and_batch_records():
     assert n_cells > 900000      # ~all 127 x 31 x 255 voxels (+ boundary cells) are active: the queues were long
 
 
+_ENTRY_KERNEL_CHILD = """
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+from contourist_amd import _ffi
+import test_gpu_level0 as T
+ctx = _ffi.Context(0)
+rng = np.random.RandomState(91)
+n = 0
+for shape, v in (((33, 31, 64), 0.0), ((20, 20, 255), 0.3), ((64, 48, 260), -0.2), ((9, 40, 12), 0.1)):
+    A = rng.standard_normal(shape).astype(np.float32)
+    for _ in range(2):
+        for ax in range(3):
+            A = (0.25 * np.roll(A, 1, ax) + 0.5 * A + 0.25 * np.roll(A, -1, ax)).astype(np.float32)
+    A = (A / A.std()).astype(np.float32)
+    n += T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310, 1)["n_triangles"]
+    T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CANONICAL, 0)
+    assert ctx.level0_path() == 1
+# samples exactly at the isovalue and within the reference's tolerances: batches on the per-cell path
+B = np.round(rng.standard_normal((12, 13, 14)) * 2) / 2
+T.check_against_oracle(ctx, B.astype(np.float32), 0.5, _ffi.CX_DIAG_CPYTHON310, 1)
+C = (100.0 + rng.standard_normal((12, 12, 12)) * 1.5e-3).astype(np.float32)
+T.check_against_oracle(ctx, C, 100.0, _ffi.CX_DIAG_CPYTHON310, 1)
+# dense white noise: every wave closes many batches, the triangle stage's waves start inside batches
+D = rng.standard_normal((64, 32, 256)).astype(np.float32)
+T.check_against_oracle(ctx, D, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+ctx.close()
+print("ENTRY_KERNEL_OK", n)
+"""
+
+
+def test_entry_walking_triangle_kernel():
+    """cx_k_emit_triangles_e (the triangle stage that walks queue entries and needs no cell records; not the default because it
+    measured slower) against the oracle, in a child process started with CX_DEBUG=1 CX_K2_ENTRIES=1: smooth
+    and white-noise fields, both diagonal modes, samples on the isovalue and inside the reference's tolerances"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CX_DEBUG="1", CX_K2_ENTRIES="1")
+    r = subprocess.run([sys.executable, "-c", _ENTRY_KERNEL_CHILD.format(root=root, tests=os.path.join(root, "tests"))],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert any(ln.startswith("ENTRY_KERNEL_OK") for ln in r.stdout.splitlines()), r.stdout[-2000:]
+
+
 def test_empty_and_full(ctx):
     from contourist_amd import _ffi
     A = np.ones((8, 8, 8), dtype=np.float32)
