@@ -1701,7 +1701,12 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 zero = make_uint4(0, 0, 0, 0);
-    auto record = [&](uint32_t at) { return (at < ncells) ? cx_load_record(P.cells + at) : zero; };
+    // A record is requested three steps before it is expanded -- UNCONDITIONALLY (from a clamped index) and without touching the
+    // result: written as `(at < ncells) ? load : zero`, the load sat in a branch whose result the compiler copied into other
+    // registers right behind it, i.e. every iteration began by waiting for the record it had just asked for.  Whether the record
+    // exists is decided when it is used (`valid`).
+    auto record = [&](uint32_t at) { return cx_load_record(P.cells + min(at, ncells - 1u)); };
+    auto valid = [&](const uint4& r, uint32_t at) { return (at < ncells) ? r : zero; };
     // prologue: record idx through both stages, record idx + stride through the first, record idx + 2 stride loaded
     cx_tri_qa Ab, Ac;
     cx_tri_in Ia, Ib;
@@ -1709,8 +1714,8 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     {
         uint4 r0 = record(idx), r1 = record(idx + stride);
         asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w) :: "memory");
-        cx_triq_stage1(P, T, L, r0, Ac);
-        cx_triq_stage1(P, T, L, r1, Ab);
+        cx_triq_stage1(P, T, L, valid(r0, idx), Ac);
+        cx_triq_stage1(P, T, L, valid(r1, idx + stride), Ab);
         cx_triq_pin1(Ac, rec_c);
         cx_triq_pin1(Ab, rec_c);
         cx_triq_stage2(P, T, hash_xy, Ac, Ia);
@@ -1719,7 +1724,7 @@ __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(c
     while (idx - lane < ncells) {   // wave-uniform
         const uint32_t nidx = idx + stride;
         uint4 rec_d = record(nidx + 2u * stride);          // the record three steps ahead
-        cx_triq_stage1(P, T, L, rec_c, Ac);           // queue words of the record two steps ahead
+        cx_triq_stage1(P, T, L, valid(rec_c, nidx + stride), Ac);   // queue words of the record two steps ahead
         cx_triq_stage2(P, T, hash_xy, Ab, Ib);              // info words (and hash prefixes) of the next record
         const uint32_t ttot = cx_tri_phase1<NEG_ORIGIN>(P, L, lane, wave, Ia);
 #if CX_PIN_BEFORE_STORES
