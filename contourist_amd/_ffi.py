@@ -24,7 +24,7 @@ CX_KERNEL_FUSED = 0x400
 # every symbol include/contourist_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
-    "cx_grid_upload", "cx_grid_adopt_device", "cx_set_origin", "cx_reserve",
+    "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
@@ -96,6 +96,7 @@ def load():
         "cx_synchronize": [vp],
         "cx_grid_upload": [vp, vp, i64, i64, i64],
         "cx_grid_adopt_device": [vp, vp, i64, i64, i64],
+        "cx_grid_shadow_f64": [vp, vp, i64, i64, i64],
         "cx_set_origin": [vp, i64, i64, i64],
         "cx_reserve": [vp, i64, i64, i64],
         "cx_extract3d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
@@ -209,6 +210,16 @@ class Context(object):
         self._check(self.lib.cx_grid_adopt_device(self.handle, ctypes.c_void_p(int(device_ptr)), *[int(n) for n in shape]))
         self.shape = tuple(int(n) for n in shape)
         self._keep = keepalive
+
+    def shadow_grid_f64(self, array=None):
+        """float64 originals of the bound samples (None drops them): Level 1 interpolates the crossings on these, as the
+        reference does on the float64 values of its callable (tetrahedral.py:471-487)"""
+        if array is None:
+            self._check(self.lib.cx_grid_shadow_f64(self.handle, None, 0, 0, 0))
+            return
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        assert tuple(a.shape) == tuple(self.shape), (a.shape, self.shape)
+        self._check(self.lib.cx_grid_shadow_f64(self.handle, a.ctypes.data, *a.shape))
 
     def set_origin(self, o0=0, o1=0, o2=0):
         self._check(self.lib.cx_set_origin(self.handle, int(o0), int(o1), int(o2)))

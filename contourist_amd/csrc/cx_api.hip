@@ -67,6 +67,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_state2_free(ctx);
     free_outputs(ctx);
     cx_release(ctx->grid_owned, ctx->grid_owned_bytes);
+    cx_release(ctx->grid64, ctx->grid64_cap);
     cx_release(ctx->celltab, ctx->tables_for);
     cx_release(ctx->queue, ctx->queue_cap);
     cx_release(ctx->wsum, ctx->wsum_cap);
@@ -112,6 +113,7 @@ static int set_grid_dims(cx_ctx* ctx, int64_t n0, int64_t n1, int64_t n2) {
     const int64_t N = n0 * n1 * n2;
     if (N > (1LL << 29)) return fail(ctx, CX_ERR_UNSUPPORTED, "more than 2^29 samples in one grid: partition into slabs");
     ctx->n0 = n0; ctx->n1 = n1; ctx->n2 = n2;
+    ctx->grid64_valid = false;   // the float64 originals belonged to the previous grid
     cx_levels_invalidate(ctx);
     ctx->extracted = false;
     ctx->post_valid = false;
@@ -142,6 +144,27 @@ extern "C" int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t
     int rc = set_grid_dims(ctx, n0, n1, n2);
     if (rc) return rc;
     ctx->grid = (const float*)device_ptr;
+    return CX_OK;
+}
+
+// The reference evaluates a callable field in float64 and interpolates its crossings on those values
+// (tetrahedral.py:471-487); the march runs on their fp32 roundings.  With the float64 originals bound here Level 1
+// (cx_postprocess3d, cx_level0_points_f64) interpolates on them, so a crossing next to a weld-bucket boundary
+// (surface_geometry.py:30-48) lands on the reference's side of it.  NULL drops them.  8 bytes per sample.
+extern "C" int cx_grid_shadow_f64(cx_ctx* ctx, const double* host, int64_t n0, int64_t n1, int64_t n2) {
+    if (!ctx) return CX_ERR_INVALID;
+    ctx->grid64_valid = false;
+    ctx->post_valid = false;
+    if (!host) return CX_OK;
+    if (!ctx->grid || n0 != ctx->n0 || n1 != ctx->n1 || n2 != ctx->n2)
+        return fail(ctx, CX_ERR_STATE, "cx_grid_shadow_f64: bind the fp32 grid of the same dimensions first");
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)(n0 * n1 * n2);
+    int rc = cx_grow(ctx, ctx->grid64, ctx->grid64_cap, N);
+    if (rc) return rc;
+    CX_HIP(ctx, hipMemcpyAsync(ctx->grid64, host, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->grid64_valid = true;
     return CX_OK;
 }
 

@@ -19,6 +19,9 @@ struct cx_ctx {
     float* grid_owned = nullptr;
     size_t grid_owned_bytes = 0;
     int64_t n0 = 0, n1 = 0, n2 = 0;
+    double* grid64 = nullptr;          // float64 originals of the samples (cx_grid_shadow_f64): Level 1 interpolates on these
+    size_t grid64_cap = 0;
+    bool grid64_valid = false;
     // side tables of the march
     uint64_t* celltab = nullptr;
     size_t tables_for = 0;

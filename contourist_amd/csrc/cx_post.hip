@@ -242,7 +242,7 @@ __global__ void cxp_k_scan_add(uint32_t* out, const uint32_t* sums, uint32_t n) 
 struct cxp_origin3 {
     double o[3];   // lattice coordinates of sample (0,0,0) in the whole volume (cx_set_origin), or zeros
 };
-__global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uint32_t n2, cx_fdiv dplane, cx_fdiv drow,
+__global__ void cxp_k_vertices_f64(const float* __restrict__ A, const double* __restrict__ A64, uint32_t n1, uint32_t n2, cx_fdiv dplane, cx_fdiv drow,
                                    double value, const cx_vrec* __restrict__ verts, uint32_t nv, double* pts, uint32_t* prio, cxp_origin3 org) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv) return;
@@ -254,7 +254,7 @@ __global__ void cxp_k_vertices_f64(const float* __restrict__ A, uint32_t n1, uin
     const uint32_t j = cx_div(r, drow);
     const uint32_t k = r - j * n2;
     const uint32_t lin2 = lin + ((d & 4u) ? plane : 0u) + ((d & 2u) ? n2 : 0u) + (d & 1u);
-    const double f0 = (double)A[lin], f1 = (double)A[lin2];
+    const double f0 = A64 ? A64[lin] : (double)A[lin], f1 = A64 ? A64[lin2] : (double)A[lin2];
     const bool owner_low = !(f0 > f1);             // reference swaps when flow > fhigh
     const double flow = owner_low ? f0 : f1, fhigh = owner_low ? f1 : f0;
     double ratio = 0.5;
@@ -1036,8 +1036,8 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     if (ctx->origin[0] < 0 || ctx->origin[1] < 0 || ctx->origin[2] < 0)
         for (int a = 0; a < 3; a++) org.o[a] = (double)ctx->origin[a];
     if (nv && nt) {
-        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, P.n1, P.n2, P.div_plane, P.div_row,
-                           P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
+        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, ctx->grid64_valid ? ctx->grid64 : nullptr, P.n1, P.n2,
+                           P.div_plane, P.div_row, P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
         CXP_HIP(ctx, hipMemcpyAsync(S->tri.p, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (ctx->keep_valid) {   // cx_select_seeded3d: only the triangles (and vertices) of the selected components exist
             CXP_HIP(ctx, hipMemcpyAsync(S->alive.p, ctx->tri_keep, nt, hipMemcpyDeviceToDevice, st));
@@ -1073,8 +1073,8 @@ extern "C" int cx_level0_points_f64(cx_ctx* ctx, double* points_xyz) {
     if ((rc = cxp_reserve(ctx, S->prio, (size_t)(nv + 1) * sizeof(uint32_t)))) return rc;
     const cx_params& P = ctx->last;
     const cxp_origin3 org{{(double)ctx->origin[0], (double)ctx->origin[1], (double)ctx->origin[2]}};
-    hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, ctx->stream, P.grid, P.n1, P.n2, P.div_plane, P.div_row, P.value,
-                       ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
+    hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, ctx->stream, P.grid, ctx->grid64_valid ? ctx->grid64 : nullptr, P.n1, P.n2,
+                       P.div_plane, P.div_row, P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
     if ((rc = cx_copy_to_host1(ctx, points_xyz, S->pts.p, (size_t)nv * 3 * sizeof(double)))) return rc;
     ctx->post_valid = false;   // the post-pass buffers no longer hold a Level-1 mesh
     return CX_OK;

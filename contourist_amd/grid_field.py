@@ -198,11 +198,32 @@ class FunctionGrid(object):
         if margin:
             assert not getattr(self, "array_backed", False), "a sample array cannot be evaluated outside itself"
             shape = tuple(int(n) + 1 + 2 * margin for n in self.grid_dimensions)
-            return np.ascontiguousarray(self._evaluate(shape, first=-margin), dtype=np.float32)
+            e = self._evaluate(shape, first=-margin)
+            self._dense64_margin = (margin, np.ascontiguousarray(e, dtype=np.float64) if e.size <= self.DENSE64_LIMIT else None)
+            return np.ascontiguousarray(e, dtype=np.float32)
         if self._dense is None:
             shape = tuple(int(n) + 1 for n in self.grid_dimensions)
-            self._dense = np.ascontiguousarray(self._evaluate(shape), dtype=np.float32)
+            e = self._evaluate(shape)
+            self._dense = np.ascontiguousarray(e, dtype=np.float32)
+            if e.size <= self.DENSE64_LIMIT:
+                self._dense64 = np.ascontiguousarray(e, dtype=np.float64)
         return self._dense
+
+    DENSE64_LIMIT = 1 << 26    # samples; beyond this the float64 originals (8 B each) are not kept
+
+    def dense_samples64(self, margin=0):
+        """float64 values of a CALLABLE field at the vertices of dense_samples(margin), or None (array-backed field, or too
+        large to keep): what the reference interpolates its crossings on (tetrahedral.py:471-487)"""
+        if getattr(self, "array_backed", False):
+            return None
+        if margin:
+            m = getattr(self, "_dense64_margin", None)
+            if m is None or m[0] != margin:
+                self.dense_samples(margin)
+                m = self._dense64_margin
+            return m[1]
+        self.dense_samples()
+        return getattr(self, "_dense64", None)
 
     def dense_samples_host(self):
         d = self.dense_samples()

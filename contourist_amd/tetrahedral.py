@@ -49,7 +49,7 @@ class GridContour3d(object):
     """
 
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True,
-                 callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None, function=None):
+                 callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None, function=None, samples64=None):
         self.corner = np.array(corner, dtype=int)
         assert self.corner.shape == (3,), "dimension must be 3"
         if segment_endpoints is not None:
@@ -73,7 +73,9 @@ class GridContour3d(object):
         self.flatten = False
         self.smooth = None
         self.samples = samples
+        self.samples64 = samples64    # float64 originals of a callable's samples (the reference interpolates on these), or None
         shape = tuple(int(n) for n in samples.shape)
+        assert samples64 is None or tuple(samples64.shape) == shape
         assert shape == tuple(int(c) + 1 for c in self.corner), (shape, self.corner)
         self.shape = shape
         self.device = _DEFAULT_DEVICE[0] if device is None else int(device)
@@ -97,6 +99,7 @@ class GridContour3d(object):
             ctx.adopt_device_grid(s.data_ptr(), self.shape, keepalive=s)
         else:
             ctx.upload_grid(s)
+        ctx.shadow_grid_f64(self.samples64)
 
     def march(self, force=False):
         "Level 0 on the device (idempotent). returns the counts dict."
@@ -295,7 +298,7 @@ def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in segment_endpoints]
             maker = GridContour3d(tuple(c + 2 * m for c in corner), g.dense_samples(margin=m), value, shifted, linear_interpolate, callback,
                                   device, voxel_range=((m, m, m), tuple(c + m for c in corner)),
-                                  function=lambda i, j, k: function(i - m, j - m, k - m))
+                                  function=lambda i, j, k: function(i - m, j - m, k - m), samples64=g.dense_samples64(margin=m))
             maker.origin = (-m, -m, -m)
             maker.grid_shift = m
             return maker
@@ -303,7 +306,8 @@ def Grid3DContour(horizontal_n, vertical_m, forward_l, function, value, segment_
     else:
         samples = function
     return GridContour3d(corner, samples, value, segment_endpoints, linear_interpolate, callback, device,
-                         function=function if callable(function) else None)
+                         function=function if callable(function) else None,
+                         samples64=g.dense_samples64() if callable(function) else None)
 
 
 class Delta3DContour(object):
@@ -363,14 +367,15 @@ class Delta3DContour(object):
             shifted = [(np.asarray(a, dtype=int) + m, np.asarray(b, dtype=int) + m) for (a, b) in grid_endpoints]
             result = GridContour3d(tuple(gd + 2 * m), grid.dense_samples(margin=m), self.value, shifted,
                                    linear_interpolate=self.linear_interpolate, device=self.device,
-                                   voxel_range=((m, m, m), tuple(gd + m)), function=self._lattice_function(m))
+                                   voxel_range=((m, m, m), tuple(gd + m)), function=self._lattice_function(m),
+                                   samples64=grid.dense_samples64(margin=m))
             result.origin = (-m, -m, -m)      # the CPython-order diagonals hash the reference's own lattice coordinates
             result.grid_shift = m
             self._grid_shift = m
         else:
             result = GridContour3d(tuple(gd), grid.dense_samples(), self.value,
                                    grid_endpoints, linear_interpolate=self.linear_interpolate, device=self.device,
-                                   function=self._lattice_function(0))
+                                   function=self._lattice_function(0), samples64=grid.dense_samples64())
         result.flatten = self.flatten
         result.smooth = self.smooth
         return result

@@ -66,6 +66,11 @@ int cx_synchronize(cx_ctx* ctx);
  * the dense fp32 array the march reads instead of calling f(x,y,z) per corner per use. */
 int cx_grid_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int64_t n2);
 int cx_grid_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2);
+/* float64 originals of the bound fp32 samples (same dimensions; NULL drops them).  The reference interpolates a
+ * crossing on the float64 values of its callable (tetrahedral.py:471-487); with these bound, Level 1
+ * (cx_postprocess3d, cx_level0_points_f64) does the same, so crossings next to a weld-bucket boundary
+ * (surface_geometry.py:30-48) fall on the reference's side of it.  The march itself stays on fp32. */
+int cx_grid_shadow_f64(cx_ctx* ctx, const double* host, int64_t n0, int64_t n1, int64_t n2);
 
 /* the grid is a sub-block of a larger volume starting at lattice point (o0,o1,o2) (slab partitions).
  * Only CX_DIAG_CPYTHON310 depends on it: the reference's set order hashes ABSOLUTE lattice

@@ -53,9 +53,18 @@ def test_reference_demo(name):
     pts, tris = obj.get_points_and_triangles()
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
     tris = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
-    # The reference evaluated these callables in float64, the device marches fp32 samples: coordinates agree to ~1e-6
-    # and a vertex next to a weld-bucket boundary may land on its other side, so triangles are matched by their
-    # centroids (1e-3 lattice units) instead of by bucket ids
+    # The reference evaluated these callables in float64; the device marches their fp32 roundings (the sign tests agree) and
+    # interpolates the crossings on the float64 originals (cx_grid_shadow_f64), so the points themselves are the
+    # reference's.  What differs is ORDER: where the surface passes within a weld bucket of a lattice point the reference's
+    # remove_tiny_simplices (tetrahedral.py:353-375) moves the vertices of a tiny triangle onto "points[0]" of a frozenset,
+    # one triangle after the other in set order, and clean_triangles (surface_geometry.py:14-50) merges what then coincides --
+    # which points survive there is its hash order (wave: 118 of 15430 triangles, all within 2e-3 of a lattice point;
+    # tools/demo_diff.py lists them).  Triangles are therefore matched by their centroids (1e-3 lattice units).
+    if not name.endswith("_nonlinear"):
+        pa = {tuple(r) for r in np.round(np.asarray(G["points"], dtype=np.float64), 9).tolist()}
+        pb = {tuple(r) for r in np.round(pts, 9).tolist()}
+        print(name, "reference points", len(pa), "found to 1e-9 among the device's", len(pa & pb))
+        assert len(pa & pb) >= 0.99 * len(pa), (name, len(pa), len(pa & pb))
     def centroids(P, T):
         c = ((P[T[:, 0]] + P[T[:, 1]] + P[T[:, 2]]) / 3.0 - mins) / delta
         return [tuple(r) for r in np.round(c, 3).tolist()]
