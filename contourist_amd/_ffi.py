@@ -26,7 +26,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_write", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_lists", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -118,6 +118,10 @@ def load():
         "cx_seeded_masks_download": [vp, vp, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
+        "cx_level1_download_keys": [vp, vp],
+        "cx_postprocess3d_shard_begin": [vp, u32, i64, i64, vp, vp, vp],
+        "cx_postprocess3d_shard_lists": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "cx_postprocess3d_shard_finish": [vp, vp, vp, i64, vp],
         "cx_level1_write": [vp, ctypes.c_int, ctypes.c_char_p, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
         "cx_debug_stamps": [vp, i64, vp],
@@ -327,6 +331,40 @@ class Context(object):
         tris = np.empty((int(counts["n_triangles"]), 3), dtype=np.int32)
         self._check(self.lib.cx_level1_download(self.handle, pts.ctypes.data, tris.ctypes.data))
         return pts, tris
+
+    def download_level1_keys(self, counts):
+        "edge ids (local to the marched array) of the vertices of download_level1, in its order"
+        keys = np.empty(int(counts["n_vertices"]), dtype=np.uint32)
+        self._check(self.lib.cx_level1_download_keys(self.handle, keys.ctypes.data))
+        return keys
+
+    def shard_begin(self, own_lo, own_hi, flags=0):
+        """sharded Level 1, local part (cx_postprocess3d_shard_begin + _lists) -> dict(counts, tri_keys (B,3) uint32 local edge
+        ids, tri_label (B,), tri_class (B,), cand_label / cand_x / cand_vertex_key / cand_nx / cand_negative / cand_has (C,))"""
+        out = np.zeros(8, dtype=np.int64)
+        nb = ctypes.c_int64(0)
+        nc = ctypes.c_int64(0)
+        self._check(self.lib.cx_postprocess3d_shard_begin(self.handle, int(flags), int(own_lo), int(own_hi), out.ctypes.data,
+                                                          ctypes.addressof(nb), ctypes.addressof(nc)))
+        B, C = int(nb.value), int(nc.value)
+        L = dict(tri_keys=np.zeros((B, 3), np.uint32), tri_label=np.zeros(B, np.uint32), tri_class=np.zeros(B, np.uint8),
+                 cand_label=np.zeros(C, np.uint32), cand_x=np.zeros(C, np.float64), cand_vertex_key=np.zeros(C, np.uint32),
+                 cand_nx=np.zeros(C, np.float64), cand_negative=np.zeros(C, np.uint8), cand_has=np.zeros(C, np.uint8))
+        if B:
+            self._check(self.lib.cx_postprocess3d_shard_lists(self.handle, *[L[k].ctypes.data for k in (
+                "tri_keys", "tri_label", "tri_class", "cand_label", "cand_x", "cand_vertex_key", "cand_nx", "cand_negative", "cand_has")]))
+        L["counts"] = dict(n_after_weld=int(out[2]), n_after_tiny=int(out[3]))
+        return L
+
+    def shard_finish(self, labels, flips):
+        "the agreed flips for the components that reach a neighbour -> counts dict for download_level1 / download_level1_keys"
+        lab = np.ascontiguousarray(labels, dtype=np.uint32).reshape(-1)
+        fl = np.ascontiguousarray(flips, dtype=np.uint8).reshape(-1)
+        assert len(lab) == len(fl)
+        out = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cx_postprocess3d_shard_finish(self.handle, lab.ctypes.data if len(lab) else None, fl.ctypes.data if len(fl) else None,
+                                                           len(lab), out.ctypes.data))
+        return dict(n_vertices=int(out[0]), n_triangles=int(out[1]), n_components=int(out[4]))
 
     def write_level1(self, path, fmt="ply", mins=None, delta=None):
         """the Level-1 mesh of the last post-pass as a binary file written straight from the device buffers (no numpy arrays):

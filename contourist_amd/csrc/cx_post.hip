@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "cx_ctx.h"
 #include "cx_state4.h"
@@ -43,6 +44,14 @@ struct cxp_dev {
 
 struct cx_post_state {
     cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
+    cxp_dev keys_out, keys_tmp, told, cls, bnd;   // edge ids of the output vertices; sharded Level 1 (cx_postprocess3d_shard_*)
+    bool keys_valid = false;
+    struct {
+        bool open = false;            // between cx_postprocess3d_shard_begin and _finish
+        uint32_t nv2 = 0, nt2 = 0;    // mesh of own + first-halo-layer triangles the labels refer to
+        uint32_t nt_in = 0;           // triangles the post-pass started from (layout of S->cls)
+        uint32_t nbnd = 0, ncand = 0;
+    } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
@@ -63,6 +72,7 @@ void cx_post_free(cx_ctx* ctx) {
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
+                      &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd,
                       &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
@@ -499,18 +509,22 @@ __global__ void cxp_k_alive_u32(const uint8_t* alive, uint32_t nt, uint32_t* out
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nt) out[t] = alive[t] ? 1u : 0u;
 }
-__global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const uint32_t* newid, uint32_t nv, double* out) {
+// (keys: the priority = edge id of every surviving vertex travels with it; told: where a surviving triangle came from)
+__global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const uint32_t* newid, uint32_t nv, double* out,
+                                  const uint32_t* keys, uint32_t* keys_out) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv || !used[v]) return;
 #pragma unroll
     for (int a = 0; a < 3; a++) out[(size_t)newid[v] * 3 + a] = pts[(size_t)v * 3 + a];
+    if (keys_out) keys_out[newid[v]] = keys[v];
 }
 __global__ void cxp_k_compact_tri(const int32_t* tri, const uint8_t* alive, const uint32_t* tnew, const uint32_t* vnew, uint32_t nt,
-                                  int32_t* out) {
+                                  int32_t* out, uint32_t* told) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
 #pragma unroll
     for (int s = 0; s < 3; s++) out[(size_t)tnew[t] * 3 + s] = (int32_t)vnew[tri[(size_t)t * 3 + s]];
+    if (told) told[tnew[t]] = t;
 }
 
 // ---- orientation ---------------------------------------------------------------------------------------
@@ -651,10 +665,12 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
         if (o != CXP_NONE) cxp_union(parent, nullptr, t, o, 0u);
     }
 }
-// per component (root triangle): largest x over its vertices
-__global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx) {
+// per component (root triangle): largest x over its vertices.  cls (sharded Level 1 only): per triangle, > 2 = a copy of a
+// neighbour slab's triangle, which takes part in the components but not in the choice of the start triangle.
+#define CXP_OWN(cls, t) (!(cls) || (cls)[t] <= 2u)
+__global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx, const uint8_t* cls) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = t < nt;
+    const bool have = t < nt && CXP_OWN(cls, t);
     uint32_t root = 0;
     u64 m = 0;
     if (have) {
@@ -664,16 +680,19 @@ __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* p
     }
     cxp_wave_max64(cmaxx, root, m, have);
 }
-// among the vertices at that x: the one with the largest index (surface_geometry.py:79 max((x, index)))
-__global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, uint32_t* cmaxv) {
+// among the vertices at that x: the one with the largest index in the reference (surface_geometry.py:79 max((x, index)), its
+// numbering being its hash order); here the one with the largest EDGE ID, which does not depend on how the mesh is numbered or
+// cut into slabs.  Packed (edge id << 32 | vertex).
+__global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, u64* cmaxv,
+                                const uint32_t* keys, const uint8_t* cls) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
+    if (t >= nt || !CXP_OWN(cls, t)) return;
     const uint32_t root = (uint32_t)parent[t];
     const u64 m = cmaxx[root];
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const uint32_t v = tri[(size_t)t * 3 + s];
-        if (cxp_orderable(pts[(size_t)v * 3]) == m) cxp_max32(&cmaxv[root], v);
+        if (cxp_orderable(pts[(size_t)v * 3]) == m) cxp_max64(&cmaxv[root], ((u64)(keys ? keys[v] : v) << 32) | (u64)v);
     }
 }
 // among that vertex's triangles: the largest |cross(a-b, a-c)[0]| (surface_geometry.py:88-94); the packed
@@ -684,21 +703,21 @@ __device__ __forceinline__ double cxp_dotx(const int32_t* tri, uint32_t t, const
     const double acy = pts[(size_t)a * 3 + 1] - pts[(size_t)c * 3 + 1], acz = pts[(size_t)a * 3 + 2] - pts[(size_t)c * 3 + 2];
     return aby * acz - abz * acy;
 }
-__global__ void cxp_k_comp_start(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cmaxv,
-                                 u64* cbest) {
+__global__ void cxp_k_comp_start(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxv,
+                                 u64* cbest, const uint8_t* cls) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
+    if (t >= nt || !CXP_OWN(cls, t)) return;
     const uint32_t root = (uint32_t)parent[t];
-    const uint32_t vm = cmaxv[root];
+    const uint32_t vm = (uint32_t)cmaxv[root];
     if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
     cxp_max64(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
 }
-__global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cmaxv,
-                                const u64* cbest, uint32_t* cstart) {
+__global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxv,
+                                const u64* cbest, uint32_t* cstart, const uint8_t* cls) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
+    if (t >= nt || !CXP_OWN(cls, t)) return;
     const uint32_t root = (uint32_t)parent[t];
-    const uint32_t vm = cmaxv[root];
+    const uint32_t vm = (uint32_t)cmaxv[root];
     if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
     if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) cxp_max32(&cstart[root], t);
 }
@@ -728,6 +747,82 @@ __global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const u64* parent, const
         tri[(size_t)t * 3 + 2] = a;
     }
 }
+
+// ---- sharded Level 1: a slab marched together with two layers of its neighbours' cells ------------------
+// Every triangle of the march lies in one cell; the smallest of its three edge ids belongs to an edge that starts in the
+// cell's lower x face (a tetrahedron has no three crossing edges inside one face of the cube), so (id >> 3) / plane is the
+// cell's layer.  Classes: 0 own, 1 / 2 own and next to the lower / upper neighbour, 3 / 4 first layer of the lower / upper
+// neighbour (kept for the components), 255 second layer (only there so that weld, tiny collapse and clean-up of the first
+// layer see everything they see in the undivided volume): dropped here.
+struct cxp_shard {
+    uint32_t plane;            // samples per x plane
+    uint32_t own_lo, own_hi;   // own cell layers [own_lo, own_hi) of the local array
+    uint32_t layers;           // cell layers of the local array
+};
+__global__ void cxp_k_shard_classify(const uint32_t* tprio3, uint8_t* alive, uint32_t nt, cxp_shard sh, cx_fdiv dplane, uint8_t* cls,
+                                     uint32_t* nbnd) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    uint8_t c = 255;
+    if (alive[t]) {
+        const uint32_t layer = cx_div(tprio3[(size_t)t * 3] >> 3, dplane);
+        if (layer >= sh.own_lo && layer < sh.own_hi) {
+            c = 0;
+            if (layer == sh.own_lo && sh.own_lo > 0u) c = 1;
+            else if (layer + 1u == sh.own_hi && sh.own_hi < sh.layers) c = 2;
+        } else if (layer + 1u == sh.own_lo) c = 3;
+        else if (layer == sh.own_hi) c = 4;
+        if (c == 255) alive[t] = 0;
+        else if (c) atomicAdd(nbnd, 1u);
+    }
+    cls[t] = c;
+}
+__global__ void cxp_k_shard_gather_cls(const uint8_t* cls, const uint32_t* told, uint32_t nt2, uint8_t* cls2) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nt2) cls2[t] = cls[told[t]];
+}
+// triangles next to a neighbour slab: (original edge-id triple, component label, class), and their components marked open
+__global__ void cxp_k_shard_boundary(const uint8_t* cls2, const uint32_t* told, const uint32_t* tprio3, const u64* parent, uint32_t nt2,
+                                     uint32_t* counter, uint32_t cap, uint32_t* bkeys, uint32_t* blabel, uint8_t* bcls, uint8_t* open) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt2 || !cls2[t]) return;
+    const uint32_t root = (uint32_t)parent[t];
+    open[root] = 1;
+    const uint32_t at = atomicAdd(counter, 1u);
+    if (at >= cap) return;
+    const uint32_t o = told[t];
+    bkeys[(size_t)at * 3] = tprio3[(size_t)o * 3]; bkeys[(size_t)at * 3 + 1] = tprio3[(size_t)o * 3 + 1]; bkeys[(size_t)at * 3 + 2] = tprio3[(size_t)o * 3 + 2];
+    blabel[at] = root;
+    bcls[at] = cls2[t];
+}
+// the start-triangle candidate of every open component, from this slab's own triangles: (label, x of the max-x vertex, its
+// edge id, |normal_x| of the start triangle, its sign, whether there is a candidate at all)
+struct cxp_cand { double x, nx; uint32_t label, vkey, sign, has; };
+__global__ void cxp_k_shard_candidates(const int32_t* tri2, const double* pts2, const uint32_t* keys2, const u64* parent, const uint8_t* open,
+                                       uint32_t nt2, const u64* cmaxx, const u64* cmaxv, const uint32_t* cstart, uint32_t* counter,
+                                       uint32_t cap, cxp_cand* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt2 || (uint32_t)parent[t] != t || !open[t]) return;
+    const uint32_t at = atomicAdd(counter, 1u);
+    if (at >= cap) return;
+    cxp_cand c;
+    c.label = t; c.has = cmaxx[t] != 0 ? 1u : 0u; c.x = 0.0; c.nx = 0.0; c.vkey = 0; c.sign = 0;
+    if (c.has) {
+        const uint32_t vm = (uint32_t)cmaxv[t];
+        const double d = cxp_dotx(tri2, cstart[t], pts2);
+        c.x = pts2[(size_t)vm * 3]; c.vkey = keys2[vm]; c.nx = fabs(d); c.sign = d < 0.0 ? 1u : 0u;
+    }
+    out[at] = c;
+}
+__global__ void cxp_k_shard_set_flips(const uint32_t* labels, const uint8_t* flips, uint32_t n, uint32_t nt2, u64* cflip) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && labels[i] < nt2) cflip[labels[i]] = (u64)(flips[i] & 1u);
+}
+__global__ void cxp_k_shard_own_alive(const uint8_t* cls2, uint32_t nt2, uint8_t* alive) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nt2) alive[t] = cls2[t] <= 2u ? 1 : 0;
+}
+
 
 // ---- host orchestration ----------------------------------------------------------------------------------
 static inline uint32_t cxp_blocks(size_t n, uint32_t b = 256) { return (uint32_t)((n + b - 1) / b); }
@@ -781,7 +876,7 @@ static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_d
 // Shared tail: clean (optional) + compaction + orientation (optional) on S->pts (nv x 3 doubles),
 // S->tri (nt x 3), S->alive.  prio = vertex priorities.  Results in S->pts_out / S->tri_out.
 static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, bool do_clean, bool do_orient,
-                            uint32_t* tprio3, int64_t* out_counts, bool coherent, uint8_t* involved = nullptr) {
+                            uint32_t* tprio3, int64_t* out_counts, bool coherent, uint8_t* involved = nullptr, const cxp_shard* shard = nullptr) {
     int rc;
     double* pts = (double*)S->pts.p;
     uint32_t* prio = (uint32_t*)S->prio.p;
@@ -789,6 +884,8 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     uint8_t* alive = (uint8_t*)S->alive.p;
     uint32_t* misc = (uint32_t*)S->misc.p;   // [0] changed flag, [1..] counters
     hipStream_t st = ctx->stream;
+    S->keys_valid = false;
+    S->shard.open = false;
     if (do_clean && nt) {
         u64* parent2 = (u64*)S->parent2.p;
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent2, nv);
@@ -800,6 +897,17 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
         hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
+    }
+    // ---- sharded: the second layer of the neighbours' cells has done its work (weld, tiny collapse and clean-up above saw it)
+    uint8_t* cls = nullptr;
+    uint32_t* told = nullptr;
+    if (shard) {
+        if ((rc = cxp_reserve(ctx, S->cls, 3 * (size_t)nt + 64))) return rc;
+        if ((rc = cxp_reserve(ctx, S->told, ((size_t)nt + 16) * sizeof(uint32_t)))) return rc;
+        cls = (uint8_t*)S->cls.p;
+        told = (uint32_t*)S->told.p;
+        CXP_HIP(ctx, hipMemsetAsync(misc + 6, 0, 3 * sizeof(uint32_t), st));
+        if (nt) hipLaunchKernelGGL(cxp_k_shard_classify, dim3(cxp_blocks(nt)), dim3(256), 0, st, tprio3, alive, nt, *shard, cx_fdiv_make(shard->plane), cls, misc + 6);
     }
     // ---- compaction of used vertices and living triangles
     if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
@@ -822,53 +930,155 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     }
     if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(nv2 + 1) * 3 * sizeof(double)))) return rc;
     if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(nt2 + 1) * 3 * sizeof(int32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->keys_out, (size_t)(nv2 + 1) * sizeof(uint32_t)))) return rc;
     double* pts2 = (double*)S->pts_out.p;
     int32_t* tri2 = (int32_t*)S->tri_out.p;
+    uint32_t* keys2 = (uint32_t*)S->keys_out.p;
     if (nt2) {
-        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2);
-        hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, tnew, vnew, nt, tri2);
+        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2, (const uint32_t*)prio, keys2);
+        hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, tnew, vnew, nt, tri2, told);
     }
     S->nv_out = nv2; S->nt_out = nt2;
+    S->keys_valid = true;
+    uint8_t* cls2 = nullptr;
+    if (shard) {
+        cls2 = cls + nt;
+        if (nt2) hipLaunchKernelGGL(cxp_k_shard_gather_cls, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls, told, nt2, cls2);
+    }
     uint32_t ncomp = 0;
     if (do_orient && nt2) {
         // ---- orientation: edge table + parity union-find over triangles
         const u64 esz = cxp_edge_table_size((size_t)nt2 * 3);
         if ((rc = cxp_reserve(ctx, S->tkeys, 2 * esz * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->parent, (size_t)nt2 * sizeof(u64)))) return rc;
-        if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t))))) return rc;
+        if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t))))) return rc;
         u64* etab = (u64*)S->tkeys.p;
         u64* parent = (u64*)S->parent.p;
         u64* cmaxx = (u64*)S->comp.p;
         u64* cbest = cmaxx + nt2;
-        uint32_t* cmaxv = (uint32_t*)(cbest + nt2);
-        uint32_t* cstart = cmaxv + nt2;
+        u64* cmaxv = cbest + nt2;
+        uint32_t* cstart = (uint32_t*)(cmaxv + nt2);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
         if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
-            uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 24 bytes per triangle that the component tables take below
+            uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 28 bytes per triangle that the component tables take below
             hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
                                emult, parent, others);
             hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
         } else
             hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
-        CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
+        CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx);
-        hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv);
-        hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest);
-        hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart);
+        const uint8_t* own = cls2;
+        hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, own);
+        hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv, (const uint32_t*)keys2, own);
+        hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, own);
+        hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart, own);
+        if (shard) {
+            // what the neighbours (through the host) need: the triangles next to them with their labels, and the start-triangle
+            // candidate of every component that reaches them.  Sizes follow the slab boundary, not the slab.
+            uint32_t hb = 0;
+            CXP_HIP(ctx, hipMemcpyAsync(&hb, misc + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CXP_HIP(ctx, hipStreamSynchronize(st));
+            const size_t nb = hb;
+            // layout of S->bnd: keys u32[3 nb] | labels u32[nb] | candidates cxp_cand[nb] | classes u8[nb]
+            if ((rc = cxp_reserve(ctx, S->bnd, (nb + 1) * (4 * sizeof(uint32_t) + sizeof(cxp_cand) + 1) + 64))) return rc;
+            uint32_t* bkeys = (uint32_t*)S->bnd.p;
+            uint32_t* blabel = bkeys + 3 * nb;
+            cxp_cand* cand = (cxp_cand*)(((uintptr_t)(blabel + nb) + 15u) & ~(uintptr_t)15u);
+            uint8_t* bcls = (uint8_t*)(cand + nb);
+            uint8_t* open = cls + 2 * (size_t)nt;
+            CXP_HIP(ctx, hipMemsetAsync(open, 0, nt2, st));
+            if (nb) {
+                hipLaunchKernelGGL(cxp_k_shard_boundary, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls2, told, tprio3, parent, nt2, misc + 7, (uint32_t)nb,
+                                   bkeys, blabel, bcls, open);
+                hipLaunchKernelGGL(cxp_k_shard_candidates, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, pts2, keys2, parent, open, nt2, cmaxx, cmaxv,
+                                   cstart, misc + 8, (uint32_t)nb, cand);
+            }
+            uint32_t h2[2] = {0, 0};
+            CXP_HIP(ctx, hipMemcpyAsync(h2, misc + 7, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CXP_HIP(ctx, hipStreamSynchronize(st));
+            if (h2[0] != nb || h2[1] > nb) { ctx->err = "sharded Level 1: boundary lists do not add up"; return CX_ERR_HIP; }
+            S->shard.nbnd = (uint32_t)nb; S->shard.ncand = h2[1];
+        }
         hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, cbest);
-        hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cbest, misc + 3);
-        CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (!shard) {
+            hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cbest, misc + 3);
+            CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
         CXP_HIP(ctx, hipStreamSynchronize(st));
+    } else if (shard) {
+        S->shard.nbnd = 0; S->shard.ncand = 0;
     }
+    if (shard) { S->shard.open = true; S->shard.nv2 = nv2; S->shard.nt2 = nt2; S->shard.nt_in = nt; }
     CXP_HIP(ctx, hipGetLastError());
     if (out_counts) {
         out_counts[0] = nv2; out_counts[1] = nt2; out_counts[4] = ncomp;
     }
+    return CX_OK;
+}
+
+// sharded Level 1, last step: the flips the ranks agreed on for the components that reach a neighbour replace the local
+// decisions, every triangle is wound, and the copies of the neighbours' triangles leave the mesh
+static int cxp_shard_finish(cx_ctx* ctx, cx_post_state* S, const uint32_t* labels, const uint8_t* flips, uint32_t n, int64_t* out_counts) {
+    int rc;
+    hipStream_t st = ctx->stream;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    const uint32_t nv2 = S->shard.nv2, nt2 = S->shard.nt2;
+    S->shard.open = false;
+    uint32_t ncomp = 0, nv3 = 0, nt3 = 0;
+    if (nt2) {
+        u64* parent = (u64*)S->parent.p;
+        u64* cflip = (u64*)S->comp.p + nt2;
+        int32_t* tri2 = (int32_t*)S->tri_out.p;
+        const uint8_t* cls2 = (const uint8_t*)S->cls.p + S->shard.nt_in;
+        if (n) {
+            if ((rc = cxp_reserve(ctx, S->keys_tmp, std::max((size_t)n * 5 + 64, (size_t)(nv2 + 1) * sizeof(uint32_t))))) return rc;
+            uint32_t* dl = (uint32_t*)S->keys_tmp.p;
+            uint8_t* df = (uint8_t*)(dl + n);
+            CXP_HIP(ctx, hipMemcpyAsync(dl, labels, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            CXP_HIP(ctx, hipMemcpyAsync(df, flips, (size_t)n, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(cxp_k_shard_set_flips, dim3(cxp_blocks(n)), dim3(256), 0, st, dl, df, n, nt2, cflip);
+        }
+        CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cflip, misc + 3);
+        // own triangles and the vertices they use
+        uint8_t* alive = (uint8_t*)S->alive.p;
+        uint32_t* used = (uint32_t*)S->flags.p;
+        uint32_t* tflag = used + nv2;
+        uint32_t* vnew = (uint32_t*)S->scan.p;
+        uint32_t* tnew = vnew + nv2;
+        hipLaunchKernelGGL(cxp_k_shard_own_alive, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls2, nt2, alive);
+        CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_mark_used, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, alive, nt2, used);
+        hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt2)), dim3(256), 0, st, alive, nt2, tflag);
+        if ((rc = cxp_scan(ctx, S, used, vnew, nv2, misc + 1))) return rc;
+        if ((rc = cxp_scan(ctx, S, tflag, tnew, nt2, misc + 2))) return rc;
+        uint32_t h[3];
+        CXP_HIP(ctx, hipMemcpyAsync(h, misc + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        nv3 = h[0]; nt3 = h[1]; ncomp = h[2];
+        // the march's own buffers are free by now: they take the final mesh, then the roles are swapped
+        if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv3 + 1) * 3 * sizeof(double)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->tri, (size_t)(nt3 + 1) * 3 * sizeof(int32_t)))) return rc;
+        if ((rc = cxp_reserve(ctx, S->keys_tmp, (size_t)(nv3 + 1) * sizeof(uint32_t)))) return rc;
+        if (nt3) {
+            hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv2)), dim3(256), 0, st, (const double*)S->pts_out.p, used, vnew, nv2, (double*)S->pts.p,
+                               (const uint32_t*)S->keys_out.p, (uint32_t*)S->keys_tmp.p);
+            hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, alive, tnew, vnew, nt2, (int32_t*)S->tri.p, (uint32_t*)nullptr);
+        }
+        CXP_HIP(ctx, hipStreamSynchronize(st));
+        std::swap(S->pts, S->pts_out);
+        std::swap(S->tri, S->tri_out);
+        std::swap(S->keys_tmp, S->keys_out);
+    }
+    S->nv_out = nv3; S->nt_out = nt3;
+    S->keys_valid = true;
+    CXP_HIP(ctx, hipGetLastError());
+    if (out_counts) { out_counts[0] = nv3; out_counts[1] = nt3; out_counts[4] = ncomp; }
     return CX_OK;
 }
 
@@ -943,7 +1153,7 @@ static int cxp_reserve3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt
 // edge_crossings: the vertices are the march's own crossings with their edge ids as priorities (cx_postprocess3d*), not points
 // handed over by a caller (cx_postprocess3d_mesh: refined points, slab meshes with global edge ids as ranks)
 static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, const double corner[3], const uint8_t* vkeep, bool do_clean,
-                     double smooth, bool coherent, int64_t* counts, bool edge_crossings = false) {
+                     double smooth, bool coherent, int64_t* counts, bool edge_crossings = false, const cxp_shard* shard = nullptr) {
     int rc;
     hipStream_t st = ctx->stream;
     double* pts = (double*)S->pts.p;
@@ -1013,7 +1223,7 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
     }
     // (`moved` is free again after cxp_k_move)
     return cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, coherent,
-                            (coherent && nv && nt && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr);
+                            (coherent && nv && nt && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr, shard);
 }
 
 extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {
@@ -1055,6 +1265,113 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
     ctx->post_valid = true;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
     return CX_OK;
+}
+
+// ---- sharded Level 1 (the reference is one process: tetrahedral.py:190-215, 353-375, surface_geometry.py:14-140) ----
+// The context holds the extraction of a slab that was marched TOGETHER with two layers of cells of each neighbour slab
+// (cx_set_origin = where the local array starts in the whole volume, cx_set_reference_corner = the whole volume's corner).
+// Weld buckets are narrower than a cell and never straddle an integer plane (tetrahedral.py:192-196), tiny and degenerate
+// triangles chain around one lattice point: with two layers, everything this step decides about the slab's own cells and
+// about the FIRST layer of its neighbours is what the undivided volume decides.  Components and the max-x rule are global:
+// begin() labels the components of own + first-layer triangles and leaves, for the host to exchange, the first-layer and
+// own-boundary triangles with their labels and one start-triangle candidate per component that reaches them (sizes follow the
+// slab boundary); finish() takes the agreed flips for those components.  own_lo / own_hi: own cell layers of the local array.
+extern "C" int cx_postprocess3d_shard_begin(cx_ctx* ctx, uint32_t flags, int64_t own_lo, int64_t own_hi, int64_t* out_counts,
+                                            int64_t* n_boundary, int64_t* n_candidates) {
+    if (!ctx || !n_boundary || !n_candidates) return CX_ERR_INVALID;
+    if (!ctx->extracted) { ctx->err = "cx_postprocess3d_shard_begin: no valid extraction"; return CX_ERR_STATE; }
+    const cx_params& P = ctx->last;
+    if (own_lo < 0 || own_hi <= own_lo || own_hi > (int64_t)P.n0 - 1) { ctx->err = "cx_postprocess3d_shard_begin: own cell layers outside the local array"; return CX_ERR_INVALID; }
+    if (ctx->keep_valid) { ctx->err = "cx_postprocess3d_shard_begin: not after a seeded selection"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S;
+    int rc = cxp_state(ctx, &S);
+    if (rc) return rc;
+    const uint32_t nv = (uint32_t)ctx->counts.n_vertices, nt = (uint32_t)ctx->counts.n_triangles;
+    hipStream_t st = ctx->stream;
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;
+    // coordinates of the WHOLE volume, added to the lattice points before the interpolation: bit for bit what the undivided
+    // volume computes, so that the weld buckets truncate identically
+    const cxp_origin3 org{{(double)ctx->origin[0], (double)ctx->origin[1], (double)ctx->origin[2]}};
+    if (nv && nt) {
+        hipLaunchKernelGGL(cxp_k_vertices_f64, dim3(cxp_blocks(nv)), dim3(256), 0, st, P.grid, ctx->grid64_valid ? ctx->grid64 : nullptr, P.n1, P.n2,
+                           P.div_plane, P.div_row, P.value, ctx->verts, nv, (double*)S->pts.p, (uint32_t*)S->prio.p, org);
+        CXP_HIP(ctx, hipMemcpyAsync(S->tri.p, ctx->tris, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        CXP_HIP(ctx, hipMemsetAsync(S->alive.p, 1, nt, st));
+    }
+    double corner[3] = {(double)(P.n0 - 1), (double)(P.n1 - 1), (double)(P.n2 - 1)};
+    for (int a = 0; a < 3; a++)
+        if (ctx->corner_ref[a] > 0) corner[a] = (double)ctx->corner_ref[a];
+    const cxp_shard sh{P.n1 * P.n2, (uint32_t)own_lo, (uint32_t)own_hi, P.n0 - 1};
+    ctx->post_valid = false;
+    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, nullptr, !(flags & 1u), 0.0, true, counts, true, &sh))) return rc;
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    *n_boundary = S->shard.nbnd;
+    *n_candidates = S->shard.ncand;
+    return CX_OK;
+}
+
+// the lists of cx_postprocess3d_shard_begin: per boundary triangle its three ORIGINAL edge ids (ascending; local to this
+// array -- add (origin_x * n1 * n2) << 3 for the ids of the whole volume), its component label and class (1 / 2: own, next
+// to the lower / upper neighbour; 3 / 4: copy of a triangle of the lower / upper neighbour); per component that reaches a
+// neighbour its label and start-triangle candidate among the OWN triangles (surface_geometry.py:79-103): x of the max-x
+// vertex, that vertex's edge id, |normal_x| of the start triangle, 1 if its normal_x is negative, 0 if the component has no
+// own triangle here.
+extern "C" int cx_postprocess3d_shard_lists(cx_ctx* ctx, uint32_t* tri_keys, uint32_t* tri_label, uint8_t* tri_class, uint32_t* cand_label,
+                                            double* cand_x, uint32_t* cand_vertex_key, double* cand_nx, uint8_t* cand_negative, uint8_t* cand_has) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post->shard.open) { ctx->err = "cx_postprocess3d_shard_lists: call cx_postprocess3d_shard_begin first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    const size_t nb = S->shard.nbnd, nc = S->shard.ncand;
+    if (!nb) return CX_OK;
+    if (!tri_keys || !tri_label || !tri_class || (nc && (!cand_label || !cand_x || !cand_vertex_key || !cand_nx || !cand_negative || !cand_has))) return CX_ERR_INVALID;
+    const uint32_t* bkeys = (const uint32_t*)S->bnd.p;
+    const uint32_t* blabel = bkeys + 3 * nb;
+    const cxp_cand* cand = (const cxp_cand*)(((uintptr_t)(blabel + nb) + 15u) & ~(uintptr_t)15u);
+    const uint8_t* bcls = (const uint8_t*)(cand + nb);
+    hipStream_t st = ctx->stream;
+    CXP_HIP(ctx, hipMemcpyAsync(tri_keys, bkeys, nb * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipMemcpyAsync(tri_label, blabel, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipMemcpyAsync(tri_class, bcls, nb, hipMemcpyDeviceToHost, st));
+    std::vector<cxp_cand> h(nc);
+    if (nc) CXP_HIP(ctx, hipMemcpyAsync(h.data(), cand, nc * sizeof(cxp_cand), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < nc; i++) {
+        cand_label[i] = h[i].label; cand_x[i] = h[i].x; cand_vertex_key[i] = h[i].vkey; cand_nx[i] = h[i].nx;
+        cand_negative[i] = (uint8_t)h[i].sign; cand_has[i] = (uint8_t)h[i].has;
+    }
+    return CX_OK;
+}
+
+// flips[i] (0 / 1) for component labels[i] of cx_postprocess3d_shard_lists: the decision of the rank that holds the component's
+// start triangle.  Components that reach no neighbour keep the local decision.  Afterwards cx_level1_download /
+// cx_level1_download_keys / cx_level1_write hand out this slab's OWN triangles and the vertices they use, in the coordinates
+// of the whole volume.  out_counts as cx_postprocess3d ([0] vertices, [1] triangles, [4] components seen locally).
+extern "C" int cx_postprocess3d_shard_finish(cx_ctx* ctx, const uint32_t* labels, const uint8_t* flips, int64_t n, int64_t* out_counts) {
+    if (!ctx || n < 0 || (n && (!labels || !flips))) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post->shard.open) { ctx->err = "cx_postprocess3d_shard_finish: call cx_postprocess3d_shard_begin first"; return CX_ERR_STATE; }
+    if (n > (int64_t)ctx->post->shard.nt2) { ctx->err = "cx_postprocess3d_shard_finish: more labels than triangles"; return CX_ERR_INVALID; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = cxp_shard_finish(ctx, ctx->post, labels, flips, (uint32_t)n, counts);
+    if (rc) return rc;
+    ctx->post_valid = true;
+    if (out_counts) memcpy(out_counts, counts, sizeof(counts));
+    return CX_OK;
+}
+
+// edge id ((linear index of the lower lattice point << 3) | direction, local to the array that was marched) of every vertex of
+// cx_level1_download, in its order: the identity of a Level-1 vertex across slabs and runs (the representative that survived
+// weld, tiny collapse and clean-up)
+extern "C" int cx_level1_download_keys(cx_ctx* ctx, uint32_t* keys) {
+    if (!ctx || !keys) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post_valid || !ctx->post->keys_valid) { ctx->err = "cx_level1_download_keys: run cx_postprocess3d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    if (!S->nv_out) return CX_OK;
+    return cx_copy_to_host1(ctx, keys, S->keys_out.p, (size_t)S->nv_out * sizeof(uint32_t));
 }
 
 // float64 coordinates of the Level-0 vertices exactly as the reference interpolates them (tetrahedral.py:471-487) in the
@@ -1858,27 +2175,29 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->parent, (size_t)ntri * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->mnext, (size_t)ntri * 3 * sizeof(uint32_t)))) return rc;
-            if ((rc = cxp_reserve(ctx, S->comp, (size_t)ntri * (2 * sizeof(u64) + 2 * sizeof(uint32_t))))) return rc;
+            if ((rc = cxp_reserve(ctx, S->comp, (size_t)ntri * (3 * sizeof(u64) + sizeof(uint32_t))))) return rc;
             u64* ekeys = (u64*)S->tkeys.p;
             u64* eheads = (u64*)S->tvals.p;
             u64* parent = (u64*)S->parent.p;
             uint32_t* next = (uint32_t*)S->mnext.p;
             u64* cmaxx = (u64*)S->comp.p;
             u64* cbest = cmaxx + ntri;
-            uint32_t* cmaxv = (uint32_t*)(cbest + ntri);
-            uint32_t* cstart = cmaxv + ntri;
+            u64* cmaxv = cbest + ntri;
+            uint32_t* cstart = (uint32_t*)(cmaxv + ntri);
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, eheads, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(ntri)), dim3(256), 0, st, parent, ntri);
             hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next);
             hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next, ttime, parent);
             if ((rc = cxp_flatten(ctx, parent, ntri, misc))) return rc;
-            CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (2 * sizeof(u64) + 2 * sizeof(uint32_t)), st));
+            CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (3 * sizeof(u64) + sizeof(uint32_t)), st));
             CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx);
-            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv);
-            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest);
-            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart);
+            const uint32_t* nokeys = nullptr;   // segment midpoints: the largest index breaks the tie
+            const uint8_t* nocls = nullptr;
+            hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, nocls);
+            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv, nokeys, nocls);
+            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, nocls);
+            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart, nocls);
             hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest);
             hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, parent, cbest, misc + 3);
             uint32_t ncomp = 0;

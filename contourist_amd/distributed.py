@@ -309,3 +309,243 @@ def level1_slabs(own_planes, value, rank, world, global_shape, device=0, clean=T
     post = ctx.postprocess3d_mesh(xyz, tris, corner, 0 if clean else 1, smooth or 0.0)
     pts, t1 = ctx.download_level1(post)
     return pts, t1, post
+
+
+# ---- Level 1 sharded over the slabs -----------------------------------------------------------------------
+# The reference post-processes one mesh in one process (tetrahedral.py:190-215 weld, :353-375 tiny collapse,
+# surface_geometry.py:14-50 clean-up, :52-140 orientation).  Here every rank post-processes ITS slab on its GPU: the slab is
+# marched together with SHARD_LAYERS layers of cells of each neighbour, which is all that weld buckets (narrower than a cell,
+# never across an integer plane), tiny and degenerate triangles (chains around one lattice point) can see of the neighbours;
+# only the orientation is global -- components and the max-x start triangle (surface_geometry.py:71-103) -- and for that the
+# ranks exchange what lies at the slab boundaries: the labels of the triangles next to a boundary and one start-triangle
+# candidate per component that reaches one.  Rank 0 unites the labels and picks the candidates (work ~ boundary size).
+SHARD_LAYERS = 2
+
+
+def exchange_planes(own, rank, world, below, above, dist=None):
+    """own: this rank's planes (tensor, n_own x n1 x n2).  -> (local, n_below): `local` = up to `below` last planes of rank-1,
+    the own planes, up to `above` first planes of rank+1 (every slab must hold that many planes)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    n_own = int(own.shape[0])
+    nb = below if rank > 0 else 0
+    na = above if rank + 1 < world else 0
+    local = torch.empty((nb + n_own + na,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+    local[nb:nb + n_own] = own
+    if world == 1:
+        return local, 0
+    assert n_own >= max(below, above), "slabs thinner than the exchanged layers"
+    staged = own.is_cuda and dist.get_backend() == "gloo"
+    up = own[n_own - below:].contiguous()        # what rank+1 sees below itself
+    down = own[:above].contiguous()              # what rank-1 sees above itself
+    rb = torch.empty((nb,) + tuple(own.shape[1:]), dtype=own.dtype, device="cpu" if staged else own.device)
+    ra = torch.empty((na,) + tuple(own.shape[1:]), dtype=own.dtype, device="cpu" if staged else own.device)
+    if staged:
+        up, down = up.cpu(), down.cpu()
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, down, rank - 1))
+        ops.append(dist.P2POp(dist.irecv, rb, rank - 1))
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, up, rank + 1))
+        ops.append(dist.P2POp(dist.irecv, ra, rank + 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if nb:
+        local[:nb].copy_(rb)
+    if na:
+        local[nb + n_own:].copy_(ra)
+    return local, nb
+
+
+def _triple_hash(k):
+    k = np.asarray(k, dtype=np.uint64).reshape(-1, 3)
+    with np.errstate(over="ignore"):
+        return (k[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (k[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F)) ^ (k[:, 2] * np.uint64(0x165667B19E3779F9))
+
+
+def merge_shard_components(lists):
+    """rank 0's part of the sharded orientation.  lists[r] = dict(tri_keys (B,3) GLOBAL edge ids int64, tri_label, tri_class,
+    cand_label, cand_x, cand_vertex_key (GLOBAL, int64), cand_nx, cand_negative, cand_has) of rank r.
+    -> ([(labels, flips) per rank], stats).  A copy of a neighbour's triangle (class 3 / 4) and the neighbour's own triangle
+    (class 2 / 1) carry the same edge-id triple: their labels name one component.  Per component the start triangle is the
+    candidate with the largest (x, vertex edge id, |normal_x|) -- surface_geometry.py:79-94 with the ties broken by edge id --
+    and the component is flipped iff that triangle's normal_x is negative (:99-103)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    world = len(lists)
+    uniq, base = [], [0]
+    for L in lists:
+        u = np.unique(np.concatenate([np.asarray(L["tri_label"], dtype=np.int64), np.asarray(L["cand_label"], dtype=np.int64)]))
+        uniq.append(u)
+        base.append(base[-1] + len(u))
+    n_nodes = base[-1]
+
+    def node(r, labels):
+        return base[r] + np.searchsorted(uniq[r], np.asarray(labels, dtype=np.int64))
+    own_k, own_n, halo_k, halo_n = [], [], [], []
+    for r, L in enumerate(lists):
+        cls = np.asarray(L["tri_class"])
+        k = np.asarray(L["tri_keys"], dtype=np.int64).reshape(-1, 3)
+        n = node(r, L["tri_label"])
+        o = (cls == 1) | (cls == 2)
+        own_k.append(k[o]); own_n.append(n[o])
+        halo_k.append(k[~o]); halo_n.append(n[~o])
+    own_k = np.concatenate(own_k) if own_k else np.zeros((0, 3), np.int64)
+    own_n = np.concatenate(own_n) if own_n else np.zeros(0, np.int64)
+    halo_k = np.concatenate(halo_k) if halo_k else np.zeros((0, 3), np.int64)
+    halo_n = np.concatenate(halo_n) if halo_n else np.zeros(0, np.int64)
+    unmatched = 0
+    pairs_a = pairs_b = np.zeros(0, np.int64)
+    if len(halo_k) and len(own_k):
+        ho, hh = _triple_hash(own_k), _triple_hash(halo_k)
+        order = np.argsort(ho, kind="stable")
+        at = np.minimum(np.searchsorted(ho[order], hh), len(order) - 1)
+        cand = order[at]
+        ok = np.all(own_k[cand] == halo_k, axis=1)
+        unmatched = int((~ok).sum())
+        pairs_a, pairs_b = halo_n[ok], own_n[cand[ok]]
+        # every own boundary triangle must have been seen by the neighbour as well
+        seen = np.zeros(len(own_k), dtype=bool)
+        seen[cand[ok]] = True
+        unmatched += int((~seen).sum())
+    else:
+        unmatched = len(halo_k) + len(own_k)
+    g = coo_matrix((np.ones(len(pairs_a), dtype=np.int8), (pairs_a, pairs_b)), shape=(n_nodes, n_nodes))
+    n_comp, comp = connected_components(g, directed=False) if n_nodes else (0, np.zeros(0, np.int64))
+    # candidates
+    cn, cx, cv, cnx, cneg = [], [], [], [], []
+    for r, L in enumerate(lists):
+        has = np.asarray(L["cand_has"]).astype(bool)
+        cn.append(node(r, np.asarray(L["cand_label"])[has]))
+        cx.append(np.asarray(L["cand_x"], dtype=np.float64)[has])
+        cv.append(np.asarray(L["cand_vertex_key"], dtype=np.int64)[has])
+        cnx.append(np.asarray(L["cand_nx"], dtype=np.float64)[has])
+        cneg.append(np.asarray(L["cand_negative"], dtype=np.int64)[has])
+    cn, cx, cv, cnx, cneg = [np.concatenate(a) if a else np.zeros(0) for a in (cn, cx, cv, cnx, cneg)]
+    flip_of_comp = np.zeros(n_comp, dtype=np.uint8)
+    decided = np.zeros(n_comp, dtype=bool)
+    if len(cn):
+        cc = comp[cn.astype(np.int64)]
+        order = np.lexsort((1 - cneg, cnx, cv, cx, cc))
+        last = np.ones(len(order), dtype=bool)
+        last[:-1] = cc[order][1:] != cc[order][:-1]
+        win = order[last]
+        flip_of_comp[cc[win]] = cneg[win].astype(np.uint8)
+        decided[cc[win]] = True
+    out = []
+    for r in range(world):
+        labels = uniq[r].astype(np.uint32)
+        c = comp[base[r]:base[r + 1]]
+        keep = decided[c]
+        out.append((labels[keep], flip_of_comp[c][keep]))
+    return out, dict(nodes=int(n_nodes), components=int(n_comp), pairs=int(len(pairs_a)), unmatched=int(unmatched))
+
+
+def shard_layout(n0, world, rank, layers=None):
+    """planes and cells of rank `rank`'s local array for the sharded Level 1 -> dict(i0, i1 own planes [i0, i1), e0, e1 local
+    planes [e0, e1), own_lo, own_hi own cell layers of the local array)"""
+    H = SHARD_LAYERS if layers is None else layers
+    i0, i1 = slab_bounds(n0, world, rank)
+    e0 = max(0, i0 - H) if rank > 0 else i0
+    e1 = min(n0, i1 + H + 1) if rank + 1 < world else i1
+    own_hi_plane = i1 if rank + 1 < world else i1 - 1          # cells [i0, own_hi_plane)
+    return dict(i0=i0, i1=i1, e0=e0, e1=e1, own_lo=i0 - e0, own_hi=own_hi_plane - e0)
+
+
+def shard_local(ctx, local, layout, value, global_shape, clean=True):
+    """first half on one rank: march the local array (own planes + neighbours' layers) and run the local post-pass.
+    -> the lists for merge_shard_components (edge ids already those of the whole volume)"""
+    from . import _ffi
+    n0, n1, n2 = [int(n) for n in global_shape]
+    ctx.set_origin(layout["e0"], 0, 0)
+    if type(local).__module__.split(".")[0] == "torch":
+        if local.is_cuda:
+            ctx.adopt_device_grid(local.data_ptr(), tuple(local.shape), keepalive=local)
+        else:
+            ctx.upload_grid(local.numpy())
+    else:
+        ctx.upload_grid(local)
+    ctx.set_reference_corner((n0 - 1, n1 - 1, n2 - 1))
+    try:
+        ctx.extract3d(float(value), _ffi.CX_DIAG_CPYTHON310)
+        L = ctx.shard_begin(layout["own_lo"], layout["own_hi"], 0 if clean else 1)
+    finally:
+        ctx.set_reference_corner((0, 0, 0))
+    off = (np.int64(layout["e0"]) * n1 * n2) << 3
+    L["tri_keys"] = L["tri_keys"].astype(np.int64) + off
+    L["cand_vertex_key"] = L["cand_vertex_key"].astype(np.int64) + off
+    L["key_offset"] = off
+    return L
+
+
+def shard_finish(ctx, L, answer, download=True):
+    "second half on one rank: the agreed flips -> dict(counts, points, triangles, keys) of the rank's own part"
+    counts = ctx.shard_finish(answer[0], answer[1])
+    counts.update(L["counts"])
+    out = dict(counts=counts)
+    if download:
+        pts, tris = ctx.download_level1(counts)
+        out.update(points=pts, triangles=tris, keys=ctx.download_level1_keys(counts).astype(np.int64) + L["key_offset"])
+    return out
+
+
+def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0, clean=True, dist=None, context=None, download=True):
+    """Level 1 of a volume spread over the ranks in slabs along axis 0, WITHOUT gathering the mesh: every rank returns its own
+    part -- dict(points (V,3) float64 in the coordinates of the whole volume, triangles (T,3) int32 into them, wound as the
+    reference winds the whole surface, keys (V,) int64 edge id of every vertex in the whole volume (vertices next to a slab
+    boundary appear on both sides with the same id and coordinates), counts, stats (rank 0), ms, boundary).  The union over the
+    ranks is the Level-1 mesh of the undivided volume (assemble_level1)."""
+    import time
+    import torch
+    from . import _ffi
+    if dist is None and world > 1:
+        import torch.distributed as dist
+    n0 = int(global_shape[0])
+    lay = shard_layout(n0, world, rank)
+    t = own_planes if isinstance(own_planes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(own_planes, dtype=np.float32))
+    assert t.shape[0] == lay["i1"] - lay["i0"]
+    t0 = time.perf_counter()
+    local, nb = exchange_planes(t, rank, world, SHARD_LAYERS, SHARD_LAYERS + 1, dist)
+    assert nb == lay["own_lo"] and local.shape[0] == lay["e1"] - lay["e0"], (nb, lay, tuple(local.shape))
+    if local.is_cuda:
+        torch.cuda.synchronize(local.device)
+    ctx = context or _ffi.Context(device)
+    t1 = time.perf_counter()
+    L = shard_local(ctx, local, lay, value, global_shape, clean)
+    t2 = time.perf_counter()
+    stats = None
+    if world == 1:
+        mine = (np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    else:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(L, gathered, dst=0)
+        answers = [None] * world
+        if rank == 0:
+            answers, stats = merge_shard_components(gathered)
+        box = [None]
+        dist.scatter_object_list(box, answers if rank == 0 else None, src=0)
+        mine = box[0]
+    t3 = time.perf_counter()
+    out = shard_finish(ctx, L, mine, download)
+    t4 = time.perf_counter()
+    out["stats"] = stats
+    out["ms"] = dict(halo=(t1 - t0) * 1e3, local=(t2 - t1) * 1e3, exchange=(t3 - t2) * 1e3, finish=(t4 - t3) * 1e3)
+    out["boundary"] = dict(triangles=int(len(L["tri_label"])), components=int(len(L["cand_label"])))
+    return out
+
+
+def assemble_level1(parts):
+    """parts: [(keys (V,) int64, points (V,3), triangles (T,3))] of all ranks -> (keys sorted unique, points, triangles): one mesh;
+    a vertex that two slabs hold must have the same coordinates in both"""
+    keys = np.concatenate([np.asarray(p[0], dtype=np.int64) for p in parts])
+    pts = np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in parts])
+    ukeys, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    if not np.array_equal(pts[first][inv], pts):
+        raise RuntimeError("a vertex has different coordinates in two slabs")
+    tris, at = [], 0
+    for p in parts:
+        tris.append(inv[at + np.asarray(p[2], dtype=np.int64).reshape(-1, 3)])
+        at += len(p[0])
+    return ukeys, pts[first], np.concatenate(tris) if tris else np.zeros((0, 3), np.int64)

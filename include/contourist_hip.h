@@ -205,6 +205,24 @@ int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv, con
                           uint32_t flags, double smooth, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
+/* edge id ((linear index of the lower lattice point << 3) | direction, local to the marched array) of every vertex of
+ * cx_level1_download, in its order: the representative that survived weld, tiny collapse and clean-up -- the identity of a
+ * Level-1 vertex across slabs (after cx_postprocess3d_mesh: the index of the input vertex). */
+int cx_level1_download_keys(cx_ctx* ctx, uint32_t* keys);
+
+/* ---- Level 1 sharded over slabs (the reference is one process: tetrahedral.py:190-215, 353-375,
+ * surface_geometry.py:14-140).  The context holds the extraction of a slab marched together with TWO layers of cells of
+ * each neighbour (cx_set_origin: where the local array starts in the whole volume; cx_set_reference_corner: the corner of
+ * the whole volume).  begin: weld / tiny collapse / clean-up of everything local, components of the own and first-layer
+ * triangles; leaves n_boundary triangles next to the neighbours and n_candidates components that reach them for the
+ * host to exchange (cx_postprocess3d_shard_lists).  finish: the agreed flip per such component; afterwards
+ * cx_level1_download / _keys / cx_level1_write hand out the slab's OWN part of the mesh in whole-volume coordinates.
+ * own_lo / own_hi: own cell layers [lo, hi) of the local array.  flags as cx_postprocess3d. */
+int cx_postprocess3d_shard_begin(cx_ctx* ctx, uint32_t flags, int64_t own_lo, int64_t own_hi, int64_t* out_counts8,
+                                 int64_t* n_boundary, int64_t* n_candidates);
+int cx_postprocess3d_shard_lists(cx_ctx* ctx, uint32_t* tri_keys3, uint32_t* tri_label, uint8_t* tri_class, uint32_t* cand_label,
+                                 double* cand_x, uint32_t* cand_vertex_key, double* cand_nx, uint8_t* cand_negative, uint8_t* cand_has);
+int cx_postprocess3d_shard_finish(cx_ctx* ctx, const uint32_t* labels, const uint8_t* flips, int64_t n, int64_t* out_counts8);
 
 /* Binary mesh file straight from the Level-1 device buffers -- the step right after get_points_and_triangles() for every caller
  * of the reference (html_demo.py:118-161), without materialising the mesh in the caller's address space: the file's records are
