@@ -265,6 +265,44 @@ def run_levels(args, torch, dist, _ffi, job, stream, device_index, flags, distri
                     "whole-job figures, max over ranks"}
 
 
+def run_sharded_level1(args, torch, dist, cxdist, job, dev, rank, world, strong, ctx):
+    """Level 1 (weld, tiny collapse, clean-up, orientation) of the bench volume WITHOUT gathering the mesh: every rank post-processes
+    its own slab (distributed.level1_slabs_sharded); the figure is the slowest rank's time from its resident slab to its part of
+    the oriented mesh on the device (second call: buffers exist).  A failure is reported in the line, never raised: the Level-0
+    figure above does not depend on it."""
+    n = args.size
+    shape = (n, n, n) if strong else (world * n, n, n)
+    own = job.slabs[0][:job.n_own]
+    res, err = None, None
+    try:
+        for _ in range(2):       # the first call allocates
+            res = cxdist.level1_slabs_sharded(own, args.value, rank, world, shape, dist=dist, context=ctx, download=False)
+    except Exception as e:       # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    ms = res["ms"] if res is not None else None
+    vals = [(ms["halo"] + ms["local"] + ms["exchange"] + ms["finish"]) if ms else -1.0, ms["halo"] if ms else -1.0, ms["local"] if ms else -1.0,
+            ms["exchange"] if ms else -1.0, ms["finish"] if ms else -1.0, float(res["boundary"]["triangles"]) if res else -1.0,
+            float(res["counts"]["n_triangles"]) if res else -1.0]
+    rdev = dev if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(vals, dtype=torch.float64, device=rdev)
+    bad = torch.tensor([0 if res is not None else 1], dtype=torch.int32, device=rdev)
+    tsum = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if int(bad.item()):
+        return {"ms": None, "error": err or "failed on another rank"}
+    t, tsum = t.tolist(), tsum.tolist()
+    out = {"ms": t[0], "halo_ms": t[1], "local_ms": t[2], "exchange_ms": t[3], "finish_ms": t[4],
+           "boundary_triangles_max": int(t[5]), "triangles_all_ranks": int(tsum[6]),
+           "note": "max over ranks; per rank: 2+3 planes from the neighbours, march of own + 2 layers of cells each side, local weld / tiny / clean / "
+                   "components on the GPU, boundary labels and start-triangle candidates to rank 0 and the flips back (gather_object / "
+                   "scatter_object_list), winding + own part compacted on the device; no mesh leaves its rank"}
+    if rank == 0 and res.get("stats"):
+        out["merge"] = res["stats"]
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -413,6 +451,12 @@ def main():
     if args.levels > 0:
         multi = run_levels(args, torch, dist, _ffi, job, streams[0], device_index, flags, distributed)
 
+    sharded = None
+    if distributed and not args.no_api:
+        sharded = run_sharded_level1(args, torch, dist, cxdist, job, dev, rank, world, strong, ctxs[0])
+        for c in ctxs:
+            c.set_origin(job.origin0, 0, 0)
+
     if rank == 0:
         local_samples = job.slabs[0].numel()
         alg_bytes = 4.0 * local_samples             # 4 B per input sample, read once
@@ -511,6 +555,10 @@ def main():
             out["levels"] = len(multi["levels"])
             out["ms_all_levels"] = multi["ms_all_levels"]
             out["Mvoxel_levels_per_s"] = multi["Mvoxel_levels_per_s"]
+        if sharded is not None:
+            out["level1_sharded"] = sharded
+            if sharded.get("ms") is not None:
+                out["level1_ms"] = sharded["ms"]
         if world == 1 and not args.no_api:
             # what the reference's API returns: Level 0 + Level 1 (weld, tiny collapse, clean, orient) + download
             buf = job.slabs[0]

@@ -513,7 +513,21 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
         torch.cuda.synchronize(local.device)
     ctx = context or _ffi.Context(device)
     t1 = time.perf_counter()
-    L = shard_local(ctx, local, lay, value, global_shape, clean)
+    # a rank whose local part fails must not leave the others waiting in the exchange: everybody learns of it first
+    err = None
+    try:
+        L = shard_local(ctx, local, lay, value, global_shape, clean)
+    except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+        err = e
+    if world > 1:
+        on_device = dist.get_backend() == "nccl"
+        flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                            device=torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise RuntimeError("sharded Level 1: the local part failed on some rank" + ("" if err is None else " (this one): %s" % err))
+    elif err is not None:
+        raise err
     t2 = time.perf_counter()
     stats = None
     if world == 1:

@@ -40,6 +40,10 @@ def test_two_ranks_on_one_gpu_strong_scaling():
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
     assert line["weak"]["value"] > 0
     assert line["levels"] == 8 and line["ms_all_levels"] > 0 and line["Mvoxel_levels_per_s"] > 0      # config 5: every rank its slab x 8 levels
+    # Level 1 sharded over the ranks: nobody gathers the mesh; the slowest rank's time is the line's level1_ms
+    sh = line["level1_sharded"]
+    assert sh.get("error") is None and sh["ms"] > 0 and line["level1_ms"] == sh["ms"]
+    assert sh["merge"]["unmatched"] == 0 and 0 < sh["boundary_triangles_max"] < sh["triangles_all_ranks"]
     one = run_bench({}, "--gpus", "1", "--size", "64", "--steps", "3", "--warmup", "1", "--passes", "40", "--no-cpu-baseline")
     assert one["n_gpus"] == 1 and one["api_ms"] > 0 and one["level1_ms"] > 0
     assert one["levels"] == 8 and len(one["multi_level"]["triangles_per_level_rank0"]) == 8 and one["ms_all_levels"] > 0
