@@ -26,7 +26,7 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_lists", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
@@ -119,8 +119,9 @@ def load():
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
         "cx_level1_download_keys": [vp, vp],
-        "cx_postprocess3d_shard_begin": [vp, u32, i64, i64, vp, vp, vp],
-        "cx_postprocess3d_shard_lists": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "cx_postprocess3d_shard_begin": [vp, u32, i64, i64, vp, vp, vp, vp],
+        "cx_postprocess3d_shard_boundary": [vp, ctypes.c_int, vp, vp],
+        "cx_postprocess3d_shard_candidates": [vp, vp, vp, vp, vp, vp, vp],
         "cx_postprocess3d_shard_finish": [vp, vp, vp, i64, vp],
         "cx_level1_write": [vp, ctypes.c_int, ctypes.c_char_p, vp, vp],
         "cx_surface_geometry": [vp, vp, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), ctypes.c_int],
@@ -339,22 +340,39 @@ class Context(object):
         return keys
 
     def shard_begin(self, own_lo, own_hi, flags=0):
-        """sharded Level 1, local part (cx_postprocess3d_shard_begin + _lists) -> dict(counts, tri_keys (B,3) uint32 local edge
-        ids, tri_label (B,), tri_class (B,), cand_label / cand_x / cand_vertex_key / cand_nx / cand_negative / cand_has (C,))"""
+        """sharded Level 1, local part (cx_postprocess3d_shard_begin + _candidates) -> dict(counts, n_own_lower, n_upper_copies,
+        cand_label / cand_x / cand_vertex_key / cand_nx / cand_negative / cand_has (C,)); the boundary lists stay on the device
+        (shard_boundary)"""
         out = np.zeros(8, dtype=np.int64)
-        nb = ctypes.c_int64(0)
-        nc = ctypes.c_int64(0)
+        n1, n4, nc = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         self._check(self.lib.cx_postprocess3d_shard_begin(self.handle, int(flags), int(own_lo), int(own_hi), out.ctypes.data,
-                                                          ctypes.addressof(nb), ctypes.addressof(nc)))
-        B, C = int(nb.value), int(nc.value)
-        L = dict(tri_keys=np.zeros((B, 3), np.uint32), tri_label=np.zeros(B, np.uint32), tri_class=np.zeros(B, np.uint8),
-                 cand_label=np.zeros(C, np.uint32), cand_x=np.zeros(C, np.float64), cand_vertex_key=np.zeros(C, np.uint32),
+                                                          ctypes.addressof(n1), ctypes.addressof(n4), ctypes.addressof(nc)))
+        C = int(nc.value)
+        L = dict(cand_label=np.zeros(C, np.uint32), cand_x=np.zeros(C, np.float64), cand_vertex_key=np.zeros(C, np.uint32),
                  cand_nx=np.zeros(C, np.float64), cand_negative=np.zeros(C, np.uint8), cand_has=np.zeros(C, np.uint8))
-        if B:
-            self._check(self.lib.cx_postprocess3d_shard_lists(self.handle, *[L[k].ctypes.data for k in (
-                "tri_keys", "tri_label", "tri_class", "cand_label", "cand_x", "cand_vertex_key", "cand_nx", "cand_negative", "cand_has")]))
-        L["counts"] = dict(n_after_weld=int(out[2]), n_after_tiny=int(out[3]))
+        if C:
+            self._check(self.lib.cx_postprocess3d_shard_candidates(self.handle, *[L[k].ctypes.data for k in (
+                "cand_label", "cand_x", "cand_vertex_key", "cand_nx", "cand_negative", "cand_has")]))
+        L.update(n_own_lower=int(n1.value), n_upper_copies=int(n4.value), counts=dict(n_after_weld=int(out[2]), n_after_tiny=int(out[3])))
         return L
+
+    def shard_boundary(self, which, n, torch_device=None):
+        """one boundary list of shard_begin (which = 1: own triangles next to the lower neighbour, 4: copies of the upper
+        neighbour's first layer) -> (hash int64 (n,), label int32 (n,)): torch tensors on `torch_device` (the lists need not
+        leave the GPU), numpy arrays without one.  The hashes are 64-bit patterns; as int64 they sort the same way on every rank."""
+        n = int(n)
+        if torch_device is not None:
+            import torch
+            h = torch.empty(n, dtype=torch.int64, device=torch_device)
+            lab = torch.empty(n, dtype=torch.int32, device=torch_device)
+            hp, lp = h.data_ptr(), lab.data_ptr()
+        else:
+            h = np.empty(n, dtype=np.int64)
+            lab = np.empty(n, dtype=np.int32)
+            hp, lp = h.ctypes.data, lab.ctypes.data
+        if n:
+            self._check(self.lib.cx_postprocess3d_shard_boundary(self.handle, int(which), ctypes.c_void_p(hp), ctypes.c_void_p(lp)))
+        return h, lab
 
     def shard_finish(self, labels, flips):
         "the agreed flips for the components that reach a neighbour -> counts dict for download_level1 / download_level1_keys"

@@ -50,7 +50,7 @@ struct cx_post_state {
         bool open = false;            // between cx_postprocess3d_shard_begin and _finish
         uint32_t nv2 = 0, nt2 = 0;    // mesh of own + first-halo-layer triangles the labels refer to
         uint32_t nt_in = 0;           // triangles the post-pass started from (layout of S->cls)
-        uint32_t nbnd = 0, ncand = 0;
+        uint32_t n1 = 0, n4 = 0, ncand = 0;   // own triangles next to the lower neighbour, copies of the upper neighbour's, open components
     } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     int64_t nv_out = 0, nt_out = 0;
@@ -760,7 +760,7 @@ struct cxp_shard {
     uint32_t layers;           // cell layers of the local array
 };
 __global__ void cxp_k_shard_classify(const uint32_t* tprio3, uint8_t* alive, uint32_t nt, cxp_shard sh, cx_fdiv dplane, uint8_t* cls,
-                                     uint32_t* nbnd) {
+                                     uint32_t* counts) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     uint8_t c = 255;
@@ -773,7 +773,8 @@ __global__ void cxp_k_shard_classify(const uint32_t* tprio3, uint8_t* alive, uin
         } else if (layer + 1u == sh.own_lo) c = 3;
         else if (layer == sh.own_hi) c = 4;
         if (c == 255) alive[t] = 0;
-        else if (c) atomicAdd(nbnd, 1u);
+        else if (c == 1) atomicAdd(&counts[0], 1u);
+        else if (c == 4) atomicAdd(&counts[1], 1u);
     }
     cls[t] = c;
 }
@@ -781,19 +782,35 @@ __global__ void cxp_k_shard_gather_cls(const uint8_t* cls, const uint32_t* told,
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nt2) cls2[t] = cls[told[t]];
 }
-// triangles next to a neighbour slab: (original edge-id triple, component label, class), and their components marked open
+// What a rank and its LOWER neighbour must agree on: the neighbour holds copies of this rank's first layer of own triangles
+// (its class 4), this rank holds the originals (class 1).  Both write (hash of the three ORIGINAL edge ids in the numbering of
+// the whole volume, component label); sorted by the hash the two lists line up entry by entry, and the label pairs say which
+// components are one.  (The copies on the other side -- classes 2 / 3 -- would say the same again: a link between two
+// slabs' triangles is seen from both.)  Components with such a triangle are marked open.
+__device__ __forceinline__ u64 cxp_triple_hash(u64 a, u64 b, u64 c) {
+    u64 h = cxp_mix(a + 0x9E3779B97F4A7C15ULL);
+    h = cxp_mix(h ^ (b + 0xC2B2AE3D27D4EB4FULL));
+    return cxp_mix(h ^ (c + 0x165667B19E3779F9ULL));
+}
 __global__ void cxp_k_shard_boundary(const uint8_t* cls2, const uint32_t* told, const uint32_t* tprio3, const u64* parent, uint32_t nt2,
-                                     uint32_t* counter, uint32_t cap, uint32_t* bkeys, uint32_t* blabel, uint8_t* bcls, uint8_t* open) {
+                                     u64 key_offset, uint32_t* counters, uint32_t cap1, uint32_t cap4, u64* hash1, uint32_t* label1,
+                                     u64* hash4, uint32_t* label4, uint8_t* open) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt2 || !cls2[t]) return;
+    if (t >= nt2) return;
+    const uint32_t c = cls2[t];
+    if (c != 1u && c != 4u) return;
     const uint32_t root = (uint32_t)parent[t];
     open[root] = 1;
-    const uint32_t at = atomicAdd(counter, 1u);
-    if (at >= cap) return;
     const uint32_t o = told[t];
-    bkeys[(size_t)at * 3] = tprio3[(size_t)o * 3]; bkeys[(size_t)at * 3 + 1] = tprio3[(size_t)o * 3 + 1]; bkeys[(size_t)at * 3 + 2] = tprio3[(size_t)o * 3 + 2];
-    blabel[at] = root;
-    bcls[at] = cls2[t];
+    const u64 h = cxp_triple_hash((u64)tprio3[(size_t)o * 3] + key_offset, (u64)tprio3[(size_t)o * 3 + 1] + key_offset,
+                                  (u64)tprio3[(size_t)o * 3 + 2] + key_offset);
+    if (c == 1u) {
+        const uint32_t at = atomicAdd(&counters[0], 1u);
+        if (at < cap1) { hash1[at] = h; label1[at] = root; }
+    } else {
+        const uint32_t at = atomicAdd(&counters[1], 1u);
+        if (at < cap4) { hash4[at] = h; label4[at] = root; }
+    }
 }
 // the start-triangle candidate of every open component, from this slab's own triangles: (label, x of the max-x vertex, its
 // edge id, |normal_x| of the start triangle, its sign, whether there is a candidate at all)
@@ -906,7 +923,7 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         if ((rc = cxp_reserve(ctx, S->told, ((size_t)nt + 16) * sizeof(uint32_t)))) return rc;
         cls = (uint8_t*)S->cls.p;
         told = (uint32_t*)S->told.p;
-        CXP_HIP(ctx, hipMemsetAsync(misc + 6, 0, 3 * sizeof(uint32_t), st));
+        CXP_HIP(ctx, hipMemsetAsync(misc + 6, 0, 2 * sizeof(uint32_t), st));
         if (nt) hipLaunchKernelGGL(cxp_k_shard_classify, dim3(cxp_blocks(nt)), dim3(256), 0, st, tprio3, alive, nt, *shard, cx_fdiv_make(shard->plane), cls, misc + 6);
     }
     // ---- compaction of used vertices and living triangles
@@ -978,31 +995,34 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, own);
         hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart, own);
         if (shard) {
-            // what the neighbours (through the host) need: the triangles next to them with their labels, and the start-triangle
-            // candidate of every component that reaches them.  Sizes follow the slab boundary, not the slab.
-            uint32_t hb = 0;
-            CXP_HIP(ctx, hipMemcpyAsync(&hb, misc + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            // what the neighbours need: the triangles at the slab boundaries with their labels (they stay on the device), and the
+            // start-triangle candidate of every component that reaches a neighbour.  Sizes follow the slab boundary, not the slab.
+            uint32_t hb[2] = {0, 0};
+            CXP_HIP(ctx, hipMemcpyAsync(hb, misc + 6, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             CXP_HIP(ctx, hipStreamSynchronize(st));
-            const size_t nb = hb;
-            // layout of S->bnd: keys u32[3 nb] | labels u32[nb] | candidates cxp_cand[nb] | classes u8[nb]
-            if ((rc = cxp_reserve(ctx, S->bnd, (nb + 1) * (4 * sizeof(uint32_t) + sizeof(cxp_cand) + 1) + 64))) return rc;
-            uint32_t* bkeys = (uint32_t*)S->bnd.p;
-            uint32_t* blabel = bkeys + 3 * nb;
-            cxp_cand* cand = (cxp_cand*)(((uintptr_t)(blabel + nb) + 15u) & ~(uintptr_t)15u);
-            uint8_t* bcls = (uint8_t*)(cand + nb);
+            const size_t n1 = hb[0], n4 = hb[1], nb = n1 + n4;
+            // layout of S->bnd: hash1 u64[n1] | hash4 u64[n4] | candidates cxp_cand[nb] | label1 u32[n1] | label4 u32[n4]
+            if ((rc = cxp_reserve(ctx, S->bnd, (nb + 2) * (sizeof(u64) + sizeof(cxp_cand) + sizeof(uint32_t)) + 64))) return rc;
+            u64* hash1 = (u64*)S->bnd.p;
+            u64* hash4 = hash1 + n1;
+            cxp_cand* cand = (cxp_cand*)(hash4 + n4);
+            uint32_t* label1 = (uint32_t*)(cand + nb);
+            uint32_t* label4 = label1 + n1;
             uint8_t* open = cls + 2 * (size_t)nt;
             CXP_HIP(ctx, hipMemsetAsync(open, 0, nt2, st));
+            CXP_HIP(ctx, hipMemsetAsync(misc + 8, 0, 3 * sizeof(uint32_t), st));
             if (nb) {
-                hipLaunchKernelGGL(cxp_k_shard_boundary, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls2, told, tprio3, parent, nt2, misc + 7, (uint32_t)nb,
-                                   bkeys, blabel, bcls, open);
+                const u64 key_offset = ((u64)ctx->origin[0] * (u64)shard->plane) << 3;
+                hipLaunchKernelGGL(cxp_k_shard_boundary, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls2, told, tprio3, parent, nt2, key_offset, misc + 8,
+                                   (uint32_t)n1, (uint32_t)n4, hash1, label1, hash4, label4, open);
                 hipLaunchKernelGGL(cxp_k_shard_candidates, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, pts2, keys2, parent, open, nt2, cmaxx, cmaxv,
-                                   cstart, misc + 8, (uint32_t)nb, cand);
+                                   cstart, misc + 10, (uint32_t)nb, cand);
             }
-            uint32_t h2[2] = {0, 0};
-            CXP_HIP(ctx, hipMemcpyAsync(h2, misc + 7, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            uint32_t h2[3] = {0, 0, 0};
+            CXP_HIP(ctx, hipMemcpyAsync(h2, misc + 8, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             CXP_HIP(ctx, hipStreamSynchronize(st));
-            if (h2[0] != nb || h2[1] > nb) { ctx->err = "sharded Level 1: boundary lists do not add up"; return CX_ERR_HIP; }
-            S->shard.nbnd = (uint32_t)nb; S->shard.ncand = h2[1];
+            if (h2[0] != n1 || h2[1] != n4 || h2[2] > nb) { ctx->err = "sharded Level 1: boundary lists do not add up"; return CX_ERR_HIP; }
+            S->shard.n1 = (uint32_t)n1; S->shard.n4 = (uint32_t)n4; S->shard.ncand = h2[2];
         }
         hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, cbest);
         if (!shard) {
@@ -1011,7 +1031,7 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         }
         CXP_HIP(ctx, hipStreamSynchronize(st));
     } else if (shard) {
-        S->shard.nbnd = 0; S->shard.ncand = 0;
+        S->shard.n1 = 0; S->shard.n4 = 0; S->shard.ncand = 0;
     }
     if (shard) { S->shard.open = true; S->shard.nv2 = nv2; S->shard.nt2 = nt2; S->shard.nt_in = nt; }
     CXP_HIP(ctx, hipGetLastError());
@@ -1277,12 +1297,13 @@ extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, i
 // own-boundary triangles with their labels and one start-triangle candidate per component that reaches them (sizes follow the
 // slab boundary); finish() takes the agreed flips for those components.  own_lo / own_hi: own cell layers of the local array.
 extern "C" int cx_postprocess3d_shard_begin(cx_ctx* ctx, uint32_t flags, int64_t own_lo, int64_t own_hi, int64_t* out_counts,
-                                            int64_t* n_boundary, int64_t* n_candidates) {
-    if (!ctx || !n_boundary || !n_candidates) return CX_ERR_INVALID;
+                                            int64_t* n_own_lower, int64_t* n_upper_copies, int64_t* n_candidates) {
+    if (!ctx || !n_own_lower || !n_upper_copies || !n_candidates) return CX_ERR_INVALID;
     if (!ctx->extracted) { ctx->err = "cx_postprocess3d_shard_begin: no valid extraction"; return CX_ERR_STATE; }
     const cx_params& P = ctx->last;
     if (own_lo < 0 || own_hi <= own_lo || own_hi > (int64_t)P.n0 - 1) { ctx->err = "cx_postprocess3d_shard_begin: own cell layers outside the local array"; return CX_ERR_INVALID; }
     if (ctx->keep_valid) { ctx->err = "cx_postprocess3d_shard_begin: not after a seeded selection"; return CX_ERR_STATE; }
+    if (ctx->origin[0] < 0) { ctx->err = "cx_postprocess3d_shard_begin: the local array starts before the volume (cx_set_origin)"; return CX_ERR_STATE; }
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     cx_post_state* S;
     int rc = cxp_state(ctx, &S);
@@ -1307,37 +1328,52 @@ extern "C" int cx_postprocess3d_shard_begin(cx_ctx* ctx, uint32_t flags, int64_t
     ctx->post_valid = false;
     if ((rc = cxp_run3d(ctx, S, nv, nt, corner, nullptr, !(flags & 1u), 0.0, true, counts, true, &sh))) return rc;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
-    *n_boundary = S->shard.nbnd;
+    *n_own_lower = S->shard.n1;
+    *n_upper_copies = S->shard.n4;
     *n_candidates = S->shard.ncand;
     return CX_OK;
 }
 
-// the lists of cx_postprocess3d_shard_begin: per boundary triangle its three ORIGINAL edge ids (ascending; local to this
-// array -- add (origin_x * n1 * n2) << 3 for the ids of the whole volume), its component label and class (1 / 2: own, next
-// to the lower / upper neighbour; 3 / 4: copy of a triangle of the lower / upper neighbour); per component that reaches a
-// neighbour its label and start-triangle candidate among the OWN triangles (surface_geometry.py:79-103): x of the max-x
-// vertex, that vertex's edge id, |normal_x| of the start triangle, 1 if its normal_x is negative, 0 if the component has no
-// own triangle here.
-extern "C" int cx_postprocess3d_shard_lists(cx_ctx* ctx, uint32_t* tri_keys, uint32_t* tri_label, uint8_t* tri_class, uint32_t* cand_label,
-                                            double* cand_x, uint32_t* cand_vertex_key, double* cand_nx, uint8_t* cand_negative, uint8_t* cand_has) {
-    if (!ctx) return CX_ERR_INVALID;
-    if (!ctx->post || !ctx->post->shard.open) { ctx->err = "cx_postprocess3d_shard_lists: call cx_postprocess3d_shard_begin first"; return CX_ERR_STATE; }
+// One of the two boundary lists of cx_postprocess3d_shard_begin: which = 1, this slab's own triangles next to its LOWER neighbour
+// (n_own_lower entries); which = 4, its copies of the UPPER neighbour's first layer (n_upper_copies).  Per triangle a 64-bit hash
+// of its three original edge ids in the numbering of the whole volume, and its component label here.  Rank r's list 4 and rank
+// r+1's list 1 hold the same triangles: sorted by hash they pair up the labels.  hash / label: DEVICE OR HOST memory (the lists
+// are meant to stay on the device: a torch tensor sorts and sends them).
+extern "C" int cx_postprocess3d_shard_boundary(cx_ctx* ctx, int which, uint64_t* hash, uint32_t* label) {
+    if (!ctx || (which != 1 && which != 4)) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post->shard.open) { ctx->err = "cx_postprocess3d_shard_boundary: call cx_postprocess3d_shard_begin first"; return CX_ERR_STATE; }
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     cx_post_state* S = ctx->post;
-    const size_t nb = S->shard.nbnd, nc = S->shard.ncand;
-    if (!nb) return CX_OK;
-    if (!tri_keys || !tri_label || !tri_class || (nc && (!cand_label || !cand_x || !cand_vertex_key || !cand_nx || !cand_negative || !cand_has))) return CX_ERR_INVALID;
-    const uint32_t* bkeys = (const uint32_t*)S->bnd.p;
-    const uint32_t* blabel = bkeys + 3 * nb;
-    const cxp_cand* cand = (const cxp_cand*)(((uintptr_t)(blabel + nb) + 15u) & ~(uintptr_t)15u);
-    const uint8_t* bcls = (const uint8_t*)(cand + nb);
-    hipStream_t st = ctx->stream;
-    CXP_HIP(ctx, hipMemcpyAsync(tri_keys, bkeys, nb * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipMemcpyAsync(tri_label, blabel, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipMemcpyAsync(tri_class, bcls, nb, hipMemcpyDeviceToHost, st));
+    const size_t n1 = S->shard.n1, n4 = S->shard.n4, nb = n1 + n4;
+    const size_t n = which == 1 ? n1 : n4;
+    if (!n) return CX_OK;
+    if (!hash || !label) return CX_ERR_INVALID;
+    const u64* hash1 = (const u64*)S->bnd.p;
+    const cxp_cand* cand = (const cxp_cand*)(hash1 + nb);
+    const uint32_t* label1 = (const uint32_t*)(cand + nb);
+    CXP_HIP(ctx, hipMemcpyAsync(hash, which == 1 ? hash1 : hash1 + n1, n * sizeof(u64), hipMemcpyDefault, ctx->stream));
+    CXP_HIP(ctx, hipMemcpyAsync(label, which == 1 ? label1 : label1 + n1, n * sizeof(uint32_t), hipMemcpyDefault, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CX_OK;
+}
+
+// the start-triangle candidates of cx_postprocess3d_shard_begin (host arrays of n_candidates entries): per component that reaches
+// a neighbour its label and, among this slab's OWN triangles (surface_geometry.py:79-103): x of the max-x vertex, that vertex's
+// edge id (local: add (origin_x * n1 * n2) << 3 for the whole volume's), |normal_x| of the start triangle, 1 if its normal_x is
+// negative; has = 0 if the component has no own triangle here.
+extern "C" int cx_postprocess3d_shard_candidates(cx_ctx* ctx, uint32_t* cand_label, double* cand_x, uint32_t* cand_vertex_key, double* cand_nx,
+                                                 uint8_t* cand_negative, uint8_t* cand_has) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post->shard.open) { ctx->err = "cx_postprocess3d_shard_candidates: call cx_postprocess3d_shard_begin first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    cx_post_state* S = ctx->post;
+    const size_t nb = (size_t)S->shard.n1 + S->shard.n4, nc = S->shard.ncand;
+    if (!nc) return CX_OK;
+    if (!cand_label || !cand_x || !cand_vertex_key || !cand_nx || !cand_negative || !cand_has) return CX_ERR_INVALID;
+    const cxp_cand* cand = (const cxp_cand*)((const u64*)S->bnd.p + nb);
     std::vector<cxp_cand> h(nc);
-    if (nc) CXP_HIP(ctx, hipMemcpyAsync(h.data(), cand, nc * sizeof(cxp_cand), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipStreamSynchronize(st));
+    CXP_HIP(ctx, hipMemcpyAsync(h.data(), cand, nc * sizeof(cxp_cand), hipMemcpyDeviceToHost, ctx->stream));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < nc; i++) {
         cand_label[i] = h[i].label; cand_x[i] = h[i].x; cand_vertex_key[i] = h[i].vkey; cand_nx[i] = h[i].nx;
         cand_negative[i] = (uint8_t)h[i].sign; cand_has[i] = (uint8_t)h[i].has;
@@ -1345,7 +1381,7 @@ extern "C" int cx_postprocess3d_shard_lists(cx_ctx* ctx, uint32_t* tri_keys, uin
     return CX_OK;
 }
 
-// flips[i] (0 / 1) for component labels[i] of cx_postprocess3d_shard_lists: the decision of the rank that holds the component's
+// flips[i] (0 / 1) for component labels[i] of cx_postprocess3d_shard_candidates: the decision of the rank that holds the component's
 // start triangle.  Components that reach no neighbour keep the local decision.  Afterwards cx_level1_download /
 // cx_level1_download_keys / cx_level1_write hand out this slab's OWN triangles and the vertices they use, in the coordinates
 // of the whole volume.  out_counts as cx_postprocess3d ([0] vertices, [1] triangles, [4] components seen locally).

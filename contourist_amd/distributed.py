@@ -359,62 +359,61 @@ def exchange_planes(own, rank, world, below, above, dist=None):
     return local, nb
 
 
-def _triple_hash(k):
-    k = np.asarray(k, dtype=np.uint64).reshape(-1, 3)
-    with np.errstate(over="ignore"):
-        return (k[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (k[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F)) ^ (k[:, 2] * np.uint64(0x165667B19E3779F9))
+def pair_labels(own_hash, own_label, copy_hash, copy_label):
+    """a rank's own triangles next to its lower neighbour (list 1 of Context.shard_boundary) against that neighbour's copies of
+    them (its list 4): torch tensors on one device.  -> (pairs (P,2) int64 numpy, distinct [own label, neighbour's label],
+    unmatched: triangles only one side knows).  The lists hold the same triangles; sorted by hash they line up."""
+    import torch
+    no = int(own_hash.numel())
+    nc = int(copy_hash.numel())
+    if no == 0 or nc == 0:
+        return np.zeros((0, 2), dtype=np.int64), no + nc
+    ho, io = torch.sort(own_hash)
+    lo = own_label[io].to(torch.int64)
+    at = torch.searchsorted(ho, copy_hash).clamp_(max=no - 1)
+    ok = ho[at] == copy_hash
+    seen = torch.zeros(no, dtype=torch.bool, device=ho.device)
+    seen[at[ok]] = True
+    dup = int((ho[1:] == ho[:-1]).sum().item()) if no > 1 else 0          # two triangles with one hash: their labels cannot be told apart
+    unmatched = int((~ok).sum().item()) + int((~seen).sum().item()) + dup
+    packed = torch.unique((lo[at[ok]] << 32) | copy_label[ok].to(torch.int64))
+    packed = packed.cpu().numpy()
+    return np.stack([packed >> 32, packed & 0xFFFFFFFF], axis=1).astype(np.int64), unmatched
 
 
 def merge_shard_components(lists):
-    """rank 0's part of the sharded orientation.  lists[r] = dict(tri_keys (B,3) GLOBAL edge ids int64, tri_label, tri_class,
-    cand_label, cand_x, cand_vertex_key (GLOBAL, int64), cand_nx, cand_negative, cand_has) of rank r.
-    -> ([(labels, flips) per rank], stats).  A copy of a neighbour's triangle (class 3 / 4) and the neighbour's own triangle
-    (class 2 / 1) carry the same edge-id triple: their labels name one component.  Per component the start triangle is the
-    candidate with the largest (x, vertex edge id, |normal_x|) -- surface_geometry.py:79-94 with the ties broken by edge id --
-    and the component is flipped iff that triangle's normal_x is negative (:99-103)."""
+    """rank 0's part of the sharded orientation.  lists[r] = dict(pairs (P,2) [label on rank r, label on rank r-1] of components
+    that are one (pair_labels), cand_label, cand_x, cand_vertex_key (edge ids of the WHOLE volume, int64), cand_nx,
+    cand_negative, cand_has) of rank r: sizes follow the number of components at the slab boundaries.
+    -> ([(labels, flips) per rank], stats).  Per component the start triangle is the candidate with the largest
+    (x, vertex edge id, |normal_x|) -- surface_geometry.py:79-94 with the ties broken by edge id -- and the component is flipped
+    iff that triangle's normal_x is negative (:99-103)."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import connected_components
     world = len(lists)
     uniq, base = [], [0]
-    for L in lists:
-        u = np.unique(np.concatenate([np.asarray(L["tri_label"], dtype=np.int64), np.asarray(L["cand_label"], dtype=np.int64)]))
+    for r, L in enumerate(lists):
+        mine = [np.asarray(L["cand_label"], dtype=np.int64), np.asarray(L["pairs"], dtype=np.int64).reshape(-1, 2)[:, 0]]
+        if r + 1 < world:
+            mine.append(np.asarray(lists[r + 1]["pairs"], dtype=np.int64).reshape(-1, 2)[:, 1])
+        u = np.unique(np.concatenate(mine))
         uniq.append(u)
         base.append(base[-1] + len(u))
     n_nodes = base[-1]
 
     def node(r, labels):
         return base[r] + np.searchsorted(uniq[r], np.asarray(labels, dtype=np.int64))
-    own_k, own_n, halo_k, halo_n = [], [], [], []
+    pa, pb = [], []
     for r, L in enumerate(lists):
-        cls = np.asarray(L["tri_class"])
-        k = np.asarray(L["tri_keys"], dtype=np.int64).reshape(-1, 3)
-        n = node(r, L["tri_label"])
-        o = (cls == 1) | (cls == 2)
-        own_k.append(k[o]); own_n.append(n[o])
-        halo_k.append(k[~o]); halo_n.append(n[~o])
-    own_k = np.concatenate(own_k) if own_k else np.zeros((0, 3), np.int64)
-    own_n = np.concatenate(own_n) if own_n else np.zeros(0, np.int64)
-    halo_k = np.concatenate(halo_k) if halo_k else np.zeros((0, 3), np.int64)
-    halo_n = np.concatenate(halo_n) if halo_n else np.zeros(0, np.int64)
-    unmatched = 0
-    pairs_a = pairs_b = np.zeros(0, np.int64)
-    if len(halo_k) and len(own_k):
-        ho, hh = _triple_hash(own_k), _triple_hash(halo_k)
-        order = np.argsort(ho, kind="stable")
-        at = np.minimum(np.searchsorted(ho[order], hh), len(order) - 1)
-        cand = order[at]
-        ok = np.all(own_k[cand] == halo_k, axis=1)
-        unmatched = int((~ok).sum())
-        pairs_a, pairs_b = halo_n[ok], own_n[cand[ok]]
-        # every own boundary triangle must have been seen by the neighbour as well
-        seen = np.zeros(len(own_k), dtype=bool)
-        seen[cand[ok]] = True
-        unmatched += int((~seen).sum())
-    else:
-        unmatched = len(halo_k) + len(own_k)
-    g = coo_matrix((np.ones(len(pairs_a), dtype=np.int8), (pairs_a, pairs_b)), shape=(n_nodes, n_nodes))
+        p = np.asarray(L["pairs"], dtype=np.int64).reshape(-1, 2)
+        if len(p):
+            assert r > 0, "rank 0 has no lower neighbour"
+            pa.append(node(r, p[:, 0]))
+            pb.append(node(r - 1, p[:, 1]))
+    pa = np.concatenate(pa) if pa else np.zeros(0, np.int64)
+    pb = np.concatenate(pb) if pb else np.zeros(0, np.int64)
+    g = coo_matrix((np.ones(len(pa), dtype=np.int8), (pa, pb)), shape=(n_nodes, n_nodes))
     n_comp, comp = connected_components(g, directed=False) if n_nodes else (0, np.zeros(0, np.int64))
-    # candidates
     cn, cx, cv, cnx, cneg = [], [], [], [], []
     for r, L in enumerate(lists):
         has = np.asarray(L["cand_has"]).astype(bool)
@@ -428,7 +427,7 @@ def merge_shard_components(lists):
     decided = np.zeros(n_comp, dtype=bool)
     if len(cn):
         cc = comp[cn.astype(np.int64)]
-        order = np.lexsort((1 - cneg, cnx, cv, cx, cc))
+        order = np.lexsort((1 - cneg, cnx, cv, cx, cc))      # per component: the last one has the largest (x, edge id, |normal_x|)
         last = np.ones(len(order), dtype=bool)
         last[:-1] = cc[order][1:] != cc[order][:-1]
         win = order[last]
@@ -440,7 +439,8 @@ def merge_shard_components(lists):
         c = comp[base[r]:base[r + 1]]
         keep = decided[c]
         out.append((labels[keep], flip_of_comp[c][keep]))
-    return out, dict(nodes=int(n_nodes), components=int(n_comp), pairs=int(len(pairs_a)), unmatched=int(unmatched))
+    return out, dict(nodes=int(n_nodes), components=int(n_comp), pairs=int(len(pa)),
+                     unmatched=int(sum(int(L.get("unmatched", 0)) for L in lists)))
 
 
 def shard_layout(n0, world, rank, layers=None):
@@ -454,9 +454,11 @@ def shard_layout(n0, world, rank, layers=None):
     return dict(i0=i0, i1=i1, e0=e0, e1=e1, own_lo=i0 - e0, own_hi=own_hi_plane - e0)
 
 
-def shard_local(ctx, local, layout, value, global_shape, clean=True):
+def shard_local(ctx, local, layout, value, global_shape, clean=True, torch_device=None):
     """first half on one rank: march the local array (own planes + neighbours' layers) and run the local post-pass.
-    -> the lists for merge_shard_components (edge ids already those of the whole volume)"""
+    -> dict: the start-triangle candidates (edge ids already those of the whole volume), own1 = (hash, label) of the own
+    triangles next to the lower neighbour, copy4 = (hash, label) of the copies of the upper neighbour's first layer (torch
+    tensors on torch_device, else numpy), counts"""
     from . import _ffi
     n0, n1, n2 = [int(n) for n in global_shape]
     ctx.set_origin(layout["e0"], 0, 0)
@@ -474,10 +476,19 @@ def shard_local(ctx, local, layout, value, global_shape, clean=True):
     finally:
         ctx.set_reference_corner((0, 0, 0))
     off = (np.int64(layout["e0"]) * n1 * n2) << 3
-    L["tri_keys"] = L["tri_keys"].astype(np.int64) + off
     L["cand_vertex_key"] = L["cand_vertex_key"].astype(np.int64) + off
     L["key_offset"] = off
+    L["own1"] = ctx.shard_boundary(1, L["n_own_lower"], torch_device)
+    L["copy4"] = ctx.shard_boundary(4, L["n_upper_copies"], torch_device)
     return L
+
+
+def shard_small(L, pairs, unmatched):
+    "what goes to rank 0: the label pairs with the lower neighbour and the candidates (no per-triangle data)"
+    out = {k: L[k] for k in ("cand_label", "cand_x", "cand_vertex_key", "cand_nx", "cand_negative", "cand_has")}
+    out["pairs"] = pairs
+    out["unmatched"] = int(unmatched)
+    return out
 
 
 def shard_finish(ctx, L, answer, download=True):
@@ -491,12 +502,52 @@ def shard_finish(ctx, L, answer, download=True):
     return out
 
 
+def exchange_boundary_lists(L, rank, world, dist, device):
+    """rank r sends its copies of rank r+1's first layer (hash, label) up and receives rank r-1's copies of its own: tensors on
+    `device` (RCCL with backend "nccl"; staged through the host for gloo).  -> (hash, label) of the lower neighbour's list, or
+    None on rank 0"""
+    import torch
+    staged = dist.get_backend() == "gloo"
+    wire = torch.device("cpu") if staged else device
+    h4, l4 = L["copy4"]
+    n_up = torch.tensor([int(h4.numel())], dtype=torch.int64, device=wire)
+    n_low = torch.zeros(1, dtype=torch.int64, device=wire)
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, n_up, rank + 1))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.irecv, n_low, rank - 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    got = None
+    ops = []
+    keep = []
+    if rank + 1 < world and int(h4.numel()):
+        sh, sl = h4.to(wire).contiguous(), l4.to(wire).contiguous()
+        keep += [sh, sl]
+        ops += [dist.P2POp(dist.isend, sh, rank + 1), dist.P2POp(dist.isend, sl, rank + 1)]
+    if rank > 0:
+        n = int(n_low.item())
+        rh = torch.empty(n, dtype=torch.int64, device=wire)
+        rl = torch.empty(n, dtype=torch.int32, device=wire)
+        if n:
+            ops += [dist.P2POp(dist.irecv, rh, rank - 1), dist.P2POp(dist.irecv, rl, rank - 1)]
+        got = (rh, rl)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if got is not None:
+        got = (got[0].to(device), got[1].to(device))
+    return got
+
+
 def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0, clean=True, dist=None, context=None, download=True):
     """Level 1 of a volume spread over the ranks in slabs along axis 0, WITHOUT gathering the mesh: every rank returns its own
     part -- dict(points (V,3) float64 in the coordinates of the whole volume, triangles (T,3) int32 into them, wound as the
     reference winds the whole surface, keys (V,) int64 edge id of every vertex in the whole volume (vertices next to a slab
     boundary appear on both sides with the same id and coordinates), counts, stats (rank 0), ms, boundary).  The union over the
-    ranks is the Level-1 mesh of the undivided volume (assemble_level1)."""
+    ranks is the Level-1 mesh of the undivided volume (assemble_level1).  Per-triangle data only travels between neighbours
+    (12 bytes per boundary triangle, device to device with RCCL); rank 0 sees label pairs and candidates."""
     import time
     import torch
     from . import _ffi
@@ -512,17 +563,17 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
     if local.is_cuda:
         torch.cuda.synchronize(local.device)
     ctx = context or _ffi.Context(device)
+    gpu = torch.device("cuda", ctx.device if hasattr(ctx, "device") else device)
     t1 = time.perf_counter()
     # a rank whose local part fails must not leave the others waiting in the exchange: everybody learns of it first
     err = None
     try:
-        L = shard_local(ctx, local, lay, value, global_shape, clean)
+        L = shard_local(ctx, local, lay, value, global_shape, clean, torch_device=gpu)
     except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
         err = e
     if world > 1:
         on_device = dist.get_backend() == "nccl"
-        flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
-                            device=torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
+        flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=gpu if on_device else torch.device("cpu"))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             raise RuntimeError("sharded Level 1: the local part failed on some rank" + ("" if err is None else " (this one): %s" % err))
@@ -533,8 +584,14 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
     if world == 1:
         mine = (np.zeros(0, np.uint32), np.zeros(0, np.uint8))
     else:
+        lower = exchange_boundary_lists(L, rank, world, dist, gpu)
+        if lower is not None:
+            pairs, unmatched = pair_labels(L["own1"][0], L["own1"][1], lower[0], lower[1])
+        else:
+            pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
+        small = shard_small(L, pairs, unmatched)
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object(L, gathered, dst=0)
+        dist.gather_object(small, gathered, dst=0)
         answers = [None] * world
         if rank == 0:
             answers, stats = merge_shard_components(gathered)
@@ -546,7 +603,7 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
     t4 = time.perf_counter()
     out["stats"] = stats
     out["ms"] = dict(halo=(t1 - t0) * 1e3, local=(t2 - t1) * 1e3, exchange=(t3 - t2) * 1e3, finish=(t4 - t3) * 1e3)
-    out["boundary"] = dict(triangles=int(len(L["tri_label"])), components=int(len(L["cand_label"])))
+    out["boundary"] = dict(triangles=int(L["n_own_lower"] + L["n_upper_copies"]), components=int(len(L["cand_label"])))
     return out
 
 

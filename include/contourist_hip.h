@@ -214,14 +214,19 @@ int cx_level1_download_keys(cx_ctx* ctx, uint32_t* keys);
  * surface_geometry.py:14-140).  The context holds the extraction of a slab marched together with TWO layers of cells of
  * each neighbour (cx_set_origin: where the local array starts in the whole volume; cx_set_reference_corner: the corner of
  * the whole volume).  begin: weld / tiny collapse / clean-up of everything local, components of the own and first-layer
- * triangles; leaves n_boundary triangles next to the neighbours and n_candidates components that reach them for the
- * host to exchange (cx_postprocess3d_shard_lists).  finish: the agreed flip per such component; afterwards
- * cx_level1_download / _keys / cx_level1_write hand out the slab's OWN part of the mesh in whole-volume coordinates.
- * own_lo / own_hi: own cell layers [lo, hi) of the local array.  flags as cx_postprocess3d. */
+ * triangles.  What the ranks must agree on follows the slab BOUNDARY: _boundary hands out (hash of the three original edge
+ * ids in the whole volume's numbering, component label) for this slab's own triangles next to its lower neighbour
+ * (which = 1) and for its copies of the upper neighbour's first layer (which = 4) -- rank r's list 4 and rank r+1's list 1
+ * are the same triangles, sorted by hash they pair the labels up; hash / label may be DEVICE pointers.  _candidates: per
+ * component that reaches a neighbour, the start-triangle candidate among the own triangles (surface_geometry.py:79-103).
+ * finish: the agreed flip per such component; afterwards cx_level1_download / _keys / cx_level1_write hand out the slab's
+ * OWN part of the mesh in whole-volume coordinates.  own_lo / own_hi: own cell layers [lo, hi) of the local array.
+ * flags as cx_postprocess3d. */
 int cx_postprocess3d_shard_begin(cx_ctx* ctx, uint32_t flags, int64_t own_lo, int64_t own_hi, int64_t* out_counts8,
-                                 int64_t* n_boundary, int64_t* n_candidates);
-int cx_postprocess3d_shard_lists(cx_ctx* ctx, uint32_t* tri_keys3, uint32_t* tri_label, uint8_t* tri_class, uint32_t* cand_label,
-                                 double* cand_x, uint32_t* cand_vertex_key, double* cand_nx, uint8_t* cand_negative, uint8_t* cand_has);
+                                 int64_t* n_own_lower, int64_t* n_upper_copies, int64_t* n_candidates);
+int cx_postprocess3d_shard_boundary(cx_ctx* ctx, int which, uint64_t* hash, uint32_t* label);
+int cx_postprocess3d_shard_candidates(cx_ctx* ctx, uint32_t* cand_label, double* cand_x, uint32_t* cand_vertex_key, double* cand_nx,
+                                      uint8_t* cand_negative, uint8_t* cand_has);
 int cx_postprocess3d_shard_finish(cx_ctx* ctx, const uint32_t* labels, const uint8_t* flips, int64_t n, int64_t* out_counts8);
 
 /* Binary mesh file straight from the Level-1 device buffers -- the step right after get_points_and_triangles() for every caller

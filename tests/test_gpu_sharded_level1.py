@@ -27,6 +27,35 @@ def fields():
     return F
 
 
+def play_ranks(A, value, world, shape=None):
+    """the ranks one after the other, a context each: -> (parts [(keys, points, triangles)], lists, stats)"""
+    import torch
+    from contourist_amd import _ffi, distributed
+    dev = torch.device("cuda", 0)
+    shape = tuple(A.shape) if shape is None else shape
+    ctxs = [_ffi.Context(0) for _ in range(world)]
+    lists = []
+    for r in range(world):
+        lay = distributed.shard_layout(shape[0], world, r)
+        local = A[lay["e0"]:lay["e1"]]
+        if not torch.is_tensor(local):
+            local = np.ascontiguousarray(local)
+        lists.append(distributed.shard_local(ctxs[r], local, lay, value, shape, torch_device=dev))
+    small = []
+    for r in range(world):
+        if r == 0:
+            pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
+        else:
+            pairs, unmatched = distributed.pair_labels(lists[r]["own1"][0], lists[r]["own1"][1], lists[r - 1]["copy4"][0], lists[r - 1]["copy4"][1])
+        small.append(distributed.shard_small(lists[r], pairs, unmatched))
+    answers, stats = distributed.merge_shard_components(small)
+    parts = []
+    for r in range(world):
+        out = distributed.shard_finish(ctxs[r], lists[r], answers[r])
+        parts.append((out["keys"], out["points"], out["triangles"]))
+    return parts, lists, stats
+
+
 def canon(keys, tris):
     "oriented triangles as rows of vertex edge ids, rotated so that the smallest comes first"
     k = np.asarray(keys, dtype=np.int64)[np.asarray(tris, dtype=np.int64).reshape(-1, 3)]
@@ -48,20 +77,10 @@ def test_sharded_level1_equals_the_undivided_volume(name, world):
     wp, wt = whole.download_level1(post)
     wk = whole.download_level1_keys(post).astype(np.int64)
     assert len(np.unique(wk)) == len(wk)
-    ctxs = [_ffi.Context(0) for _ in range(world)]
-    lists, lays = [], []
-    for r in range(world):
-        lay = distributed.shard_layout(A.shape[0], world, r)
-        lays.append(lay)
-        lists.append(distributed.shard_local(ctxs[r], np.ascontiguousarray(A[lay["e0"]:lay["e1"]]), lay, value, A.shape))
-    answers, stats = distributed.merge_shard_components(lists)
+    parts, lists, stats = play_ranks(A, value, world)
     assert stats["unmatched"] == 0, stats
-    parts = []
-    for r in range(world):
-        out = distributed.shard_finish(ctxs[r], lists[r], answers[r])
-        parts.append((out["keys"], out["points"], out["triangles"]))
     keys, pts, tris = distributed.assemble_level1(parts)
-    print(name, world, "vertices", len(wk), "triangles", len(wt), "boundary", [len(L["tri_label"]) for L in lists], stats)
+    print(name, world, "vertices", len(wk), "triangles", len(wt), "boundary", [L["n_own_lower"] + L["n_upper_copies"] for L in lists], stats)
     order = np.argsort(wk)
     assert np.array_equal(keys, wk[order])
     assert np.array_equal(pts, wp[order])                     # bit for bit
@@ -70,4 +89,36 @@ def test_sharded_level1_equals_the_undivided_volume(name, world):
     # the work rank 0 does follows the boundary, not the volume
     # (four layers of cells per boundary: at most 4 x the fullest layer of the surface, with room for welded-away triangles)
     per_layer = np.bincount(np.floor(wp[wt].min(axis=1)[:, 0]).astype(np.int64), minlength=A.shape[0]) if len(wt) else np.zeros(1)
-    assert sum(len(L["tri_label"]) for L in lists) <= 6 * (world - 1) * int(per_layer.max()) + 64
+    assert sum(L["n_own_lower"] + L["n_upper_copies"] for L in lists) <= 3 * (world - 1) * int(per_layer.max()) + 64
+    # ... and what reaches rank 0 is a list of components, not of triangles
+    assert stats["pairs"] <= stats["nodes"] ** 2 and stats["nodes"] <= 2 * sum(len(L["cand_label"]) for L in lists)
+
+
+def test_sharded_level1_at_full_size():
+    """BASELINE's 512^3 bench field in 8 slabs of 64 planes (the ranks played one after the other on the one GPU): the union of
+    the 8 parts is the undivided volume's Level-1 mesh, bit for bit; what goes through rank 0 is a few per cent of the mesh"""
+    torch = pytest.importorskip("torch")
+    import time
+    from contourist_amd import _ffi, distributed, synthetic
+    dev = torch.device("cuda", 0)
+    n, world = 512, 8
+    A = synthetic.smooth_noise_torch((n, n, n), 1235, 1400, dev)    # the bench's field (bench.py defaults)
+    whole = _ffi.Context(0)
+    whole.adopt_device_grid(A.data_ptr(), (n, n, n), keepalive=A)
+    whole.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
+    post = whole.postprocess3d(0)
+    wp, wt = whole.download_level1(post)
+    wk = whole.download_level1_keys(post).astype(np.int64)
+    del whole
+    t0 = time.perf_counter()
+    parts, lists, stats = play_ranks(A, 0.0, world)
+    all_ms = (time.perf_counter() - t0) * 1e3
+    assert stats["unmatched"] == 0
+    boundary = sum(L["n_own_lower"] + L["n_upper_copies"] for L in lists)
+    print("512^3 in 8 slabs: %.0f ms for the 8 ranks one after the other (first calls, downloads included); %d boundary triangles of %d stay "
+          "between neighbours, rank 0 sees %s" % (all_ms, boundary, len(wt), stats))
+    assert sum(len(p[2]) for p in parts) == len(wt) and boundary < 0.04 * len(wt)
+    keys, pts, tris = distributed.assemble_level1(parts)
+    order = np.argsort(wk)
+    assert np.array_equal(keys, wk[order]) and np.array_equal(pts, wp[order])
+    assert np.array_equal(canon(keys, tris), canon(wk, wt))

@@ -6,11 +6,10 @@ import numpy as np
 from contourist_amd import distributed as cd
 
 
-def lists_of(tri, cand):
-    "tri: [(k0,k1,k2,label,cls)], cand: [(label,x,vkey,nx,neg,has)]"
-    tri = np.array(tri, dtype=np.int64).reshape(-1, 5)
+def small(pairs, cand, unmatched=0):
+    "pairs: [(my label, lower neighbour's label)], cand: [(label, x, vkey, nx, neg, has)]"
     cand = np.array(cand, dtype=np.float64).reshape(-1, 6)
-    return dict(tri_keys=tri[:, :3], tri_label=tri[:, 3].astype(np.uint32), tri_class=tri[:, 4].astype(np.uint8),
+    return dict(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 2), unmatched=unmatched,
                 cand_label=cand[:, 0].astype(np.uint32), cand_x=cand[:, 1], cand_vertex_key=cand[:, 2].astype(np.int64),
                 cand_nx=cand[:, 3], cand_negative=cand[:, 4].astype(np.uint8), cand_has=cand[:, 5].astype(np.uint8))
 
@@ -18,17 +17,11 @@ def lists_of(tri, cand):
 def test_chain_over_three_ranks_and_a_separate_component():
     # component X runs through ranks 0-1-2 (labels 7 / 3 and 4 / 9); rank 1 holds it in TWO local pieces (3, 4) that only meet
     # through rank 2; component Y lives on the 0|1 boundary only (labels 20 / 21)
-    r0 = lists_of([(10, 11, 12, 7, 2), (13, 14, 15, 7, 4),          # own triangle next to rank 1, copy of rank 1's triangle
-                   (50, 51, 52, 20, 2), (53, 54, 55, 20, 4)],
-                  [(7, 5.0, 100, 1.0, 0, 1), (20, 4.0, 400, 1.0, 1, 1)])
-    r1 = lists_of([(10, 11, 12, 3, 3), (13, 14, 15, 3, 1),
-                   (30, 31, 32, 4, 2), (33, 34, 35, 4, 4), (36, 37, 38, 3, 2), (39, 40, 41, 3, 4),
-                   (50, 51, 52, 21, 3), (53, 54, 55, 21, 1)],
-                  [(3, 9.0, 200, 2.0, 0, 1), (4, 9.5, 210, 0.5, 0, 1), (21, 4.5, 410, 1.0, 0, 1)])
-    r2 = lists_of([(30, 31, 32, 9, 3), (33, 34, 35, 9, 1), (36, 37, 38, 9, 3), (39, 40, 41, 9, 1)],
-                  [(9, 14.0, 300, 3.0, 1, 1)])
+    r0 = small([], [(7, 5.0, 100, 1.0, 0, 1), (20, 4.0, 400, 1.0, 1, 1)])
+    r1 = small([(3, 7), (21, 20)], [(3, 9.0, 200, 2.0, 0, 1), (4, 9.5, 210, 0.5, 0, 1), (21, 4.5, 410, 1.0, 0, 1)])
+    r2 = small([(9, 3), (9, 4)], [(9, 14.0, 300, 3.0, 1, 1)])
     out, stats = cd.merge_shard_components([r0, r1, r2])
-    assert stats["unmatched"] == 0 and stats["components"] == 2 and stats["pairs"] == 8
+    assert stats["unmatched"] == 0 and stats["components"] == 2 and stats["pairs"] == 4
     flips = [dict(zip(l.tolist(), f.tolist())) for l, f in out]
     # X: the candidate of rank 2 has the largest x (14.0) and a negative normal -> everything of X flips, on every rank
     assert flips[0][7] == 1 and flips[1][3] == 1 and flips[1][4] == 1 and flips[2][9] == 1
@@ -37,21 +30,38 @@ def test_chain_over_three_ranks_and_a_separate_component():
 
 
 def test_ties_go_to_the_larger_edge_id_then_the_larger_normal():
-    a = lists_of([(1, 2, 3, 0, 2), (4, 5, 6, 0, 4)], [(0, 8.0, 77, 1.0, 1, 1)])
-    b = lists_of([(1, 2, 3, 5, 3), (4, 5, 6, 5, 1)], [(5, 8.0, 78, 0.1, 0, 1)])
+    a = small([], [(0, 8.0, 77, 1.0, 1, 1)])
+    b = small([(5, 0)], [(5, 8.0, 78, 0.1, 0, 1)])
     out, _ = cd.merge_shard_components([a, b])
     assert out[0][1].tolist() == [0] and out[1][1].tolist() == [0]          # same x: vertex 78 > 77 decides
-    b = lists_of([(1, 2, 3, 5, 3), (4, 5, 6, 5, 1)], [(5, 8.0, 77, 0.1, 0, 1)])
+    b = small([(5, 0)], [(5, 8.0, 77, 0.1, 0, 1)])
     out, _ = cd.merge_shard_components([a, b])
     assert out[0][1].tolist() == [1] and out[1][1].tolist() == [1]          # same vertex from both sides: |normal_x| 1.0 > 0.1
 
 
-def test_a_triangle_only_one_side_knows_is_reported():
-    a = lists_of([(1, 2, 3, 0, 2)], [(0, 1.0, 1, 1.0, 0, 1)])
-    b = lists_of([(1, 2, 4, 5, 3)], [(5, 2.0, 2, 1.0, 0, 0)])
+def test_components_without_a_candidate_and_reported_mismatches():
+    a = small([], [(0, 1.0, 1, 1.0, 0, 1)], unmatched=2)
+    b = small([], [(5, 2.0, 2, 1.0, 0, 0)], unmatched=1)          # a component made of copies only: no own triangle, no candidate
     out, stats = cd.merge_shard_components([a, b])
-    assert stats["unmatched"] == 2 and stats["pairs"] == 0
-    assert out[0][0].tolist() == [0] and out[1][0].tolist() == []            # a component without any candidate gets no answer
+    assert stats["unmatched"] == 3 and stats["pairs"] == 0
+    assert out[0][0].tolist() == [0] and out[1][0].tolist() == []            # ... and no answer for it
+
+
+def test_pair_labels_lines_the_two_lists_up():
+    "a rank's own boundary triangles against the neighbour's copies of them: any order, distinct label pairs, strangers counted"
+    import torch
+    rng = np.random.RandomState(3)
+    h = torch.from_numpy(rng.randint(-2 ** 62, 2 ** 62, size=1000).astype(np.int64))
+    own_label = torch.from_numpy((np.arange(1000) % 7).astype(np.int32))
+    copy_label = torch.from_numpy((np.arange(1000) % 7 + 100).astype(np.int32))
+    perm = torch.from_numpy(rng.permutation(1000))
+    pairs, unmatched = cd.pair_labels(h, own_label, h[perm], copy_label[perm])
+    assert unmatched == 0 and sorted(map(tuple, pairs.tolist())) == [(k, k + 100) for k in range(7)]
+    # one triangle the neighbour does not know, one copy of a triangle this rank does not own
+    pairs, unmatched = cd.pair_labels(h, own_label, torch.cat([h[perm][:-1], torch.tensor([12345], dtype=torch.int64)]), copy_label[perm])
+    assert unmatched == 2 and len(pairs) == 7
+    pairs, unmatched = cd.pair_labels(h[:0], own_label[:0], h[:5], copy_label[:5])
+    assert unmatched == 5 and pairs.shape == (0, 2)
 
 
 def test_layout_covers_every_cell_once():
