@@ -1081,7 +1081,7 @@ static int cxp_shard_finish(cx_ctx* ctx, cx_post_state* S, const uint32_t* label
         CXP_HIP(ctx, hipMemcpyAsync(h, misc + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
         nv3 = h[0]; nt3 = h[1]; ncomp = h[2];
-        // the march's own buffers are free by now: they take the final mesh, then the roles are swapped
+        // the march's own buffers are free by now: they take the final mesh on its way back into the output buffers
         if ((rc = cxp_reserve(ctx, S->pts, (size_t)(nv3 + 1) * 3 * sizeof(double)))) return rc;
         if ((rc = cxp_reserve(ctx, S->tri, (size_t)(nt3 + 1) * 3 * sizeof(int32_t)))) return rc;
         if ((rc = cxp_reserve(ctx, S->keys_tmp, (size_t)(nv3 + 1) * sizeof(uint32_t)))) return rc;
@@ -1090,10 +1090,13 @@ static int cxp_shard_finish(cx_ctx* ctx, cx_post_state* S, const uint32_t* label
                                (const uint32_t*)S->keys_out.p, (uint32_t*)S->keys_tmp.p);
             hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, alive, tnew, vnew, nt2, (int32_t*)S->tri.p, (uint32_t*)nullptr);
         }
+        // back into the output buffers (every buffer keeps its size from call to call: nothing is reallocated for the next volume)
+        if (nt3) {
+            CXP_HIP(ctx, hipMemcpyAsync(S->pts_out.p, S->pts.p, (size_t)nv3 * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            CXP_HIP(ctx, hipMemcpyAsync(S->tri_out.p, S->tri.p, (size_t)nt3 * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            CXP_HIP(ctx, hipMemcpyAsync(S->keys_out.p, S->keys_tmp.p, (size_t)nv3 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        }
         CXP_HIP(ctx, hipStreamSynchronize(st));
-        std::swap(S->pts, S->pts_out);
-        std::swap(S->tri, S->tri_out);
-        std::swap(S->keys_tmp, S->keys_out);
     }
     S->nv_out = nv3; S->nt_out = nt3;
     S->keys_valid = true;
