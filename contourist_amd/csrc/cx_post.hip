@@ -167,14 +167,23 @@ __global__ void cxp_k_fill64(u64* a, size_t n, u64 v) {
 __global__ void cxp_k_jump(u64* parent, uint32_t n, uint32_t* changed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u64 w = parent[i];
-    const uint32_t p = (uint32_t)w;
+    u64 w = parent[i];
+    uint32_t p = (uint32_t)w;
     if (p == i) return;
-    const u64 wp = parent[p];
-    const uint32_t pp = (uint32_t)wp;
-    if (pp == p) return;
-    parent[i] = ((((w >> 32) ^ (wp >> 32)) & 1ULL) << 32) | (u64)pp;
-    *changed = 1u;
+    bool moved = false;
+#pragma unroll 1
+    for (int hop = 0; hop < 3; hop++) {          // up to three hops per launch: fewer launches and host round trips
+        const u64 wp = parent[p];
+        const uint32_t pp = (uint32_t)wp;
+        if (pp == p) break;
+        w = ((((w >> 32) ^ (wp >> 32)) & 1ULL) << 32) | (u64)pp;
+        p = pp;
+        moved = true;
+    }
+    if (moved) {
+        parent[i] = w;
+        *changed = 1u;
+    }
 }
 
 // ---- exclusive scan of u32 (n up to 2^32) ----------------------------------------------------------
@@ -600,7 +609,9 @@ __global__ void cxp_k_edges_link(const int32_t* tri, uint32_t nt, const u64* tab
 // the memory side of the fabric and bound the one-step kernel), writes the block's forest into the global parent words with
 // plain stores -- nobody else touches them in this kernel -- and leaves the partners outside the block in `others` for the
 // second kernel, which unites them with the global routine as before.  The roots are the smallest ids either way.
+#ifndef CXP_LINK_BLOCK
 #define CXP_LINK_BLOCK 2048u
+#endif
 #define CXP_LINK_PER_THREAD (CXP_LINK_BLOCK / 256u)
 __device__ __forceinline__ uint32_t cxp_lfind(uint32_t* lp, uint32_t x) {
     for (;;) {
@@ -668,9 +679,13 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
 // per component (root triangle): largest x over its vertices.  cls (sharded Level 1 only): per triangle, > 2 = a copy of a
 // neighbour slab's triangle, which takes part in the components but not in the choice of the start triangle.
 #define CXP_OWN(cls, t) (!(cls) || (cls)[t] <= 2u)
+// Triangles are visited from the LAST to the first: the march numbers them by ascending x, so the first waves to run establish
+// the maximum and everybody after them sees in a plain read that it has nothing to add (visited in ascending order every wave
+// raises the maximum, and same-address atomics serialise).
 __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, u64* cmaxx, const uint8_t* cls) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = t < nt && CXP_OWN(cls, t);
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = nt - 1u - idx;
+    const bool have = idx < nt && CXP_OWN(cls, t);
     uint32_t root = 0;
     u64 m = 0;
     if (have) {
@@ -680,20 +695,46 @@ __global__ void cxp_k_comp_maxx(const int32_t* tri, uint32_t nt, const double* p
     }
     cxp_wave_max64(cmaxx, root, m, have);
 }
+// The triangles that can hold the start triangle of their component: those with a vertex AT the component's largest x.  A handful
+// per component (a face of the volume that the surface runs along: thousands) -- the four kernels below visit this list instead of
+// every triangle.  One atomic per wave.
+__global__ void cxp_k_comp_list(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, const uint8_t* cls,
+                                uint32_t* list, uint32_t* nlist) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (t < nt && CXP_OWN(cls, t)) {
+        const u64 m = cmaxx[(uint32_t)parent[t]];
+#pragma unroll
+        for (int s = 0; s < 3; s++) hit = hit || cxp_orderable(pts[(size_t)tri[(size_t)t * 3 + s] * 3]) == m;
+    }
+    const uint64_t hits = __ballot(hit);
+    if (hits == 0ULL) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)hits) - 1)) base = atomicAdd(nlist, (uint32_t)__popcll(hits));
+    base = (uint32_t)__shfl((int)base, __ffsll((long long)hits) - 1);
+    if (hit) list[base + (uint32_t)__popcll(hits & ((1ULL << lane) - 1ULL))] = t;
+}
+// visit either every triangle (list == nullptr: one per thread) or the triangles of a list (grid-stride)
+#define CXP_FOR_TRI(t)                                                                                                   \
+    for (uint32_t i_ = blockIdx.x * blockDim.x + threadIdx.x, n_ = list ? *nlist : nt; i_ < n_; i_ += gridDim.x * blockDim.x) { \
+        const uint32_t t = list ? list[i_] : i_;
+#define CXP_END_FOR }
 // among the vertices at that x: the one with the largest index in the reference (surface_geometry.py:79 max((x, index)), its
 // numbering being its hash order); here the one with the largest EDGE ID, which does not depend on how the mesh is numbered or
 // cut into slabs.  Packed (edge id << 32 | vertex).
 __global__ void cxp_k_comp_maxv(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxx, u64* cmaxv,
-                                const uint32_t* keys, const uint8_t* cls) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt || !CXP_OWN(cls, t)) return;
-    const uint32_t root = (uint32_t)parent[t];
-    const u64 m = cmaxx[root];
+                                const uint32_t* keys, const uint8_t* cls, const uint32_t* list, const uint32_t* nlist) {
+    CXP_FOR_TRI(t)
+        if (!CXP_OWN(cls, t)) continue;
+        const uint32_t root = (uint32_t)parent[t];
+        const u64 m = cmaxx[root];
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const uint32_t v = tri[(size_t)t * 3 + s];
-        if (cxp_orderable(pts[(size_t)v * 3]) == m) cxp_max64(&cmaxv[root], ((u64)(keys ? keys[v] : v) << 32) | (u64)v);
-    }
+        for (int s = 0; s < 3; s++) {
+            const uint32_t v = tri[(size_t)t * 3 + s];
+            if (cxp_orderable(pts[(size_t)v * 3]) == m) cxp_max64(&cmaxv[root], ((u64)(keys ? keys[v] : v) << 32) | (u64)v);
+        }
+    CXP_END_FOR
 }
 // among that vertex's triangles: the largest |cross(a-b, a-c)[0]| (surface_geometry.py:88-94); the packed
 // word keeps the triangle id so that the next kernel can read its sign
@@ -704,34 +745,37 @@ __device__ __forceinline__ double cxp_dotx(const int32_t* tri, uint32_t t, const
     return aby * acz - abz * acy;
 }
 __global__ void cxp_k_comp_start(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxv,
-                                 u64* cbest, const uint8_t* cls) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt || !CXP_OWN(cls, t)) return;
-    const uint32_t root = (uint32_t)parent[t];
-    const uint32_t vm = (uint32_t)cmaxv[root];
-    if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
-    cxp_max64(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
+                                 u64* cbest, const uint8_t* cls, const uint32_t* list, const uint32_t* nlist) {
+    CXP_FOR_TRI(t)
+        if (!CXP_OWN(cls, t)) continue;
+        const uint32_t root = (uint32_t)parent[t];
+        const uint32_t vm = (uint32_t)cmaxv[root];
+        if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) continue;
+        cxp_max64(&cbest[root], cxp_orderable(fabs(cxp_dotx(tri, t, pts))));
+    CXP_END_FOR
 }
 __global__ void cxp_k_comp_pick(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const u64* cmaxv,
-                                const u64* cbest, uint32_t* cstart, const uint8_t* cls) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt || !CXP_OWN(cls, t)) return;
-    const uint32_t root = (uint32_t)parent[t];
-    const uint32_t vm = (uint32_t)cmaxv[root];
-    if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) return;
-    if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) cxp_max32(&cstart[root], t);
+                                const u64* cbest, uint32_t* cstart, const uint8_t* cls, const uint32_t* list, const uint32_t* nlist) {
+    CXP_FOR_TRI(t)
+        if (!CXP_OWN(cls, t)) continue;
+        const uint32_t root = (uint32_t)parent[t];
+        const uint32_t vm = (uint32_t)cmaxv[root];
+        if ((uint32_t)tri[(size_t)t * 3] != vm && (uint32_t)tri[(size_t)t * 3 + 1] != vm && (uint32_t)tri[(size_t)t * 3 + 2] != vm) continue;
+        if (cxp_orderable(fabs(cxp_dotx(tri, t, pts))) == cbest[root]) cxp_max32(&cstart[root], t);
+    CXP_END_FOR
 }
 // the root's flip, so that the start triangle gets dotx > 0 (surface_geometry.py:99-103).  Decided in its own kernel,
 // BEFORE any triangle is rewritten: cxp_k_orient reverses triangles in place, and reading the start triangle there
 // raced with the thread that reverses it (a component came out partly wound one way and partly the other, rarely)
-__global__ void cxp_k_comp_decide(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, u64* cflip) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    const u64 w = parent[t];
-    const uint32_t root = (uint32_t)w;
-    if (cstart[root] != t) return;
-    const uint32_t spar = (uint32_t)(w >> 32) & 1u;
-    cflip[root] = (u64)((((cxp_dotx(tri, t, pts) < 0.0) ? 1u : 0u) ^ spar) & 1u);   // in the root's frame
+__global__ void cxp_k_comp_decide(const int32_t* tri, uint32_t nt, const double* pts, const u64* parent, const uint32_t* cstart, u64* cflip,
+                                  const uint32_t* list, const uint32_t* nlist) {
+    CXP_FOR_TRI(t)
+        const u64 w = parent[t];
+        const uint32_t root = (uint32_t)w;
+        if (cstart[root] != t) continue;
+        const uint32_t spar = (uint32_t)(w >> 32) & 1u;
+        cflip[root] = (u64)((((cxp_dotx(tri, t, pts) < 0.0) ? 1u : 0u) ^ spar) & 1u);   // in the root's frame
+    CXP_END_FOR
 }
 // final winding: triangle parity relative to the root, and the root's flip
 __global__ void cxp_k_orient(int32_t* tri, uint32_t nt, const u64* parent, const u64* cflip, uint32_t* ncomp) {
@@ -856,6 +900,9 @@ static inline u64 cxp_edge_table_size(size_t n) {
     while (s < (5 * (u64)n) / 4 + 16) s <<= 1;
     return s;
 }
+// (measured and dropped: half that size for the meshes of the march, whose edges are nearly all shared by two triangles, with a
+// repeat on overflow -- the fill gets 0.23 ms cheaper, the claim kernel 0.74 ms dearer: rows of 5 slots per vertex instead of 11
+// run into each other)
 
 static int cxp_scan(cx_ctx* ctx, cx_post_state* S, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev) {
     const uint32_t nb = cxp_blocks(n, CXP_SCAN_BLOCK);
@@ -965,17 +1012,19 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     uint32_t ncomp = 0;
     if (do_orient && nt2) {
         // ---- orientation: edge table + parity union-find over triangles
+        // (measured and dropped: clearing the table on a second stream while weld / tiny collapse / clean-up run -- no gain, the fill
+        // takes from them what it saves)
         const u64 esz = cxp_edge_table_size((size_t)nt2 * 3);
         if ((rc = cxp_reserve(ctx, S->tkeys, 2 * esz * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->parent, (size_t)nt2 * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t))))) return rc;
         u64* etab = (u64*)S->tkeys.p;
+        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
         u64* parent = (u64*)S->parent.p;
         u64* cmaxx = (u64*)S->comp.p;
         u64* cbest = cmaxx + nt2;
         u64* cmaxv = cbest + nt2;
         uint32_t* cstart = (uint32_t*)(cmaxv + nt2);
-        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
@@ -991,9 +1040,15 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
         const uint8_t* own = cls2;
         hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, own);
-        hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv, (const uint32_t*)keys2, own);
-        hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, own);
-        hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart, own);
+        // (the scan / flag arrays of the compaction are free by now: the list of possible start triangles goes there)
+        uint32_t* clist = (uint32_t*)S->flags.p;
+        const uint32_t* cn = misc + 11;
+        const dim3 lgrid(std::min(cxp_blocks(nt2), 1024u));
+        CXP_HIP(ctx, hipMemsetAsync(misc + 11, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(cxp_k_comp_list, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, own, clist, misc + 11);
+        hipLaunchKernelGGL(cxp_k_comp_maxv, lgrid, dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxx, cmaxv, (const uint32_t*)keys2, own, (const uint32_t*)clist, cn);
+        hipLaunchKernelGGL(cxp_k_comp_start, lgrid, dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, own, (const uint32_t*)clist, cn);
+        hipLaunchKernelGGL(cxp_k_comp_pick, lgrid, dim3(256), 0, st, tri2, nt2, pts2, parent, cmaxv, cbest, cstart, own, (const uint32_t*)clist, cn);
         if (shard) {
             // what the neighbours need: the triangles at the slab boundaries with their labels (they stay on the device), and the
             // start-triangle candidate of every component that reaches a neighbour.  Sizes follow the slab boundary, not the slab.
@@ -1024,7 +1079,7 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
             if (h2[0] != n1 || h2[1] != n4 || h2[2] > nb) { ctx->err = "sharded Level 1: boundary lists do not add up"; return CX_ERR_HIP; }
             S->shard.n1 = (uint32_t)n1; S->shard.n4 = (uint32_t)n4; S->shard.ncand = h2[2];
         }
-        hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, cbest);
+        hipLaunchKernelGGL(cxp_k_comp_decide, lgrid, dim3(256), 0, st, tri2, nt2, pts2, parent, cstart, cbest, (const uint32_t*)clist, cn);
         if (!shard) {
             hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cbest, misc + 3);
             CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2234,10 +2289,11 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             const uint32_t* nokeys = nullptr;   // segment midpoints: the largest index breaks the tie
             const uint8_t* nocls = nullptr;
             hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, nocls);
-            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv, nokeys, nocls);
-            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, nocls);
-            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart, nocls);
-            hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest);
+            const uint32_t* nolist = nullptr;
+            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv, nokeys, nocls, nolist, nolist);
+            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, nocls, nolist, nolist);
+            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart, nocls, nolist, nolist);
+            hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest, nolist, nolist);
             hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, parent, cbest, misc + 3);
             uint32_t ncomp = 0;
             CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

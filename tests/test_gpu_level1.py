@@ -194,3 +194,21 @@ def test_random_fields_level1_equals_oracle():
         cmp = postpass.compare_level1(L1, pts, tris, corner, reach=0)
         assert not cmp["missing"] and not cmp["extra"] and not cmp["winding"], where
         assert cmp["excused_rows"] == 0, where
+
+
+def test_open_mesh_of_separate_triangles():
+    """17 000 triangles without a common edge: three distinct edges per triangle, the worst case of the orientation stage's edge
+    table (cx_post.hip, cxp_edge_table_size) -- every triangle its own component, nothing lost"""
+    from contourist_amd import _ffi
+    nt = 17000
+    rng = np.random.RandomState(2)
+    base = rng.rand(nt, 1, 3) * 200.0 + 10.0
+    pts = (base + np.array([[[0.0, 0.0, 0.0], [1.0, 0.0, 0.25], [0.0, 1.0, 0.5]]])).reshape(-1, 3)
+    tris = np.arange(3 * nt, dtype=np.int32).reshape(nt, 3)
+    ctx = _ffi.Context(0)
+    post = ctx.postprocess3d_mesh(pts, tris, [255, 255, 255])
+    assert post["n_triangles"] == nt and post["n_vertices"] == 3 * nt and post["n_components"] == nt
+    p1, t1 = ctx.download_level1(post)
+    # every triangle wound so that its normal_x is positive (each is its own component: surface_geometry.py:99-103)
+    n = np.cross(p1[t1[:, 1]] - p1[t1[:, 0]], p1[t1[:, 2]] - p1[t1[:, 0]])
+    assert np.all(n[:, 0] > 0)
