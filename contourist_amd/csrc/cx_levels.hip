@@ -55,6 +55,9 @@ struct cx_level_slot {
     uint32_t vcap = 0, ccap = 0, tcap = 0;
 };
 
+#ifndef CXL_SIDES
+#define CXL_SIDES 3      // side streams the emit stages CAN use (knob); one is used by default
+#endif
 struct cx_levels_state {
     std::vector<cx_level_slot> slots;
     int nvalid = 0;                    // levels of the last cx_extract3d_levels
@@ -66,10 +69,11 @@ struct cx_levels_state {
     uint32_t flags = 0;
     // the emit stages of two levels run side by side (each kernel alone leaves part of the chip idle): a second stream, and a
     // second set of info words for the levels that run on it
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint64_t* info64b = nullptr;
-    size_t info64b_cap = 0;
+    // the emit stages of the levels run on CXL_SIDES + 1 streams (the context's and these), level l on stream l % (CXL_SIDES + 1)
+    hipStream_t side[CXL_SIDES] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[CXL_SIDES] = {};
+    uint64_t* info_side[CXL_SIDES] = {};       // info words of the levels in flight on the side streams (unpooled queues)
+    size_t info_side_cap[CXL_SIDES] = {};
     // ONE pool of queue entries for all levels (every level a slice of every streaming wave's region); false after a call
     // whose surface overflowed a slice: that grid then gets full-size regions per level, as in round 2
     bool pooled = true;
@@ -99,11 +103,13 @@ void cx_levels_free(cx_ctx* ctx) {
     for (auto& S : L->slots) free_slot(S);
     cx_release(L->dparams, L->dparams_cap);
     if (L->hcounters) (void)hipHostFree(L->hcounters);
-    cx_release(L->info64b, L->info64b_cap);
+    for (int k = 0; k < CXL_SIDES; k++) cx_release(L->info_side[k], L->info_side_cap[k]);
     cx_release(L->qpool, L->qpool_cap);
-    if (L->stream2) (void)hipStreamDestroy(L->stream2);
+    for (int k = 0; k < CXL_SIDES; k++) {
+        if (L->side[k]) (void)hipStreamDestroy(L->side[k]);
+        if (L->ev_join[k]) (void)hipEventDestroy(L->ev_join[k]);
+    }
     if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
-    if (L->ev_join) (void)hipEventDestroy(L->ev_join);
     delete L;
     ctx->lv = nullptr;
 }
@@ -193,7 +199,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
     if (pooled) {
         if ((rc = grow(ctx, L->qpool, L->qpool_cap, need))) return rc;
         for (auto& S : L->slots) cx_release(S.queue, S.queue_cap);      // full-size regions of an earlier call
-        cx_release(L->info64b, L->info64b_cap);
+        for (int k = 0; k < CXL_SIDES; k++) cx_release(L->info_side[k], L->info_side_cap[k]);
     } else {
         cx_release(L->qpool, L->qpool_cap);
     }
@@ -296,38 +302,44 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             S.P.vcap = S.vcap; S.P.ccap = S.ccap; S.P.tcap = S.tcap;
             S.P.info64 = pooled ? ctx->info64 + (size_t)l * sub : ctx->info64;
         }
-        // vertex and triangle stages, two levels side by side: even levels on the context's stream, odd ones on a second stream
-        // with their own info words (the staged kernels of one level hand over through them)
-        const bool two = nlevels > 1 && !cx_debug_knob("CX_LEVELS_ONE_STREAM", 0);
-        if (two) {
-            if (!L->stream2) {
-                CXL_HIP(ctx, hipStreamCreateWithFlags(&L->stream2, hipStreamNonBlocking));
-                CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
-                CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
+        // vertex and triangle stages, several levels side by side: level l on stream l % nstr (0 = the context's stream), the side
+        // streams with their own info words (the staged kernels of one level hand over through them)
+        // Two by default: three and four were measured (CX_DEBUG=1 CX_LEVELS_STREAMS=n, tools/levels_streams.py) and change nothing
+        // (2.33-2.42 ms for 8 levels of the bench grid whatever n): two levels in flight already fill the chip.
+        int nstr = (nlevels > 1 && !cx_debug_knob("CX_LEVELS_ONE_STREAM", 0)) ? 2 : 1;
+        if (nstr > 1) {
+            const int want = cx_debug_knob("CX_LEVELS_STREAMS", 0);
+            if (want >= 2 && want <= CXL_SIDES + 1) nstr = std::min(nlevels, want);
+        }
+        if (nstr > 1) {
+            if (!L->ev_fork) CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
+            for (int k = 0; k + 1 < nstr; k++) {
+                if (!L->side[k]) CXL_HIP(ctx, hipStreamCreateWithFlags(&L->side[k], hipStreamNonBlocking));
+                if (!L->ev_join[k]) CXL_HIP(ctx, hipEventCreateWithFlags(&L->ev_join[k], hipEventDisableTiming));
+                if (!pooled && (rc = grow(ctx, L->info_side[k], L->info_side_cap[k], ctx->info64_cap))) return rc;   // pooled: every level has its own slice of the info words
             }
-            if (!pooled && (rc = grow(ctx, L->info64b, L->info64b_cap, ctx->info64_cap))) return rc;   // pooled: every level has its own slice of the info words
             CXL_HIP(ctx, hipEventRecord(L->ev_fork, ctx->stream));
-            CXL_HIP(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
+            for (int k = 0; k + 1 < nstr; k++) CXL_HIP(ctx, hipStreamWaitEvent(L->side[k], L->ev_fork, 0));
         }
         for (int l = 0; l < nlevels; l++) {
             cx_level_slot& S = L->slots[l];
-            const bool side = two && (l & 1);
-            hipStream_t st = side ? L->stream2 : ctx->stream;
-            if (!pooled) S.P.info64 = side ? L->info64b : ctx->info64;
+            const int k = l % nstr;
+            hipStream_t st = k ? L->side[k - 1] : ctx->stream;
+            if (!pooled) S.P.info64 = k ? L->info_side[k - 1] : ctx->info64;
             cx_launch_emit_vertices(S.P, T, st);
             cx_launch_emit_triangles_q(S.P, T, ctx->hash_xy, st);
         }
         {
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) {
-                if (two) (void)hipStreamSynchronize(L->stream2);   // the forked stream is not left running behind an error return
+                for (int k = 0; k + 1 < nstr; k++) (void)hipStreamSynchronize(L->side[k]);   // no forked stream is left running behind an error return
                 ctx->err = std::string("cx_extract3d_levels: ") + hipGetErrorString(le);
                 return CX_ERR_HIP;
             }
         }
-        if (two) {
-            CXL_HIP(ctx, hipEventRecord(L->ev_join, L->stream2));
-            CXL_HIP(ctx, hipStreamWaitEvent(ctx->stream, L->ev_join, 0));
+        for (int k = 0; k + 1 < nstr; k++) {
+            CXL_HIP(ctx, hipEventRecord(L->ev_join[k], L->side[k]));
+            CXL_HIP(ctx, hipStreamWaitEvent(ctx->stream, L->ev_join[k], 0));
         }
         CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
