@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--value", type=float, default=0.0)
     ap.add_argument("--rotate", type=int, default=0, help="number of distinct grids cycled (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-api", action="store_true", help="skip the Level-1 / API timing after the timed region")
+    ap.add_argument("--no-api", action="store_true", help="skip the Level-1 / API timing after the timed region (N > 1: the sharded Level 1)")
     ap.add_argument("--generic", action="store_true", help="force the shape-agnostic classify kernel")
     ap.add_argument("--weak", action="store_true", help="one size^3 slab PER GPU instead of one volume split over the GPUs")
     ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
@@ -274,9 +274,18 @@ def run_sharded_level1(args, torch, dist, cxdist, job, dev, rank, world, strong,
     shape = (n, n, n) if strong else (world * n, n, n)
     own = job.slabs[0][:job.n_own]
     res, err = None, None
+    # the two small object collectives go over a gloo group with a timeout: a rank that dies there raises on the others
+    # instead of leaving them waiting (RCCL would wait for ever); the per-triangle lists travel device to device over RCCL
+    obj_group = None
+    if dist.get_backend() == "nccl":
+        try:
+            import datetime
+            obj_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+        except Exception:        # noqa: BLE001 -- collective: fails or succeeds on every rank alike
+            obj_group = None
     try:
         for k in range(3):       # the first call allocates; of the other two the faster one counts (same call count on every rank)
-            r_ = cxdist.level1_slabs_sharded(own, args.value, rank, world, shape, dist=dist, context=ctx, download=False)
+            r_ = cxdist.level1_slabs_sharded(own, args.value, rank, world, shape, dist=dist, context=ctx, download=False, object_group=obj_group)
             if k == 1 or (k == 2 and sum(r_["ms"].values()) < sum(res["ms"].values())):
                 res = r_
     except Exception as e:       # noqa: BLE001

@@ -45,6 +45,7 @@ struct cxp_dev {
 struct cx_post_state {
     cxp_dev pts, prio, rep, tri, alive, parent, parent2, tkeys, tvals, flags, scan, blocksums, pts_out, tri_out, comp, misc;
     cxp_dev keys_out, keys_tmp, told, cls, bnd;   // edge ids of the output vertices; sharded Level 1 (cx_postprocess3d_shard_*)
+    cxp_dev ever;                                 // vertices something was ever merged into: u8[nv] before | u8[nv2] after the compaction
     bool keys_valid = false;
     struct {
         bool open = false;            // between cx_postprocess3d_shard_begin and _finish
@@ -72,7 +73,7 @@ void cx_post_free(cx_ctx* ctx) {
     cx_post_state* S = ctx->post;
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
-                      &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd,
+                      &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd, &S->ever,
                       &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
@@ -358,7 +359,10 @@ __global__ void cxp_k_weld_lookup(const double* pts, uint32_t nv, cxp_weld_param
 // involved (optional): flags the vertices something was merged INTO.  Two different triangles of the march can only become the
 // same vertex set through a merge, and then both contain such a vertex: the dedupe that follows only has to look at triangles
 // with a flagged vertex (a few per cent of a mesh) instead of putting all of them through its table of compare-and-swaps.
-__global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uint32_t* map, const u64* parent, uint8_t* involved = nullptr) {
+// ever (optional): the same flags, never cleared between the stages -- an edge of the march's mesh can only come to lie on more than
+// two triangles through such a vertex (cxp_k_edges_block).
+__global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uint32_t* map, const u64* parent, uint8_t* involved = nullptr,
+                            uint8_t* ever = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
     uint32_t v[3];
@@ -368,7 +372,10 @@ __global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uin
         uint32_t par;
         v[s] = map ? map[x] : cxp_find(parent, x, par);
         tri[(size_t)t * 3 + s] = (int32_t)v[s];
-        if (involved && v[s] != x) involved[v[s]] = 1;
+        if (v[s] != x) {
+            if (involved) involved[v[s]] = 1;
+            if (ever) ever[v[s]] = 1;
+        }
     }
     if (v[0] == v[1] || v[0] == v[2] || v[1] == v[2]) alive[t] = 0;
 }
@@ -520,12 +527,13 @@ __global__ void cxp_k_alive_u32(const uint8_t* alive, uint32_t nt, uint32_t* out
 }
 // (keys: the priority = edge id of every surviving vertex travels with it; told: where a surviving triangle came from)
 __global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const uint32_t* newid, uint32_t nv, double* out,
-                                  const uint32_t* keys, uint32_t* keys_out) {
+                                  const uint32_t* keys, uint32_t* keys_out, const uint8_t* ever = nullptr, uint8_t* ever_out = nullptr) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv || !used[v]) return;
 #pragma unroll
     for (int a = 0; a < 3; a++) out[(size_t)newid[v] * 3 + a] = pts[(size_t)v * 3 + a];
     if (keys_out) keys_out[newid[v]] = keys[v];
+    if (ever_out) ever_out[newid[v]] = ever[v];
 }
 __global__ void cxp_k_compact_tri(const int32_t* tri, const uint8_t* alive, const uint32_t* tnew, const uint32_t* vnew, uint32_t nt,
                                   int32_t* out, uint32_t* told) {
@@ -674,6 +682,144 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
     for (int e = 0; e < 3; e++) {
         const uint32_t o = others[(size_t)t * 3 + e];
         if (o != CXP_NONE) cxp_union(parent, nullptr, t, o, 0u);
+    }
+}
+// ---- the same linking for the MARCH'S OWN meshes, most of it in LDS ------------------------------------------------------
+// An edge of the march's mesh lies on at most two triangles (a face of a tetrahedron has two sides), unless weld or clean-up
+// merged something into one of its end points (`ever`).  Triangle ids follow the march: 86 % of the edges of the bench mesh join two
+// triangles within the same 256 ids, 92 % within 1024 (tools/edge_locality.py).  A workgroup takes CXP_EB consecutive triangles and
+// matches their edges in an LDS hash table; visitors of one edge are united in the block's LDS forest.  An edge found twice whose
+// end points were never merged into is DONE and never sees the global table.  Only the rest goes through the device-scope table,
+// one visit per block (the slot's taker): edges with one triangle in the block (the partner is in another block, or there is none)
+// and edges with a flagged end point (their visitors in other blocks do the same, so three or more triangles on one edge still
+// meet at the claimant, as in cxp_k_edges_link).  The table's compare-and-swaps (executed at the memory side) and the random
+// 16-byte reads of the link step shrink to a sixth.  others[t*3+e]: CXP_NONE = settled here, CXP_FAR = look the edge up in the
+// second kernel.
+#ifndef CXP_EB
+#define CXP_EB 512u
+#endif
+#define CXP_EB_PER (CXP_EB / 256u)      // triangles per thread
+#define CXP_EB_SLOTS (4u * CXP_EB)       // > 3 * CXP_EB: an insert always finds a free slot
+#define CXP_FAR 0xFFFFFFFEu
+__global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uint32_t nt, const uint8_t* ever, u64* tab, u64 mask, u64 mult,
+                                                         u64* parent, uint32_t* others) {
+    __shared__ u64 lkey[CXP_EB_SLOTS];
+    __shared__ uint16_t lfirst[CXP_EB_SLOTS];
+    __shared__ uint8_t lpair[CXP_EB_SLOTS];
+    __shared__ uint32_t lp[CXP_EB];
+    const uint32_t b0 = blockIdx.x * CXP_EB;
+    for (uint32_t x = threadIdx.x; x < CXP_EB_SLOTS; x += 256u) { lkey[x] = CXP_EMPTY; lpair[x] = 0; }
+    for (uint32_t x = threadIdx.x; x < CXP_EB; x += 256u) lp[x] = x;
+    uint32_t lo_[CXP_EB_PER][3], hi_[CXP_EB_PER][3];
+    uint32_t flag_[CXP_EB_PER][3];
+    uint16_t slot_[CXP_EB_PER][3];
+    // the triangles and the flags of their end points: all requested before anything is used
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EB_PER; i++) {
+        const uint32_t t = min(b0 + i * 256u + threadIdx.x, nt - 1u);
+        const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            lo_[i][e] = min(v[e], v[(e + 1) % 3]);
+            hi_[i][e] = max(v[e], v[(e + 1) % 3]);
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EB_PER; i++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) flag_[i][e] = (uint32_t)ever[lo_[i][e]] | (uint32_t)ever[hi_[i][e]];
+    __syncthreads();
+    // pass 1: every edge visit finds or takes its slot; the taker leaves its triangle there
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EB_PER; i++) {
+        const uint32_t lt = i * 256u + threadIdx.x;
+        if (b0 + lt >= nt) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const u64 key = ((u64)lo_[i][e] << 32) | (u64)hi_[i][e];
+            uint32_t slot = (uint32_t)cxp_mix(key) & (CXP_EB_SLOTS - 1u);
+            for (uint32_t probes = 0; probes < CXP_EB_SLOTS; probes++) {      // (always ends earlier: the table cannot fill up)
+                const u64 cur = atomicCAS((unsigned long long*)&lkey[slot], (unsigned long long)CXP_EMPTY, (unsigned long long)key);
+                if (cur == CXP_EMPTY) { lfirst[slot] = (uint16_t)lt; break; }
+                if (cur == key) break;
+                slot = (slot + 1u) & (CXP_EB_SLOTS - 1u);
+            }
+            slot_[i][e] = (uint16_t)slot;
+        }
+    }
+    __syncthreads();
+    // pass 2: the other visitors of a slot unite with the taker in the block's forest
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EB_PER; i++) {
+        const uint32_t lt = i * 256u + threadIdx.x;
+        if (b0 + lt >= nt) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const uint32_t first = lfirst[slot_[i][e]];
+            if (first == lt) continue;
+            lpair[slot_[i][e]] = 1;
+            uint32_t a = lt, b = first;
+            for (;;) {
+                a = cxp_lfind(lp, a);
+                b = cxp_lfind(lp, b);
+                if (a == b) break;
+                const uint32_t win = min(a, b), lose = max(a, b);
+                if (atomicCAS(&lp[lose], lose, win) == lose) break;
+            }
+        }
+    }
+    __syncthreads();
+    // pass 3: what the block could not settle claims its place in the global table: an edge with one visitor here, and -- through
+    // its taker alone, the block's other visitors are united with it already -- an edge with a flagged end point (its visitors in
+    // OTHER blocks do the same and meet at the claimant)
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EB_PER; i++) {
+        const uint32_t lt = i * 256u + threadIdx.x, t = b0 + lt;
+        if (t >= nt) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const uint32_t lo = lo_[i][e], hi = hi_[i][e];
+            const bool taker = lfirst[slot_[i][e]] == lt;
+            uint32_t far = CXP_NONE;
+            if (taker && (flag_[i][e] != 0u || !lpair[slot_[i][e]])) {
+                far = CXP_FAR;
+                const u64 key = ((u64)lo << 32) | (u64)hi;
+                u64 slot = cxp_edge_slot(lo, hi, mask, mult);
+                for (;;) {
+                    u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
+                    if (cur == CXP_EMPTY) { __hip_atomic_store(&tab[2 * slot + 1], (u64)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (cur == key) break;
+                    slot = (slot + 1) & mask;
+                }
+            }
+            others[(size_t)t * 3 + e] = far;
+        }
+    }
+    // the block's forest into the global parent words (nobody else touches them in this kernel); roots = smallest ids
+    for (uint32_t x = threadIdx.x; x < CXP_EB; x += 256u) {
+        if (b0 + x >= nt) continue;
+        const uint32_t r = cxp_lfind(lp, x);
+        if (r != x) parent[b0 + x] = (u64)(b0 + r);      // parity 0
+    }
+}
+// second kernel: the visitors the first one sent to the global table unite with the edge's claimant
+__global__ void cxp_k_edges_link_far(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, const uint32_t* others, u64* parent) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t f[3] = {others[(size_t)t * 3], others[(size_t)t * 3 + 1], others[(size_t)t * 3 + 2]};
+    if (f[0] != CXP_FAR && f[1] != CXP_FAR && f[2] != CXP_FAR) return;
+    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        if (f[e] != CXP_FAR) continue;
+        const uint32_t p = v[e], q = v[(e + 1) % 3];
+        const uint32_t lo = min(p, q), hi = max(p, q);
+        const u64 key = ((u64)lo << 32) | (u64)hi;
+        u64 slot = cxp_edge_slot(lo, hi, mask, mult);
+        while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every such key was inserted by the first kernel
+        const uint32_t o = (uint32_t)tab[2 * slot + 1];
+        if (o != t) cxp_union(parent, nullptr, t, o, 0u);
     }
 }
 // per component (root triangle): largest x over its vertices.  cls (sharded Level 1 only): per triangle, > 2 = a copy of a
@@ -940,7 +1086,8 @@ static int cxp_flatten(cx_ctx* ctx, u64* parent, uint32_t n, uint32_t* changed_d
 // Shared tail: clean (optional) + compaction + orientation (optional) on S->pts (nv x 3 doubles),
 // S->tri (nt x 3), S->alive.  prio = vertex priorities.  Results in S->pts_out / S->tri_out.
 static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, bool do_clean, bool do_orient,
-                            uint32_t* tprio3, int64_t* out_counts, bool coherent, uint8_t* involved = nullptr, const cxp_shard* shard = nullptr) {
+                            uint32_t* tprio3, int64_t* out_counts, bool coherent, uint8_t* involved = nullptr, const cxp_shard* shard = nullptr,
+                            uint8_t* ever = nullptr) {   // ever != nullptr: the march's own mesh (cxp_k_edges_block); u8[nv] flags, room for nv more behind them
     int rc;
     double* pts = (double*)S->pts.p;
     uint32_t* prio = (uint32_t*)S->prio.p;
@@ -955,7 +1102,7 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nv)), dim3(256), 0, st, parent2, nv);
         hipLaunchKernelGGL(cxp_k_degenerate, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, pts, parent2, prio);
         if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
-        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2, involved);
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2, involved, ever);
         const u64 tsz = cxp_table_size(nt);
         if ((rc = cxp_reserve(ctx, S->tkeys, tsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
@@ -999,7 +1146,8 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     int32_t* tri2 = (int32_t*)S->tri_out.p;
     uint32_t* keys2 = (uint32_t*)S->keys_out.p;
     if (nt2) {
-        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2, (const uint32_t*)prio, keys2);
+        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2, (const uint32_t*)prio, keys2,
+                           (const uint8_t*)ever, ever ? ever + nv : nullptr);
         hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, tnew, vnew, nt, tri2, told);
     }
     S->nv_out = nv2; S->nt_out = nt2;
@@ -1027,14 +1175,21 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         uint32_t* cstart = (uint32_t*)(cmaxv + nt2);
         hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
         const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
-        hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-        if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
-            uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 28 bytes per triangle that the component tables take below
-            hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
+        uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 28 bytes per triangle that the component tables take below
+        if (ever && coherent && !cx_debug_knob("CX_LINK_GLOBAL", 0)) {
+            // the march's own mesh: edges matched inside a block of triangles never reach the global table
+            hipLaunchKernelGGL(cxp_k_edges_block, dim3((nt2 + CXP_EB - 1u) / CXP_EB), dim3(256), 0, st, tri2, nt2, (const uint8_t*)(ever + nv), etab, esz - 1,
                                emult, parent, others);
-            hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
-        } else
-            hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
+            hipLaunchKernelGGL(cxp_k_edges_link_far, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, (const uint32_t*)others, parent);
+        } else {
+            hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
+            if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
+                hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
+                                   emult, parent, others);
+                hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
+            } else
+                hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
+        }
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t)), st));
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
@@ -1242,6 +1397,12 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
     uint32_t* tprio3 = (uint32_t*)(tri + (size_t)(nt + 1) * 3);
     uint8_t* alive = (uint8_t*)S->alive.p;
     uint32_t* misc = (uint32_t*)S->misc.p;
+    uint8_t* ever = nullptr;      // the march's own crossings: which vertices weld or clean-up merge something into
+    if (nv && nt && edge_crossings && coherent) {
+        if ((rc = cxp_reserve(ctx, S->ever, 2 * (size_t)nv + 64))) return rc;
+        ever = (uint8_t*)S->ever.p;
+        CXP_HIP(ctx, hipMemsetAsync(ever, 0, nv, st));
+    }
     if (nv && nt) {
         hipLaunchKernelGGL(cxp_k_tri_prio, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, prio, nt, tprio3);
         // ---- weld (tetrahedral.py:190-215): expander = int(10000 / corner)
@@ -1263,7 +1424,7 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
         // (`moved` is free until the tiny collapse: it carries the flags)
         uint8_t* involved = (coherent && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr;
         if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
-        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr, involved);
+        hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr, involved, ever);
         const u64 tsz = cxp_table_size(nt);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
@@ -1301,7 +1462,7 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
     }
     // (`moved` is free again after cxp_k_move)
     return cxp_clean_orient(ctx, S, nv, nt, do_clean, true, tprio3, counts, coherent,
-                            (coherent && nv && nt && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr, shard);
+                            (coherent && nv && nt && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr, shard, ever);
 }
 
 extern "C" int cx_postprocess3d_ex(cx_ctx* ctx, uint32_t flags, double smooth, int64_t* out_counts) {

@@ -541,13 +541,16 @@ def exchange_boundary_lists(L, rank, world, dist, device):
     return got
 
 
-def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0, clean=True, dist=None, context=None, download=True):
+def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0, clean=True, dist=None, context=None, download=True,
+                         object_group=None):
     """Level 1 of a volume spread over the ranks in slabs along axis 0, WITHOUT gathering the mesh: every rank returns its own
     part -- dict(points (V,3) float64 in the coordinates of the whole volume, triangles (T,3) int32 into them, wound as the
     reference winds the whole surface, keys (V,) int64 edge id of every vertex in the whole volume (vertices next to a slab
     boundary appear on both sides with the same id and coordinates), counts, stats (rank 0), ms, boundary).  The union over the
     ranks is the Level-1 mesh of the undivided volume (assemble_level1).  Per-triangle data only travels between neighbours
-    (12 bytes per boundary triangle, device to device with RCCL); rank 0 sees label pairs and candidates."""
+    (12 bytes per boundary triangle, device to device with RCCL); rank 0 sees label pairs and candidates.
+    object_group: process group for the two small object collectives (gather_object / scatter_object_list), e.g. a gloo group
+    with a timeout beside an RCCL job; default: the default group."""
     import time
     import torch
     from . import _ffi
@@ -591,12 +594,12 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
             pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
         small = shard_small(L, pairs, unmatched)
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object(small, gathered, dst=0)
+        dist.gather_object(small, gathered, dst=0, group=object_group)
         answers = [None] * world
         if rank == 0:
             answers, stats = merge_shard_components(gathered)
         box = [None]
-        dist.scatter_object_list(box, answers if rank == 0 else None, src=0)
+        dist.scatter_object_list(box, answers if rank == 0 else None, src=0, group=object_group)
         mine = box[0]
     t3 = time.perf_counter()
     out = shard_finish(ctx, L, mine, download)
