@@ -157,6 +157,30 @@ __device__ __forceinline__ void cxp_union(u64* parent, const uint32_t* prio, uin
     }
 }
 
+// The same for forests without parities and priorities (connectivity only: the march's own meshes), with path HALVING: on the way
+// up every node is pointed at its grandparent -- with a device-scope store, which is executed where the compare-and-swaps are, so
+// the two cannot disagree (see above) -- and only ever at an ancestor.  Most unions of a large component find both sides in one
+// tree already; without the halving each of them walks the whole chain again (roots are the smallest ids, not the flattest trees).
+__device__ __forceinline__ uint32_t cxp_find0(u64* parent, uint32_t x) {
+    for (;;) {
+        const uint32_t p = (uint32_t)__hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        const uint32_t g = (uint32_t)__hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == p) return p;
+        __hip_atomic_store(&parent[x], (u64)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = g;
+    }
+}
+__device__ __forceinline__ void cxp_union0(u64* parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        const uint32_t ra = cxp_find0(parent, a), rb = cxp_find0(parent, b);
+        if (ra == rb) return;
+        const uint32_t win = min(ra, rb), lose = max(ra, rb);
+        if (atomicCAS(&parent[lose], (u64)lose, (u64)win) == (u64)lose) return;
+        a = ra; b = rb;       // somebody else moved the loser: go on from the roots seen so far
+    }
+}
+
 __global__ void cxp_k_iota64(u64* a, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = (u64)i;
@@ -681,7 +705,7 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const uint32_t o = others[(size_t)t * 3 + e];
-        if (o != CXP_NONE) cxp_union(parent, nullptr, t, o, 0u);
+        if (o != CXP_NONE) cxp_union0(parent, t, o);
     }
 }
 // ---- the same linking for the MARCH'S OWN meshes, most of it in LDS ------------------------------------------------------
@@ -819,7 +843,7 @@ __global__ void cxp_k_edges_link_far(const int32_t* tri, uint32_t nt, const u64*
         u64 slot = cxp_edge_slot(lo, hi, mask, mult);
         while (tab[2 * slot] != key) slot = (slot + 1) & mask;   // every such key was inserted by the first kernel
         const uint32_t o = (uint32_t)tab[2 * slot + 1];
-        if (o != t) cxp_union(parent, nullptr, t, o, 0u);
+        if (o != t) cxp_union0(parent, t, o);
     }
 }
 // per component (root triangle): largest x over its vertices.  cls (sharded Level 1 only): per triangle, > 2 = a copy of a
