@@ -12,3 +12,5 @@ cp gpurun_out/prof/kernel_stats_4d.csv profiles/${R}_kernel_stats_4d.csv
 cp gpurun_out/prof/kernel_stats_level1_512.csv profiles/${R}_kernel_stats_level1_512.csv
 cp gpurun_out/prof/kernel_stats_512_one_stream.csv profiles/${R}_kernel_stats_512_one_stream.csv
 cp gpurun_out/prof/bench_one_stream_under_rocprof.json profiles/${R}_bench_line_512_one_stream_under_rocprof.json
+cp gpurun_out/prof/bench_level1_512.json profiles/${R}_bench_level1_512.json
+grep -v amdgpu.ids gpurun_out/prof/shard_time_512x8.txt > profiles/${R}_shard_time_512x8.txt

@@ -21,6 +21,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/traffic.py gpurun_out/pmc gpurun_out/prof > gpurun_out/prof/traffic.log
 timeout -k 10 300 python3 tools/bench_levels.py 512 > gpurun_out/prof/bench_levels_512.json 2> gpurun_out/prof/levels.err
+# Level 1 of the bench mesh: kernel trace of three post-passes (tools/l1_stats.py prints the per-pass table), and what one rank of an
+# 8-way sharded Level 1 does (one GPU playing the ranks)
+rm -rf gpurun_out/prof/ktl1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/ktl1 -- python3 tools/bench_level1.py 512 > gpurun_out/prof/bench_level1_512.json 2> gpurun_out/prof/ktl1.err
+f=$(find gpurun_out/prof/ktl1 -name "*kernel_stats.csv" | head -1)
+grep -E "^\"Name\"|cxp_k|cx_k" "$f" > gpurun_out/prof/kernel_stats_level1_512.csv
+timeout -k 10 300 python3 tools/shard_time.py 512 8 > gpurun_out/prof/shard_time_512x8.txt 2> gpurun_out/prof/shard.err
 # config 4 (4-D): bench line without the profiler, then the kernel trace of the same command
 timeout -k 10 300 python3 tools/bench4d.py > gpurun_out/prof/bench4d.json 2> gpurun_out/prof/bench4d.err
 bash tools/prof4d.sh > /dev/null
