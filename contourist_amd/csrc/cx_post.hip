@@ -2372,7 +2372,7 @@ __global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u
             if (o >= t) continue;                                  // each unordered pair once
             const double l2 = fmax(lo, ttime[(size_t)o * 2]), h2 = fmin(hi, ttime[(size_t)o * 2 + 1]);
             if (!(l2 < h2)) continue;
-            cxp_union(parent, nullptr, t, o, 0u);   // connectivity only: the slices are wound alike (cxp_morph_slices)
+            cxp_union0(parent, t, o);   // connectivity only: the slices are wound alike (cxp_morph_slices); path halving (cxp_find0)
         }
     }
 }

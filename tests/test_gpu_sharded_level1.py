@@ -24,6 +24,10 @@ def fields():
     # values on a coarse set: equal samples, crossings exactly at lattice points, degenerate triangles everywhere
     F["steps"] = ((np.round(np.sin(x * 0.3) * np.sin(y * 0.31) * np.sin(z * 0.29) * 4) / 4).astype(np.float32), 0.25)
     F["noise"] = (rng.rand(n, n, n).astype(np.float32), 0.5)
+    # one ball in the first slab, one that just reaches INTO the copies of the next slab's cells, nothing anywhere else: ranks
+    # without a single triangle, components that consist of a neighbour's triangles only
+    F["lonely"] = (np.minimum(np.sqrt((x - 9.0) ** 2 + (y - 30) ** 2 + (z - 30) ** 2) - 5.0,
+                              np.sqrt((x - 36.6) ** 2 + (y - 20) ** 2 + (z - 50) ** 2) - 1.2).astype(np.float32), 0.0)
     return F
 
 
@@ -65,7 +69,7 @@ def canon(keys, tris):
     return k[np.lexsort(k.T[::-1])]
 
 
-@pytest.mark.parametrize("name", ["gyroid", "balls", "steps", "noise"])
+@pytest.mark.parametrize("name", ["gyroid", "balls", "steps", "noise", "lonely"])
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_level1_equals_the_undivided_volume(name, world):
     from contourist_amd import _ffi, distributed
