@@ -304,6 +304,9 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         }
         // vertex and triangle stages, several levels side by side: level l on stream l % nstr (0 = the context's stream), the side
         // streams with their own info words (the staged kernels of one level hand over through them)
+        // (Also measured and dropped: the levels in two groups, the second group's pass over the samples on its own stream while the
+        // first group is in its emit stages -- 2.59 against 2.35 ms: the stream kernel works the samples once per level, 1.03 ms for 8
+        // levels, bound by its own instructions as much as by HBM, and the emit stages are issue-bound too: nothing to overlap.)
         // Two by default: three and four were measured (CX_DEBUG=1 CX_LEVELS_STREAMS=n, tools/levels_streams.py) and change nothing
         // (2.33-2.42 ms for 8 levels of the bench grid whatever n): two levels in flight already fill the chip.
         int nstr = (nlevels > 1 && !cx_debug_knob("CX_LEVELS_ONE_STREAM", 0)) ? 2 : 1;
