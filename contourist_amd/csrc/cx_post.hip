@@ -389,14 +389,21 @@ __global__ void cxp_k_remap(int32_t* tri, uint8_t* alive, uint32_t nt, const uin
                             uint8_t* ever = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
+    // the three indices, then the three look-ups, then the stores: written as one loop -- load, look up, store -- every load waited
+    // for the store before it (they may alias as far as the compiler knows): seven round trips one after the other per triangle
+    const uint32_t x[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
     uint32_t v[3];
+    if (map) {
+        v[0] = map[x[0]]; v[1] = map[x[1]]; v[2] = map[x[2]];
+    } else {
+        uint32_t par;
+#pragma unroll
+        for (int s = 0; s < 3; s++) v[s] = cxp_find(parent, x[s], par);
+    }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-        const uint32_t x = (uint32_t)tri[(size_t)t * 3 + s];
-        uint32_t par;
-        v[s] = map ? map[x] : cxp_find(parent, x, par);
-        tri[(size_t)t * 3 + s] = (int32_t)v[s];
-        if (v[s] != x) {
+        if (v[s] != x[s]) {
+            tri[(size_t)t * 3 + s] = (int32_t)v[s];
             if (involved) involved[v[s]] = 1;
             if (ever) ever[v[s]] = 1;
         }
@@ -543,7 +550,8 @@ __global__ void cxp_k_degenerate(const int32_t* tri, uint8_t* alive, uint32_t nt
 __global__ void cxp_k_mark_used(const int32_t* tri, const uint8_t* alive, uint32_t nt, uint32_t* used) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
-    used[tri[(size_t)t * 3]] = 1u; used[tri[(size_t)t * 3 + 1]] = 1u; used[tri[(size_t)t * 3 + 2]] = 1u;
+    const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];   // all loads before the first store
+    used[a] = 1u; used[b] = 1u; used[c] = 1u;
 }
 __global__ void cxp_k_alive_u32(const uint8_t* alive, uint32_t nt, uint32_t* out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,18 +562,24 @@ __global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const
                                   const uint32_t* keys, uint32_t* keys_out, const uint8_t* ever = nullptr, uint8_t* ever_out = nullptr) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv || !used[v]) return;
-#pragma unroll
-    for (int a = 0; a < 3; a++) out[(size_t)newid[v] * 3 + a] = pts[(size_t)v * 3 + a];
-    if (keys_out) keys_out[newid[v]] = keys[v];
-    if (ever_out) ever_out[newid[v]] = ever[v];
+    // everything is loaded before the first store (stores and loads may alias as far as the compiler knows: it waited for each)
+    const uint32_t id = newid[v];
+    const double x = pts[(size_t)v * 3], y = pts[(size_t)v * 3 + 1], z = pts[(size_t)v * 3 + 2];
+    const uint32_t k = keys_out ? keys[v] : 0u;
+    const uint8_t e = ever_out ? ever[v] : (uint8_t)0;
+    out[(size_t)id * 3] = x; out[(size_t)id * 3 + 1] = y; out[(size_t)id * 3 + 2] = z;
+    if (keys_out) keys_out[id] = k;
+    if (ever_out) ever_out[id] = e;
 }
 __global__ void cxp_k_compact_tri(const int32_t* tri, const uint8_t* alive, const uint32_t* tnew, const uint32_t* vnew, uint32_t nt,
                                   int32_t* out, uint32_t* told) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
-#pragma unroll
-    for (int s = 0; s < 3; s++) out[(size_t)tnew[t] * 3 + s] = (int32_t)vnew[tri[(size_t)t * 3 + s]];
-    if (told) told[tnew[t]] = t;
+    const uint32_t id = tnew[t];
+    const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];
+    const uint32_t na = vnew[a], nb = vnew[b], nc = vnew[c];      // three look-ups in flight, then the stores
+    out[(size_t)id * 3] = (int32_t)na; out[(size_t)id * 3 + 1] = (int32_t)nb; out[(size_t)id * 3 + 2] = (int32_t)nc;
+    if (told) told[id] = t;
 }
 
 // ---- orientation ---------------------------------------------------------------------------------------
