@@ -598,7 +598,10 @@ __device__ __forceinline__ uint32_t cxp_edge_dir(const int32_t* tri, uint32_t t,
 // the whole chip: PMC TCC_ATOMIC / WRITE_SIZE), so they are what this stage is bound by: ONE read-modify-write per
 // edge visit claims the key, the claimant publishes its triangle with a plain store (kernel 1); after the kernel
 // boundary every other visitor finds the slot again with plain loads and links itself to the claimant (kernel 2).
+// (mult == 0: plain hashing -- the small first table of cxp_k_edges_block, where the edges that arrive are the ones around merged
+// vertices, clustered in space: rows per vertex ran into each other there, chains of hundreds of probes)
 __device__ __forceinline__ u64 cxp_edge_slot(uint32_t lo, uint32_t hi, u64 mask, u64 mult) {
+    if (mult == 0) return cxp_mix(((u64)lo << 32) | (u64)hi) & mask;
     return ((u64)lo * mult + (cxp_mix((u64)hi) % mult)) & mask;
 }
 __global__ void cxp_k_edges_claim(const int32_t* tri, uint32_t nt, u64* tab, u64 mask, u64 mult) {
@@ -739,8 +742,10 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
 #define CXP_EB_PER (CXP_EB / 256u)      // triangles per thread
 #define CXP_EB_SLOTS (4u * CXP_EB)       // > 3 * CXP_EB: an insert always finds a free slot
 #define CXP_FAR 0xFFFFFFFEu
+// (probe_limit / overflow: the global table is first sized for what usually reaches it -- a sixth of the edges -- and a probe
+// sequence that long says it was too small for this mesh: the host repeats the stage with the table of the worst case)
 __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uint32_t nt, const uint8_t* ever, u64* tab, u64 mask, u64 mult,
-                                                         u64* parent, uint32_t* others) {
+                                                         u64* parent, uint32_t* others, uint32_t probe_limit, uint32_t* overflow) {
     __shared__ u64 lkey[CXP_EB_SLOTS];
     __shared__ uint16_t lfirst[CXP_EB_SLOTS];
     __shared__ uint8_t lpair[CXP_EB_SLOTS];
@@ -823,7 +828,8 @@ __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uin
                 far = CXP_FAR;
                 const u64 key = ((u64)lo << 32) | (u64)hi;
                 u64 slot = cxp_edge_slot(lo, hi, mask, mult);
-                for (;;) {
+                for (uint32_t probes = 0;; probes++) {
+                    if (probes >= probe_limit) { *overflow = 1u; break; }
                     u64 cur = __hip_atomic_load(&tab[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cur == CXP_EMPTY) cur = atomicCAS(&tab[2 * slot], CXP_EMPTY, key);
                     if (cur == CXP_EMPTY) { __hip_atomic_store(&tab[2 * slot + 1], (u64)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -1200,33 +1206,55 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         // ---- orientation: edge table + parity union-find over triangles
         // (measured and dropped: clearing the table on a second stream while weld / tiny collapse / clean-up run -- no gain, the fill
         // takes from them what it saves)
-        const u64 esz = cxp_edge_table_size((size_t)nt2 * 3);
-        if ((rc = cxp_reserve(ctx, S->tkeys, 2 * esz * sizeof(u64)))) return rc;
+        const u64 esz_full = cxp_edge_table_size((size_t)nt2 * 3);
+        const bool blocks = ever && coherent && !cx_debug_knob("CX_LINK_GLOBAL", 0);
+        // the march's own mesh: most edges are settled inside a block of triangles and never reach the table (cxp_k_edges_block): a
+        // sixth of them for the bench mesh.  First attempt: one slot per TRIANGLE (a quarter of the worst case: 0.5 instead of 2 GB to
+        // clear and to probe); a mesh that needs more says so and the stage is repeated with the full table.
+        u64 esz = esz_full;
+        if (blocks && !cx_debug_knob("CX_EDGE_TABLE_FULL", 0)) {
+            esz = 1024;
+            while (esz < (u64)nt2 + 16) esz <<= 1;
+            if (cx_debug_knob("CX_EDGE_TABLE_TINY", 0)) esz = 1024;     // tests: force the repeat
+            if (esz > esz_full) esz = esz_full;
+        }
         if ((rc = cxp_reserve(ctx, S->parent, (size_t)nt2 * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->comp, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t))))) return rc;
-        u64* etab = (u64*)S->tkeys.p;
-        hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
         u64* parent = (u64*)S->parent.p;
         u64* cmaxx = (u64*)S->comp.p;
         u64* cbest = cmaxx + nt2;
         u64* cmaxv = cbest + nt2;
         uint32_t* cstart = (uint32_t*)(cmaxv + nt2);
-        hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
-        const u64 emult = std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
         uint32_t* others = (uint32_t*)S->comp.p;   // 12 of the 28 bytes per triangle that the component tables take below
-        if (ever && coherent && !cx_debug_knob("CX_LINK_GLOBAL", 0)) {
-            // the march's own mesh: edges matched inside a block of triangles never reach the global table
-            hipLaunchKernelGGL(cxp_k_edges_block, dim3((nt2 + CXP_EB - 1u) / CXP_EB), dim3(256), 0, st, tri2, nt2, (const uint8_t*)(ever + nv), etab, esz - 1,
-                               emult, parent, others);
-            hipLaunchKernelGGL(cxp_k_edges_link_far, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, (const uint32_t*)others, parent);
-        } else {
-            hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
-            if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
-                hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
-                                   emult, parent, others);
-                hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
-            } else
-                hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
+        for (;;) {
+            if ((rc = cxp_reserve(ctx, S->tkeys, 2 * esz * sizeof(u64)))) return rc;
+            u64* etab = (u64*)S->tkeys.p;
+            // (measured and dropped: clearing the table on a second stream while weld / tiny collapse / clean-up run -- no gain, the fill
+            // takes from them what it saves)
+            hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, etab, (size_t)(2 * esz), CXP_EMPTY);
+            hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(nt2)), dim3(256), 0, st, parent, nt2);
+            const u64 emult = (blocks && esz != esz_full) ? 0 : std::max<u64>(1, esz / std::max<u64>(1, (u64)nv2));
+            if (blocks) {
+                CXP_HIP(ctx, hipMemsetAsync(misc + 12, 0, sizeof(uint32_t), st));
+                hipLaunchKernelGGL(cxp_k_edges_block, dim3((nt2 + CXP_EB - 1u) / CXP_EB), dim3(256), 0, st, tri2, nt2, (const uint8_t*)(ever + nv), etab, esz - 1,
+                                   emult, parent, others, esz == esz_full ? 0xFFFFFFFFu : 256u, misc + 12);
+                if (esz != esz_full) {
+                    uint32_t over = 0;
+                    CXP_HIP(ctx, hipMemcpyAsync(&over, misc + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    CXP_HIP(ctx, hipStreamSynchronize(st));
+                    if (over) { esz = esz_full; continue; }
+                }
+                hipLaunchKernelGGL(cxp_k_edges_link_far, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, (const uint32_t*)others, parent);
+            } else {
+                hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
+                if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
+                    hipLaunchKernelGGL(cxp_k_edges_link_local, dim3((nt2 + CXP_LINK_BLOCK - 1u) / CXP_LINK_BLOCK), dim3(256), 0, st, tri2, nt2, etab, esz - 1,
+                                       emult, parent, others);
+                    hipLaunchKernelGGL(cxp_k_edges_link_cross, dim3(cxp_blocks(nt2)), dim3(256), 0, st, nt2, others, parent);
+                } else
+                    hipLaunchKernelGGL(cxp_k_edges_link, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, parent, coherent ? 1 : 0);
+            }
+            break;
         }
         if ((rc = cxp_flatten(ctx, parent, nt2, misc))) return rc;
         CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)nt2 * (3 * sizeof(u64) + sizeof(uint32_t)), st));

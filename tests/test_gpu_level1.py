@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, golden_names
+from conftest import GOLDEN_DIR, ROOT, golden_names
 
 pytestmark = pytest.mark.gpu
 
@@ -212,3 +212,43 @@ def test_open_mesh_of_separate_triangles():
     # every triangle wound so that its normal_x is positive (each is its own component: surface_geometry.py:99-103)
     n = np.cross(p1[t1[:, 1]] - p1[t1[:, 0]], p1[t1[:, 2]] - p1[t1[:, 0]])
     assert np.all(n[:, 0] > 0)
+
+
+def _level1_digest(extra_env):
+    """Level 1 of a 72^3 noise field in a child process (debug knobs are only read by a process started with CX_DEBUG=1):
+    -> (n_vertices, n_triangles, n_components, sha1 of the oriented triangles written as edge ids)"""
+    import hashlib  # noqa: F401
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from contourist_amd import _ffi
+from test_gpu_sharded_level1 import canon
+A = np.random.RandomState(11).rand(72, 72, 72).astype(np.float32)
+ctx = _ffi.Context(0)
+ctx.upload_grid(A)
+ctx.extract3d(0.5, 1)
+post = ctx.postprocess3d(0)
+pts, tris = ctx.download_level1(post)
+keys = ctx.download_level1_keys(post).astype(np.int64)
+print("DIGEST", post["n_vertices"], post["n_triangles"], post["n_components"], hashlib.sha1(canon(keys, tris).tobytes()).hexdigest())
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ)
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("DIGEST")]
+    assert out.returncode == 0 and lines, out.stderr.decode()[-2000:]
+    return lines[0].split()[1:]
+
+
+def test_linking_paths_agree():
+    """the orientation stage of the march's own meshes links most edges inside blocks of triangles and sends the rest through a
+    global table that is first sized small (cx_post.hip, cxp_k_edges_block).  The same mesh must come out when that table is too
+    small and the stage is repeated with the full one (CX_EDGE_TABLE_TINY), with the full table at once (CX_EDGE_TABLE_FULL), and
+    with every edge through the global table as for a caller's mesh (CX_LINK_GLOBAL): same components, same winding."""
+    base = _level1_digest({})
+    assert int(base[1]) > 100000 and int(base[2]) >= 1
+    for knob in ("CX_EDGE_TABLE_TINY", "CX_EDGE_TABLE_FULL", "CX_LINK_GLOBAL"):
+        assert _level1_digest({"CX_DEBUG": "1", knob: "1"}) == base, knob
