@@ -5,7 +5,9 @@ import os
 import sys
 import time
 
+import gc
 import numpy as np
+gc.disable()   # (a cyclic collection in the middle of a timed call would look like a 70 ms kernel)
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
