@@ -54,6 +54,7 @@ struct cx_post_state {
         uint32_t n1 = 0, n4 = 0, ncand = 0;   // own triangles next to the lower neighbour, copies of the upper neighbour's, open components
     } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
+    cxp_dev mrange;                                     // per block of CXP_SCAN_BLOCK morph triangles: earliest start, latest end of their time ranges
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
     int64_t me_points = 0, me_tris = 0;   // last cx_morph_eval
@@ -74,7 +75,7 @@ void cx_post_free(cx_ctx* ctx) {
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
                       &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd, &S->ever,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->mrange};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -2419,6 +2420,8 @@ __global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u
     }
 }
 
+__global__ void cxp_k_me_block_ranges(const double* ttime, uint32_t nt, double* range);   // with cx_morph_eval, below
+
 extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
     if (!ctx) return CX_ERR_INVALID;
     cx_state4* G = ctx->s4;
@@ -2488,6 +2491,8 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             int32_t* tris = (int32_t*)S->mtris.p;
             hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
             hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, smult, stime, mm, tris, ttime);
+            if ((rc = cxp_reserve(ctx, S->mrange, (size_t)(cxp_blocks(ntri, CXP_SCAN_BLOCK) + 1) * 2 * sizeof(double)))) return rc;
+            hipLaunchKernelGGL(cxp_k_me_block_ranges, dim3(cxp_blocks(ntri, CXP_SCAN_BLOCK)), dim3(256), 0, st, (const double*)ttime, ntri, (double*)S->mrange.p);
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
             const u64 esz = cxp_table_size((size_t)ntri * 3);
@@ -2560,30 +2565,139 @@ __device__ __forceinline__ bool cxp_seg_inside(const double* P4, const int32_t* 
 }
 // (a triangle is visible while all three of its segments exist: lo <= t <= hi with the intersection of their ranges, which
 // cxp_k_tri_segments left per triangle -- 16 bytes read in order instead of 12 gathers through segments and points per triangle)
-__global__ void cxp_k_morph_visible(const double* ttime, const int32_t* tris, uint32_t nt, double t, uint32_t* tflag, uint32_t* sused) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nt) return;
-    const bool vis = ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1];
-    tflag[q] = vis ? 1u : 0u;
-    if (vis) { sused[tris[(size_t)q * 3]] = 1u; sused[tris[(size_t)q * 3 + 1]] = 1u; sused[tris[(size_t)q * 3 + 2]] = 1u; }
+//
+// Ordered compaction without materialised scans: flags are bytes, a workgroup covers CXP_SCAN_BLOCK consecutive elements and counts
+// its flags (first pass), one workgroup turns the block counts into offsets, and the consumer kernels redo the scan INSIDE their
+// block while they write (second pass).  (Until round 3: two full exclusive scans per call -- each three kernels that read and
+// write 4 bytes per element twice -- 15 of the 27 ms of the 64 surfaces of config 4.)
+// time range of every block of CXP_SCAN_BLOCK consecutive morph triangles (once, in cx_morph_triangles): triangle ids follow the march,
+// whose fastest axis is time, so a block lives for a few time layers and cx_morph_eval skips the blocks that do not exist at its t
+// without reading their 16 KB of ranges
+__global__ __launch_bounds__(256) void cxp_k_me_block_ranges(const double* ttime, uint32_t nt, double* range) {
+    __shared__ double s_lo[4], s_hi[4];
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    double lo = 1.0e300, hi = -1.0e300;
+    for (uint32_t k = 0; k < 4 && base + k < nt; k++) {
+        lo = fmin(lo, ttime[(size_t)(base + k) * 2]);
+        hi = fmax(hi, ttime[(size_t)(base + k) * 2 + 1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o));
+        hi = fmax(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63u) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        range[(size_t)blockIdx.x * 2] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
+        range[(size_t)blockIdx.x * 2 + 1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
+    }
 }
-__global__ void cxp_k_morph_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint32_t* sused,
-                                   const uint32_t* snew, double* out) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns || !sused[s]) return;
-    const double* a = P4 + (size_t)segs[(size_t)s * 2] * 4;
-    const double* b = P4 + (size_t)segs[(size_t)s * 2 + 1] * 4;
-    const double lo = a[3], hi = b[3];
-    const double lam = (hi > lo) ? (t - lo) / (hi - lo) : 0.0;
-    double* o = out + (size_t)snew[s] * 3;
-    o[0] = a[0] + lam * (b[0] - a[0]); o[1] = a[1] + lam * (b[1] - a[1]); o[2] = a[2] + lam * (b[2] - a[2]);
+__device__ __forceinline__ uint32_t cxp_block_excl4(const uint32_t v[4], uint32_t* s, uint32_t& block_total) {
+    // exclusive prefix of this thread's 4 consecutive elements within the workgroup of 256 threads (s: 256 words of LDS)
+    const uint32_t t = v[0] + v[1] + v[2] + v[3];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    block_total = s[255];
+    return s[threadIdx.x] - t;
 }
-__global__ void cxp_k_morph_tris(const int32_t* tris, uint32_t nt, const uint32_t* tflag, const uint32_t* tnew, const uint32_t* snew,
-                                 int32_t* out) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nt || !tflag[q]) return;
-    int32_t* o = out + (size_t)tnew[q] * 3;
-    o[0] = (int32_t)snew[tris[(size_t)q * 3]]; o[1] = (int32_t)snew[tris[(size_t)q * 3 + 1]]; o[2] = (int32_t)snew[tris[(size_t)q * 3 + 2]];
+__global__ __launch_bounds__(256) void cxp_k_me_visible(const double* ttime, const int32_t* tris, uint32_t nt, double t, uint8_t* tflag, uint8_t* sused,
+                                                        uint32_t* tcount, const double* range) {
+    __shared__ uint32_t s_n;
+    if (!(range[(size_t)blockIdx.x * 2] <= t && t <= range[(size_t)blockIdx.x * 2 + 1])) {      // nothing of this block exists at t
+        if (threadIdx.x == 0) tcount[blockIdx.x] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t q = base + k;
+        if (q >= nt) break;
+        const bool vis = ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1];
+        tflag[q] = vis ? 1 : 0;
+        if (vis) {
+            const uint32_t a = (uint32_t)tris[(size_t)q * 3], b = (uint32_t)tris[(size_t)q * 3 + 1], c = (uint32_t)tris[(size_t)q * 3 + 2];
+            sused[a] = 1; sused[b] = 1; sused[c] = 1;
+            n++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) tcount[blockIdx.x] = s_n;
+}
+__global__ __launch_bounds__(256) void cxp_k_me_count(const uint8_t* flags, uint32_t n, uint32_t* count) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t c = 0;
+    if (base + 3u < n) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(flags + base);   // 4 flags (0 / 1 each); base is a multiple of 4
+        c = __popc(w & 0x01010101u);
+    } else {
+        for (uint32_t k = 0; k < 4 && base + k < n; k++) c += flags[base + k] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = s_n;
+}
+__global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint8_t* sused,
+                                                       const uint32_t* soff, uint32_t* snew, double* out) {
+    __shared__ uint32_t s[256];
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) v[k] = (base + k < ns && sused[base + k]) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t id = soff[blockIdx.x] + cxp_block_excl4(v, s, tot);
+    if (tot == 0u) return;       // (after the barriers inside the scan: uniform)
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (!v[k]) continue;
+        const uint32_t sg = base + k;
+        snew[sg] = id;
+        const double* a = P4 + (size_t)segs[(size_t)sg * 2] * 4;
+        const double* b = P4 + (size_t)segs[(size_t)sg * 2 + 1] * 4;
+        const double lo = a[3], hi = b[3];
+        const double lam = (hi > lo) ? (t - lo) / (hi - lo) : 0.0;
+        double* o = out + (size_t)id * 3;
+        o[0] = a[0] + lam * (b[0] - a[0]); o[1] = a[1] + lam * (b[1] - a[1]); o[2] = a[2] + lam * (b[2] - a[2]);
+        id++;
+    }
+}
+__global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32_t nt, const uint8_t* tflag, const uint32_t* toff, const uint32_t* snew,
+                                                     int32_t* out, const double* range, double t) {
+    __shared__ uint32_t s[256];
+    if (!(range[(size_t)blockIdx.x * 2] <= t && t <= range[(size_t)blockIdx.x * 2 + 1])) return;      // cxp_k_me_visible wrote no flags for this block
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) v[k] = (base + k < nt && tflag[base + k]) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t id = toff[blockIdx.x] + cxp_block_excl4(v, s, tot);
+    if (tot == 0u) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (!v[k]) continue;
+        const uint32_t q = base + k;
+        const uint32_t a = snew[tris[(size_t)q * 3]], b = snew[tris[(size_t)q * 3 + 1]], c = snew[tris[(size_t)q * 3 + 2]];
+        int32_t* o = out + (size_t)id * 3;
+        o[0] = (int32_t)a; o[1] = (int32_t)b; o[2] = (int32_t)c;
+        id++;
+    }
 }
 extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
@@ -2595,28 +2709,34 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     if (out_counts) { out_counts[0] = 0; out_counts[1] = 0; }
     if (!ns || !nt) return CX_OK;
     int rc;
-    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(ns + nt + 32) * sizeof(uint32_t)))) return rc;
-    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + nt + 32) * sizeof(uint32_t)))) return rc;
-    uint32_t* sused = (uint32_t*)S->flags.p;
-    uint32_t* tflag = sused + ns + 8;
+    const uint32_t nbs = cxp_blocks(ns, CXP_SCAN_BLOCK), nbt = cxp_blocks(nt, CXP_SCAN_BLOCK);
+    if ((rc = cxp_reserve(ctx, S->flags, (size_t)ns + nt + 256))) return rc;                         // one byte per segment / triangle
+    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + 32) * sizeof(uint32_t)))) return rc;            // new ids of the segments in use
+    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(nbs + nbt + 16) * sizeof(uint32_t)))) return rc;
+    uint8_t* sused = (uint8_t*)S->flags.p;
+    uint8_t* tflag = sused + (((size_t)ns + 127u) & ~(size_t)63u);
     uint32_t* snew = (uint32_t*)S->scan.p;
-    uint32_t* tnew = snew + ns + 8;
+    uint32_t* soff = (uint32_t*)S->blocksums.p;
+    uint32_t* toff = soff + nbs + 8;
     uint32_t* misc = (uint32_t*)S->misc.p;
     const double* P4 = (const double*)S->pts.p;
     const int32_t* segs = (const int32_t*)S->msegs.p;
     const int32_t* tris = (const int32_t*)S->mtris.p;
-    CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns * sizeof(uint32_t), st));
+    CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns, st));
     const double* ttime = (const double*)S->mtime.p + (size_t)(ns + 1) * 2;   // behind the segments' ranges (cx_morph_triangles)
-    hipLaunchKernelGGL(cxp_k_morph_visible, dim3(cxp_blocks(nt)), dim3(256), 0, st, ttime, tris, nt, t, tflag, sused);
-    if ((rc = cxp_scan(ctx, S, sused, snew, ns, misc + 8))) return rc;
-    if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 9))) return rc;
+    if (S->mrange.bytes < (size_t)nbt * 2 * sizeof(double)) { ctx->err = "cx_morph_eval: run cx_morph_triangles first"; return CX_ERR_STATE; }
+    const double* range = (const double*)S->mrange.p;
+    hipLaunchKernelGGL(cxp_k_me_visible, dim3(nbt), dim3(256), 0, st, ttime, tris, nt, t, tflag, sused, toff, range);
+    hipLaunchKernelGGL(cxp_k_me_count, dim3(nbs), dim3(256), 0, st, (const uint8_t*)sused, ns, soff);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, st, soff, nbs, misc + 8, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, st, toff, nbt, misc + 9, (unsigned long long*)nullptr);
     uint32_t tot[2] = {0, 0};
     CXP_HIP(ctx, hipMemcpyAsync(tot, misc + 8, sizeof(tot), hipMemcpyDeviceToHost, st));
     CXP_HIP(ctx, hipStreamSynchronize(st));
     if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(tot[0] + 1) * 3 * sizeof(double)))) return rc;
     if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(tot[1] + 1) * 3 * sizeof(int32_t)))) return rc;
-    if (tot[0]) hipLaunchKernelGGL(cxp_k_morph_points, dim3(cxp_blocks(ns)), dim3(256), 0, st, P4, segs, ns, t, sused, snew, (double*)S->pts_out.p);
-    if (tot[1]) hipLaunchKernelGGL(cxp_k_morph_tris, dim3(cxp_blocks(nt)), dim3(256), 0, st, tris, nt, tflag, tnew, snew, (int32_t*)S->tri_out.p);
+    if (tot[0]) hipLaunchKernelGGL(cxp_k_me_points, dim3(nbs), dim3(256), 0, st, P4, segs, ns, t, (const uint8_t*)sused, (const uint32_t*)soff, snew, (double*)S->pts_out.p);
+    if (tot[1]) hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, (const uint8_t*)tflag, (const uint32_t*)toff, (const uint32_t*)snew, (int32_t*)S->tri_out.p, range, t);
     CXP_HIP(ctx, hipGetLastError());
     S->me_points = tot[0]; S->me_tris = tot[1];
     if (out_counts) { out_counts[0] = tot[0]; out_counts[1] = tot[1]; }
