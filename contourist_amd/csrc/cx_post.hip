@@ -2328,16 +2328,41 @@ __global__ void cxp_k_morph_emit(const int32_t* tets, uint32_t nt, const double*
 // segments = distinct vertex pairs
 // (slots by the first vertex of the pair, as in the 3-D edge table: vertex ids follow the march, so the triangles of a wave
 // probe neighbouring lines; segment ids = slot order then follow the vertices too, which carries on into the edge table)
-__global__ void cxp_k_seg_insert(const u64* pairs, size_t n, u64* tkeys, u64 mask, u64 mult) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 key = pairs[i];
-    u64 slot = cxp_edge_slot((uint32_t)(key >> 32), (uint32_t)key, mask, mult);
-    for (;;) {
-        u64 cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see cxp_k_edge_lists)
-        if (cur == CXP_EMPTY) cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key);
-        if (cur == CXP_EMPTY || cur == key) break;
-        slot = (slot + 1) & mask;
+// A workgroup takes 1024 consecutive keys (the three pairs of ~340 neighbouring triangles: every segment shows up several times
+// among them) and puts them through a set in LDS first; only the first of each key in the block goes on to the device-scope table,
+// whose reads and compare-and-swaps are executed at the memory side of the fabric and bound this kernel.
+#define CXP_SEG_KEYS 1024u
+#define CXP_SEG_SLOTS 2048u
+__global__ __launch_bounds__(256) void cxp_k_seg_insert(const u64* pairs, size_t n, u64* tkeys, u64 mask, u64 mult) {
+    __shared__ u64 lset[CXP_SEG_SLOTS];
+    for (uint32_t x = threadIdx.x; x < CXP_SEG_SLOTS; x += 256u) lset[x] = CXP_EMPTY;
+    __syncthreads();
+    const size_t b0 = (size_t)blockIdx.x * CXP_SEG_KEYS;
+    u64 key[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const size_t i = b0 + k * 256u + threadIdx.x;
+        key[k] = (i < n) ? pairs[i] : CXP_EMPTY;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (key[k] == CXP_EMPTY) continue;
+        uint32_t ls = (uint32_t)cxp_mix(key[k]) & (CXP_SEG_SLOTS - 1u);
+        bool first = false;
+        for (uint32_t probes = 0; probes < CXP_SEG_SLOTS; probes++) {      // (ends earlier: 1024 keys, 2048 slots)
+            const u64 cur = atomicCAS((unsigned long long*)&lset[ls], (unsigned long long)CXP_EMPTY, (unsigned long long)key[k]);
+            if (cur == CXP_EMPTY) { first = true; break; }
+            if (cur == key[k]) break;
+            ls = (ls + 1u) & (CXP_SEG_SLOTS - 1u);
+        }
+        if (!first) continue;
+        u64 slot = cxp_edge_slot((uint32_t)(key[k] >> 32), (uint32_t)key[k], mask, mult);
+        for (;;) {
+            u64 cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see cxp_k_edge_lists)
+            if (cur == CXP_EMPTY) cur = atomicCAS(&tkeys[slot], CXP_EMPTY, key[k]);
+            if (cur == CXP_EMPTY || cur == key[k]) break;
+            slot = (slot + 1) & mask;
+        }
     }
 }
 __global__ void cxp_k_slot_flags(const u64* tkeys, size_t n, uint32_t* flags) {
@@ -2474,7 +2499,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             uint32_t* sid = (uint32_t*)S->scan.p;
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, skeys, (size_t)ssz, CXP_EMPTY);
             const u64 smult = std::max<u64>(1, ssz / std::max<u64>(1, (u64)nv));
-            hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np)), dim3(256), 0, st, pairs, np, skeys, ssz - 1, smult);
+            hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np, CXP_SEG_KEYS)), dim3(256), 0, st, pairs, np, skeys, ssz - 1, smult);
             hipLaunchKernelGGL(cxp_k_slot_flags, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, (size_t)ssz, sflag);
             if ((rc = cxp_scan(ctx, S, sflag, sid, (uint32_t)ssz, misc + 2))) return rc;
             uint32_t nseg = 0;
