@@ -2399,26 +2399,68 @@ __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tke
     }
     ttime[(size_t)t * 2] = lo; ttime[(size_t)t * 2 + 1] = hi;
 }
-// edge table with a linked list of the triangles on each edge (an "edge" = pair of segment ids)
-__global__ void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u64* eheads, u64 mask, u64 mult, uint32_t* next) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+// edge table with a linked list of the triangles on each edge (an "edge" = pair of segment ids).  A workgroup takes CXP_EL consecutive
+// triangles: their visits of one edge are chained in LDS first (a table of keys with a head per slot, one LDS exchange per visit), and
+// only the block's FIRST visitor of an edge -- the tail of that chain -- goes to the device-scope table: it finds or claims the key,
+// swaps the block's local head in as the edge's new head and hangs the old head behind itself.  One device-scope exchange per (edge,
+// block) instead of one per visit (triangle ids follow the march: most of an edge's triangles sit in one block); the reads and
+// read-modify-writes at the memory side of the fabric are what this stage is bound by.  The order inside a list is of no consequence
+// (cxp_k_edge_union_compat looks at every pair).
+#define CXP_EL 512u
+#define CXP_EL_PER (CXP_EL / 256u)
+#define CXP_EL_SLOTS (4u * CXP_EL)
+__global__ __launch_bounds__(256) void cxp_k_edge_lists(const int32_t* tri, uint32_t nt, u64* ekeys, u64* eheads, u64 mask, u64 mult, uint32_t* next) {
+    __shared__ u64 lkey[CXP_EL_SLOTS];
+    __shared__ uint32_t lhead[CXP_EL_SLOTS];
+    for (uint32_t x = threadIdx.x; x < CXP_EL_SLOTS; x += 256u) { lkey[x] = CXP_EMPTY; lhead[x] = CXP_NONE; }
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * CXP_EL;
+    u64 key_[CXP_EL_PER][3];
+    uint16_t slot_[CXP_EL_PER][3];
+    uint32_t tails = 0;       // bit 3 i + e: this visit is the block's first of its edge
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const uint32_t p = v[e], q = v[(e + 1) % 3];
-        const u64 key = ((u64)min(p, q) << 32) | (u64)max(p, q);
-        u64 slot = cxp_edge_slot(min(p, q), max(p, q), mask, mult);
-        for (;;) {
-            // device-scope read first: every visitor of an edge but the first finds the key there and needs no read-modify-write
-            // (they execute at the memory side of the fabric, ~21 G/s for the whole chip: what this stage is bound by)
-            u64 cur = __hip_atomic_load(&ekeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == CXP_EMPTY) cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
-            if (cur == CXP_EMPTY || cur == key) break;
-            slot = (slot + 1) & mask;
+    for (uint32_t i = 0; i < CXP_EL_PER; i++) {
+        const uint32_t t = b0 + i * 256u + threadIdx.x;
+        if (t >= nt) continue;
+        const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const uint32_t p = v[e], q = v[(e + 1) % 3];
+            const u64 key = ((u64)min(p, q) << 32) | (u64)max(p, q);
+            key_[i][e] = key;
+            uint32_t ls = (uint32_t)cxp_mix(key) & (CXP_EL_SLOTS - 1u);
+            for (uint32_t probes = 0; probes < CXP_EL_SLOTS; probes++) {      // (ends earlier: 3 CXP_EL visits, 4 CXP_EL slots)
+                const u64 cur = atomicCAS((unsigned long long*)&lkey[ls], (unsigned long long)CXP_EMPTY, (unsigned long long)key);
+                if (cur == CXP_EMPTY || cur == key) break;
+                ls = (ls + 1u) & (CXP_EL_SLOTS - 1u);
+            }
+            slot_[i][e] = (uint16_t)ls;
+            const uint32_t me = t * 3u + (uint32_t)e;
+            const uint32_t prev = atomicExch(&lhead[ls], me);
+            if (prev == CXP_NONE) tails |= 1u << (3u * i + (uint32_t)e);
+            else next[me] = prev;
         }
-        const u64 old = atomicExch(&eheads[slot], (u64)(t * 3u + (uint32_t)e));
-        next[t * 3u + (uint32_t)e] = (old == CXP_EMPTY) ? CXP_NONE : (uint32_t)old;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < CXP_EL_PER; i++) {
+        const uint32_t t = b0 + i * 256u + threadIdx.x;
+        if (t >= nt) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            if (!((tails >> (3u * i + (uint32_t)e)) & 1u)) continue;
+            const u64 key = key_[i][e];
+            u64 slot = cxp_edge_slot((uint32_t)(key >> 32), (uint32_t)key, mask, mult);
+            for (;;) {
+                // device-scope read first: every visitor of an edge but the first finds the key there and needs no read-modify-write
+                u64 cur = __hip_atomic_load(&ekeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == CXP_EMPTY) cur = atomicCAS(&ekeys[slot], CXP_EMPTY, key);
+                if (cur == CXP_EMPTY || cur == key) break;
+                slot = (slot + 1) & mask;
+            }
+            const u64 old = atomicExch(&eheads[slot], (u64)lhead[slot_[i][e]]);      // the block's chain in front of what was there
+            next[t * 3u + (uint32_t)e] = (old == CXP_EMPTY) ? CXP_NONE : (uint32_t)old;
+        }
     }
 }
 // link every pair of time-compatible triangles on a common edge (morph_geometry.py:61-67, surface_geometry.py:117-128)
@@ -2538,7 +2580,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, ekeys, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, eheads, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(ntri)), dim3(256), 0, st, parent, ntri);
-            hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next);
+            hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri, CXP_EL)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next);
             hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next, ttime, parent);
             if ((rc = cxp_flatten(ctx, parent, ntri, misc))) return rc;
             CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (3 * sizeof(u64) + sizeof(uint32_t)), st));
