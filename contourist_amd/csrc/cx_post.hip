@@ -241,7 +241,16 @@ __global__ __launch_bounds__(256) void cxp_k_scan_blocks(const uint32_t* in, uin
 }
 // one workgroup turns the block sums into exclusive offsets: 16 consecutive sums per thread, 16384 per pass
 #define CXP_SUMS_PER_THREAD 16u
+__device__ __forceinline__ void cxp_scan_sums_body(uint32_t* sums, uint32_t nb, uint32_t* total, unsigned long long* total64);
+// two arrays in one launch (cx_morph_eval: the block counts of the segments and of the triangles), a workgroup each
+__global__ __launch_bounds__(1024) void cxp_k_scan_sums2(uint32_t* sums_a, uint32_t na, uint32_t* total_a, uint32_t* sums_b, uint32_t nb, uint32_t* total_b) {
+    if (blockIdx.x == 0) cxp_scan_sums_body(sums_a, na, total_a, nullptr);
+    else cxp_scan_sums_body(sums_b, nb, total_b, nullptr);
+}
 __global__ __launch_bounds__(1024) void cxp_k_scan_sums(uint32_t* sums, uint32_t nb, uint32_t* total, unsigned long long* total64) {
+    cxp_scan_sums_body(sums, nb, total, total64);
+}
+__device__ __forceinline__ void cxp_scan_sums_body(uint32_t* sums, uint32_t nb, uint32_t* total, unsigned long long* total64) {
     __shared__ uint32_t s[1024];
     uint32_t carry = 0;
     unsigned long long wide = 0;   // the same total without the wrap at 2^32 (each pass adds less than 2^32)
@@ -2795,8 +2804,7 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     const double* range = (const double*)S->mrange.p;
     hipLaunchKernelGGL(cxp_k_me_visible, dim3(nbt), dim3(256), 0, st, ttime, tris, nt, t, tflag, sused, toff, range);
     hipLaunchKernelGGL(cxp_k_me_count, dim3(nbs), dim3(256), 0, st, (const uint8_t*)sused, ns, soff);
-    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, st, soff, nbs, misc + 8, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, st, toff, nbt, misc + 9, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, soff, nbs, misc + 8, toff, nbt, misc + 9);
     uint32_t tot[2] = {0, 0};
     CXP_HIP(ctx, hipMemcpyAsync(tot, misc + 8, sizeof(tot), hipMemcpyDeviceToHost, st));
     CXP_HIP(ctx, hipStreamSynchronize(st));
