@@ -557,39 +557,98 @@ __global__ void cxp_k_degenerate(const int32_t* tri, uint8_t* alive, uint32_t nt
     }
 }
 
-__global__ void cxp_k_mark_used(const int32_t* tri, const uint8_t* alive, uint32_t nt, uint32_t* used) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt || !alive[t]) return;
-    const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];   // all loads before the first store
-    used[a] = 1u; used[b] = 1u; used[c] = 1u;
-}
 __global__ void cxp_k_alive_u32(const uint8_t* alive, uint32_t nt, uint32_t* out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nt) out[t] = alive[t] ? 1u : 0u;
 }
+// ---- ordered compaction without materialised scans (Level 1 of the 3-D path, cx_morph_eval) -------------------------------------
 // (keys: the priority = edge id of every surviving vertex travels with it; told: where a surviving triangle came from)
-__global__ void cxp_k_compact_pts(const double* pts, const uint32_t* used, const uint32_t* newid, uint32_t nv, double* out,
-                                  const uint32_t* keys, uint32_t* keys_out, const uint8_t* ever = nullptr, uint8_t* ever_out = nullptr) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv || !used[v]) return;
-    // everything is loaded before the first store (stores and loads may alias as far as the compiler knows: it waited for each)
-    const uint32_t id = newid[v];
-    const double x = pts[(size_t)v * 3], y = pts[(size_t)v * 3 + 1], z = pts[(size_t)v * 3 + 2];
-    const uint32_t k = keys_out ? keys[v] : 0u;
-    const uint8_t e = ever_out ? ever[v] : (uint8_t)0;
-    out[(size_t)id * 3] = x; out[(size_t)id * 3 + 1] = y; out[(size_t)id * 3 + 2] = z;
-    if (keys_out) keys_out[id] = k;
-    if (ever_out) ever_out[id] = e;
+// Flags are bytes; a workgroup covers CXP_SCAN_BLOCK consecutive elements: first pass counts its flags (cxp_k_me_count), one
+// workgroup turns the block counts into offsets (cxp_k_scan_sums2), the consumer kernels redo the scan INSIDE their block while they
+// write.  (Until round 3: a full exclusive scan per array -- three kernels that read and write 4 bytes per element twice.)
+__device__ __forceinline__ uint32_t cxp_block_excl4(const uint32_t v[4], uint32_t* s, uint32_t& block_total) {
+    // exclusive prefix of this thread's 4 consecutive elements within the workgroup of 256 threads (s: 256 words of LDS)
+    const uint32_t t = v[0] + v[1] + v[2] + v[3];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    block_total = s[255];
+    return s[threadIdx.x] - t;
 }
-__global__ void cxp_k_compact_tri(const int32_t* tri, const uint8_t* alive, const uint32_t* tnew, const uint32_t* vnew, uint32_t nt,
-                                  int32_t* out, uint32_t* told) {
+__global__ __launch_bounds__(256) void cxp_k_me_count(const uint8_t* flags, uint32_t n, uint32_t* count) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t c = 0;
+    if (base + 3u < n) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(flags + base);   // 4 flags (0 / 1 each); base is a multiple of 4
+        c = __popc(w & 0x01010101u);
+    } else {
+        for (uint32_t k = 0; k < 4 && base + k < n; k++) c += flags[base + k] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = s_n;
+}
+__global__ void cxp_k_mark_used8(const int32_t* tri, const uint8_t* alive, uint32_t nt, uint8_t* used) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt || !alive[t]) return;
-    const uint32_t id = tnew[t];
-    const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];
-    const uint32_t na = vnew[a], nb = vnew[b], nc = vnew[c];      // three look-ups in flight, then the stores
-    out[(size_t)id * 3] = (int32_t)na; out[(size_t)id * 3 + 1] = (int32_t)nb; out[(size_t)id * 3 + 2] = (int32_t)nc;
-    if (told) told[id] = t;
+    const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];   // all loads before the first store
+    used[a] = 1; used[b] = 1; used[c] = 1;
+}
+// vertices in use -> their new ids (vnew, for the triangles) and their data in the compacted arrays
+__global__ __launch_bounds__(256) void cxp_k_compact_pts_fused(const double* pts, const uint8_t* used, const uint32_t* voff, uint32_t nv, uint32_t* vnew,
+                                                               double* out, const uint32_t* keys, uint32_t* keys_out, const uint8_t* ever, uint8_t* ever_out) {
+    __shared__ uint32_t s[256];
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t f[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) f[k] = (base + k < nv && used[base + k]) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t id = voff[blockIdx.x] + cxp_block_excl4(f, s, tot);
+    if (tot == 0u) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (!f[k]) continue;
+        const uint32_t v = base + k;
+        const double x = pts[(size_t)v * 3], y = pts[(size_t)v * 3 + 1], z = pts[(size_t)v * 3 + 2];
+        const uint32_t key = keys_out ? keys[v] : 0u;
+        const uint8_t e = ever_out ? ever[v] : (uint8_t)0;
+        vnew[v] = id;
+        out[(size_t)id * 3] = x; out[(size_t)id * 3 + 1] = y; out[(size_t)id * 3 + 2] = z;
+        if (keys_out) keys_out[id] = key;
+        if (ever_out) ever_out[id] = e;
+        id++;
+    }
+}
+__global__ __launch_bounds__(256) void cxp_k_compact_tri_fused(const int32_t* tri, const uint8_t* alive, const uint32_t* toff, const uint32_t* vnew, uint32_t nt,
+                                                               int32_t* out, uint32_t* told) {
+    __shared__ uint32_t s[256];
+    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
+    uint32_t f[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) f[k] = (base + k < nt && alive[base + k]) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t id = toff[blockIdx.x] + cxp_block_excl4(f, s, tot);
+    if (tot == 0u) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (!f[k]) continue;
+        const uint32_t t = base + k;
+        const uint32_t a = (uint32_t)tri[(size_t)t * 3], b = (uint32_t)tri[(size_t)t * 3 + 1], c = (uint32_t)tri[(size_t)t * 3 + 2];
+        const uint32_t na = vnew[a], nb = vnew[b], nc = vnew[c];      // three look-ups in flight, then the stores
+        out[(size_t)id * 3] = (int32_t)na; out[(size_t)id * 3 + 1] = (int32_t)nb; out[(size_t)id * 3 + 2] = (int32_t)nc;
+        if (told) told[id] = t;
+        id++;
+    }
 }
 
 // ---- orientation ---------------------------------------------------------------------------------------
@@ -1174,20 +1233,22 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         CXP_HIP(ctx, hipMemsetAsync(misc + 6, 0, 2 * sizeof(uint32_t), st));
         if (nt) hipLaunchKernelGGL(cxp_k_shard_classify, dim3(cxp_blocks(nt)), dim3(256), 0, st, tprio3, alive, nt, *shard, cx_fdiv_make(shard->plane), cls, misc + 6);
     }
-    // ---- compaction of used vertices and living triangles
-    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
-    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;
-    uint32_t* used = (uint32_t*)S->flags.p;
-    uint32_t* tflag = used + nv;
+    // ---- compaction of used vertices and living triangles (byte flags, per-block counts, the scan redone inside the two consumers)
+    if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nv + nt + 16) * sizeof(uint32_t)))) return rc;      // (also: the list of possible start triangles below)
+    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nv + 16) * sizeof(uint32_t)))) return rc;
+    const uint32_t nbv = cxp_blocks(nv, CXP_SCAN_BLOCK), nbt = cxp_blocks(nt, CXP_SCAN_BLOCK);
+    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(nbv + nbt + 16) * sizeof(uint32_t)))) return rc;
+    uint8_t* used = (uint8_t*)S->flags.p;
     uint32_t* vnew = (uint32_t*)S->scan.p;
-    uint32_t* tnew = vnew + nv;
-    CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv * sizeof(uint32_t), st));
+    uint32_t* voff = (uint32_t*)S->blocksums.p;
+    uint32_t* toff = voff + nbv + 8;
     uint32_t nv2 = 0, nt2 = 0;
     if (nt) {
-        hipLaunchKernelGGL(cxp_k_mark_used, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, used);
-        hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt)), dim3(256), 0, st, alive, nt, tflag);
-        if ((rc = cxp_scan(ctx, S, used, vnew, nv, misc + 1))) return rc;
-        if ((rc = cxp_scan(ctx, S, tflag, tnew, nt, misc + 2))) return rc;
+        CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv, st));
+        hipLaunchKernelGGL(cxp_k_mark_used8, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, used);
+        hipLaunchKernelGGL(cxp_k_me_count, dim3(nbv), dim3(256), 0, st, (const uint8_t*)used, nv, voff);
+        hipLaunchKernelGGL(cxp_k_me_count, dim3(nbt), dim3(256), 0, st, (const uint8_t*)alive, nt, toff);
+        hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, voff, nbv, misc + 1, toff, nbt, misc + 2);
         uint32_t h[2];
         CXP_HIP(ctx, hipMemcpyAsync(h, misc + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
@@ -1200,9 +1261,10 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
     int32_t* tri2 = (int32_t*)S->tri_out.p;
     uint32_t* keys2 = (uint32_t*)S->keys_out.p;
     if (nt2) {
-        hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, used, vnew, nv, pts2, (const uint32_t*)prio, keys2,
-                           (const uint8_t*)ever, ever ? ever + nv : nullptr);
-        hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, tnew, vnew, nt, tri2, told);
+        hipLaunchKernelGGL(cxp_k_compact_pts_fused, dim3(nbv), dim3(256), 0, st, (const double*)pts, (const uint8_t*)used, (const uint32_t*)voff, nv, vnew, pts2,
+                           (const uint32_t*)prio, keys2, (const uint8_t*)ever, ever ? ever + nv : nullptr);
+        hipLaunchKernelGGL(cxp_k_compact_tri_fused, dim3(nbt), dim3(256), 0, st, (const int32_t*)tri, (const uint8_t*)alive, (const uint32_t*)toff,
+                           (const uint32_t*)vnew, nt, tri2, told);
     }
     S->nv_out = nv2; S->nt_out = nt2;
     S->keys_valid = true;
@@ -1351,18 +1413,20 @@ static int cxp_shard_finish(cx_ctx* ctx, cx_post_state* S, const uint32_t* label
         }
         CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, parent, cflip, misc + 3);
-        // own triangles and the vertices they use
+        // own triangles and the vertices they use (the same ordered compaction as in cxp_clean_orient)
         uint8_t* alive = (uint8_t*)S->alive.p;
-        uint32_t* used = (uint32_t*)S->flags.p;
-        uint32_t* tflag = used + nv2;
+        uint8_t* used = (uint8_t*)S->flags.p;
         uint32_t* vnew = (uint32_t*)S->scan.p;
-        uint32_t* tnew = vnew + nv2;
+        const uint32_t nbv = cxp_blocks(nv2, CXP_SCAN_BLOCK), nbt = cxp_blocks(nt2, CXP_SCAN_BLOCK);
+        if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(nbv + nbt + 16) * sizeof(uint32_t)))) return rc;
+        uint32_t* voff = (uint32_t*)S->blocksums.p;
+        uint32_t* toff = voff + nbv + 8;
         hipLaunchKernelGGL(cxp_k_shard_own_alive, dim3(cxp_blocks(nt2)), dim3(256), 0, st, cls2, nt2, alive);
-        CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(cxp_k_mark_used, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, alive, nt2, used);
-        hipLaunchKernelGGL(cxp_k_alive_u32, dim3(cxp_blocks(nt2)), dim3(256), 0, st, alive, nt2, tflag);
-        if ((rc = cxp_scan(ctx, S, used, vnew, nv2, misc + 1))) return rc;
-        if ((rc = cxp_scan(ctx, S, tflag, tnew, nt2, misc + 2))) return rc;
+        CXP_HIP(ctx, hipMemsetAsync(used, 0, (size_t)nv2, st));
+        hipLaunchKernelGGL(cxp_k_mark_used8, dim3(cxp_blocks(nt2)), dim3(256), 0, st, (const int32_t*)tri2, (const uint8_t*)alive, nt2, used);
+        hipLaunchKernelGGL(cxp_k_me_count, dim3(nbv), dim3(256), 0, st, (const uint8_t*)used, nv2, voff);
+        hipLaunchKernelGGL(cxp_k_me_count, dim3(nbt), dim3(256), 0, st, (const uint8_t*)alive, nt2, toff);
+        hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, voff, nbv, misc + 1, toff, nbt, misc + 2);
         uint32_t h[3];
         CXP_HIP(ctx, hipMemcpyAsync(h, misc + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
@@ -1372,9 +1436,10 @@ static int cxp_shard_finish(cx_ctx* ctx, cx_post_state* S, const uint32_t* label
         if ((rc = cxp_reserve(ctx, S->tri, (size_t)(nt3 + 1) * 3 * sizeof(int32_t)))) return rc;
         if ((rc = cxp_reserve(ctx, S->keys_tmp, (size_t)(nv3 + 1) * sizeof(uint32_t)))) return rc;
         if (nt3) {
-            hipLaunchKernelGGL(cxp_k_compact_pts, dim3(cxp_blocks(nv2)), dim3(256), 0, st, (const double*)S->pts_out.p, used, vnew, nv2, (double*)S->pts.p,
-                               (const uint32_t*)S->keys_out.p, (uint32_t*)S->keys_tmp.p);
-            hipLaunchKernelGGL(cxp_k_compact_tri, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, alive, tnew, vnew, nt2, (int32_t*)S->tri.p, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(cxp_k_compact_pts_fused, dim3(nbv), dim3(256), 0, st, (const double*)S->pts_out.p, (const uint8_t*)used, (const uint32_t*)voff, nv2, vnew,
+                               (double*)S->pts.p, (const uint32_t*)S->keys_out.p, (uint32_t*)S->keys_tmp.p, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+            hipLaunchKernelGGL(cxp_k_compact_tri_fused, dim3(nbt), dim3(256), 0, st, (const int32_t*)tri2, (const uint8_t*)alive, (const uint32_t*)toff,
+                               (const uint32_t*)vnew, nt2, (int32_t*)S->tri.p, (uint32_t*)nullptr);
         }
         // back into the output buffers (every buffer keeps its size from call to call: nothing is reallocated for the next volume)
         if (nt3) {
@@ -2669,20 +2734,6 @@ __global__ __launch_bounds__(256) void cxp_k_me_block_ranges(const double* ttime
         range[(size_t)blockIdx.x * 2 + 1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
     }
 }
-__device__ __forceinline__ uint32_t cxp_block_excl4(const uint32_t v[4], uint32_t* s, uint32_t& block_total) {
-    // exclusive prefix of this thread's 4 consecutive elements within the workgroup of 256 threads (s: 256 words of LDS)
-    const uint32_t t = v[0] + v[1] + v[2] + v[3];
-    s[threadIdx.x] = t;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256; o <<= 1) {
-        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += x;
-        __syncthreads();
-    }
-    block_total = s[255];
-    return s[threadIdx.x] - t;
-}
 __global__ __launch_bounds__(256) void cxp_k_me_visible(const double* ttime, const int32_t* tris, uint32_t nt, double t, uint8_t* tflag, uint8_t* sused,
                                                         uint32_t* tcount, const double* range) {
     __shared__ uint32_t s_n;
@@ -2711,24 +2762,6 @@ __global__ __launch_bounds__(256) void cxp_k_me_visible(const double* ttime, con
     if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&s_n, n);
     __syncthreads();
     if (threadIdx.x == 0) tcount[blockIdx.x] = s_n;
-}
-__global__ __launch_bounds__(256) void cxp_k_me_count(const uint8_t* flags, uint32_t n, uint32_t* count) {
-    __shared__ uint32_t s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
-    uint32_t c = 0;
-    if (base + 3u < n) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(flags + base);   // 4 flags (0 / 1 each); base is a multiple of 4
-        c = __popc(w & 0x01010101u);
-    } else {
-        for (uint32_t k = 0; k < 4 && base + k < n; k++) c += flags[base + k] ? 1u : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
-    __syncthreads();
-    if (threadIdx.x == 0) count[blockIdx.x] = s_n;
 }
 __global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint8_t* sused,
                                                        const uint32_t* soff, uint32_t* snew, double* out) {
