@@ -1216,7 +1216,8 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
         hipLaunchKernelGGL(cxp_k_degenerate, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, pts, parent2, prio);
         if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
         hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (const uint32_t*)nullptr, parent2, involved, ever);
-        const u64 tsz = cxp_table_size(nt);
+        // (with the filter only triangles next to a merge enter the table: 5/4 of the bound is plenty and half as much to clear)
+        const u64 tsz = involved ? cxp_edge_table_size(nt) : cxp_table_size(nt);
         if ((rc = cxp_reserve(ctx, S->tkeys, tsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
@@ -1554,7 +1555,8 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
             const double exmin = std::min(W.ex[0], std::min(W.ex[1], W.ex[2]));
             if (exmin >= 16.0) W.thr = 2.0 / exmin + 1e-9;
         }
-        const u64 wsz = cxp_table_size(nv);
+        // (W.thr > 0: four of five crossings are alone in their bucket and skip the table -- 5/4 of the bound instead of twice it)
+        const u64 wsz = W.thr > 0.0 ? cxp_edge_table_size(nv) : cxp_table_size(nv);
         if ((rc = cxp_reserve(ctx, S->tkeys, std::max(wsz, cxp_table_size(nt)) * sizeof(u64)))) return rc;
         if ((rc = cxp_reserve(ctx, S->tvals, wsz * sizeof(u64)))) return rc;
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)wsz, CXP_EMPTY);
@@ -1566,7 +1568,7 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
         uint8_t* involved = (coherent && !cx_debug_knob("CX_DEDUPE_ALL", 0)) ? moved : nullptr;
         if (involved) CXP_HIP(ctx, hipMemsetAsync(involved, 0, nv, st));
         hipLaunchKernelGGL(cxp_k_remap, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, rep, (const u64*)nullptr, involved, ever);
-        const u64 tsz = cxp_table_size(nt);
+        const u64 tsz = involved ? cxp_edge_table_size(nt) : cxp_table_size(nt);
         hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, (u64*)S->tkeys.p, (size_t)tsz, CXP_EMPTY);
         hipLaunchKernelGGL(cxp_k_dedupe_insert, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, tprio3, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
         hipLaunchKernelGGL(cxp_k_dedupe_resolve, dim3(cxp_blocks(nt)), dim3(256), 0, st, tri, alive, nt, (u64*)S->tkeys.p, tsz - 1, (const uint8_t*)involved);
@@ -2606,7 +2608,9 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_morph_emit, dim3(cxp_blocks(nt)), dim3(256), 0, st, tets, nt, pts, prio, mm, off, pairs);
             // ---- segments
             const size_t np = (size_t)ntri * 3;
-            const u64 ssz = cxp_table_size(np);
+            // (n keys of which a third or less are distinct -- every segment shows up in several triangles: the edge-table rule, 5/4 of the
+            // bound, keeps the load below 0.8 in the worst case and near 0.25 here with half the slots to clear, flag and scan)
+            const u64 ssz = cxp_edge_table_size(np);
             if ((rc = cxp_reserve(ctx, S->tkeys, ssz * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->flags, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
             if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
@@ -2636,7 +2640,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_me_block_ranges, dim3(cxp_blocks(ntri, CXP_SCAN_BLOCK)), dim3(256), 0, st, (const double*)ttime, ntri, (double*)S->mrange.p);
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
-            const u64 esz = cxp_table_size((size_t)ntri * 3);
+            const u64 esz = cxp_edge_table_size((size_t)ntri * 3);
             const u64 emult4 = std::max<u64>(1, esz / std::max<u64>(1, (u64)nseg));
             if ((rc = cxp_reserve(ctx, S->tkeys, esz * sizeof(u64)))) return rc;
             if ((rc = cxp_reserve(ctx, S->tvals, esz * sizeof(u64)))) return rc;
