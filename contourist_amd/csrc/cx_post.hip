@@ -2463,16 +2463,27 @@ __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tke
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     double lo = cxp_from_orderable(mm[0]), hi = cxp_from_orderable(mm[1]);
+    // the three keys, their three probes side by side, the three ids, the six times -- and only then the stores (one edge after the
+    // other with its store at the end of each round, every load of the next round waited for that store: they may alias for all the
+    // compiler knows)
+    const u64 key[3] = {pairs[(size_t)t * 3], pairs[(size_t)t * 3 + 1], pairs[(size_t)t * 3 + 2]};
+    u64 slot[3];
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const u64 key = pairs[(size_t)t * 3 + e];
-        u64 slot = cxp_edge_slot((uint32_t)(key >> 32), (uint32_t)key, mask, mult);
-        while (tkeys[slot] != key) slot = (slot + 1) & mask;
-        const uint32_t s = ids[slot];
-        tris[(size_t)t * 3 + e] = (int32_t)s;
-        lo = fmax(lo, stime[(size_t)s * 2]);
-        hi = fmin(hi, stime[(size_t)s * 2 + 1]);
+    for (int e = 0; e < 3; e++) slot[e] = cxp_edge_slot((uint32_t)(key[e] >> 32), (uint32_t)key[e], mask, mult);
+    for (;;) {
+        const u64 k0 = tkeys[slot[0]], k1 = tkeys[slot[1]], k2 = tkeys[slot[2]];
+        const bool m0 = k0 == key[0], m1 = k1 == key[1], m2 = k2 == key[2];
+        if (m0 && m1 && m2) break;
+        if (!m0) slot[0] = (slot[0] + 1) & mask;
+        if (!m1) slot[1] = (slot[1] + 1) & mask;
+        if (!m2) slot[2] = (slot[2] + 1) & mask;
     }
+    const uint32_t s0 = ids[slot[0]], s1 = ids[slot[1]], s2 = ids[slot[2]];
+    const double a0 = stime[(size_t)s0 * 2], b0 = stime[(size_t)s0 * 2 + 1], a1 = stime[(size_t)s1 * 2], b1 = stime[(size_t)s1 * 2 + 1];
+    const double a2 = stime[(size_t)s2 * 2], b2 = stime[(size_t)s2 * 2 + 1];
+    lo = fmax(fmax(lo, a0), fmax(a1, a2));
+    hi = fmin(fmin(hi, b0), fmin(b1, b2));
+    tris[(size_t)t * 3] = (int32_t)s0; tris[(size_t)t * 3 + 1] = (int32_t)s1; tris[(size_t)t * 3 + 2] = (int32_t)s2;
     ttime[(size_t)t * 2] = lo; ttime[(size_t)t * 2 + 1] = hi;
 }
 // edge table with a linked list of the triangles on each edge (an "edge" = pair of segment ids).  A workgroup takes CXP_EL consecutive
@@ -2666,11 +2677,17 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             const uint32_t* nokeys = nullptr;   // segment midpoints: the largest index breaks the tie
             const uint8_t* nocls = nullptr;
             hipLaunchKernelGGL(cxp_k_comp_maxx, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, nocls);
-            const uint32_t* nolist = nullptr;
-            hipLaunchKernelGGL(cxp_k_comp_maxv, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv, nokeys, nocls, nolist, nolist);
-            hipLaunchKernelGGL(cxp_k_comp_start, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, nocls, nolist, nolist);
-            hipLaunchKernelGGL(cxp_k_comp_pick, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart, nocls, nolist, nolist);
-            hipLaunchKernelGGL(cxp_k_comp_decide, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest, nolist, nolist);
+            // the four kernels that pick a component's start triangle visit the list of triangles AT the component's largest x
+            // (cxp_k_comp_list; the list sits where the edge lists' `next` words were: free by now)
+            uint32_t* clist = (uint32_t*)S->mnext.p;
+            const uint32_t* cn = misc + 11;
+            const dim3 lgrid(std::min(cxp_blocks(ntri), 1024u));
+            CXP_HIP(ctx, hipMemsetAsync(misc + 11, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(cxp_k_comp_list, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, nocls, clist, misc + 11);
+            hipLaunchKernelGGL(cxp_k_comp_maxv, lgrid, dim3(256), 0, st, tris, ntri, mid, parent, cmaxx, cmaxv, nokeys, nocls, (const uint32_t*)clist, cn);
+            hipLaunchKernelGGL(cxp_k_comp_start, lgrid, dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, nocls, (const uint32_t*)clist, cn);
+            hipLaunchKernelGGL(cxp_k_comp_pick, lgrid, dim3(256), 0, st, tris, ntri, mid, parent, cmaxv, cbest, cstart, nocls, (const uint32_t*)clist, cn);
+            hipLaunchKernelGGL(cxp_k_comp_decide, lgrid, dim3(256), 0, st, tris, ntri, mid, parent, cstart, cbest, (const uint32_t*)clist, cn);
             hipLaunchKernelGGL(cxp_k_orient, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, parent, cbest, misc + 3);
             uint32_t ncomp = 0;
             CXP_HIP(ctx, hipMemcpyAsync(&ncomp, misc + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
