@@ -2450,12 +2450,16 @@ __global__ void cxp_k_seg_write(const u64* tkeys, const uint32_t* ids, size_t n,
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n || tkeys[i] == CXP_EMPTY) return;
     uint32_t a = (uint32_t)(tkeys[i] >> 32), b = (uint32_t)tkeys[i];
-    if (pts[(size_t)a * 4 + 3] > pts[(size_t)b * 4 + 3]) { const uint32_t t = a; a = b; b = t; }
-    const uint32_t s = ids[i];
-    segs[(size_t)s * 2] = (int32_t)a; segs[(size_t)s * 2 + 1] = (int32_t)b;
+    // both points whole and the id before the first store (loads behind a store waited for it: they may alias for all the compiler knows)
+    double pa[4], pb[4];
 #pragma unroll
-    for (int c = 0; c < 3; c++) mid[(size_t)s * 3 + c] = 0.5 * (pts[(size_t)a * 4 + c] + pts[(size_t)b * 4 + c]);
-    stime[(size_t)s * 2] = pts[(size_t)a * 4 + 3]; stime[(size_t)s * 2 + 1] = pts[(size_t)b * 4 + 3];
+    for (int c = 0; c < 4; c++) { pa[c] = pts[(size_t)a * 4 + c]; pb[c] = pts[(size_t)b * 4 + c]; }
+    const uint32_t s = ids[i];
+    const bool swap = pa[3] > pb[3];
+    segs[(size_t)s * 2] = (int32_t)(swap ? b : a); segs[(size_t)s * 2 + 1] = (int32_t)(swap ? a : b);
+#pragma unroll
+    for (int c = 0; c < 3; c++) mid[(size_t)s * 3 + c] = swap ? 0.5 * (pb[c] + pa[c]) : 0.5 * (pa[c] + pb[c]);
+    stime[(size_t)s * 2] = swap ? pb[3] : pa[3]; stime[(size_t)s * 2 + 1] = swap ? pa[3] : pb[3];
 }
 // triangles as segment-id triples + their time range (morph_geometry.py:69-89)
 __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tkeys, const uint32_t* ids, u64 mask, u64 mult, const double* stime,
