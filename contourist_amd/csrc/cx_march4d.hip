@@ -246,11 +246,20 @@ __global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uin
             const uint32_t valid = (left >= 32u) ? 0xFFFFFFFFu : ((1u << left) - 1u);
             const uint32_t edge = (left <= 32u) ? (1u << (left - 1u)) : 0u;
             uint32_t any = 0, all = 0xFFFFFFFFu;
+            // all 16 words are requested before the first is used, the second of each pair unconditionally (where the row ends it
+            // re-reads the first: a conditional load made the compiler wait for every load at its use)
+            uint32_t w8[8], n8[8];
+            const uint32_t step = more ? 1u : 0u;
 #pragma unroll
             for (uint32_t c = 0; c < 8; c++) {
                 const uint32_t at = ic + ((c & 4u) ? o0 : 0u) + ((c & 2u) ? o1 : 0u) + ((c & 1u) ? o2 : 0u);
-                const uint32_t w = W[at];
-                const uint32_t nx = more ? W[at + 1u] : 0u;
+                w8[c] = W[at];
+                n8[c] = W[at + step];
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t w = w8[c];
+                const uint32_t nx = more ? n8[c] : 0u;
                 uint32_t sh = (w >> 1) | (nx << 31);          // the samples at l+1
                 sh = (sh & ~edge) | (w & edge);               // clamped at the end of the row
                 any |= w | sh;
