@@ -48,12 +48,16 @@ __device__ __forceinline__ uint32_t cx_load_corners4(const cx_params4& P, uint32
     const bool v0 = q[0] + 1 < P.n0, v1 = q[1] + 1 < P.n1, v2 = q[2] + 1 < P.n2, v3 = q[3] + 1 < P.n3;
     const uint32_t o0 = v0 ? P.n1 * P.n2 * P.n3 : 0u, o1 = v1 ? P.n2 * P.n3 : 0u, o2 = v2 ? P.n3 : 0u;
     const uint32_t base = v3 ? lin : lin - 1u;   // at the array edge in l read (l-1, l) and repeat l
+    cx_f2 raw[8];      // the eight pairs are requested before any is looked at (a select right behind a load made the compiler wait there)
 #pragma unroll
     for (uint32_t c = 0; c < 8; c++) {
         const uint32_t ofs = ((c & 4u) ? o0 : 0u) + ((c & 2u) ? o1 : 0u) + ((c & 1u) ? o2 : 0u);
-        const cx_f2 p = *reinterpret_cast<const cx_f2*>(A + base + ofs);
-        f[2 * c] = v3 ? p.x : p.y;
-        f[2 * c + 1] = p.y;
+        raw[c] = *reinterpret_cast<const cx_f2*>(A + base + ofs);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        f[2 * c] = v3 ? raw[c].x : raw[c].y;
+        f[2 * c + 1] = raw[c].y;
     }
     uint32_t vm = 0;
 #pragma unroll
