@@ -162,7 +162,7 @@ bool cx_fast_classify_supported_dims(int64_t n2, const float* grid);
 cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2);
 void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s);
 void cx_launch_scan_waves(const cx_params& P, const cx_task& T, hipStream_t s);
-void cx_launch_stream_levels(const cx_params* device_params, const cx_params& P0, const cx_task& T, uint32_t nlevels, hipStream_t s);
+void cx_launch_stream_levels(const cx_params* host_params, const cx_task& T, uint32_t nlevels, hipStream_t s);   // parameters by value, 8 levels per launch
 void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uint32_t nlevels, hipStream_t s);
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s);
 uint32_t cx_vertex_stage_waves(const cx_params& P);

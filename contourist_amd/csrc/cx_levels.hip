@@ -263,7 +263,7 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         CXL_HIP(ctx, hipMemcpyAsync(L->dparams, hp.data(), (size_t)nlevels * sizeof(cx_params), hipMemcpyHostToDevice, ctx->stream));
         CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // hp goes out of scope
         // ONE pass over the samples for all levels, then the scans
-        cx_launch_stream_levels(L->dparams, L->slots[0].P, T, (uint32_t)nlevels, ctx->stream);
+        cx_launch_stream_levels(hp.data(), T, (uint32_t)nlevels, ctx->stream);
         cx_launch_scan_levels(L->dparams, T, (uint32_t)nlevels, ctx->stream);
         for (int l = 0; l < nlevels; l++)
             CXL_HIP(ctx, hipMemcpyAsync(L->hcounters + (size_t)l * CX_CNT_WORDS, L->slots[l].counters, CX_CNT_WORDS * sizeof(uint32_t),

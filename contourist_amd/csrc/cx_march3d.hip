@@ -925,12 +925,21 @@ __global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream(const cx_par
 // inside an XCD's sequence: the nlevels workgroups that stream one tile run next to each other on one XCD, so the tile comes
 // from HBM once and from that XCD's L2 / the Infinity Cache for the other levels.  LP[level] = parameters of a level
 // (isovalue, its queues and side tables).
+// The parameters of up to CX_LEVELS_PER_LAUNCH levels travel BY VALUE as a kernel argument.  Read from a device array, as they were
+// until the end of round 3, their pointers are generic as far as the compiler knows: loads and stores through them came out as FLAT
+// instructions, which count on both memory counters -- every wait in the kernel was `vmcnt(0) lgkmcnt(0)`, the plane requested for the
+// NEXT step was waited for together with the current one.  Pointers inside a kernel argument are known to be global: the waits are
+// the counted ones of cx_k_stream again.  (It did not change the time -- 2.33 ms for 8 levels either way: the kernel is bound by its
+// instructions, DESIGN section 10 -- but it is the code the single-level kernel runs.)
+#define CX_LEVELS_PER_LAUNCH 8u
+struct cx_params_pack {
+    cx_params p[CX_LEVELS_PER_LAUNCH];
+};
 template <bool ALIGNED>
-__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream_levels(const cx_params* __restrict__ LP, const cx_task T, const uint32_t nlevels) {
+__global__ __launch_bounds__(256, CX_K1_MIN_WAVES) void cx_k_stream_levels(const cx_params_pack LP, const cx_task T, const uint32_t nlevels) {
     const uint32_t seq = blockIdx.x >> 3;                   // position in this XCD's sequence of workgroups
     const uint32_t tile_seq = seq / nlevels, level = seq - tile_seq * nlevels;
-    const cx_params P = LP[level];
-    cx_stream_tile<ALIGNED>(P, T, (blockIdx.x & 7u) * T.chunk + tile_seq);
+    cx_stream_tile<ALIGNED>(LP.p[level], T, (blockIdx.x & 7u) * T.chunk + tile_seq);
 }
 
 // ---- S2 in one launch: workgroup g owns the streaming waves [256 g, 256 g + 256).  It sums the totals of ALL waves before its
@@ -2343,10 +2352,16 @@ void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
     else hipLaunchKernelGGL(cx_k_stream<false>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
 }
 
-void cx_launch_stream_levels(const cx_params* device_params, const cx_params& P0, const cx_task& T, uint32_t nlevels, hipStream_t s) {
+void cx_launch_stream_levels(const cx_params* host_params, const cx_task& T, uint32_t nlevels, hipStream_t s) {
+    const cx_params& P0 = host_params[0];
     const bool aligned = (P0.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P0.grid) & 15u) == 0u);
-    if (aligned) hipLaunchKernelGGL(cx_k_stream_levels<true>, dim3(T.chunk * 8u * nlevels), dim3(256), 0, s, device_params, T, nlevels);
-    else hipLaunchKernelGGL(cx_k_stream_levels<false>, dim3(T.chunk * 8u * nlevels), dim3(256), 0, s, device_params, T, nlevels);
+    for (uint32_t l0 = 0; l0 < nlevels; l0 += CX_LEVELS_PER_LAUNCH) {      // more than 8 levels: another pass over the samples per 8
+        const uint32_t n = std::min(CX_LEVELS_PER_LAUNCH, nlevels - l0);
+        cx_params_pack pack;
+        for (uint32_t k = 0; k < CX_LEVELS_PER_LAUNCH; k++) pack.p[k] = host_params[l0 + std::min(k, n - 1u)];
+        if (aligned) hipLaunchKernelGGL(cx_k_stream_levels<true>, dim3(T.chunk * 8u * n), dim3(256), 0, s, pack, T, n);
+        else hipLaunchKernelGGL(cx_k_stream_levels<false>, dim3(T.chunk * 8u * n), dim3(256), 0, s, pack, T, n);
+    }
 }
 void cx_launch_scan_levels(const cx_params* device_params, const cx_task& T, uint32_t nlevels, hipStream_t s) {
     const uint32_t nw = T.nblocks * 4u;
