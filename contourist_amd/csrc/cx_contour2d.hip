@@ -132,20 +132,24 @@ __global__ void c2_k_count(c2_grid G, uint32_t* cnt, uint32_t* tie) {
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= G.n * G.m) return;
     const uint32_t i = lin / G.m, j = lin - i * G.m;
-    const double f0 = c2_f(G, i, j);
+    // the point and its three forward neighbours are requested together, the neighbours at clamped positions whether their edge
+    // exists or not, and the three counts are stored at the end (one edge after the other -- a conditional load, a binary search, a
+    // store -- every load waited for the store before it: four round trips per lattice point)
+    const uint32_t i1 = min(i + 1u, G.n - 1u), j1 = min(j + 1u, G.m - 1u);
+    const float r0 = G.A[(size_t)i * G.m + j], ra = G.A[(size_t)i1 * G.m + j], rb = G.A[(size_t)i * G.m + j1], rc = G.A[(size_t)i1 * G.m + j1];
+    const double f0 = (r0 == r0) ? (double)r0 : (double)INFINITY;
+    const double fn[3] = {(ra == ra) ? (double)ra : (double)INFINITY, (rb == rb) ? (double)rb : (double)INFINITY, (rc == rc) ? (double)rc : (double)INFINITY};
     const uint32_t u0 = c2_upper(G, f0);
     if (u0 > 0 && G.values[u0 - 1] == f0) *tie = 1u;
+    uint32_t c[3] = {0, 0, 0};
+#pragma unroll
     for (int d = 0; d < 3; d++) {
-        uint32_t c = 0;
-        if (c2_edge_valid(G, i, j, d)) {
-            const double f1 = c2_f(G, i + (d != 1), j + (d != 0));
-            if (f0 != f1) {
-                const uint32_t u1 = c2_upper(G, f1);
-                c = (u1 > u0) ? (u1 - u0) : (u0 - u1);
-            }
+        if (c2_edge_valid(G, i, j, d) && f0 != fn[d]) {
+            const uint32_t u1 = c2_upper(G, fn[d]);
+            c[d] = (u1 > u0) ? (u1 - u0) : (u0 - u1);
         }
-        cnt[3u * lin + d] = c;
     }
+    cnt[3u * lin] = c[0]; cnt[3u * lin + 1u] = c[1]; cnt[3u * lin + 2u] = c[2];
 }
 
 // the segment of level z inside the counter-clockwise triangle (v0, v1, v2): links crossing `id`, which lies on the
