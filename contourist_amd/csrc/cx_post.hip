@@ -54,7 +54,10 @@ struct cx_post_state {
         uint32_t n1 = 0, n4 = 0, ncand = 0;   // own triangles next to the lower neighbour, copies of the upper neighbour's, open components
     } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
-    cxp_dev mrange;                                     // per block of CXP_SCAN_BLOCK morph triangles: earliest start, latest end of their time ranges
+    cxp_dev morder;                                     // morph triangles sorted by the bin of their start time (u32 ids), for cx_morph_eval
+    uint32_t mbin_start[1025] = {0};                    // first position in morder of every bin (CXP_ME_BINS + 1 entries)
+    double mt_lo = 0.0, mt_hi = 0.0, mt_maxdur = 0.0;   // range of the start times, longest life of a triangle
+    bool morder_valid = false;
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
     int64_t me_points = 0, me_tris = 0;   // last cx_morph_eval
@@ -75,7 +78,7 @@ void cx_post_free(cx_ctx* ctx) {
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
                       &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd, &S->ever,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->mrange};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->morder};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -2578,7 +2581,6 @@ __global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u
     }
 }
 
-__global__ void cxp_k_me_block_ranges(const double* ttime, uint32_t nt, double* range);   // with cx_morph_eval, below
 
 extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
     if (!ctx) return CX_ERR_INVALID;
@@ -2651,8 +2653,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             int32_t* tris = (int32_t*)S->mtris.p;
             hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
             hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, smult, stime, mm, tris, ttime);
-            if ((rc = cxp_reserve(ctx, S->mrange, (size_t)(cxp_blocks(ntri, CXP_SCAN_BLOCK) + 1) * 2 * sizeof(double)))) return rc;
-            hipLaunchKernelGGL(cxp_k_me_block_ranges, dim3(cxp_blocks(ntri, CXP_SCAN_BLOCK)), dim3(256), 0, st, (const double*)ttime, ntri, (double*)S->mrange.p);
+            S->morder_valid = false;     // the index by start time is built by the first cx_morph_eval of these triangles
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
             const u64 esz = cxp_edge_table_size((size_t)ntri * 3);
@@ -2736,57 +2737,75 @@ __device__ __forceinline__ bool cxp_seg_inside(const double* P4, const int32_t* 
 // its flags (first pass), one workgroup turns the block counts into offsets, and the consumer kernels redo the scan INSIDE their
 // block while they write (second pass).  (Until round 3: two full exclusive scans per call -- each three kernels that read and
 // write 4 bytes per element twice -- 15 of the 27 ms of the 64 surfaces of config 4.)
-// time range of every block of CXP_SCAN_BLOCK consecutive morph triangles (once, in cx_morph_triangles): triangle ids follow the march,
-// whose fastest axis is time, so a block lives for a few time layers and cx_morph_eval skips the blocks that do not exist at its t
-// without reading their 16 KB of ranges
-__global__ __launch_bounds__(256) void cxp_k_me_block_ranges(const double* ttime, uint32_t nt, double* range) {
-    __shared__ double s_lo[4], s_hi[4];
-    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
-    double lo = 1.0e300, hi = -1.0e300;
-    for (uint32_t k = 0; k < 4 && base + k < nt; k++) {
-        lo = fmin(lo, ttime[(size_t)(base + k) * 2]);
-        hi = fmax(hi, ttime[(size_t)(base + k) * 2 + 1]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, o));
-        hi = fmax(hi, __shfl_xor(hi, o));
-    }
-    if ((threadIdx.x & 63u) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        range[(size_t)blockIdx.x * 2] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
-        range[(size_t)blockIdx.x * 2 + 1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
-    }
+// An index of the morph triangles by START TIME (once, in cx_morph_triangles): bins of equal width over the range of the start times,
+// the triangle ids of a bin next to each other in `order`.  A triangle lives for a layer or two of the 64, so the triangles that exist at
+// a time t start inside a narrow window of bins -- [bin(t - longest life) - 1, bin(t) + 1] -- and cx_morph_eval tests only those (ids
+// follow the march, whose fastest axis is time: in id order nearly every block of 1 024 triangles exists at every t).
+#define CXP_ME_BINS 1024u
+__device__ __forceinline__ uint32_t cxp_me_bin(double x, double lo, double inv_width) {
+    const double b = (x - lo) * inv_width;
+    return b <= 0.0 ? 0u : (b >= (double)(CXP_ME_BINS - 1u) ? CXP_ME_BINS - 1u : (uint32_t)b);
 }
-__global__ __launch_bounds__(256) void cxp_k_me_visible(const double* ttime, const int32_t* tris, uint32_t nt, double t, uint8_t* tflag, uint8_t* sused,
-                                                        uint32_t* tcount, const double* range) {
-    __shared__ uint32_t s_n;
-    if (!(range[(size_t)blockIdx.x * 2] <= t && t <= range[(size_t)blockIdx.x * 2 + 1])) {      // nothing of this block exists at t
-        if (threadIdx.x == 0) tcount[blockIdx.x] = 0;
-        return;
-    }
-    if (threadIdx.x == 0) s_n = 0;
+// (neighbouring triangles start at the same few times: the lanes of a wave that share a bin add up among themselves and issue ONE
+// atomic per bin -- one per lane meant 25 M read-modify-writes on some 64 addresses)
+__global__ __launch_bounds__(256) void cxp_k_me_hist(const double* ttime, uint32_t nt, double lo, double inv_width, uint32_t* hist, u64* maxdur) {
+    __shared__ uint32_t h[CXP_ME_BINS];
+    for (uint32_t x = threadIdx.x; x < CXP_ME_BINS; x += 256u) h[x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
-    uint32_t n = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t q = base + k;
-        if (q >= nt) break;
-        const bool vis = ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1];
-        tflag[q] = vis ? 1 : 0;
-        if (vis) {
-            const uint32_t a = (uint32_t)tris[(size_t)q * 3], b = (uint32_t)tris[(size_t)q * 3 + 1], c = (uint32_t)tris[(size_t)q * 3 + 2];
-            sused[a] = 1; sused[b] = 1; sused[c] = 1;
-            n++;
+    double dur = 0.0;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t q0 = (blockIdx.x * 256u + (threadIdx.x & ~63u)); q0 < nt; q0 += gridDim.x * 256u) {      // wave-uniform
+        const uint32_t q = q0 + lane;
+        const bool in = q < nt;
+        uint32_t bin = 0;
+        if (in) {
+            const double a = ttime[(size_t)q * 2], b = ttime[(size_t)q * 2 + 1];
+            bin = cxp_me_bin(a, lo, inv_width);
+            dur = fmax(dur, b - a);
+        }
+        uint64_t todo = __ballot(in);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t bb = (uint32_t)__shfl((int)bin, (int)leader);
+            const uint64_t same = __ballot(in && bin == bb) & todo;
+            if (lane == leader) atomicAdd(&h[bb], (uint32_t)__popcll(same));
+            todo &= ~same;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
-    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&s_n, n);
+    for (int o = 32; o > 0; o >>= 1) dur = fmax(dur, __shfl_xor(dur, o));
+    if (lane == 0) cxp_max64(maxdur, cxp_orderable(dur));
     __syncthreads();
-    if (threadIdx.x == 0) tcount[blockIdx.x] = s_n;
+    for (uint32_t x = threadIdx.x; x < CXP_ME_BINS; x += 256u)
+        if (h[x]) atomicAdd(&hist[x], h[x]);
+}
+__global__ __launch_bounds__(256) void cxp_k_me_scatter(const double* ttime, uint32_t nt, double lo, double inv_width, uint32_t* cursor, uint32_t* order) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool in = q < nt;
+    const uint32_t bin = in ? cxp_me_bin(ttime[(size_t)q * 2], lo, inv_width) : 0u;
+    uint64_t todo = __ballot(in);
+    while (todo) {      // wave-uniform: one reservation per bin present in the wave (ids keep their order inside the reservation)
+        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t bb = (uint32_t)__shfl((int)bin, (int)leader);
+        const uint64_t same = __ballot(in && bin == bb) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[bb], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        if (in && bin == bb) order[base + (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL))] = q;
+        todo &= ~same;
+    }
+}
+// the triangles of the window that exist at t: their flags (bytes, zeroed before) and the flags of their segments
+__global__ void cxp_k_me_visible(const double* ttime, const int32_t* tris, const uint32_t* order, uint32_t first, uint32_t n, double t, uint8_t* tflag,
+                                 uint8_t* sused) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t q = order[first + x];
+    if (!(ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1])) return;
+    const uint32_t a = (uint32_t)tris[(size_t)q * 3], b = (uint32_t)tris[(size_t)q * 3 + 1], c = (uint32_t)tris[(size_t)q * 3 + 2];
+    tflag[q] = 1;
+    sused[a] = 1; sused[b] = 1; sused[c] = 1;
 }
 __global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint8_t* sused,
                                                        const uint32_t* soff, uint32_t* snew, double* out) {
@@ -2813,9 +2832,8 @@ __global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const i
     }
 }
 __global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32_t nt, const uint8_t* tflag, const uint32_t* toff, const uint32_t* snew,
-                                                     int32_t* out, const double* range, double t) {
+                                                     int32_t* out) {
     __shared__ uint32_t s[256];
-    if (!(range[(size_t)blockIdx.x * 2] <= t && t <= range[(size_t)blockIdx.x * 2 + 1])) return;      // cxp_k_me_visible wrote no flags for this block
     const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
     uint32_t v[4];
 #pragma unroll
@@ -2832,6 +2850,48 @@ __global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32
         o[0] = (int32_t)a; o[1] = (int32_t)b; o[2] = (int32_t)c;
         id++;
     }
+}
+static inline double cxp_host_from_orderable(u64 o) {
+    const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+// the index of the morph triangles by start time (see cxp_k_me_hist): bins over the time range of all points (S->misc + 16: its
+// orderable min / max, left by cx_morph_triangles), a histogram, its scan on the host (1 024 numbers), a scatter
+static int cxp_me_index(cx_ctx* ctx, cx_post_state* S, const double* ttime, uint32_t ntri) {
+    int rc;
+    hipStream_t st = ctx->stream;
+    S->morder_valid = false;
+    if (!ntri) return CX_OK;
+    u64 h[2];
+    CXP_HIP(ctx, hipMemcpyAsync(h, (const u64*)((const uint32_t*)S->misc.p + 16), sizeof(h), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    const double lo = cxp_host_from_orderable(h[0]), hi = cxp_host_from_orderable(h[1]);
+    const double inv_width = (hi > lo) ? (double)CXP_ME_BINS / (hi - lo) : 0.0;
+    if ((rc = cxp_reserve(ctx, S->morder, (size_t)(ntri + 16) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(2 * CXP_ME_BINS + 16) * sizeof(uint32_t)))) return rc;
+    uint32_t* hist = (uint32_t*)S->blocksums.p;
+    uint32_t* cursor = hist + CXP_ME_BINS;
+    u64* maxdur = (u64*)(cursor + CXP_ME_BINS);
+    CXP_HIP(ctx, hipMemsetAsync(hist, 0, (2 * CXP_ME_BINS + 4) * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(cxp_k_me_hist, dim3(std::min(cxp_blocks(ntri), 2048u)), dim3(256), 0, st, ttime, ntri, lo, inv_width, hist, maxdur);
+    std::vector<uint32_t> hh(CXP_ME_BINS);
+    u64 md = 0;
+    CXP_HIP(ctx, hipMemcpyAsync(hh.data(), hist, CXP_ME_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipMemcpyAsync(&md, maxdur, sizeof(md), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < CXP_ME_BINS; b++) { S->mbin_start[b] = run; run += hh[b]; }
+    S->mbin_start[CXP_ME_BINS] = run;
+    if (run != ntri) { ctx->err = "cx_morph_triangles: the start-time histogram does not add up"; return CX_ERR_HIP; }
+    CXP_HIP(ctx, hipMemcpyAsync(cursor, S->mbin_start, CXP_ME_BINS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(cxp_k_me_scatter, dim3(cxp_blocks(ntri)), dim3(256), 0, st, ttime, ntri, lo, inv_width, cursor, (uint32_t*)S->morder.p);
+    CXP_HIP(ctx, hipStreamSynchronize(st));      // (S->mbin_start is read by the copy above)
+    S->mt_lo = lo; S->mt_hi = hi;
+    S->mt_maxdur = md ? cxp_host_from_orderable(md) : 0.0;
+    S->morder_valid = true;
+    return CX_OK;
 }
 extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
@@ -2857,10 +2917,24 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     const int32_t* segs = (const int32_t*)S->msegs.p;
     const int32_t* tris = (const int32_t*)S->mtris.p;
     CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns, st));
+    CXP_HIP(ctx, hipMemsetAsync(tflag, 0, (size_t)nt, st));
     const double* ttime = (const double*)S->mtime.p + (size_t)(ns + 1) * 2;   // behind the segments' ranges (cx_morph_triangles)
-    if (S->mrange.bytes < (size_t)nbt * 2 * sizeof(double)) { ctx->err = "cx_morph_eval: run cx_morph_triangles first"; return CX_ERR_STATE; }
-    const double* range = (const double*)S->mrange.p;
-    hipLaunchKernelGGL(cxp_k_me_visible, dim3(nbt), dim3(256), 0, st, ttime, tris, nt, t, tflag, sused, toff, range);
+    if (!S->morder_valid && (rc = cxp_me_index(ctx, S, ttime, nt))) return rc;      // first surface of these morph triangles: ~2 ms once
+    {
+        // the window of start-time bins in which a triangle that exists at t can start (one bin of slack on either side: the bin of
+        // a start time was computed on the device, these two on the host)
+        const double width = (S->mt_hi > S->mt_lo) ? (S->mt_hi - S->mt_lo) / (double)CXP_ME_BINS : 1.0;
+        auto bin_of = [&](double x) {
+            const double b = (x - S->mt_lo) / width;
+            return b <= 0.0 ? 0u : (b >= (double)(CXP_ME_BINS - 1u) ? CXP_ME_BINS - 1u : (uint32_t)b);
+        };
+        const uint32_t b_hi = std::min(bin_of(t) + 1u, CXP_ME_BINS - 1u);
+        const uint32_t b_lo0 = bin_of(t - S->mt_maxdur);
+        const uint32_t b_lo = b_lo0 ? b_lo0 - 1u : 0u;
+        const uint32_t first = S->mbin_start[b_lo], n = S->mbin_start[b_hi + 1u] - first;
+        if (n) hipLaunchKernelGGL(cxp_k_me_visible, dim3(cxp_blocks(n)), dim3(256), 0, st, ttime, tris, (const uint32_t*)S->morder.p, first, n, t, tflag, sused);
+    }
+    hipLaunchKernelGGL(cxp_k_me_count, dim3(nbt), dim3(256), 0, st, (const uint8_t*)tflag, nt, toff);
     hipLaunchKernelGGL(cxp_k_me_count, dim3(nbs), dim3(256), 0, st, (const uint8_t*)sused, ns, soff);
     hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, soff, nbs, misc + 8, toff, nbt, misc + 9);
     uint32_t tot[2] = {0, 0};
@@ -2869,7 +2943,7 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(tot[0] + 1) * 3 * sizeof(double)))) return rc;
     if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(tot[1] + 1) * 3 * sizeof(int32_t)))) return rc;
     if (tot[0]) hipLaunchKernelGGL(cxp_k_me_points, dim3(nbs), dim3(256), 0, st, P4, segs, ns, t, (const uint8_t*)sused, (const uint32_t*)soff, snew, (double*)S->pts_out.p);
-    if (tot[1]) hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, (const uint8_t*)tflag, (const uint32_t*)toff, (const uint32_t*)snew, (int32_t*)S->tri_out.p, range, t);
+    if (tot[1]) hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, (const uint8_t*)tflag, (const uint32_t*)toff, (const uint32_t*)snew, (int32_t*)S->tri_out.p);
     CXP_HIP(ctx, hipGetLastError());
     S->me_points = tot[0]; S->me_tris = tot[1];
     if (out_counts) { out_counts[0] = tot[0]; out_counts[1] = tot[1]; }
