@@ -185,6 +185,9 @@ __device__ __forceinline__ uint32_t cx_corner_valid(const cx_params& P, uint32_t
 #ifndef CX_NT_TRIS
 #define CX_NT_TRIS 1
 #endif
+#ifndef CX_S1_SHIFT_OR
+#define CX_S1_SHIFT_OR 0
+#endif
 #ifndef CX_NT_GRID
 #define CX_NT_GRID 0
 #endif
@@ -706,9 +709,12 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
         // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
         auto plane_bits = [&](const plane_raw& R) -> uint32_t {
+            // The sign bits are shifted in from the right, last row first: one v_alignbit_b32 per sample ({word, difference} >> 31 = the
+            // word moved up by one with the sign bit of the difference behind it) instead of a shift and a shift-or; rows are
+            // CX_ROWBITS apart: two more places after each row of four.  (The stream kernel is bound by its instructions.)
             uint32_t own = 0, halo = 0;
 #pragma unroll
-            for (int r = 0; r <= CX_RJ; r++) {
+            for (int r = CX_RJ; r >= 0; r--) {
                 float vx = R.v[r].x, vy = R.v[r].y, vz = R.v[r].z;
                 const float vw = R.v[r].w;
                 if (!ALIGNED) {   // lane at the end of the row: samples kofs.. of (n2-4 .. n2-1), the last one repeated
@@ -718,11 +724,21 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                 }
                 const float dx = vx - P.vcmp, dy = vy - P.vcmp, dz = vz - P.vcmp, dw = vw - P.vcmp;
                 const float dh = R.hv[r] - P.vcmp;
+#if CX_S1_SHIFT_OR      // A/B: a shift and a shift-or per sample
                 own |= (__float_as_uint(dx) >> 31) << (CX_ROWBITS * r + 0);
                 own |= (__float_as_uint(dy) >> 31) << (CX_ROWBITS * r + 1);
                 own |= (__float_as_uint(dz) >> 31) << (CX_ROWBITS * r + 2);
                 own |= (__float_as_uint(dw) >> 31) << (CX_ROWBITS * r + 3);
                 halo |= (__float_as_uint(dh) >> 31) << (CX_ROWBITS * r);
+#else
+                own <<= (CX_ROWBITS - 4u);                                     // the two unused places of the row above
+                own = __builtin_amdgcn_alignbit(own, __float_as_uint(dw), 31);   // bit 3 of the row
+                own = __builtin_amdgcn_alignbit(own, __float_as_uint(dz), 31);
+                own = __builtin_amdgcn_alignbit(own, __float_as_uint(dy), 31);
+                own = __builtin_amdgcn_alignbit(own, __float_as_uint(dx), 31);   // bit 0
+                halo <<= (CX_ROWBITS - 1u);
+                halo = __builtin_amdgcn_alignbit(halo, __float_as_uint(dh), 31);
+#endif
                 dnear = fminf(dnear, fminf(fminf(fabsf(dx), fabsf(dy)), fminf(fabsf(dz), fminf(fabsf(dw), fabsf(dh)))));
             }
             // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
