@@ -2557,26 +2557,24 @@ __global__ __launch_bounds__(256) void cxp_k_edge_lists(const int32_t* tri, uint
         }
     }
 }
-// link every pair of time-compatible triangles on a common edge (morph_geometry.py:61-67, surface_geometry.py:117-128)
-__global__ void cxp_k_edge_union_compat(const int32_t* tri, uint32_t nt, const u64* ekeys, const u64* eheads, u64 mask, u64 mult, const uint32_t* next,
-                                        const double* ttime, u64* parent) {
+// link every pair of time-compatible triangles on a common edge (morph_geometry.py:61-67, surface_geometry.py:117-128).
+// Every visit walks the REST of its edge's list -- from the node behind its own to the end -- so each pair of nodes is looked at
+// once, by the one nearer the head; no visit has to find the edge's slot in the table again.  (Until round 3 every visit probed the
+// table for its edge and walked the whole list from the head, keeping the triangles with a smaller id: a random table read per
+// visit and twice the hops.)
+__global__ void cxp_k_edge_union_compat(uint32_t nt, const uint32_t* next, const double* ttime, u64* parent) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
-    const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
     const double lo = ttime[(size_t)t * 2], hi = ttime[(size_t)t * 2 + 1];
+    uint32_t it[3] = {next[t * 3u], next[t * 3u + 1u], next[t * 3u + 2u]};      // the three walks side by side
+    while (it[0] != CXP_NONE || it[1] != CXP_NONE || it[2] != CXP_NONE) {
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const uint32_t p = v[e], q = v[(e + 1) % 3];
-        const uint32_t elo = min(p, q), ehi = max(p, q);
-        const u64 key = ((u64)elo << 32) | (u64)ehi;
-        u64 slot = cxp_edge_slot(elo, ehi, mask, mult);
-        while (ekeys[slot] != key) slot = (slot + 1) & mask;
-        for (uint32_t it = (uint32_t)eheads[slot]; it != CXP_NONE; it = next[it]) {
-            const uint32_t o = it / 3u;
-            if (o >= t) continue;                                  // each unordered pair once
+        for (int e = 0; e < 3; e++) {
+            if (it[e] == CXP_NONE) continue;
+            const uint32_t o = it[e] / 3u;
             const double l2 = fmax(lo, ttime[(size_t)o * 2]), h2 = fmin(hi, ttime[(size_t)o * 2 + 1]);
-            if (!(l2 < h2)) continue;
-            cxp_union0(parent, t, o);   // connectivity only: the slices are wound alike (cxp_morph_slices); path halving (cxp_find0)
+            it[e] = next[it[e]];
+            if (l2 < h2 && o != t) cxp_union0(parent, t, o);   // connectivity only: the slices are wound alike (cxp_morph_slices); path halving (cxp_find0)
         }
     }
 }
@@ -2675,7 +2673,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, eheads, (size_t)esz, CXP_EMPTY);
             hipLaunchKernelGGL(cxp_k_iota64, dim3(cxp_blocks(ntri)), dim3(256), 0, st, parent, ntri);
             hipLaunchKernelGGL(cxp_k_edge_lists, dim3(cxp_blocks(ntri, CXP_EL)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next);
-            hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ntri, ekeys, eheads, esz - 1, emult4, next, ttime, parent);
+            hipLaunchKernelGGL(cxp_k_edge_union_compat, dim3(cxp_blocks(ntri)), dim3(256), 0, st, ntri, (const uint32_t*)next, (const double*)ttime, parent);
             if ((rc = cxp_flatten(ctx, parent, ntri, misc))) return rc;
             CXP_HIP(ctx, hipMemsetAsync(cmaxx, 0, (size_t)ntri * (3 * sizeof(u64) + sizeof(uint32_t)), st));
             CXP_HIP(ctx, hipMemsetAsync(misc + 3, 0, sizeof(uint32_t), st));
