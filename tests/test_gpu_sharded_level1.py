@@ -98,6 +98,45 @@ def test_sharded_level1_equals_the_undivided_volume(name, world):
     assert stats["pairs"] <= stats["nodes"] ** 2 and stats["nodes"] <= 2 * sum(len(L["cand_label"]) for L in lists)
 
 
+def test_one_slab_is_the_undivided_volume_and_clean_can_be_switched_off():
+    """world = 1: no neighbours, no lists, the local decisions stand; clean=False (the reference's extract_surface_geometry(clean=False))
+    goes through the sharded path as well"""
+    from contourist_amd import _ffi, distributed
+    A, value = fields()["balls"]
+    for clean in (True, False):
+        whole = _ffi.Context(0)
+        whole.upload_grid(A)
+        whole.extract3d(value, _ffi.CX_DIAG_CPYTHON310)
+        post = whole.postprocess3d(0 if clean else 1)
+        wp, wt = whole.download_level1(post)
+        wk = whole.download_level1_keys(post).astype(np.int64)
+        for world in (1, 3):
+            ctxs = [_ffi.Context(0) for _ in range(world)]
+            lists = []
+            for r in range(world):
+                lay = distributed.shard_layout(A.shape[0], world, r)
+                lists.append(distributed.shard_local(ctxs[r], np.ascontiguousarray(A[lay["e0"]:lay["e1"]]), lay, value, A.shape, clean=clean))
+            small = []
+            for r in range(world):
+                if r == 0:
+                    pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
+                else:
+                    import torch
+                    pairs, unmatched = distributed.pair_labels(*[torch.from_numpy(np.asarray(x)) for x in (
+                        lists[r]["own1"][0], lists[r]["own1"][1], lists[r - 1]["copy4"][0], lists[r - 1]["copy4"][1])])
+                small.append(distributed.shard_small(lists[r], pairs, unmatched))
+            answers, stats = distributed.merge_shard_components(small)
+            assert stats["unmatched"] == 0
+            parts = []
+            for r in range(world):
+                out = distributed.shard_finish(ctxs[r], lists[r], answers[r])
+                parts.append((out["keys"], out["points"], out["triangles"]))
+            keys, pts, tris = distributed.assemble_level1(parts)
+            order = np.argsort(wk)
+            assert np.array_equal(keys, wk[order]) and np.array_equal(pts, wp[order]), (clean, world)
+            assert np.array_equal(canon(keys, tris), canon(wk, wt)), (clean, world)
+
+
 def test_sharded_level1_at_full_size():
     """BASELINE's 512^3 bench field in 8 slabs of 64 planes (the ranks played one after the other on the one GPU): the union of
     the 8 parts is the undivided volume's Level-1 mesh, bit for bit; what goes through rank 0 is a few per cent of the mesh"""
