@@ -80,7 +80,9 @@ def cpu_baseline(field_host, value, budget_s=20.0):
     dt = time.time() - t0
     out = {"value": sub.size / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
            "sample": "planes 0:%d of the %s field (%d samples, %d triangles) in %.1f s, oracle/march_oracle.c single thread"
-                     % (planes, "x".join(str(n) for n in field_host.shape), sub.size, len(O["tris"]), dt)}
+                     % (planes, "x".join(str(n) for n in field_host.shape), sub.size, len(O["tris"]), dt),
+           "sample_planes": planes,
+           "oracle_counts": {"n_vertices": int(len(O["pairs"])), "n_triangles": int(len(O["tris"])), "n_border_voxels": int(O["nborder_mixed"])}}
     tpath = os.path.join(ROOT, "tests", "golden", "reference_timings.json")
     if os.path.exists(tpath):
         # the reference's pure Python never travels to the GPU box: its rate was measured where the fixtures were
@@ -364,9 +366,9 @@ def main():
     strong = not args.weak
     if args.streams <= 0:
         args.streams = 3 if world >= 4 else 2
-    # distinct volumes cycled through: a 512^3 grid (537 MB) is twice the Infinity Cache, but half of it could stay
-    # resident from step to step, so at least two are rotated; small grids need enough to exceed 256 MB several times
-    nrot = args.rotate or (2 if 4 * n ** 3 > 300e6 else max(5, int(1.5e9 // (4 * n ** 3))))
+    # distinct volumes cycled through: at least four (a 512^3 grid is 537 MB = twice the 256 MB Infinity Cache, so with four a
+    # volume comes back after 1.6 GB of other samples); small grids need enough to exceed 256 MB several times
+    nrot = args.rotate or max(4, int(1.5e9 // (4 * n ** 3)))
     overlap_halo = distributed and os.environ.get("BENCH_SYNC_HALO", "0") != "1"
     if overlap_halo:
         # the halo of the next volume is exchanged while the current one is extracted, and with S extractions in flight the buffer
@@ -472,6 +474,27 @@ def main():
     if rank == 0:
         local_samples = job.slabs[0].numel()
         alg_bytes = 4.0 * local_samples             # 4 B per input sample, read once
+        transport = ("RCCL over xGMI" if dist.get_backend() == "nccl" else "gloo, host-staged (a rehearsal, not RCCL)") if distributed else None
+        # sum of the fp32 bit patterns of rank 0's first volume (its slab + halo plane): the field is generated on the host and is the
+        # same bits in every environment (under rocprofv3 too); tests/test_gpu_bench_fields.py holds the whole-volume values
+        field_checksum = synthetic.field_checksum(job.slabs[0][:job.n_own])
+        # the ceiling as measured HERE, beside the 8 TB/s of the data sheet: a plain streaming read of the rotated volumes (16-byte
+        # loads; best launch) and a device-to-device copy of one of them (hipMemcpyDtoD through torch: bytes read + bytes written)
+        measured_read = 0.0
+        for _rnd in range(2):
+            for buf in job.slabs:
+                measured_read = max(measured_read, ctx.measure_read_bandwidth(buf.data_ptr(), buf.numel() * 4, 1))
+        dst = torch.empty_like(job.slabs[0])
+        dst.copy_(job.slabs[0])
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for buf in job.slabs[:4]:
+            dst.copy_(buf)
+        ev1.record()
+        torch.cuda.synchronize()
+        measured_copy = 2.0 * 4.0 * dst.numel() * len(job.slabs[:4]) / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        del dst
 
         def kernel_table(tmg):
             """per-kernel durations (HIP events on the extraction streams, inside a timed region) with the algorithmic bytes of
@@ -502,6 +525,7 @@ def main():
         # (their durations add up to MORE than the time an extraction takes), so the time is the step time of the timed region
         level0_ms = kernel_sum_ms if nstreams == 1 else step_ms
         achieved = alg_bytes / (level0_ms * 1e-3) / 1e9 if level0_ms > 0 else 0.0
+        bytes_necessary = alg_bytes + 8.0 * final["n_vertices"] + 12.0 * final["n_triangles"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -525,10 +549,12 @@ def main():
             "config": {
                 "workload": "%dx%dx%d fp32 smooth-noise %s ([1,2,1]/4 x %d passes, closed interior), isovalue %g, marching tetrahedra Level-0 (classify+interpolate+emit indexed mesh)"
                             % (n, n, n, ("volume split over %d GPUs" % world if distributed else "volume") if strong else "slab per GPU", args.passes, args.value),
-                "partition": ("one volume in axis-0 slabs, 1-plane halo over RCCL" if strong else
-                              "one slab per GPU (axis 0), 1-plane halo over RCCL") if distributed else "single GPU",
+                "partition": (("one volume in axis-0 slabs, 1-plane halo over %s" if strong else
+                               "one slab per GPU (axis 0), 1-plane halo over %s") % transport) if distributed else "single GPU",
                 "halo_exchange": ("one C call per step: RCCL send / receive on the extraction stream (the context's own communicator), then the extraction" if c_halo else
-                                  ("torch.distributed, overlapped with the previous volume's extraction" if overlap_halo else "torch.distributed, in line")) if distributed else None,
+                                  ("torch.distributed (%s), overlapped with the previous volume's extraction" % transport if overlap_halo
+                                   else "torch.distributed (%s), in line" % transport)) if distributed else None,
+                "field_checksum": field_checksum,
                 "active_voxel_fraction": final["n_border_voxels"] / float(max((job.n_own - (0 if job.has_upper else 1)) * (n - 1) ** 2, 1)),
                 "vertices_rank0": final["n_vertices"], "triangles_rank0": final["n_triangles"],
                 "grids_rotated": nrot,
@@ -548,6 +574,19 @@ def main():
                 "kernel_sum_ms": kernel_sum_ms,
                 "level0_ms": level0_ms,
                 "level0_frac": achieved / HBM_PEAK_GBS,
+                # "also report measured stream-read / DtoD bandwidth on the box and quote both fractions"
+                "measured_peak_GBps": measured_read,
+                "frac_of_measured": achieved / measured_read if measured_read > 0 else None,
+                "measured_copy_GBps": measured_copy,
+                "measured_peak_note": "stream read: cx_measure_read_bandwidth over the rotated volumes (16-byte loads, best launch); copy: "
+                                      "hipMemcpyDtoD of one volume, bytes read + written",
+                # what an extraction cannot avoid moving: the samples once + the mesh it leaves (8-byte vertex records, 12-byte triangles)
+                "bytes_necessary": bytes_necessary,
+                "necessary_GBps": bytes_necessary / (level0_ms * 1e-3) / 1e9 if level0_ms > 0 else 0.0,
+                "frac_necessary": bytes_necessary / (level0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if level0_ms > 0 else 0.0,
+                "traffic_note": "HBM bytes of one extraction from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/prof_step.py "
+                                "on the same field (profiles/traffic.json, tools/traffic.py: FETCH_SIZE doubled for the 16-byte streams as "
+                                "MI355X_MICROARCH.md prescribes); counters cannot be read inside this process",
             },
         }
         if single is not None:
@@ -596,10 +635,28 @@ def main():
                           "Mvoxels_per_s_through_api": n ** 3 / (t3 - t0) / 1e6,
                           "note": "get_points_and_triangles() equivalent: extract + post-pass + download of float64 points / int32 triangles (second call on the context: allocations exist)"}
             del pts, tris
+        parity_error = None
         if world == 1 and not args.no_cpu_baseline:
             host = job.slabs[0].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, args.value)
+            # the HIP path on the very sample the CPU leg marched (planes 0:P of rank 0's first volume, as a grid of its own): the
+            # counts must be equal -- a cheap end-to-end parity check inside every bench run (the exact comparison of the whole mesh
+            # is tests/test_gpu_bench_fields.py)
+            P_ = out["cpu_baseline"]["sample_planes"]
+            sub = job.slabs[0][:P_]
+            ctx.set_origin(0, 0, 0)
+            ctx.adopt_device_grid(sub.data_ptr(), tuple(sub.shape), keepalive=sub)
+            hc = ctx.extract3d(args.value, flags)
+            hip_counts = {k: int(hc[k]) for k in ("n_vertices", "n_triangles", "n_border_voxels")}
+            out["cpu_baseline"]["hip_counts_same_sample"] = hip_counts
+            out["cpu_baseline"]["counts_equal"] = hip_counts == out["cpu_baseline"]["oracle_counts"]
+            if not out["cpu_baseline"]["counts_equal"]:
+                parity_error = "HIP counts %r != oracle counts %r on the CPU leg's sample" % (hip_counts, out["cpu_baseline"]["oracle_counts"])
+                out["parity_error"] = parity_error
         print(json.dumps(out), flush=True)
+        if parity_error:
+            print("# PARITY ERROR: " + parity_error, file=sys.stderr, flush=True)
+            sys.exit(3)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

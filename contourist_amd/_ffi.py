@@ -29,7 +29,7 @@ SYMBOLS = [
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
     "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
-    "cx_timing_enable", "cx_timing_read", "cx_debug_stamps", "cx_version",
+    "cx_timing_enable", "cx_timing_read", "cx_measure_read_bandwidth", "cx_debug_stamps", "cx_version",
 ]
 CX2_ALL_CHAINS = 1
 CX2_NO_DEDUPE = 2
@@ -151,6 +151,7 @@ def load():
         "cx_contour2d_download": [vp, vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
         "cx_timing_read": [vp, ctypes.POINTER(dbl), ctypes.POINTER(ctypes.c_int)],
+        "cx_measure_read_bandwidth": [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(dbl)],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
@@ -569,12 +570,19 @@ class Context(object):
     def vertex_stage_bytes(self, counts):
         if self.level0_path() == 2:     # fused emit: 8 B per vertex record + 12 B per triangle written
             return 8.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
-        # 8-byte vertex records + 16-byte cell records + one 8-byte word per queue entry written
-        return 8.0 * counts["n_vertices"] + 24.0 * counts["n_cells"]
+        # what the stage must leave: 8-byte vertex records.  (Its cell records and per-entry words are the pipeline's own
+        # intermediates -- traffic, not algorithmic bytes.)
+        return 8.0 * counts["n_vertices"]
 
     @staticmethod
     def triangle_stage_bytes(counts):
         return 12.0 * counts["n_triangles"]
+
+    def measure_read_bandwidth(self, device_ptr, nbytes, reps=5):
+        "GB/s of a plain streaming read of nbytes at device_ptr (best of reps launches)"
+        g = ctypes.c_double()
+        self._check(self.lib.cx_measure_read_bandwidth(self.handle, ctypes.c_void_p(int(device_ptr)), int(nbytes), int(reps), ctypes.byref(g)))
+        return g.value
 
     def timing_enable(self, on=True):
         self._check(self.lib.cx_timing_enable(self.handle, int(bool(on))))

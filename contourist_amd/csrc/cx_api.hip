@@ -535,6 +535,51 @@ extern "C" int cx_debug_stamps(cx_ctx* ctx, int64_t words, unsigned long long* h
     return CX_OK;
 }
 
+// ---- measurement: what a plain streaming read of `bytes` bytes gets on this device (16-byte loads, grid-stride, 8 in flight per
+// lane, result folded into one word per workgroup so that nothing is optimised away).  The ceiling the stream kernel is compared
+// with in bench.py (`roofline.measured_peak_GBps`), measured in the process that runs the bench.
+__global__ __launch_bounds__(256) void cx_k_read_bw(const uint4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7u * stride < n16; i += 8u * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[i + (size_t)u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x & 255u] = acc;    // (practically never: keeps the loads alive)
+}
+extern "C" int cx_measure_read_bandwidth(cx_ctx* ctx, const void* device_ptr, int64_t bytes, int reps, double* out_GBps) {
+    if (!ctx || !device_ptr || bytes < (1 << 20) || reps < 1 || !out_GBps) return ctx ? fail(ctx, CX_ERR_INVALID, "cx_measure_read_bandwidth: bad argument") : CX_ERR_INVALID;
+    CX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->counters) return fail(ctx, CX_ERR_STATE, "context has no scratch words yet (extract once first)");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CX_HIP(ctx, hipEventCreate(&e0));
+    CX_HIP(ctx, hipEventCreate(&e1));
+    const size_t n16 = (size_t)bytes / 16u;
+    uint32_t* sink = nullptr;
+    CX_HIP(ctx, hipMalloc(&sink, 256 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(cx_k_read_bw, dim3(256 * 8), dim3(256), 0, ctx->stream, static_cast<const uint4*>(device_ptr), n16, sink);   // warm
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+        CX_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(cx_k_read_bw, dim3(256 * 8), dim3(256), 0, ctx->stream, static_cast<const uint4*>(device_ptr), n16, sink);
+        CX_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        CX_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        CX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (ms > 0.f) best = fmax(best, (double)n16 * 16.0 / (ms * 1e-3) / 1e9);
+    }
+    (void)hipFree(sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *out_GBps = best;
+    return CX_OK;
+}
+
 extern "C" int cx_timing_enable(cx_ctx* ctx, int on) {
     if (!ctx) return CX_ERR_INVALID;
     ctx->timing = on != 0;

@@ -1077,6 +1077,10 @@ __device__ __forceinline__ void cx_skip_rounds(const cx_params& P, const cx_fast
 #define CX_S3_MIN_WAVES 1
 #endif
 __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
+#ifdef CX_OCC_PAD   // experiment: fewer workgroups per CU (what does the time do with the occupancy?)
+    __shared__ uint32_t s_pad[CX_OCC_PAD / 4];
+    if (P.n0 == 0xFFFFFFFFu) reinterpret_cast<volatile uint32_t*>(s_pad)[threadIdx.x] = 1u;
+#endif
     __shared__ float4 s_vstage[4][CX_VSTAGE_LDS];
     __shared__ uint8_t s_ntri[256];
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
@@ -1715,6 +1719,10 @@ __device__ __forceinline__ void cx_triq_pin2(cx_tri_in& I) {
 #endif
 template <bool NEG_ORIGIN>
 __global__ __launch_bounds__(256, CX_K2Q_MIN_WAVES) void cx_k_emit_triangles_q(const cx_params P, const cx_task T, const uint64_t* __restrict__ hash_xy) {
+#ifdef CX_OCC_PAD   // experiment: fewer workgroups per CU (what does the time do with the occupancy?)
+    __shared__ uint32_t s_pad[CX_OCC_PAD / 4];
+    if (P.n0 == 0xFFFFFFFFu) reinterpret_cast<volatile uint32_t*>(s_pad)[threadIdx.x] = 1u;
+#endif
     __shared__ cx_tri_lds L;
     const uint32_t ncells = min(P.counters[CX_CNT_CELLS], P.ccap);
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;  // host re-runs with more room

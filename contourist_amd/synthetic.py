@@ -4,44 +4,92 @@ outermost 2 samples forced below the minimum ("closed interior").
 
 The smoothing is applied in Fourier space -- `passes` applications of [1,2,1]/4 along one axis are
 exactly a multiplication by cos(w/2)^(2*passes) -- so large pass counts cost one FFT pair.
-Works on a HIP device through torch (fields are generated straight into HBM) or on the CPU.
+The bench field is computed on the HOST (pocketfft) and copied to the device, so that it is bit for bit the same
+in every environment (plain run, under rocprofv3, another box): see smooth_noise_host.
 """
 import math
 
 import numpy as np
 
 
-def smooth_noise_torch(shape, seed, passes, device, slab=None, dtype=None):
-    """fp32 tensor of `shape` on `device`.  slab=(i0, i1): return only planes i0:i1 of axis 0
-    (the field itself is always generated whole so that slabs of different ranks agree)."""
+_FIELD_CACHE = {}      # (shape, seed, passes) -> fp32 numpy array; one entry (a 512^3 field is 537 MB)
+
+
+def smooth_noise_host(shape, seed, passes):
+    """The bench field as an fp32 numpy array, computed entirely on the host: the noise from torch's CPU generator (plane by
+    plane, as every round has drawn it), the filter with scipy's pocketfft (every 1-D transform is computed by one thread:
+    the result does not depend on the worker count), mean and deviation accumulated in float64.  Nothing here depends on
+    a GPU library's kernel selection.  (Rounds 1-3 ran the two FFTs on the device, torch.fft = rocFFT: under rocprofv3 the
+    forward transform came out with different roundings -- tools/field_check.py: same noise checksum, different spectrum
+    checksum -- so that ~100 of the 134 M samples within 1e-6 of the isovalue changed and the profiled mesh had 12 441 978
+    vertices where the plain run had 12 441 984.)"""
+    import scipy.fft as sfft
     import torch
+    key = (tuple(int(n) for n in shape), int(seed), int(passes))
+    hit = _FIELD_CACHE.get(key)
+    if hit is not None:
+        return hit
+    n0, n1, n2 = key[0]
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
-    n0, n1, n2 = (int(n) for n in shape)
-    # counter-based, device independent: draw on the CPU generator in planes, move to the device
-    x = torch.empty((n0, n1, n2), dtype=torch.float32, device=device)
-    for i in range(n0):
-        x[i] = torch.randn((n1, n2), generator=g, dtype=torch.float32).to(device)
-    X = torch.fft.rfftn(x)
+    # ONE call draws the same stream as the plane-by-plane draws of rounds 1-3 (torch's CPU generator fills serially,
+    # whatever the thread count: checked at 512^3, checksum of the noise -2240853796164619 either way)
+    x = torch.randn((n0, n1, n2), generator=g, dtype=torch.float32).numpy()
+    import os
+    workers = max(1, min(16, os.cpu_count() or 1))
+    X = sfft.rfftn(x, workers=workers)
     del x
     for axis, n in enumerate((n0, n1, n2)):
         m = X.shape[axis]
-        w = 2.0 * math.pi * torch.arange(m, device=device, dtype=torch.float64) / n
-        filt = torch.cos(w / 2.0).abs().pow(2 * passes).to(torch.float32)
+        w = 2.0 * np.pi * np.arange(m, dtype=np.float64) / n
+        filt = (np.abs(np.cos(w / 2.0)) ** (2 * passes)).astype(np.float32)
         view = [1, 1, 1]
         view[axis] = m
-        X *= filt.view(view)
-    y = torch.fft.irfftn(X, s=(n0, n1, n2))
+        X *= filt.reshape(view)
+    y = sfft.irfftn(X, s=(n0, n1, n2), workers=workers)
     del X
-    y -= y.mean()
-    y /= y.std()
-    lo = float(y.min()) - 1.0
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    mean = float(y.mean(dtype=np.float64))
+    y -= np.float32(mean)
+    std = float(np.sqrt(_sumsq64(y) / y.size))
+    y /= np.float32(std)
+    lo = np.float32(float(y.min()) - 1.0)
     for axis in range(3):
+        sl = [slice(None)] * 3
         for idx in (0, 1, -1, -2):
-            y.select(axis, idx).fill_(lo)
+            sl[axis] = idx
+            y[tuple(sl)] = lo
+    _FIELD_CACHE.clear()
+    _FIELD_CACHE[key] = y
+    return y
+
+
+def _sumsq64(y):
+    "sum of squares in float64, plane by plane (no 1 GB temporary)"
+    acc = 0.0
+    for i in range(y.shape[0]):
+        acc += float(np.square(y[i], dtype=np.float64).sum())     # numpy's pairwise summation: one fixed order
+    return acc
+
+
+def field_checksum(a):
+    """order-free checksum of a field: the sum of its fp32 bit patterns as signed 32-bit integers, in 64 bits (numpy array
+    or torch tensor on any device).  Equal fields have equal checksums in every environment."""
+    if type(a).__module__.split(".")[0] == "torch":
+        import torch
+        return int(a.contiguous().view(torch.int32).to(torch.int64).sum().item())
+    return int(np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64).sum())
+
+
+def smooth_noise_torch(shape, seed, passes, device, slab=None, dtype=None):
+    """fp32 tensor of `shape` on `device`.  slab=(i0, i1): return only planes i0:i1 of axis 0
+    (the field itself is always generated whole so that slabs of different ranks agree).  Generated on the host
+    (smooth_noise_host: bit-identical in every environment), then copied to the device."""
+    import torch
+    y = smooth_noise_host(shape, seed, passes)
     if slab is not None:
-        y = y[slab[0]:slab[1]].contiguous()
-    return y.contiguous()
+        y = y[slab[0]:slab[1]]
+    return torch.from_numpy(y).to(device).contiguous()
 
 
 def smooth_noise_numpy(shape, seed, passes):

@@ -349,6 +349,10 @@ int cx_contour2d_download(cx_ctx* ctx, double* points_xy, int64_t* keys, cx_chai
  * classify kernel is reported in ms[3]), ms[6..7] reserved.  *n = number of extracts accumulated. */
 int cx_timing_enable(cx_ctx* ctx, int on);
 int cx_timing_read(cx_ctx* ctx, double ms[8], int* n);
+/* what a plain streaming READ of `bytes` bytes at device_ptr reaches on this device (16-byte loads, grid-stride; best of `reps`
+ * launches on the context's stream, HIP events): the measured ceiling beside the 8 TB/s data-sheet figure that bench.py quotes
+ * the stream kernel against ("also report measured stream-read BW on the box").  No counterpart in the reference. */
+int cx_measure_read_bandwidth(cx_ctx* ctx, const void* device_ptr, int64_t bytes, int reps, double* out_GBps);
 
 /* diagnostics: per-wave s_memtime stamps of the stream kernel (4 words per wave: [0] start, [1] end; [2..3]
  * unused).  words > 0 allocates, host != NULL copies out, 0/NULL frees. */

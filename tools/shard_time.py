@@ -29,7 +29,8 @@ for _ in range(2):
 print("undivided %d^3: extract %.2f ms, Level 1 %.2f ms, %d triangles" % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, post["n_triangles"]))
 del whole
 ctxs = [_ffi.Context(0) for _ in range(world)]
-for rnd in range(3):      # later rounds: buffers exist
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+for rnd in range(rounds):      # later rounds: buffers exist
     lists, t_local = [], []
     for r in range(world):
         lay = distributed.shard_layout(n, world, r)
@@ -38,6 +39,8 @@ for rnd in range(3):      # later rounds: buffers exist
         t0 = time.perf_counter()
         lists.append(distributed.shard_local(ctxs[r], local, lay, 0.0, (n, n, n), torch_device=dev))
         t_local.append((time.perf_counter() - t0) * 1e3)
+        if rnd > 0 and t_local[-1] > 20.0:     # the stall: when (CLOCK_MONOTONIC ns, to line up with a rocprofv3 --hip-trace)
+            print("SLOW local call: round %d rank %d %.2f ms, ended at monotonic %d ns" % (rnd, r, t_local[-1], time.clock_gettime_ns(time.CLOCK_MONOTONIC)), flush=True)
     small, t_pair = [], []
     for r in range(world):
         t0 = time.perf_counter()
