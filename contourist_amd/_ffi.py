@@ -26,8 +26,8 @@ SYMBOLS = [
     "cx_ctx_create", "cx_ctx_destroy", "cx_last_error", "cx_set_stream", "cx_synchronize",
     "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
-    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
+    "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_device_ptrs", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_rccl_available", "cx_rccl_comm_share", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_measure_read_bandwidth", "cx_debug_stamps", "cx_version",
 ]
@@ -118,6 +118,7 @@ def load():
         "cx_seeded_masks_download": [vp, vp, vp],
         "cx_set_reference_corner": [vp, i64, i64, i64],
         "cx_level1_download": [vp, vp, vp],
+        "cx_level1_device_ptrs": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64)],
         "cx_level1_download_keys": [vp, vp],
         "cx_postprocess3d_shard_begin": [vp, u32, i64, i64, vp, vp, vp, vp],
         "cx_postprocess3d_shard_boundary": [vp, ctypes.c_int, vp, vp],
@@ -138,6 +139,8 @@ def load():
         "cx_rccl_unique_id": [vp],
         "cx_rccl_comm_init": [vp, vp, ctypes.c_int, ctypes.c_int],
         "cx_rccl_comm_destroy": [vp],
+        "cx_rccl_available": [],
+        "cx_rccl_comm_share": [vp, vp],
         "cx_slab_step": [vp, vp, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_uint32],
         "cx_level0_4d_download": [vp, vp, vp, vp],
         "cx_postprocess4d": [vp, ctypes.c_int32, vp],
@@ -334,6 +337,31 @@ class Context(object):
         self._check(self.lib.cx_level1_download(self.handle, pts.ctypes.data, tris.ctypes.data))
         return pts, tris
 
+    def level1_device_ptrs(self):
+        "(points pointer, triangles pointer, n_vertices, n_triangles) of the Level-1 mesh ON THE DEVICE (no copy; valid until the next post-pass)"
+        pp, tp, nv, nt = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.cx_level1_device_ptrs(self.handle, ctypes.byref(pp), ctypes.byref(tp), ctypes.byref(nv), ctypes.byref(nt)))
+        return pp.value or 0, tp.value or 0, nv.value, nt.value
+
+    def level1_torch(self, copy=True):
+        """the Level-1 mesh as torch tensors on the context's device: points (V,3) float64, triangles (T,3) int32 (device order).
+        copy=True: tensors that own their memory (one device-to-device copy); copy=False: views of the context's buffers,
+        valid only until the next post-pass / extraction on this context."""
+        import torch
+        pp, tp, nv, nt = self.level1_device_ptrs()
+        dev = torch.device("cuda", self.device)
+
+        class _View(object):
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        pts = torch.as_tensor(_View(pp, (nv, 3), "<f8"), device=dev) if nv else torch.zeros((0, 3), dtype=torch.float64, device=dev)
+        tris = torch.as_tensor(_View(tp, (nt, 3), "<i4"), device=dev) if nt else torch.zeros((0, 3), dtype=torch.int32, device=dev)
+        if copy:
+            pts, tris = pts.clone(), tris.clone()
+        else:
+            pts._cx_keep = tris._cx_keep = self
+        return pts, tris
+
     def download_level1_keys(self, counts):
         "edge ids (local to the marched array) of the vertices of download_level1, in its order"
         keys = np.empty(int(counts["n_vertices"]), dtype=np.uint32)
@@ -456,6 +484,19 @@ class Context(object):
         buf = np.ascontiguousarray(id128, dtype=np.uint8)
         assert buf.size == 128
         self._check(self.lib.cx_rccl_comm_init(self.handle, buf.ctypes.data, int(rank), int(world)))
+
+    def rccl_available(self):
+        "local, no collective: can this process run the C-side halo exchange (an RCCL copy is loaded and exports what is needed)?"
+        return self.lib.cx_rccl_available() == CX_OK
+
+    def rccl_comm_share(self, owner):
+        "use `owner`'s communicator (another context of this rank, which keeps the ownership and must outlive this one)"
+        self._check(self.lib.cx_rccl_comm_share(self.handle, owner.handle))
+        self._comm_owner = owner
+
+    def rccl_comm_destroy(self):
+        self._check(self.lib.cx_rccl_comm_destroy(self.handle))
+        self._comm_owner = None
 
     def slab_step(self, local_ptr, n_own, n1, n2, rank, world, value, flags=CX_DIAG_CPYTHON310, keepalive=None):
         """one rank's whole step for one volume in ONE call: adopt the device buffer (n_own planes + room for the halo plane unless

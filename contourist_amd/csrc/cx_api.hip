@@ -564,15 +564,17 @@ extern "C" int cx_measure_read_bandwidth(cx_ctx* ctx, const void* device_ptr, in
     CX_HIP(ctx, hipMalloc(&sink, 256 * sizeof(uint32_t)));
     hipLaunchKernelGGL(cx_k_read_bw, dim3(256 * 8), dim3(256), 0, ctx->stream, static_cast<const uint4*>(device_ptr), n16, sink);   // warm
     double best = 0.0;
-    for (int r = 0; r < reps; r++) {
-        CX_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(cx_k_read_bw, dim3(256 * 8), dim3(256), 0, ctx->stream, static_cast<const uint4*>(device_ptr), n16, sink);
-        CX_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        CX_HIP(ctx, hipEventSynchronize(e1));
-        float ms = 0.f;
-        CX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-        if (ms > 0.f) best = fmax(best, (double)n16 * 16.0 / (ms * 1e-3) / 1e9);
-    }
+    const uint32_t grids[3] = {256u * 8u, 256u * 16u, 256u * 32u};     // workgroups: 8, 16, 32 per CU's worth (the best one counts)
+    for (int r = 0; r < reps; r++)
+        for (uint32_t g : grids) {
+            CX_HIP(ctx, hipEventRecord(e0, ctx->stream));
+            hipLaunchKernelGGL(cx_k_read_bw, dim3(g), dim3(256), 0, ctx->stream, static_cast<const uint4*>(device_ptr), n16, sink);
+            CX_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            CX_HIP(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            CX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (ms > 0.f) best = fmax(best, (double)n16 * 16.0 / (ms * 1e-3) / 1e9);
+        }
     (void)hipFree(sink);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

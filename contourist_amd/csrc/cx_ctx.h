@@ -90,6 +90,7 @@ struct cx_ctx {
     size_t stamps_words = 0;
     // the context's own RCCL communicator (cx_rccl_comm_init, cx_halo.hip), or null
     void* rccl_comm = nullptr;
+    bool rccl_owned = true;              // false: the communicator belongs to another context of this rank (cx_rccl_comm_share)
     int rccl_rank = 0, rccl_world = 1;
     // device -> host copies of mesh-sized buffers (cx_xfer.hip): two pinned staging buffers and their events
     void* xfer_stage[2] = {nullptr, nullptr};

@@ -62,6 +62,14 @@ bool cx_rccl_resolve() {
 const char* CX_NO_RCCL = "no RCCL loaded in this process (librccl.so with ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd)";
 }   // namespace
 
+// can this process run the C-side exchange at all?  Purely local (no collective): a host calls it on every rank and agrees on the
+// answer BEFORE anybody enters the collective cx_rccl_comm_init -- a rank that found no RCCL would otherwise leave the others
+// waiting inside ncclCommInitRank for ever.
+extern "C" int cx_rccl_available(void) {
+    if (!cx_rccl_resolve() || !g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy) return CX_ERR_UNSUPPORTED;
+    return CX_OK;
+}
+
 extern "C" int cx_rccl_unique_id(uint8_t* out128) {
     if (!out128) return CX_ERR_INVALID;
     if (!cx_rccl_resolve() || !g_rccl.get_uid) return CX_ERR_UNSUPPORTED;
@@ -75,20 +83,39 @@ extern "C" int cx_rccl_comm_init(cx_ctx* ctx, const uint8_t* id128, int rank, in
     if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return CX_ERR_INVALID;
     if (!cx_rccl_resolve() || !g_rccl.init_rank || !g_rccl.destroy) { ctx->err = CX_NO_RCCL; return CX_ERR_UNSUPPORTED; }
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "cx_rccl_comm_init: hipSetDevice failed"; return CX_ERR_HIP; }
-    if (ctx->rccl_comm) { (void)g_rccl.destroy(ctx->rccl_comm); ctx->rccl_comm = nullptr; }
+    cx_rccl_comm_free(ctx);
     cx_nccl_uid id;
     memcpy(id.internal, id128, sizeof(id.internal));
     void* comm = nullptr;
     const int rc = g_rccl.init_rank(&comm, world, id, rank);
     if (rc != 0 || !comm) { ctx->err = "cx_rccl_comm_init: ncclCommInitRank returned " + std::to_string(rc); return CX_ERR_HIP; }
     ctx->rccl_comm = comm;
+    ctx->rccl_owned = true;
     ctx->rccl_rank = rank; ctx->rccl_world = world;
     return CX_OK;
 }
 
+// the contexts of ONE rank (its extractions in flight, one HIP stream each) share one communicator: every exchange is a group on
+// the calling context's stream, issued by the host's single thread in volume order -- the same order on every rank.  (Round 3 gave
+// every context a communicator of its own: exchanges of different communicators may then run side by side on the device, which
+// RCCL only promises to survive when every rank issues them in one order AND the device can hold both at once; one communicator
+// leaves nothing to promise.  RCCL orders the exchanges of a communicator behind each other across streams; the extractions
+// behind them still overlap.)
+extern "C" int cx_rccl_comm_share(cx_ctx* ctx, cx_ctx* owner) {
+    if (!ctx || !owner || ctx == owner) return CX_ERR_INVALID;
+    if (!owner->rccl_comm) { ctx->err = "cx_rccl_comm_share: the owner has no communicator"; return CX_ERR_STATE; }
+    if (ctx->device != owner->device) { ctx->err = "cx_rccl_comm_share: contexts on different devices"; return CX_ERR_INVALID; }
+    cx_rccl_comm_free(ctx);
+    ctx->rccl_comm = owner->rccl_comm;
+    ctx->rccl_owned = false;
+    ctx->rccl_rank = owner->rccl_rank; ctx->rccl_world = owner->rccl_world;
+    return CX_OK;
+}
+
 void cx_rccl_comm_free(cx_ctx* ctx) {
-    if (ctx->rccl_comm && g_rccl.destroy) (void)g_rccl.destroy(ctx->rccl_comm);
+    if (ctx->rccl_comm && ctx->rccl_owned && g_rccl.destroy) (void)g_rccl.destroy(ctx->rccl_comm);
     ctx->rccl_comm = nullptr;
+    ctx->rccl_owned = true;
 }
 extern "C" int cx_rccl_comm_destroy(cx_ctx* ctx) {
     if (!ctx) return CX_ERR_INVALID;

@@ -629,6 +629,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
     uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
     uint32_t nr = 0;                       // wave-uniform: rounds of 64 cells of the closed batches
+    uint32_t qa_steps = 0;                 // wave-uniform: plane steps that queued cells (bit per step)
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
@@ -743,7 +744,8 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             }
             // k+1 neighbour of m=3: m=0 of the next lane; the last valid lane takes the halo sample or,
             // at the array edge, repeats its own m=3 (clamped corner)
-            uint32_t nbr = (uint32_t)__shfl_down((int)own, 1) & CX_M0_MASK;
+            // lane l takes the word of lane l + 1 (DPP wave_shl:1, a VALU move; __shfl_down is a ds_bpermute: an LDS round trip per step)
+            uint32_t nbr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x130, 0xF, 0xF, false) & CX_M0_MASK;
             if (lane == last_lane) nbr = halo_in ? halo : ((own >> 3) & CX_M0_MASK);
             return own | (nbr << 4);
         };
@@ -763,6 +765,18 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         // one step: plane p+1 is in `cur`, plane p+2 is on its way, plane p+3 is requested into `nxt` (whose plane is used up)
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 3u, nxt);
+#elif CX_S1_DEPTH == 3
+        // TWO planes in flight with two buffers: a buffer is requested again right after its sign bits are taken (its samples are
+        // dead from then on), so while a step's active cells are worked on both the next plane and the one after are on their way
+        plane_raw rawA, rawB;
+        load_plane(p, rawB);
+        load_plane(p + 1u, rawA);
+        uint32_t wprev = plane_bits(rawB);
+        load_plane(p + 2u, rawB);
+        auto step = [&](plane_raw& cur, plane_raw& unused_) {
+            (void)unused_;
+            const uint32_t wcur = plane_bits(cur);
+            load_plane(p + 3u, cur);
 #else
         plane_raw rawA, rawB;
         load_plane(p, rawB);
@@ -772,7 +786,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 2u, nxt);
 #endif
+#if CX_S1_DEPTH != 3
             const uint32_t wcur = plane_bits(cur);
+#endif
             // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
             const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
             const uint32_t oc = wcur | (wcur >> 1), ac = wcur & (wcur >> 1);
@@ -789,6 +805,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                 // where the lane's cells of this step sit in the wave's queue, and which they are (bit 4r+m): lets the
                 // fused emit kernel find the queue entry of ANY active cell of the volume without a table per sample
                 s_qa[wave][p - G.pstart][lane] = ((qn + pre) << 16) | (act0 & 0xFu) | ((act0 >> 2) & 0xF0u) | ((act0 >> 4) & 0xF00u) | ((act0 >> 6) & 0xF000u);
+                qa_steps |= 1u << (p - G.pstart);
                 while (act) {
                     const uint32_t bit = __ffs(act) - 1u;
                     act &= act - 1u;
@@ -882,7 +899,12 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         const uint32_t nsteps = p - G.pstart;
         uint32_t* __restrict__ gqa = P.qa + (size_t)w * (CX_SWP * 64u);
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t sidx = 0; sidx < nsteps; sidx++) gqa[sidx * 64u + lane] = s_qa[wave][sidx][lane];
+        // only the steps that queued cells (round 3 wrote all of them, 50 MB per 512^3 extraction, three fifths of it never read)
+        (void)nsteps;
+        for (uint32_t m = qa_steps; m; m &= m - 1u) {
+            const uint32_t sidx = (uint32_t)__builtin_ctz(m);
+            gqa[sidx * 64u + lane] = s_qa[wave][sidx][lane];
+        }
     }
 #ifndef CX_S3_STAMPS
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();

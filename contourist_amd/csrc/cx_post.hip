@@ -1842,6 +1842,22 @@ extern "C" int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris
     return cx_copy_to_host(ctx, 2, d, sp, nb);   // pinned, double-buffered, several host threads (cx_xfer.hip)
 }
 
+// device pointers of the Level-1 mesh: for consumers that live on the GPU (a torch tensor, a renderer's vertex buffer) the 541 MB
+// download of a 512^3 mesh -- 60 % of the API path's time -- never has to happen.  Everything enqueued on the context's stream
+// is complete when this returns.
+extern "C" int cx_level1_device_ptrs(cx_ctx* ctx, void** points_xyz, void** tris, int64_t* n_vertices, int64_t* n_triangles) {
+    if (!ctx) return CX_ERR_INVALID;
+    if (!ctx->post || !ctx->post_valid) { ctx->err = "cx_level1_device_ptrs: run cx_postprocess3d first"; return CX_ERR_STATE; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    CXP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cx_post_state* S = ctx->post;
+    if (points_xyz) *points_xyz = S->nv_out ? S->pts_out.p : nullptr;
+    if (tris) *tris = S->nt_out ? S->tri_out.p : nullptr;
+    if (n_vertices) *n_vertices = (int64_t)S->nv_out;
+    if (n_triangles) *n_triangles = (int64_t)S->nt_out;
+    return CX_OK;
+}
+
 // ---- binary mesh files straight from the Level-1 device buffers (what every caller of the reference does next,
 // html_demo.py:118-161, without the detour through Python arrays).  The file's records are laid out ON THE DEVICE, a chunk at a
 // time (world coordinates = grid * delta + mins, rounded as numpy rounds them: no fused multiply-add), and streamed through two
@@ -2904,7 +2920,11 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     const uint32_t nbs = cxp_blocks(ns, CXP_SCAN_BLOCK), nbt = cxp_blocks(nt, CXP_SCAN_BLOCK);
     if ((rc = cxp_reserve(ctx, S->flags, (size_t)ns + nt + 256))) return rc;                         // one byte per segment / triangle
     if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + 32) * sizeof(uint32_t)))) return rc;            // new ids of the segments in use
-    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(nbs + nbt + 16) * sizeof(uint32_t)))) return rc;
+    // block counts of the two compactions -- and, on the first call for these morph triangles, the histogram of cxp_me_index, which
+    // lives in the same buffer: reserved HERE, for the larger of the two, before any pointer into it is taken (until round 4 the
+    // index reserved its own 2 x 1 024 words afterwards; when that was more than nbs + nbt + 16 the buffer moved and soff / toff
+    // below pointed into freed memory: a GPU memory fault on small morphs whenever the allocator had unmapped the old block)
+    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)std::max<size_t>(nbs + nbt + 16, 2 * CXP_ME_BINS + 16) * sizeof(uint32_t)))) return rc;
     uint8_t* sused = (uint8_t*)S->flags.p;
     uint8_t* tflag = sused + (((size_t)ns + 127u) & ~(size_t)63u);
     uint32_t* snew = (uint32_t*)S->scan.p;

@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <string>
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -47,8 +49,8 @@ static int xfer_threads() {
 
 // several device buffers -> host buffers, back to back through the same pipeline (one pipeline fill for a whole mesh).
 // Ordered after everything enqueued on the context's stream; returns when the host buffers are complete.
-// The host side: nt - 1 worker threads live for the duration of the call; piece k is announced through `ready`, every
-// thread copies its page-aligned slice of it, `done[k]` counts the slices.
+// The host side: nt - 1 worker threads live for the duration of the call and sleep on a condition variable between pieces; piece k
+// is announced through `ready`, every thread copies its page-aligned slice of it, `done[k]` counts the slices.
 int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const* src, const size_t* bytes) {
     size_t total = 0;
     for (int p = 0; p < nparts; p++) total += (dst[p] && src[p]) ? bytes[p] : 0;
@@ -70,44 +72,59 @@ int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const
         for (size_t off = 0; off < bytes[p]; off += CX_XFER_CHUNK)
             pieces.push_back({(char*)dst[p] + off, (const char*)src[p] + off, std::min(CX_XFER_CHUNK, bytes[p] - off)});
     }
-    int nt = xfer_threads();
+    // host threads: no more than the bytes justify (a worker per 16 MB of mesh, at most xfer_threads()), and they SLEEP while they
+    // wait (condition variables): with several ranks or contexts per node a pool of spinning threads per download would take the
+    // cores the ranks' own host threads run on (round 3 spun in yield loops for the whole duration of every DMA chunk)
+    int nt = std::max(1, std::min(xfer_threads(), (int)(total / ((size_t)16 << 20)) + 1));
     const size_t np = pieces.size();
-    std::atomic<long> ready{-1};                    // pieces 0..ready sit in their staging buffers
-    std::atomic<bool> abort_flag{false};
-    std::vector<std::atomic<int>> done(np);
-    for (auto& d : done) d.store(0);
+    std::mutex mtx;
+    std::condition_variable cv_ready, cv_done;
+    long ready = -1;                                // pieces 0..ready sit in their staging buffers      (guarded by mtx)
+    bool go = false, abort_flag = false;            //                                                   (guarded by mtx)
+    std::vector<int> done(np, 0);                   // slices of piece k copied out                      (guarded by mtx)
     void* const stage0 = ctx->xfer_stage[0];
     void* const stage1 = ctx->xfer_stage[1];
-    auto slice = [&](size_t k, int t) {
+    auto slice = [&](size_t k, int t, int nthreads) {
         const piece& pc = pieces[k];
-        const size_t per = ((pc.n + (size_t)nt - 1) / (size_t)nt + 4095u) & ~(size_t)4095u;
+        const size_t per = ((pc.n + (size_t)nthreads - 1) / (size_t)nthreads + 4095u) & ~(size_t)4095u;
         const size_t off = per * (size_t)t;
         if (off < pc.n) memcpy(pc.dst + off, (const char*)((k & 1) ? stage1 : stage0) + off, std::min(per, pc.n - off));
-        done[k].fetch_add(1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            done[k]++;
+        }
+        cv_done.notify_one();
     };
     // the workers wait for `go` before they look at nt: if the system refuses a thread, the copy runs with those it granted
-    std::atomic<bool> go{false};
     std::vector<std::thread> workers;
     workers.reserve((size_t)nt);
     try {
         for (int t = 1; t < nt; t++)
             workers.emplace_back([&, t] {
-                while (!go.load(std::memory_order_acquire)) {
-                    if (abort_flag.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
+                int nthreads = 0;
+                {
+                    std::unique_lock<std::mutex> lk(mtx);
+                    cv_ready.wait(lk, [&] { return go || abort_flag; });
+                    if (abort_flag) return;
+                    nthreads = nt;
                 }
                 for (size_t k = 0; k < np; k++) {
-                    while (ready.load(std::memory_order_acquire) < (long)k) {
-                        if (abort_flag.load(std::memory_order_relaxed)) return;
-                        std::this_thread::yield();
+                    {
+                        std::unique_lock<std::mutex> lk(mtx);
+                        cv_ready.wait(lk, [&] { return ready >= (long)k || abort_flag; });
+                        if (abort_flag) return;
                     }
-                    slice(k, t);
+                    slice(k, t, nthreads);
                 }
             });
     } catch (...) {
     }
-    nt = (int)workers.size() + 1;      // slices are cut for the threads that exist (read by slice() only after `go`)
-    go.store(true, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        nt = (int)workers.size() + 1;      // slices are cut for the threads that exist (read by the workers only after `go`)
+        go = true;
+    }
+    cv_ready.notify_all();
     int rc = CX_OK;
     // piece i travels through staging buffer i & 1: its DMA is enqueued before piece i-1 is copied out on the host
     for (size_t i = 0; i <= np && rc == CX_OK; i++) {
@@ -119,9 +136,14 @@ int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const
         if (e == hipSuccess && i >= 1) {
             e = hipEventSynchronize(ctx->xfer_ev[(i - 1) & 1]);
             if (e == hipSuccess) {
-                ready.store((long)(i - 1), std::memory_order_release);
-                slice(i - 1, 0);
-                while (done[i - 1].load(std::memory_order_acquire) < nt) std::this_thread::yield();   // the buffer is free again
+                {
+                    std::lock_guard<std::mutex> lk(mtx);
+                    ready = (long)(i - 1);
+                }
+                cv_ready.notify_all();
+                slice(i - 1, 0, nt);
+                std::unique_lock<std::mutex> lk(mtx);
+                cv_done.wait(lk, [&] { return done[i - 1] >= nt; });   // the buffer is free again
             }
         }
         if (e != hipSuccess) {
@@ -129,7 +151,13 @@ int cx_copy_to_host(cx_ctx* ctx, int nparts, void* const* dst, const void* const
             rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP;
         }
     }
-    if (rc != CX_OK) abort_flag.store(true);
+    if (rc != CX_OK) {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            abort_flag = true;
+        }
+        cv_ready.notify_all();
+    }
     for (auto& w : workers) w.join();
     return rc;
 }

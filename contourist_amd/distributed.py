@@ -81,39 +81,50 @@ class HaloExchange(object):
 
 
 def own_communicators(ctxs, rank, world, dist=None):
-    """Give every context of this rank its own RCCL communicator (cx_rccl_comm_init), so that the halo exchange of a step is
-    part of ONE C call (Context.slab_step) instead of a Python batch_isend_irecv: context k of every rank joins communicator k.
-    The 128-byte ids travel by torch.distributed (whatever backend it runs).  Collective; returns True on EVERY rank only if
-    every rank succeeded with every context (otherwise the callers stay on exchange_halo / HaloExchange)."""
+    """Give this rank's contexts ONE RCCL communicator (cx_rccl_comm_init on the first, cx_rccl_comm_share on the others), so that
+    the halo exchange of a step is part of ONE C call (Context.slab_step) instead of a Python batch_isend_irecv.  The 128-byte id
+    travels by torch.distributed (whatever backend it runs).  Collective; returns True on EVERY rank only if every rank succeeded
+    (otherwise the callers stay on exchange_halo / HaloExchange) -- and nobody enters the blocking collective ncclCommInitRank
+    unless every rank has said, after checking everything that can fail locally, that it will enter it too."""
     import torch
     if dist is None:
         import torch.distributed as dist
     if world == 1:
         return True
-    ok = 1
     on_device = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
-    for k, ctx in enumerate(ctxs):
-        uid = np.zeros(128, dtype=np.uint8)
-        if rank == 0:
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    # 1. everything local: RCCL resolves in this process, the id can be made (rank 0), every context is alive
+    ok, uid = True, np.zeros(128, dtype=np.uint8)
+    try:
+        ok = len(ctxs) > 0 and all(getattr(c, "handle", None) for c in ctxs) and ctxs[0].rccl_available()
+        if ok and rank == 0:
+            uid = ctxs[0].rccl_unique_id()
+    except Exception:       # noqa: BLE001 -- reported through the agreed flag
+        ok = False
+    if not all_agree(ok):
+        return False
+    t = torch.from_numpy(np.ascontiguousarray(uid).copy()).to(dev)
+    dist.broadcast(t, src=0)
+    # 2. the collective init, on ONE context; the others of this rank share its communicator
+    try:
+        ctxs[0].rccl_comm_init(t.cpu().numpy(), rank, world)
+        for c in ctxs[1:]:
+            c.rccl_comm_share(ctxs[0])
+    except Exception:       # noqa: BLE001
+        ok = False
+    if not all_agree(ok):
+        for c in ctxs:          # nobody keeps half a setup: every rank falls back together
             try:
-                uid = ctx.rccl_unique_id()
-            except Exception:
-                ok = 0
-        t = torch.from_numpy(uid.copy()).to(dev)
-        dist.broadcast(t, src=0)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:          # rank 0 has no RCCL to ask: nobody calls the collective init
-            return False
-        try:
-            ctx.rccl_comm_init(t.cpu().numpy(), rank, world)
-        except Exception:
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            return False
+                c.rccl_comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+        return False
     return True
 
 
@@ -560,6 +571,13 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
     lay = shard_layout(n0, world, rank)
     t = own_planes if isinstance(own_planes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(own_planes, dtype=np.float32))
     assert t.shape[0] == lay["i1"] - lay["i0"]
+    # every rank checks EVERY rank's slab (slab_bounds is the same arithmetic everywhere): a slab thinner than the layers it has to
+    # hand to its neighbours raises on all ranks alike, before anybody waits in a collective
+    if world > 1:
+        thin = [r for r in range(world) if slab_bounds(n0, world, r)[1] - slab_bounds(n0, world, r)[0] < SHARD_LAYERS + 1]
+        if thin:
+            raise ValueError("sharded Level 1: %d planes over %d ranks leaves rank(s) %s fewer than the %d planes a slab hands to its neighbours"
+                             % (n0, world, thin, SHARD_LAYERS + 1))
     t0 = time.perf_counter()
     local, nb = exchange_planes(t, rank, world, SHARD_LAYERS, SHARD_LAYERS + 1, dist)
     assert nb == lay["own_lo"] and local.shape[0] == lay["e1"] - lay["e0"], (nb, lay, tuple(local.shape))
@@ -587,20 +605,41 @@ def level1_slabs_sharded(own_planes, value, rank, world, global_shape, device=0,
     if world == 1:
         mine = (np.zeros(0, np.uint32), np.zeros(0, np.uint8))
     else:
-        lower = exchange_boundary_lists(L, rank, world, dist, gpu)
-        if lower is not None:
-            pairs, unmatched = pair_labels(L["own1"][0], L["own1"][1], lower[0], lower[1])
-        else:
-            pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
-        small = shard_small(L, pairs, unmatched)
+        # Everything between here and the scatter can fail on ONE rank (the neighbour exchange, the pairing, rank 0's merge) while
+        # the others sit in a collective.  So nobody raises in between: an error travels WITH the small object every rank sends to
+        # rank 0, rank 0 adds its own (and `unmatched` boundary triangles: components that are one surface would stay apart and the
+        # slabs' windings could disagree), and the verdict comes back to every rank in place of its flips.
+        small, err = None, None
+        try:
+            lower = exchange_boundary_lists(L, rank, world, dist, gpu)
+            if lower is not None:
+                pairs, unmatched = pair_labels(L["own1"][0], L["own1"][1], lower[0], lower[1])
+            else:
+                pairs, unmatched = np.zeros((0, 2), dtype=np.int64), 0
+            small = shard_small(L, pairs, unmatched)
+        except Exception as e:      # noqa: BLE001 -- carried to rank 0, raised below on every rank
+            err = "%s: %s" % (type(e).__name__, e)
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object(small, gathered, dst=0, group=object_group)
+        dist.gather_object({"error": err} if err is not None else small, gathered, dst=0, group=object_group)
         answers = [None] * world
         if rank == 0:
-            answers, stats = merge_shard_components(gathered)
+            failed = ["rank %d: %s" % (r, g["error"]) for r, g in enumerate(gathered) if g is not None and g.get("error")]
+            if not failed:
+                try:
+                    n_unmatched = sum(int(g.get("unmatched", 0)) for g in gathered)
+                    if n_unmatched:
+                        failed = ["%d boundary triangles are known to one slab only (or share a hash): the slabs' components cannot be united" % n_unmatched]
+                    else:
+                        answers, stats = merge_shard_components(gathered)
+                except Exception as e:      # noqa: BLE001
+                    failed = ["rank 0 (merge): %s: %s" % (type(e).__name__, e)]
+            if failed:
+                answers = [{"error": "; ".join(failed)}] * world
         box = [None]
         dist.scatter_object_list(box, answers if rank == 0 else None, src=0, group=object_group)
         mine = box[0]
+        if isinstance(mine, dict) and mine.get("error"):
+            raise RuntimeError("sharded Level 1 failed (raised on every rank): " + mine["error"])
     t3 = time.perf_counter()
     out = shard_finish(ctx, L, mine, download)
     t4 = time.perf_counter()

@@ -125,8 +125,15 @@ class GridContour4D(object):
         coordinates, keys (V,) edge ids, tetrahedra (T,4) int32, counts)"""
         L = self.march()
         ctx = self.context()
+        self._interp_vertices = None
         if self.end_points is not None and len(self.end_points):
             self.seeded = ctx.select_seeded4d(self.end_points, self.voxel_range, self.keep_in_range)
+            # the reference only ever interpolates the edges of the hyper-voxels its search reaches (interpolated_contour_pairs,
+            # tetrahedral.py:176-188): those are the vertices of the tetrahedra the selection keeps.  collect_morph_triangles
+            # hands exactly these on as points4d (pentatopes.py:316-322), so that MorphTriangles.to_json -- whose shift, scale
+            # and counts come from ALL points it holds (morph_geometry.py:91-125) -- writes what the reference writes.
+            keep = ctx.seeded4d_mask(L["counts"]).astype(bool)
+            self._interp_vertices = np.unique(L["tetrahedra"][keep].reshape(-1)) if keep.any() else np.zeros(0, dtype=np.int64)
         if self.linear_interpolate:
             post = ctx.postprocess4d(nbins)
         else:
@@ -173,6 +180,14 @@ class GridContour4D(object):
             self.find_tetrahedra()
         pts, segs, tris, ncomp = self.context().morph_triangles()
         self.n_components = ncomp
+        used = getattr(self, "_interp_vertices", None)
+        if used is not None:       # explicit end points: only the points the reference's search interpolated (see find_tetrahedra)
+            renum = -np.ones(len(pts), dtype=np.int64)
+            renum[used] = np.arange(len(used))
+            segs = renum[np.asarray(segs, dtype=np.int64)]
+            assert segs.min(initial=0) >= 0, "a morph segment uses a vertex outside the seeded selection"
+            pts = pts[used]
+        self.morph_vertex_ids = np.arange(len(pts)) if used is None else used     # points4d[n] is Level-0 vertex morph_vertex_ids[n]
         return morph_geometry.MorphTriangles(pts, segs, tris)
 
 

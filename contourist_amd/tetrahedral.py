@@ -217,8 +217,15 @@ class GridContour3d(object):
             corner = [int(c) for c in self.corner]
         return ctx.postprocess3d_mesh(pts, renum[tris], corner, 0 if clean else 1, self.smooth or 0.0)
 
-    def get_points_and_triangles(self, clean=True):
-        "(grid_points (V,3) float64, triangles (T,3) int32 sorted rows)  (tetrahedral.py:528-552)"
+    def get_points_and_triangles(self, clean=True, device=False):
+        """(grid_points (V,3) float64, triangles (T,3) int32 sorted rows)  (tetrahedral.py:528-552).
+        device=True: the same mesh as torch tensors ON THE GPU (points float64, triangles int32 in device order, each row wound
+        as the host rows are) -- no download; for consumers that live on the device (cx_level1_device_ptrs)."""
+        if device:
+            ctx = self._ensure_post(clean)
+            if self.callback:
+                self.callback(self)
+            return ctx.level1_torch(copy=True)
         geometry = self.extract_surface_geometry(clean)
         if self.callback:
             self.callback(self)
@@ -251,13 +258,17 @@ def unpack_edge_ids(keys, shape):
     return lo, hi
 
 
-def bisect_endpoints(lattice_function, value, pairs, lo, hi):
+def bisect_endpoints(lattice_function, value, pairs, lo, hi, dropped=None):
     """The bisection of GridContour.find_initial_voxels (tetrahedral.py:408-423) on the host, for end points that lie OUTSIDE the
     sampled array: the reference evaluates its callable wherever the end points are (its own demos pass (20,20,20) on a 12^3
     grid and (100,100,100) in world coordinates, html_demo.py:147-161, 277-282) and halves the lattice segment until the two
     points are neighbours.  Same swaps, same assert, same integer midpoints, the callable in float64.  A pair inside the box
     [lo, hi] per axis is handed on untouched (the device bisects it on the samples, as before); a pair that leaves the box is
-    replaced by the neighbouring pair its bisection ends at.  -> list of (low_point, high_point) int arrays"""
+    replaced by the neighbouring pair its bisection ends at.  A pair whose bisection ENDS outside the box (the crossing it brackets
+    is not in the sampled array, rim included) is left out and appended to `dropped` if given: the reference would emit the
+    triangles of that one voxel out there -- evaluating its callable where this build has no samples -- and grow nothing from it
+    (in_range, tetrahedral.py:465-469); the device cannot, and refusing the whole call for it (CX_ERR_INVALID, as round 3 did)
+    is worse than leaving the stray voxel out.  -> list of (low_point, high_point) int arrays"""
     out = []
     lo, hi = np.asarray(lo), np.asarray(hi)
     for a, b in pairs:
@@ -277,7 +288,10 @@ def bisect_endpoints(lattice_function, value, pairs, lo, hi):
                 low_point = mid_point
             else:
                 high_point = mid_point
-        out.append((low_point, high_point))
+        if np.all(low_point >= lo) and np.all(low_point <= hi) and np.all(high_point >= lo) and np.all(high_point <= hi):
+            out.append((low_point, high_point))
+        elif dropped is not None:
+            dropped.append((low_point, high_point))
     return out
 
 
@@ -439,7 +453,15 @@ class Delta3DContour(object):
         S = np.asarray(self.grid.dense_samples_host(), dtype=np.float64)     # vertices 0 .. gd inclusive
         return rim_crossing_segments(S, gd, float(self.value), shell)
 
-    def get_points_and_triangles(self):
+    def get_points_and_triangles(self, device=False):
+        """(points in world coordinates, triangles)  (tetrahedral.py:83-87).  device=True: torch tensors on the GPU -- the world
+        transform grid * delta + mins (grid_field.py:89-93) is applied there too; nothing comes to the host."""
+        if device:
+            import torch
+            (grid_points, triangles) = self.contour_maker.get_points_and_triangles(device=True)
+            delta = torch.as_tensor(np.asarray(self.grid.delta, dtype=np.float64), device=grid_points.device)
+            mins = torch.as_tensor(np.asarray(self.grid.mins, dtype=np.float64), device=grid_points.device)
+            return (grid_points * delta + mins, triangles)
         (grid_points, triangles) = self.contour_maker.get_points_and_triangles()      # (the maker undoes its own shift)
         points = self.grid.from_grid_coordinates(grid_points) if len(grid_points) else np.zeros((0, 3))
         return (points, triangles)

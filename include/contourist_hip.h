@@ -167,6 +167,14 @@ int cx_halo_exchange(cx_ctx* ctx, void* rccl_comm, int rank, int world, float* l
 int cx_rccl_unique_id(uint8_t* out128);
 int cx_rccl_comm_init(cx_ctx* ctx, const uint8_t* id128, int rank, int world);
 int cx_rccl_comm_destroy(cx_ctx* ctx);
+/* CX_OK if this process can run the C-side exchange (an RCCL copy is loaded and exports what is needed), CX_ERR_UNSUPPORTED if not.
+ * Local, no collective: the host asks every rank and agrees on the answers BEFORE the collective cx_rccl_comm_init, so that a
+ * rank without RCCL cannot leave the others waiting inside ncclCommInitRank. */
+int cx_rccl_available(void);
+/* the contexts of one rank (several extractions in flight) share ONE communicator: `ctx` uses `owner`'s from now on (the owner
+ * must outlive it and keeps the ownership; cx_rccl_comm_destroy on `ctx` only drops the reference).  Exchanges are issued by the
+ * host's single thread in volume order, each on the calling context's stream. */
+int cx_rccl_comm_share(cx_ctx* ctx, cx_ctx* owner);
 /* One rank's whole step for one volume of a slab-partitioned stream of volumes, as ONE call: adopt the device buffer
  * (n_own planes of n1 x n2 samples, followed by room for the halo plane unless rank == world - 1), exchange the halo on the
  * context's stream with the context's own communicator, enqueue cx_extract3d_async behind it.  (A 64-plane slab of a 512^3
@@ -205,6 +213,10 @@ int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv, con
                           uint32_t flags, double smooth, int64_t* out_counts);
 /* copy the Level-1 mesh to host: points = nv*3 doubles (grid coordinates), tris = nt*3 int32 */
 int cx_level1_download(cx_ctx* ctx, double* points_xyz, int32_t* tris);
+/* device pointers of the same mesh (no copy): points = n_vertices*3 doubles (grid coordinates), tris = n_triangles*3 int32, valid
+ * until the next post-pass / extraction / destroy on the context; the context's stream is synchronised before they are handed out.
+ * For consumers on the GPU: what get_points_and_triangles() returns (tetrahedral.py:83-87, 528-552) without the trip to the host. */
+int cx_level1_device_ptrs(cx_ctx* ctx, void** points_xyz, void** tris, int64_t* n_vertices, int64_t* n_triangles);
 /* edge id ((linear index of the lower lattice point << 3) | direction, local to the marched array) of every vertex of
  * cx_level1_download, in its order: the representative that survived weld, tiny collapse and clean-up -- the identity of a
  * Level-1 vertex across slabs (after cx_postprocess3d_mesh: the index of the input vertex). */

@@ -51,3 +51,23 @@ def test_no_gpu_fails_loudly():
     S = tetrahedral.TriangulatedIsosurfaces([-1] * 3, [1] * 3, [0.5] * 3, sphere, 0.5, [])
     with pytest.raises(_ffi.CxError):
         S.search_for_endpoints()
+
+
+def test_bisect_endpoints_leaves_out_pairs_that_end_outside_the_samples():
+    """an end point pair far outside the grid whose crossing is ALSO outside the sampled array must not reach the
+    device (cx_select_seeded3d would reject the whole call); pairs that end inside are bisected exactly as the reference does
+    (tetrahedral.py:408-423)."""
+    import numpy as np
+    from contourist_amd import tetrahedral
+
+    def f(i, j, k):                     # a plane at i = 40.5: the crossing is far outside a 12^3 grid
+        return float(i) - 40.5
+    dropped = []
+    out = tetrahedral.bisect_endpoints(f, 0.0, [((0, 0, 0), (100, 100, 100)), ((3, 3, 3), (4, 3, 3))], [-1] * 3, [13] * 3, dropped)
+    assert len(out) == 1 and tuple(out[0][0]) == (3, 3, 3)            # the inside pair is handed on untouched
+    assert len(dropped) == 1 and np.all(np.abs(dropped[0][0] - dropped[0][1]) <= 1) and dropped[0][0][0] == 40
+
+    def g(i, j, k):                     # a plane at i = 5.5: the far pair's bisection ends inside the grid
+        return float(i) - 5.5
+    out = tetrahedral.bisect_endpoints(g, 0.0, [((0, 0, 0), (100, 100, 100))], [-1] * 3, [13] * 3)
+    assert len(out) == 1 and out[0][0][0] == 5 and out[0][1][0] == 6

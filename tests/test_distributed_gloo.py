@@ -217,3 +217,146 @@ def test_slabs_levels_reproduce_single_volume(world, tmp_path):
         assert np.array_equal(ref[0], out[0])
         assert np.allclose(ref[1], out[1], rtol=0, atol=1e-12)
         assert np.array_equal(ref[2], out[2])
+
+
+# ---- pre-flight of the N > 1 paths that cannot run on a one-GPU box (round 4) -------------------------------------------------
+class _FakeCtx(object):
+    """stands in for _ffi.Context in own_communicators: records what was called; can be told to fail in one place"""
+    handle = 1
+
+    def __init__(self, fail=None):
+        self.fail, self.calls, self.comm = fail, [], None
+
+    def rccl_available(self):
+        self.calls.append("available")
+        return self.fail != "available"
+
+    def rccl_unique_id(self):
+        self.calls.append("unique_id")
+        if self.fail == "unique_id":
+            raise RuntimeError("no id")
+        return np.arange(128, dtype=np.uint8)
+
+    def rccl_comm_init(self, uid, rank, world):
+        self.calls.append("init")
+        assert np.array_equal(np.asarray(uid), np.arange(128, dtype=np.uint8))     # the id rank 0 made reached this rank
+        if self.fail == "init":
+            raise RuntimeError("ncclCommInitRank failed")
+        self.comm = "own"
+
+    def rccl_comm_share(self, owner):
+        self.calls.append("share")
+        self.comm = "shared"
+
+    def rccl_comm_destroy(self):
+        self.calls.append("destroy")
+        self.comm = None
+
+
+def own_comm_worker(rank, world, port, outdir, fail_rank, fail_where):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ctxs = [_FakeCtx(fail_where if rank == fail_rank else None) for _ in range(3)]
+    ok = cd.own_communicators(ctxs, rank, world, dist)
+    json.dump({"ok": bool(ok), "calls": [c.calls for c in ctxs], "comm": [c.comm for c in ctxs]}, open(os.path.join(outdir, "r%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank,fail_where", [(-1, None), (1, "available"), (0, "unique_id"), (1, "init"), (0, "init")])
+def test_own_communicators_all_ranks_fall_back_together(fail_rank, fail_where, tmp_path):
+    """ADVICE round 3 / VERDICT item 6: whatever fails on ONE rank (no RCCL in the process, no id, ncclCommInitRank), every rank
+    learns of it and returns False -- and a rank that cannot enter the collective init says so BEFORE anybody enters it."""
+    import json
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(own_comm_worker, args=(world, free_port(), str(tmp_path), fail_rank, fail_where), nprocs=world, join=True)
+    R = [json.load(open(os.path.join(str(tmp_path), "r%d.json" % r))) for r in range(world)]
+    want = fail_rank < 0
+    assert all(r["ok"] == want for r in R), R
+    for r in R:
+        if want:
+            assert r["comm"] == ["own", "shared", "shared"]          # ONE communicator per rank, shared by its contexts
+            assert r["calls"][0].count("init") == 1 and "init" not in r["calls"][1]
+        else:
+            assert r["comm"] == [None, None, None]                   # nobody keeps half a setup
+        if fail_where in ("available", "unique_id"):
+            assert all("init" not in c for c in r["calls"]), "a rank entered the collective init although another had said it could not"
+
+
+def shard_error_worker(rank, world, port, outdir, mode):
+    """level1_slabs_sharded with the GPU parts replaced: what happens to the other ranks when ONE rank's pairing raises, when rank 0's
+    merge raises, or when boundary triangles do not match"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from contourist_amd import distributed as cd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n0 = 24
+    lay = cd.shard_layout(n0, world, rank)
+
+    class Ctx(object):
+        device = 0
+
+    def fake_local(ctx, local, layout, value, global_shape, clean=True, torch_device=None):
+        e = np.zeros(0)
+        return dict(cand_label=e.astype(np.uint32), cand_x=e, cand_vertex_key=e.astype(np.int64), cand_nx=e, cand_negative=e.astype(np.uint8),
+                    cand_has=e.astype(np.uint8), own1=(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32)),
+                    copy4=(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32)), n_own_lower=0, n_upper_copies=0,
+                    counts={}, key_offset=0)
+    cd.shard_local = fake_local
+    cd.exchange_boundary_lists = lambda L, r, w, d, dev: None if r == 0 else (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32))
+    if mode == "pair_raises":
+        def pl(*a):
+            raise ValueError("pairing broke on rank 1")
+        cd.pair_labels = pl if rank == 1 else (lambda *a: (np.zeros((0, 2), np.int64), 0))
+    elif mode == "unmatched":
+        cd.pair_labels = lambda *a: (np.zeros((0, 2), np.int64), 7 if rank == 1 else 0)
+    else:
+        cd.pair_labels = lambda *a: (np.zeros((0, 2), np.int64), 0)
+    if mode == "merge_raises":
+        def mg(lists):
+            raise KeyError("merge broke")
+        cd.merge_shard_components = mg
+    cd.shard_finish = lambda ctx, L, answer, download=True: dict(counts={})
+    import torch as _t
+    _t.device = (lambda *a, **k: "cpu") if False else _t.device
+    own = torch.zeros((lay["i1"] - lay["i0"], 4, 4), dtype=torch.float32)
+    msg = "ok"
+    try:
+        cd.level1_slabs_sharded(own, 0.0, rank, world, (n0, 4, 4), dist=dist, context=Ctx(), download=False)
+    except Exception as e:      # noqa: BLE001
+        msg = "%s: %s" % (type(e).__name__, e)
+    open(os.path.join(outdir, "r%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fine", "pair_raises", "unmatched", "merge_raises"])
+def test_sharded_level1_errors_reach_every_rank(mode, tmp_path):
+    """an exception on one rank between the agreed flag and the scatter, rank 0's merge raising, or `unmatched`
+    boundary triangles must end the call on EVERY rank with an error -- nobody waits in a collective, nobody returns a mesh whose
+    winding may disagree across slabs."""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(shard_error_worker, args=(world, free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    msgs = [open(os.path.join(str(tmp_path), "r%d.txt" % r)).read() for r in range(world)]
+    if mode == "fine":
+        assert msgs == ["ok"] * world, msgs
+    else:
+        assert all(m.startswith("RuntimeError: sharded Level 1 failed") for m in msgs), msgs
+        key = {"pair_raises": "pairing broke on rank 1", "unmatched": "7 boundary triangles", "merge_raises": "merge broke"}[mode]
+        assert all(key in m for m in msgs), msgs
+
+
+def test_sharded_level1_thin_slab_raises_everywhere_before_any_exchange():
+    """a slab thinner than the layers it must hand over: every rank raises from the same arithmetic, no communication needed"""
+    import torch
+    from contourist_amd import distributed as cd
+    for rank in range(8):
+        i0, i1 = cd.slab_bounds(16, 8, rank)        # 2 planes per rank < SHARD_LAYERS + 1
+        with pytest.raises(ValueError, match="fewer than"):
+            cd.level1_slabs_sharded(torch.zeros((i1 - i0, 4, 4)), 0.0, rank, 8, (16, 4, 4), dist=object())

@@ -233,7 +233,13 @@ def test_seeded_growth_4d():
     MT = maker.collect_morph_triangles()
     assert len(MT.triangle_segment_indices) == len(G["mt_triangles"]) and len(MT.segment_point_indices) == len(G["mt_segments"])
     rk = level0_4d.edge_keys4(G["mt_point_pairs"], A.shape)
-    got_seg = set((int(kh[i]), int(kh[j])) for i, j in MT.segment_point_indices)
+    # with explicit end points the morph triangles carry only the points the reference's search interpolated (its
+    # interpolated_contour_pairs): exactly as many as the reference's own MorphTriangles holds, numbered 0..n-1;
+    # maker.morph_vertex_ids maps them back to the Level-0 vertices
+    assert len(MT.points4d) == len(G["mt_points4d"]) == len(maker.morph_vertex_ids)
+    km = kh[maker.morph_vertex_ids]
+    assert set(int(k) for k in km) == set(int(k) for k in rk)
+    got_seg = set((int(km[i]), int(km[j])) for i, j in MT.segment_point_indices)
     assert got_seg == set((int(rk[i]), int(rk[j])) for i, j in G["mt_segments"])
     # end points on the other blob select the other component; both together everything
     ctx = maker.context()
@@ -396,3 +402,70 @@ def test_search_for_endpoints_with_skip_4d():
     used_all = np.unique(R_all["tetrahedra"])
     assert (np.linalg.norm(R_all["points4d"][used_all][:, :3] - 21.5, axis=1) < 2.5).any()                    # exhaustive: both
     assert M.contour_maker.seeded["groups_kept"] == 1
+
+
+@pytest.mark.parametrize("name,tag", [("two_blobs_seeded_12x12x12x7", "all"), ("two_blobs_seeded_12x12x12x7", "clipped"),
+                                      ("paraboloid_11x11x11x9", "clipped")])
+def test_device_morph_triangles_through_to_json_into_the_viewer(name, tag):
+    """SURVEY 8(f) N2 on the GPU path, end to end: GridContour4D.collect_morph_triangles() on the DEVICE -> MorphTriangles.to_json()
+    (morph_geometry.py:91-125) -> the bytes parsed the way the reference's viewer parses them (misc/morph_triangles.js:26-52:
+    positions = shift + scale * integer) -> oracle/morph_eval.surface_at (the viewer's :53-204, pinned bit for bit by
+    tests/test_oracle_viewer.py) at the viewer goldens' own times == cx_morph_eval on the device, and the header of the JSON
+    (counts, shift, scale, min / max value) equals that of the bytes the REAL reference wrote for the fixture."""
+    import gzip
+    import json
+    from contourist_amd import pentatopes
+    from oracle import morph_eval
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = np.load(os.path.join(G4, name + ".npz"))
+    A, v = G["A"], float(G["value"])
+    eps = [[tuple(a), tuple(b)] for a, b in G["end_points"].tolist()] if "end_points" in G.files else None
+    maker = pentatopes.GridContour4D(tuple(np.array(A.shape) - 1), A, v, eps) if eps else pentatopes.GridContour4D(tuple(np.array(A.shape) - 1), A, v)
+    maker.find_tetrahedra()
+    MT = maker.collect_morph_triangles()
+    lo, hi = float(MT.min_value), float(MT.max_value)
+    kw = {} if tag == "all" else dict(min_value=lo + 0.25 * (hi - lo), max_value=hi - 0.125 * (hi - lo), maxint=4095)
+    text = MT.to_json(**kw)
+    mine = json.loads(text)
+    ref = json.loads(gzip.open(os.path.join(root, "tests", "golden_wire", "%s.to_json.%s.txt.gz" % (name, tag))).read().decode("ascii"))
+    # ---- the header: the device's morph triangles are the reference's (as sets), so every number derived from them agrees
+    assert mine["description"] == ref["description"] and mine["counts"] == ref["counts"]
+    assert mine["min_value"] == ref["min_value"] and mine["max_value"] == ref["max_value"]
+    assert np.allclose(mine["shift"], ref["shift"], rtol=0, atol=1e-12) and np.allclose(mine["scale"], ref["scale"], rtol=1e-12, atol=0)
+    assert len(mine["positions"]) == 4 * mine["counts"][0] and len(mine["segments"]) == 2 * mine["counts"][1] and len(mine["triangles"]) == 3 * mine["counts"][2]
+    # the quantised positions are the reference's as a multiset (the numbering differs)
+    qa = np.array(mine["positions"], dtype=np.int64).reshape(-1, 4)
+    qb = np.array(ref["positions"], dtype=np.int64).reshape(-1, 4)
+    assert np.array_equal(qa[np.lexsort(qa.T[::-1])], qb[np.lexsort(qb.T[::-1])])
+    # ---- what the viewer draws from these bytes, against cx_morph_eval on the device
+    P = np.array(mine["shift"], dtype=np.float64) + np.array(mine["scale"], dtype=np.float64) * qa
+    seg = np.array(mine["segments"], dtype=np.int64).reshape(-1, 2)
+    tri = np.array(mine["triangles"], dtype=np.int64).reshape(-1, 3)
+    vpath = os.path.join(root, "tests", "golden_viewer", "viewer_%s_%s.npz" % (name, tag))
+    times = np.load(vpath)["times"].tolist() if os.path.exists(vpath) else [lo + f * (hi - lo) for f in (0.3, 0.5, 0.7)]
+    step = np.array(mine["scale"], dtype=np.float64)[:3]
+    V = np.load(vpath) if os.path.exists(vpath) else None
+    drawn = 0
+    for n, t in enumerate(times):
+        W = morph_eval.surface_at(P, seg, tri, t, float(mine["min_value"]), float(mine["max_value"]))
+        pd, td = maker.triangles_at(t)                       # device: cx_morph_eval on the unquantised morph triangles
+        # A triangle is drawn while t lies inside its segments' intervals; quantising the TIMES (scale[3] per step) can move an
+        # interval's end across t, so the counts agree up to the triangles whose interval ends within one step of t
+        tr_min, tr_max, valid = morph_eval.triangle_intervals(P, seg, tri)
+        near = int(np.sum(valid & ((np.abs(tr_min - t) <= 2 * mine["scale"][3]) | (np.abs(tr_max - t) <= 2 * mine["scale"][3]))))
+        assert abs(len(td) - len(W["faces"])) <= near, (len(td), len(W["faces"]), near)
+        if V is not None:                                    # and the reference's own viewer on the reference's bytes drew as many
+            assert abs(len(V["faces_%d" % n]) - len(W["faces"])) <= near
+        if len(td) and near == 0:
+            # every drawn point of the viewer lies within the quantisation step (plus its share of the time step) of a device point
+            from scipy.spatial import cKDTree
+            d, _ = cKDTree(np.asarray(pd)).query(W["points"])
+            # a drawn point sits at lam = (t - lo) / (hi - lo) along its segment: the quantisation moves the end points by up to a
+            # step in space, and lo / hi by up to a step in TIME, which moves lam by up to ~3 steps / (hi - lo)
+            sid = np.asarray(W["segment_ids"], dtype=np.int64)
+            a, b = P[seg[sid, 0]], P[seg[sid, 1]]
+            dlam = np.minimum(1.0, 3.0 * mine["scale"][3] / np.maximum(b[:, 3] - a[:, 3], 1e-300))
+            bound = 2.0 * np.linalg.norm(step) + np.linalg.norm(b[:, :3] - a[:, :3], axis=1) * dlam + 1e-9
+            assert np.all(d <= bound), float((d - bound).max())
+        drawn += len(td) > 0
+    assert drawn >= 2

@@ -252,3 +252,30 @@ def test_linking_paths_agree():
     assert int(base[1]) > 100000 and int(base[2]) >= 1
     for knob in ("CX_EDGE_TABLE_TINY", "CX_EDGE_TABLE_FULL", "CX_LINK_GLOBAL"):
         assert _level1_digest({"CX_DEBUG": "1", knob: "1"}) == base, knob
+
+
+def test_level1_device_export_equals_download():
+    """cx_level1_device_ptrs / get_points_and_triangles(device=True): the Level-1 mesh as torch tensors ON THE GPU is, bit for
+    bit, the mesh cx_level1_download brings to the host (tetrahedral.py:83-87, 528-552 without the trip)."""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import tetrahedral
+
+    def f(x, y, z):
+        return np.sin(3.1 * x) * np.cos(2.3 * y) + 0.7 * z * z - 0.35 * x * y
+    S = tetrahedral.TriangulatedIsosurfaces([-1.0, -1.2, -0.9], [1.1, 1.0, 1.2], [0.05, 0.055, 0.06], f, 0.21, [])
+    S.search_for_endpoints()
+    pts_h, tris_h = S.get_points_and_triangles()
+    pts_d, tris_d = S.get_points_and_triangles(device=True)
+    assert pts_d.is_cuda and tris_d.is_cuda and pts_d.dtype == torch.float64 and tris_d.dtype == torch.int32
+    assert tuple(pts_d.shape) == tuple(np.asarray(pts_h).shape) and len(tris_h) > 1000
+    assert np.array_equal(pts_d.cpu().numpy().view(np.uint64), np.asarray(pts_h, dtype=np.float64).view(np.uint64))
+    td = tris_d.cpu().numpy()
+    assert np.array_equal(td[np.lexsort((td[:, 2], td[:, 1], td[:, 0]))], np.asarray(tris_h))
+    # grid coordinates from the maker, and the raw pointers / counts of the C ABI
+    gp_h, gt_h = S.contour_maker.get_points_and_triangles()
+    gp_d, gt_d = S.contour_maker.get_points_and_triangles(device=True)
+    assert np.array_equal(gp_d.cpu().numpy().view(np.uint64), np.asarray(gp_h, dtype=np.float64).view(np.uint64))
+    pp, tp, nv, nt = S.contour_maker.context().level1_device_ptrs()
+    assert pp and tp and nv == len(gp_h) and nt == len(gt_h)
+    view_p, view_t = S.contour_maker.context().level1_torch(copy=False)
+    assert view_p.data_ptr() == pp and view_t.data_ptr() == tp and torch.equal(view_p, gp_d)
