@@ -79,6 +79,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_release(ctx->qa, ctx->qa_cap);
     cx_release(ctx->info, ctx->info_cap);
     cx_release(ctx->info64, ctx->info64_cap);
+    cx_release(ctx->tq, ctx->tq_cap);
     cx_release(ctx->chunksum, ctx->chunksum_cap);
     cx_release(ctx->rstart, ctx->rstart_cap);
     cx_release(ctx->kstart, ctx->kstart_cap);
@@ -320,6 +321,17 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         P.qa = ctx->qa; P.info = ctx->info; P.info64 = ctx->info64; P.chunksum = ctx->chunksum;
         P.div_ci = cx_fdiv_make(T.ci);
         P.qlimit = T.wcap;
+        // The stream of interpolation fractions between the stream kernel and the vertex stage (round 4): the stream
+        // kernel computes the fractions where the samples are, the vertex stage reads them in order instead of gathering samples from
+        // half of the grid's cache lines.  Bit-identical meshes and 185 MB less HBM traffic per 512^3 extraction -- but MEASURED SLOWER:
+        // the vertex stage drops from 0.105 to 0.072 ms while the stream kernel, whose every wave is on the critical path of its
+        // own loads, goes from 0.131 to 0.176 ms (~125 instructions per step that queued cells, at three waves per SIMD).  So it is
+        // built, tested (tests/test_gpu_level0.py::test_fraction_stream) and OFF; CX_DEBUG=1 CX_TQ=1 turns it on.
+        P.tq = nullptr; P.tlimit = 0;
+        if (!fused && cx_debug_knob("CX_TQ", 0u)) {
+            if ((rc = cx_grow(ctx, ctx->tq, ctx->tq_cap, need))) return rc;
+            P.tq = ctx->tq; P.tlimit = T.wcap;
+        }
         // the triangle stage walks the vertex stage's cell records.  The kernel that walks queue entries instead (no records: 80 MB
         // less HBM traffic per 512^3 extraction) is built and bit-identical, and measured no faster at 512^3 and slower on thin slabs
         // (DESIGN.md section 4): it runs on request (CX_DEBUG=1 CX_K2_ENTRIES=1)

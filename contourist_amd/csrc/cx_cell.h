@@ -194,6 +194,13 @@ __device__ __forceinline__ cx_cell_info cx_classify_cell(const cx_params& P, con
 }
 
 // vertex records of one cell: calls sink(r, record) for the r-th owned crossing (ascending direction d)
+// THE fraction of a crossing along its lattice edge, (v - f(q)) / (f(q+d) - f(q)), in fp32: reciprocal and product (v_rcp_f32 is
+// good to one unit in the last place, so the fraction is good to ~1.5: 2e-7 of a voxel, a fifth of the 1e-6 the coordinates are
+// held to).  ONE definition for the stream kernel, the vertex stage's gather path, the per-cell path and the fused kernel, so that
+// whichever of them interpolates a crossing writes the same bits.  (Until round 4: __fdividef, which hipcc expands to the IEEE
+// division sequence -- ~11 instructions where this takes 2; Level 1 recomputes every point in float64 from the grid anyway.)
+__device__ __forceinline__ float cx_fraction(float num, float den) { return num * __builtin_amdgcn_rcpf(den); }
+
 template <typename Sink>
 __device__ __forceinline__ void cx_emit_vertices(const cx_params& P, const float f[8], uint32_t emask, uint32_t lin,
                                                  uint32_t i, uint32_t j, uint32_t k, Sink sink) {
@@ -208,7 +215,7 @@ __device__ __forceinline__ void cx_emit_vertices(const cx_params& P, const float
             // interpolates from the low end with ratio=(v-flow)/(fhigh-flow), or 0.5 when
             // |fhigh-flow| <= 1e-8 (tetrahedral.py:483-487) -- identical in exact arithmetic.
             const float den = f[d] - f[0];
-            float t = __fdividef(num, den);
+            float t = cx_fraction(num, den);
             if (fabsf(den) <= 1.001e-8f) {   // rare: decide the reference's |den| <= 1e-8 test in float64
                 const double dd = (double)f[d] - (double)f[0];
                 t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f[0]) / dd);

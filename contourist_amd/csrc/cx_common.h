@@ -91,6 +91,11 @@ struct cx_params {
     uint32_t* kstart;         // [nkw] triangle stage: the batch in which wave m's share of the rounds starts (as rstart for the vertex stage)
     uint32_t nkw;             // waves of the triangle stage (4 x its grid)
     uint32_t write_records;   // 1: the vertex stage also writes the 16-byte cell records (seeded selection, the record-walking triangle kernel)
+    // the stream of interpolation fractions (round 4): the stream kernel, which has the samples, computes t = (v - f(q)) / (f(q+d) - f(q))
+    // of every crossing and writes them per streaming wave in the order the vertex stage numbers the vertices; the vertex stage reads
+    // them back in order instead of gathering samples from half of the grid's cache lines.  null: the vertex stage gathers (levels, fused).
+    float* tq;                // [nwaves * wcap] one region per streaming wave, filled from the front
+    uint32_t tlimit;          // fractions a streaming wave may store (T.wcap); a wave with more hands its cells to the per-cell path
 };
 #ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15

@@ -39,6 +39,8 @@ struct cx_ctx {
     size_t qa_cap = 0;
     uint32_t* info = nullptr;          // fused emit: per queue entry, first vertex of the cell in its wave | crossing mask
     size_t info_cap = 0;
+    float* tq = nullptr;               // staged kernels: the stream kernel's interpolation fractions, one region per streaming wave (cx_params::tq)
+    size_t tq_cap = 0;
     uint64_t* info64 = nullptr;        // staged kernels: per queue entry, (crossing mask << 32) | first vertex
     size_t info64_cap = 0;
     uint32_t* chunksum = nullptr;      // totals of every 256 streaming waves (cx_params::chunksum)

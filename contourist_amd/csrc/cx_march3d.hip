@@ -271,7 +271,7 @@ __device__ __forceinline__ void cx_vround_pin(cx_vround& R) {
 __device__ __forceinline__ cx_vrec cx_vertex_record(const cx_params& P, const cx_fast_geom& G, uint32_t e2, uint32_t d, float f0, float f1) {
     const uint32_t lin2 = cx_entry_lin(P, G, e2);
     // same arithmetic as cx_emit_vertices; |f1 - f0| > 1e-8 here (cx_k_stream keeps waves with flatter crossings off this path)
-    const float t = __fdividef((P.vhi - f0) + P.vlo, f1 - f0);
+    const float t = cx_fraction((P.vhi - f0) + P.vlo, f1 - f0);
     return make_uint2((lin2 << 3) | d, __float_as_uint(t));
 }
 
@@ -363,6 +363,112 @@ __device__ __forceinline__ void cx_emit_queue_fast(const cx_params& P, const cx_
         if (more) cx_vround_pin(Rb);   // the next round's samples are waited for AFTER this round's stores went out (see CX_PIN_BEFORE_STORES)
 #endif
         CX_S3_T(3)
+        if (more) Ra = Rb;
+        par ^= 1u;
+    }
+}
+
+// The same walk with the interpolation fractions READ from the stream kernel's stream (P.tq) instead of computed from gathered
+// samples: vertex n of a streaming wave has its fraction at tq[w * wcap + n], so a round's fractions are one coalesced run.  What
+// is left of the vertex stage is bookkeeping: the prefix sums of a round, the slot table that turns "vertex o of the round" into
+// (cell, direction), the edge id, and the stores.  `tq_wave`: the wave's region minus its first vertex (indexed by GLOBAL vertex).
+struct cx_tround {
+    uint32_t e, lin, sm, emask, ntri, vpre, tpre, vtot, ttot, ctot, real_voxel;
+    uint64_t recm;
+    cx_run base;
+    uint32_t tv[CX_VR];                // fractions of the round's first CX_VR x 64 vertices, as loaded
+    uint32_t e_next;
+};
+__device__ __forceinline__ void cx_tround_front(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t n, uint32_t b0,
+                                                uint32_t lane, uint32_t e, const cx_run& base, uint32_t* slot, const uint8_t* ntri_lut,
+                                                const uint32_t* tq_wave, cx_tround& R) {
+    const uint32_t idx = b0 + lane;
+    const bool have = idx < n;
+    R.e = e;
+    R.e_next = (idx + 64u < n) ? q[idx + 64u] : 0u;
+    uint32_t i, j, k;
+    cx_decode_entry(P, G, e, i, j, k);
+    R.lin = (i * P.n1 + j) * P.n2 + k;
+    R.sm = cx_entry_signs(e);
+    const uint32_t vm = have ? cx_corner_valid(P, i, j, k) : 0u;
+    R.real_voxel = (have && vm == 0xFFu) ? 1u : 0u;
+    const uint32_t s0 = (R.sm & 1u) ? 0xFFu : 0u;
+    R.emask = have ? (((R.sm ^ s0) & vm) & 0xFEu) : 0u;
+    R.ntri = R.real_voxel ? (uint32_t)ntri_lut[R.sm] : 0u;
+    const uint32_t nv = __popc(R.emask);
+    R.vpre = cx_wave_prefix_small<3>(nv, R.vtot);
+    R.tpre = cx_wave_prefix_small<4>(R.ntri, R.ttot);
+    R.recm = __ballot((nv | R.ntri) != 0u);
+    R.ctot = (uint32_t)__popcll(R.recm);
+    R.base = base;
+    // the round's fractions: requested here, used in the back half (no arithmetic on them in between: a use would wait for them here)
+#pragma unroll
+    for (uint32_t r = 0; r < CX_VR; r++) {
+        const uint32_t o = 64u * r + lane;
+        R.tv[r] = 0u;
+        if (o < R.vtot && !(P.flags & CX_DBG_NO_VLOADS)) R.tv[r] = __builtin_nontemporal_load(tq_wave + base.v + o);
+    }
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d++)
+        if ((R.emask >> d) & 1u) slot[R.vpre + __popc(R.emask & ((1u << d) - 1u))] = (lane << 3) | d;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void cx_tround_pin(cx_tround& R) {
+#pragma unroll
+    for (uint32_t r = 0; r < CX_VR; r++) asm volatile("" : "+v"(R.tv[r]) :: "memory");
+    asm volatile("" : "+v"(R.e_next) :: "memory");
+}
+__device__ __forceinline__ void cx_emit_queue_t(const cx_params& P, const cx_fast_geom& G, const uint32_t* q, uint32_t first, uint32_t n,
+                                                uint32_t lane, cx_run run, uint32_t* slot2, const uint8_t* ntri_lut, uint64_t* info,
+                                                const uint32_t* tq_wave) {
+    cx_tround Ra, Rb;
+    uint32_t e0 = (first + lane < n) ? q[first + lane] : 0u;
+    asm volatile("" : "+v"(e0) :: "memory");
+    cx_tround_front(P, G, q, n, first, lane, e0, run, slot2, ntri_lut, tq_wave, Ra);
+    cx_tround_pin(Ra);
+    uint32_t par = 0;
+    for (uint32_t b0 = first; b0 < n; b0 += 64u) {
+        const bool more = b0 + 64u < n;   // wave-uniform
+        if (more) {
+            cx_run nb = Ra.base;
+            nb.v += Ra.vtot; nb.t += Ra.ttot; nb.c += Ra.ctot;
+            cx_tround_front(P, G, q, n, b0 + 64u, lane, Ra.e_next, nb, slot2 + (par ^ 1u) * 448u, ntri_lut, tq_wave, Rb);
+        }
+        const bool vroom = Ra.base.v + Ra.vtot <= P.vcap;   // wave-uniform
+        const uint32_t* slot = slot2 + par * 448u;
+        if (vroom) {
+#pragma unroll
+            for (uint32_t r = 0; r < CX_VR; r++) {
+                if (64u * r >= Ra.vtot) continue;   // wave-uniform
+                const uint32_t o = 64u * r + lane;
+                const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
+                const uint32_t cell = sl >> 3, d = sl & 7u;
+                const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
+                const cx_vrec rec = make_uint2((cx_entry_lin(P, G, e2) << 3) | d, Ra.tv[r]);
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec);
+            }
+            for (uint32_t o0 = 64u * CX_VR; o0 < Ra.vtot; o0 += 64u) {   // more than CX_VR x 64 vertices: the rest one round at a time
+                const uint32_t o = o0 + lane;
+                const uint32_t sl = slot[(o < Ra.vtot) ? o : 0u];
+                const uint32_t cell = sl >> 3, d = sl & 7u;
+                const uint32_t e2 = (uint32_t)__shfl((int)Ra.e, (int)cell);
+                const uint32_t tb = (o < Ra.vtot) ? tq_wave[Ra.base.v + o] : 0u;
+                const cx_vrec rec = make_uint2((cx_entry_lin(P, G, e2) << 3) | d, tb);
+                if (o < Ra.vtot && !(P.flags & CX_DBG_NO_VERTS)) CX_STORE_VERT(&P.verts[Ra.base.v + o], rec);
+            }
+            if (b0 + lane < n && !(P.flags & CX_DBG_NO_CELLTAB))
+                info[b0 + lane] = cx_info_word(Ra.base.v + Ra.vpre, Ra.emask, Ra.ntri, Ra.real_voxel ? 0u : 0x3Fu);
+        }
+        if (P.write_records && (Ra.emask | Ra.ntri) != 0u && Ra.base.c + Ra.ctot <= P.ccap && !(P.flags & CX_DBG_NO_CELLS)) {
+            uint4 c4;
+            c4.x = Ra.lin;
+            c4.y = Ra.sm | ((Ra.real_voxel ? 0u : 0x3Fu) << 8) | (Ra.ntri << 16) | (Ra.emask << 24);
+            c4.z = Ra.base.t + Ra.tpre;
+            c4.w = Ra.base.v + Ra.vpre;
+            P.cells[Ra.base.c + cx_mbcnt(Ra.recm)] = c4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) cx_tround_pin(Rb);   // the next round's fractions are waited for AFTER this round's stores went out
         if (more) Ra = Rb;
         par ^= 1u;
     }
@@ -593,9 +699,11 @@ __device__ __forceinline__ cx_tile cx_tile_of(const cx_params& P, const cx_task&
 // Queue entries and batch records are staged in LDS and copied out in bulk: `s_waitcnt vmcnt` retires
 // loads, stores and atomics in issue order, so a store issued between two plane loads would make the
 // second wait for the store's round trip (measured: +45 % kernel time with one store per active step).
-#define CX_SQ 1024u     // queue entries a wave stages (one step adds at most 1024)
+#define CX_SQ 512u      // queue entries a wave stages; a step adds at most 1024: more than CX_SQ go in two halves of the lanes (32 lanes hold at most 512 cells)
+#define CX_PLW 260u     // floats per row of a staged sample plane: 256 samples of the segment + the one right of it (+ 3: bank spread)
 #define CX_SBR 32u      // batch records a wave stages: all a wave can close (at most one per CX_BATCH_MIN cells of its (CX_SWP - 1) x 1024)
 static_assert((CX_SWP - 1u) * 1024u / CX_BATCH_MIN + 1u <= CX_SBR, "a streaming wave can close more batches than its LDS stage holds");
+static_assert(CX_SQ >= 512u, "half a wave's lanes queue up to 512 cells per step");
 // ALIGNED: n2 % 4 == 0 and a 16-byte aligned grid (rows start on 16-byte boundaries, every lane holds 4 samples
 // of one row).  Otherwise the 16-byte loads are only 4-byte aligned and the lane that holds the end of a row
 // loads the row's last 4 samples and shifts them into place, repeating the last one (a clamped corner).
@@ -603,9 +711,18 @@ template <bool ALIGNED>
 __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task& T, const uint32_t b) {
     __shared__ uint32_t s_q[4][CX_SQ];
     __shared__ uint32_t s_br[4][CX_SBR][5];
-    __shared__ uint32_t s_qa[4][CX_SWP][64];   // per plane step and lane: (queue position of the lane's first cell << 16) | active cells
+    // the two sample planes a step's cells lie between, per wave, row by row as the array has them ([CX_RJ + 1 rows][256 samples + the
+    // one to the right]): what lets ONE LANE PER QUEUED CELL read its 8 corners, wherever the cell's streaming lane holds them in
+    // registers -- the interpolation fractions of the crossings are computed HERE, where the samples already are, instead of being
+    // gathered again from HBM by the vertex stage (round 4: those gathers pulled 274 MB of 128-byte lines per 512^3 extraction,
+    // half of the grid, for 100 MB of vertex records)
+    __shared__ float s_pl[4][2][CX_RJ + 1][CX_PLW];
     __shared__ uint32_t s_tot[4][8];
     __shared__ uint8_t s_ntri[256];      // triangles of a voxel by its corner sign mask
+#ifdef CX_S1_OCC_PAD   // experiment: fewer workgroups per CU (what does the stream kernel lose with less occupancy?)
+    __shared__ uint32_t s_pad[CX_S1_OCC_PAD / 4];
+    if (P.n0 == 0xFFFFFFFFu) reinterpret_cast<volatile uint32_t*>(s_pad)[threadIdx.x] = 1u;
+#endif
     if (b >= T.nblocks) return;
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
     __syncthreads();
@@ -629,7 +746,8 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     uint32_t qn = 0, qstart = 0, nb = 0;   // wave-uniform: queued cells, start of the open batch, closed batches
     uint32_t rv = 0, rt = 0, rc = 0;       // wave-uniform: vertices / triangles / records of the closed batches
     uint32_t nr = 0;                       // wave-uniform: rounds of 64 cells of the closed batches
-    uint32_t qa_steps = 0;                 // wave-uniform: plane steps that queued cells (bit per step)
+    uint32_t tv = 0;                       // wave-uniform: fractions written to the wave's stream so far (== vertices of its cells)
+    bool overflow_t = false;               // wave-uniform: the stream of fractions ran out of room
     float dnear = 3.0e38f;       // per-lane: smallest |f - vcmp| among the samples seen (tolerance screen)
     cx_fast_geom G;
     G.pstart = p; G.j0 = j0; G.k0 = k0;
@@ -709,7 +827,14 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         };
         // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
         // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
-        auto plane_bits = [&](const plane_raw& R) -> uint32_t {
+        float (*ring)[CX_RJ + 1][CX_PLW] = s_pl[wave];
+        const bool stage_t = P.tq != nullptr;      // wave-uniform: this extraction hands fractions on (else the vertex stage gathers samples)
+#ifdef CX_FORCE_RING      // experiment: what the staging of the planes costs by itself
+        const bool stage_ring = true;
+#else
+        const bool stage_ring = stage_t;
+#endif
+        auto plane_bits = [&](const plane_raw& R, const uint32_t slot) -> uint32_t {
             // The sign bits are shifted in from the right, last row first: one v_alignbit_b32 per sample ({word, difference} >> 31 = the
             // word moved up by one with the sign bit of the difference behind it) instead of a shift and a shift-or; rows are
             // CX_ROWBITS apart: two more places after each row of four.  (The stream kernel is bound by its instructions.)
@@ -722,6 +847,10 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                     vx = (kshift == 1u) ? vy : ((kshift == 2u) ? vz : ((kshift == 3u) ? vw : vx));
                     vy = (kshift == 0u) ? vy : ((kshift == 1u) ? vz : vw);
                     vz = (kshift == 0u) ? vz : vw;
+                }
+                if (stage_ring) {   // the lane's four samples of row r, in place; the sample right of the segment behind them
+                    *reinterpret_cast<float4*>(&ring[slot][r][4u * lane]) = make_float4(vx, vy, vz, vw);
+                    if (lane == 0u) ring[slot][r][256] = R.hv[r];
                 }
                 const float dx = vx - P.vcmp, dy = vy - P.vcmp, dz = vz - P.vcmp, dw = vw - P.vcmp;
                 const float dh = R.hv[r] - P.vcmp;
@@ -761,7 +890,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
         load_plane(p + 2u, rawC);
-        uint32_t wprev = plane_bits(rawB);
+        uint32_t wprev = plane_bits(rawB, 0u);
         // one step: plane p+1 is in `cur`, plane p+2 is on its way, plane p+3 is requested into `nxt` (whose plane is used up)
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 3u, nxt);
@@ -771,23 +900,23 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         plane_raw rawA, rawB;
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
-        uint32_t wprev = plane_bits(rawB);
+        uint32_t wprev = plane_bits(rawB, 0u);
         load_plane(p + 2u, rawB);
         auto step = [&](plane_raw& cur, plane_raw& unused_) {
             (void)unused_;
-            const uint32_t wcur = plane_bits(cur);
+            const uint32_t wcur = plane_bits(cur, (p + 1u - G.pstart) & 1u);
             load_plane(p + 3u, cur);
 #else
         plane_raw rawA, rawB;
         load_plane(p, rawB);
         load_plane(p + 1u, rawA);
-        uint32_t wprev = plane_bits(rawB);
+        uint32_t wprev = plane_bits(rawB, 0u);
         // one step: plane p+1 is in `cur` (loaded one step ago), plane p+2 is requested into `nxt`
         auto step = [&](const plane_raw& cur, plane_raw& nxt) {
             load_plane(p + 2u, nxt);
 #endif
 #if CX_S1_DEPTH != 3
-            const uint32_t wcur = plane_bits(cur);
+            const uint32_t wcur = plane_bits(cur, (p + 1u - G.pstart) & 1u);
 #endif
             // per sample row: OR / AND over (k, k+1); then over rows (r, r+1); then over both planes
             const uint32_t op = wprev | (wprev >> 1), ap = wprev & (wprev >> 1);
@@ -798,78 +927,91 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
                 uint32_t tot;
                 const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
-                if (ql + tot > CX_SQ) flush_queue();   // wave-uniform, dense surfaces only
-                uint32_t act = act0;
-                uint32_t pos = ql + pre;
-                const uint32_t ebase = (lane << 15) | ((p - G.pstart) << 21);
-                // where the lane's cells of this step sit in the wave's queue, and which they are (bit 4r+m): lets the
-                // fused emit kernel find the queue entry of ANY active cell of the volume without a table per sample
-                s_qa[wave][p - G.pstart][lane] = ((qn + pre) << 16) | (act0 & 0xFu) | ((act0 >> 2) & 0xF0u) | ((act0 >> 4) & 0xF00u) | ((act0 >> 6) & 0xF000u);
-                qa_steps |= 1u << (p - G.pstart);
-                while (act) {
-                    const uint32_t bit = __ffs(act) - 1u;
-                    act &= act - 1u;
-                    // corners (k,k+1) of rows (r,r+1): bits (bit, bit+1, bit+6, bit+7) of the two plane words
-                    q[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
+                const uint32_t sidx = p - G.pstart;
+                const uint32_t ebase = (lane << 15) | (sidx << 21);
+                // where the lane's cells of this step sit in the wave's queue, and which they are (bit 4r+m): lets the triangle stage
+                // find the queue entry of ANY active cell of the volume without a table per sample.  Straight to global memory, one
+                // coalesced 256-byte store per step that queued cells (round 3 staged all steps' words in 17 KB of LDS and wrote them
+                // out at the end, active or not; measured: the direct store is 3 % FASTER, and the LDS goes to the sample planes)
+                if (P.qa) (P.qa + (size_t)w * (CX_SWP * 64u))[sidx * 64u + lane] =
+                    ((qn + pre) << 16) | (act0 & 0xFu) | ((act0 >> 2) & 0xF0u) | ((act0 >> 4) & 0xF00u) | ((act0 >> 6) & 0xF000u);
+                // The step's cells go through the entry stage in the order of the lanes; more than the stage holds (CX_SQ; up to 1024
+                // on white noise) go in two halves of the lanes -- the order in the queue is the same either way.
+                const uint32_t nhalf = (tot > CX_SQ) ? 2u : 1u;            // wave-uniform
+                const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)pre, 32);   // cells of lanes 0..31
+                const float* __restrict__ plo = &ring[sidx & 1u][0][0];          // sample plane p   (the cells' lower corners)
+                const float* __restrict__ phi = &ring[(sidx + 1u) & 1u][0][0];   // sample plane p+1
+                float* __restrict__ tqw = stage_t ? P.tq + (size_t)w * T.wcap : nullptr;
+                for (uint32_t h = 0; h < nhalf; h++) {
+                    const uint32_t cbase = (nhalf == 2u && h == 1u) ? mid : 0u;
+                    const uint32_t ctot = (nhalf == 2u) ? (h == 0u ? mid : tot - mid) : tot;
+                    if (ql + ctot > CX_SQ) flush_queue();   // wave-uniform
+                    uint32_t act = (nhalf == 1u || (lane >> 5) == h) ? act0 : 0u;
+                    uint32_t pos = ql + pre - cbase;
+                    while (act) {
+                        const uint32_t bit = __ffs(act) - 1u;
+                        act &= act - 1u;
+                        // corners (k,k+1) of rows (r,r+1): bits (bit, bit+1, bit+6, bit+7) of the two plane words
+                        q[pos++] = ebase | (bit << 10) | ((wprev >> bit) & 0xC3u) | (((wcur >> bit) & 0xC3u) << 2);
+                    }
+                    // One lane per queued ENTRY: the counts of the cells just queued, with the vertex stage's own formulas
+                    // (cx_vround_front), and -- with the samples of both planes in LDS -- the fraction t = (v - f(q)) / (f(q+d) - f(q))
+                    // of every crossing the cell owns, written to the wave's stream of fractions in the order the vertex stage numbers
+                    // the vertices (cell after cell, direction after direction).
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t o0 = 0; o0 < ctot; o0 += 64u) {      // wave-uniform
+                        const uint32_t o = o0 + lane;
+                        const bool have = o < ctot;
+                        const uint32_t e = have ? q[ql + o] : 0u;
+                        uint32_t ci, cj, ck;
+                        cx_decode_entry(P, G, e, ci, cj, ck);
+                        const uint32_t vm = have ? cx_corner_valid(P, ci, cj, ck) : 0u;
+                        const uint32_t sm = cx_entry_signs(e);
+                        const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+                        const uint32_t emask = ((sm ^ s0) & vm) & 0xFEu;
+                        const uint32_t nv = __popc(emask);
+                        const bool real = (vm == 0xFFu);
+                        const uint32_t nt = real ? (uint32_t)s_ntri[sm] : 0u;
+                        acc.v += nv;
+                        acc.t += nt;
+                        acc.c += (nv | nt) ? 1u : 0u;
+                        acc.b += real ? 1u : 0u;
+                        if (stage_t) {      // wave-uniform
+                            // corner c = 4 di + 2 dj + dk of the cell: plane di, row rr + dj, sample + dk.  All eight are requested at
+                            // once, ahead of the prefix sums below (written as seven guarded loads, each crossing waited for its own
+                            // LDS round trip: measured +43 us on the kernel), and all seven fractions are computed -- two
+                            // instructions each -- whether the edge is crossed or not; only the stores are guarded.
+                            const uint32_t bit = (e >> 10) & 31u;
+                            const uint32_t rr = (bit * 11u) >> 6;
+                            const uint32_t at = rr * CX_PLW + 4u * ((e >> 15) & 63u) + (bit - 6u * rr);
+                            float f0 = plo[at], f1 = plo[at + 1u], f2 = plo[at + CX_PLW], f3 = plo[at + CX_PLW + 1u];
+                            float f4 = phi[at], f5 = phi[at + 1u], f6 = phi[at + CX_PLW], f7 = phi[at + CX_PLW + 1u];
+                            uint32_t vtot;
+                            const uint32_t vpre = cx_wave_prefix_small<3>(nv, vtot);
+                            if (tv + vtot <= P.tlimit) {    // wave-uniform
+                                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7));
+                                const float num = (P.vhi - f0) + P.vlo;
+                                const float t1 = cx_fraction(num, f1 - f0), t2 = cx_fraction(num, f2 - f0), t3 = cx_fraction(num, f3 - f0);
+                                const float t4 = cx_fraction(num, f4 - f0), t5 = cx_fraction(num, f5 - f0), t6 = cx_fraction(num, f6 - f0);
+                                const float t7 = cx_fraction(num, f7 - f0);
+                                float* __restrict__ dst = tqw + tv + vpre;
+                                if (emask & 0x02u) dst[0] = t1;
+                                if (emask & 0x04u) dst[__popc(emask & 0x02u)] = t2;
+                                if (emask & 0x08u) dst[__popc(emask & 0x06u)] = t3;
+                                if (emask & 0x10u) dst[__popc(emask & 0x0Eu)] = t4;
+                                if (emask & 0x20u) dst[__popc(emask & 0x1Eu)] = t5;
+                                if (emask & 0x40u) dst[__popc(emask & 0x3Eu)] = t6;
+                                if (emask & 0x80u) dst[__popc(emask & 0x7Eu)] = t7;
+                            } else {
+                                overflow_t = true;          // more crossings than the wave's region holds: its cells take the per-cell path downstream
+                            }
+                            tv += vtot;
+                        }
+                    }
+                    ql += ctot;
+                    qn += ctot;
+                    __builtin_amdgcn_wave_barrier();
                 }
-#ifndef CX_S1_COUNTS
-#define CX_S1_COUNTS 1   // 1: one lane per queued ENTRY; 0: bit-sliced over the lane's 16 cells (round 1, ~2.5 x the instructions)
-#endif
-#if CX_S1_COUNTS == 1
-                // counts of the cells just queued, one lane per ENTRY and with the vertex stage's own formulas (cx_vround_front):
-                // ~40 instructions for the step's ~30 cells.  (Round 1 counted all 16 cells of every lane at once on the packed
-                // sign words with bit-sliced adders over the 6 tetrahedra: ~150 instructions per step whatever is active --
-                // a quarter of this kernel's VALU work, and VALU issue is what bounds it next to the sample loads.)
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t o = lane; o < tot; o += 64u) {
-                    const uint32_t e = q[ql + o];
-                    uint32_t ci, cj, ck;
-                    cx_decode_entry(P, G, e, ci, cj, ck);
-                    const uint32_t vm = cx_corner_valid(P, ci, cj, ck);
-                    const uint32_t sm = cx_entry_signs(e);
-                    const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
-                    const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
-                    const bool real = (vm == 0xFFu);
-                    const uint32_t nt = real ? (uint32_t)s_ntri[sm] : 0u;
-                    acc.v += nv;
-                    acc.t += nt;
-                    acc.c += (nv | nt) ? 1u : 0u;
-                    acc.b += real ? 1u : 0u;
-                }
-                ql += tot;
-#else
-                ql += tot;
-                // counts of this lane's 16 cells, all at once on the packed sign words: corner
-                // c = (di,dj,dk) of the cell at bit b is bit b of (plane di word) >> (6*dj + dk).
-                // Cells without a sign change contribute nothing, so no masking by `act0` is needed.
-                const uint32_t mi = ((p + 1u) < P.n0) ? mr : 0u;               // plane p+1 exists
-                const uint32_t real = mk & mj & mi;                           // cells that are voxels
-                const uint32_t b0 = wprev, b1 = wprev >> 1, b2 = wprev >> CX_ROWBITS, b3 = wprev >> (CX_ROWBITS + 1u);
-                const uint32_t b4 = wcur, b5 = wcur >> 1, b6 = wcur >> CX_ROWBITS, b7 = wcur >> (CX_ROWBITS + 1u);
-                uint32_t xw[8];
-                cx_cross_words(wprev, wcur, LM, mi, xw);
-                const uint32_t x1 = xw[1], x2 = xw[2], x3 = xw[3], x4 = xw[4], x5 = xw[5], x6 = xw[6], x7 = xw[7];
-                acc.v += __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);
-                const uint32_t owners = x1 | x2 | x3 | x4 | x5 | x6 | x7;
-                acc.c += __popc(owners | (act0 & real));
-                acc.b += __popc(act0 & real);
-                // triangles: per tetrahedron {0,7,c,d} the number of low corners n = b0+b7+bc+bd;
-                // n odd -> 1 triangle, n == 2 -> 2 triangles  (only voxels emit)
-                const uint32_t x07 = b0 ^ b7, y07 = b0 & b7;
-                uint32_t nt = 0;
-#define CX_TET_COUNT(bc, bd)                                                          \
-    {                                                                                 \
-        const uint32_t xcd = (bc) ^ (bd);                                             \
-        const uint32_t s0 = x07 ^ xcd;                                                \
-        const uint32_t s1 = y07 ^ ((bc) & (bd)) ^ (x07 & xcd);                         \
-        nt += __popc(s0 & real) + 2u * __popc(s1 & ~s0 & real);                        \
-    }
-                CX_TET_COUNT(b1, b3) CX_TET_COUNT(b3, b2) CX_TET_COUNT(b2, b6)
-                CX_TET_COUNT(b6, b4) CX_TET_COUNT(b4, b5) CX_TET_COUNT(b5, b1)
-#undef CX_TET_COUNT
-                acc.t += nt;
-#endif
-                qn += tot;
                 if (qn - qstart >= CX_BATCH_MIN) close_batch();
             }
             wprev = wcur;
@@ -894,18 +1036,6 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     if (qn > qstart) close_batch();
     flush_queue();
     flush_brec();
-    if (P.qa && nrows != 0u && p > G.pstart) {
-        // the queue positions of the active steps (garbage for steps without an active cell: nobody asks for those)
-        const uint32_t nsteps = p - G.pstart;
-        uint32_t* __restrict__ gqa = P.qa + (size_t)w * (CX_SWP * 64u);
-        __builtin_amdgcn_wave_barrier();
-        // only the steps that queued cells (round 3 wrote all of them, 50 MB per 512^3 extraction, three fifths of it never read)
-        (void)nsteps;
-        for (uint32_t m = qa_steps; m; m &= m - 1u) {
-            const uint32_t sidx = (uint32_t)__builtin_ctz(m);
-            gqa[sidx * 64u + lane] = s_qa[wave][sidx][lane];
-        }
-    }
 #ifndef CX_S3_STAMPS
     if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -925,15 +1055,18 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         // voxel count is the exact one.  Otherwise: ONE batch that takes the per-cell path downstream.
         really_near = !(ex.v == rv && ex.t == rt && ex.c == rc && ex.s == 0u);
         run.b = ex.b;
-        if (really_near) {
-            run.v = ex.v; run.t = ex.t; run.c = ex.c;
-            nb = 1;
-            nr = (qn + 63u) >> 6;
-            if (lane == 0) {
-                cx_brec R;
-                R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
-                brec[0] = R;
-            }
+        if (really_near) { run.v = ex.v; run.t = ex.t; run.c = ex.c; }
+    }
+    // a wave whose stream of fractions ran out of room (more crossings than one per cell of its tile: white noise) hands its cells
+    // to the per-cell path too -- which interpolates from the samples itself; its counts are the ones the signs gave
+    if (overflow_t && qn != 0u && !overflow) really_near = true;
+    if (really_near) {
+        nb = 1;
+        nr = (qn + 63u) >> 6;
+        if (lane == 0) {
+            cx_brec R;
+            R.qoff = 0; R.n = qn; R.vpre = 0; R.tpre = 0; R.cpre = 0; R.near = 1; R.pad0 = 0; R.pad1 = 0;
+            brec[0] = R;
         }
     }
     if (lane == 0) {
@@ -1098,6 +1231,7 @@ __device__ __forceinline__ void cx_skip_rounds(const cx_params& P, const cx_fast
 #ifndef CX_S3_MIN_WAVES
 #define CX_S3_MIN_WAVES 1
 #endif
+template <bool TQ>     // TQ: the interpolation fractions come from the stream kernel's stream (P.tq); else the samples are gathered here
 __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const cx_params P, const cx_task T) {
 #ifdef CX_OCC_PAD   // experiment: fewer workgroups per CU (what does the time do with the occupancy?)
     __shared__ uint32_t s_pad[CX_OCC_PAD / 4];
@@ -1141,7 +1275,11 @@ __global__ __launch_bounds__(256, CX_S3_MIN_WAVES) void cx_k_emit_vertices(const
             nrounds += r1 - r0;
             cx_emit_queue_fast(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info, tacc);
 #else
-            cx_emit_queue_fast(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
+            if (TQ)        // the fractions come from the stream kernel (the pointer is the wave's region minus its first vertex: indexed by GLOBAL vertex)
+                cx_emit_queue_t(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info,
+                                reinterpret_cast<const uint32_t*>(P.tq) + ((size_t)D.w * T.wcap) - __builtin_amdgcn_readfirstlane(P.wbase[D.w].v));
+            else
+                cx_emit_queue_fast(P, G, q, r0 * 64u, min(D.n, r1 * 64u), lane, run, reinterpret_cast<uint32_t*>(s_vstage[wave]), s_ntri, info);
 #endif
         } else if (r0 == 0u) {
             cx_process_queue<true>(P, [&](uint32_t x) { return cx_entry_lin(P, G, q[x]); }, D.n, lane, true, run, reinterpret_cast<cx_vrec*>(s_vstage[wave]), info);
@@ -2434,7 +2572,7 @@ static uint32_t cx_vertex_grid(const cx_params& P) {
     static const uint32_t resident = [] {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cx_k_emit_vertices, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cx_k_emit_vertices<true>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256u * (uint32_t)per_cu;
         return (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }();
@@ -2444,7 +2582,8 @@ static uint32_t cx_vertex_grid(const cx_params& P) {
 }
 uint32_t cx_vertex_stage_waves(const cx_params& P) { return 4u * cx_vertex_grid(P); }
 void cx_launch_emit_vertices(const cx_params& P, const cx_task& T, hipStream_t s) {
-    hipLaunchKernelGGL(cx_k_emit_vertices, dim3(P.nvw / 4u), dim3(256), 0, s, P, T);
+    if (P.tq) hipLaunchKernelGGL(cx_k_emit_vertices<true>, dim3(P.nvw / 4u), dim3(256), 0, s, P, T);
+    else hipLaunchKernelGGL(cx_k_emit_vertices<false>, dim3(P.nvw / 4u), dim3(256), 0, s, P, T);
 }
 
 

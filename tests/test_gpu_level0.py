@@ -241,3 +241,19 @@ def test_context_reuse_across_shapes_and_kernels(ctx):
     for shape, extra in seq:
         A = rng.standard_normal(shape).astype(np.float32)
         check_against_oracle(ctx, A, 0.4, _ffi.CX_DIAG_CPYTHON310 | extra, 1)
+
+
+def test_fraction_stream():
+    """The stream kernel computing the interpolation fractions itself and handing them to the vertex stage (cx_params::tq, round 4:
+    no sample gathers in the vertex stage; bit-identical, but measured slower and therefore off -- DESIGN.md section 4) against the
+    oracle, in a child process started with CX_DEBUG=1 CX_TQ=1: the same fields as the entry-walking kernel's test -- smooth and
+    white noise (white noise overflows the waves' regions of fractions: those waves take the per-cell path), both diagonal modes,
+    samples on the isovalue and inside the reference's tolerances."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CX_DEBUG="1", CX_TQ="1")
+    r = subprocess.run([sys.executable, "-c", _ENTRY_KERNEL_CHILD.format(root=root, tests=os.path.join(root, "tests"))],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("ENTRY_KERNEL_OK")], r.stdout[-2000:]
