@@ -333,6 +333,16 @@ def main():
     from contourist_amd import _ffi, synthetic
     from contourist_amd import distributed as cxdist
 
+    # stdout carries ONE line, the JSON line of rank 0: everything else that lands on file descriptor 1 -- gloo announces its
+    # connections there from C++ ("[Gloo] Rank 0 is connected to ...") -- goes to stderr; the line itself is written to the saved
+    # descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_line(text):
+        sys.stdout.flush()
+        os.write(line_fd, (text + "\n").encode())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -350,9 +360,9 @@ def main():
             assert int(t.item()) == world
         lo, hi = cxdist.slab_bounds(args.size, world, rank) if not args.weak else (0, args.size)
         if rank == 0:
-            print(json.dumps({"metric": "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % args.size, "value": None, "unit": "Mvoxels/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak" if args.weak else "strong",
-                              "dry_run": True, "planes_rank0": [lo, hi]}), flush=True)
+            emit_line(json.dumps({"metric": "Mvoxels/s isosurface extraction on %d^3 fp32 grid" % args.size, "value": None, "unit": "Mvoxels/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak" if args.weak else "strong",
+                                  "dry_run": True, "planes_rank0": [lo, hi]}))
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -609,9 +619,14 @@ def main():
                 "bytes_necessary": bytes_necessary,
                 "necessary_GBps": bytes_necessary / (level0_ms * 1e-3) / 1e9 if level0_ms > 0 else 0.0,
                 "frac_necessary": bytes_necessary / (level0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if level0_ms > 0 else 0.0,
-                "traffic_note": "HBM bytes of one extraction from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/prof_step.py "
-                                "on the same field (profiles/traffic.json, tools/traffic.py: FETCH_SIZE doubled for the 16-byte streams as "
-                                "MI355X_MICROARCH.md prescribes); counters cannot be read inside this process",
+                # what the pipeline actually moves, and how close that is to what this device streams: the extraction is bound by its
+                # bytes -- each of its three big kernels runs at 4.5-5 TB/s of fabric traffic
+                "traffic_GBps": (traffic / (level0_ms * 1e-3) / 1e9) if (traffic and level0_ms > 0) else None,
+                "traffic_over_measured_peak": (traffic / (level0_ms * 1e-3) / 1e9 / measured_read) if (traffic and level0_ms > 0 and measured_read > 0) else None,
+                "traffic_note": "HBM-side bytes of one extraction = the L2's fabric requests, each at its size (TCC_EA0_RDREQ_32B/_64B/_128B, "
+                                "TCC_EA0_WRREQ_64B / TCC_EA0_WRREQ), from separate rocprofv3 --pmc passes over tools/prof_step.py on the same field "
+                                "(profiles/traffic.json, tools/traffic.py); counters cannot be read inside this process.  Rounds 1-3 derived it from "
+                                "FETCH_SIZE, which tallies the emit stages' 128-byte gather requests at 64 bytes: 1.40 GB was reported where 1.66 GB moved",
             },
         }
         if single is not None:
@@ -678,7 +693,7 @@ def main():
             if not out["cpu_baseline"]["counts_equal"]:
                 parity_error = "HIP counts %r != oracle counts %r on the CPU leg's sample" % (hip_counts, out["cpu_baseline"]["oracle_counts"])
                 out["parity_error"] = parity_error
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
         if parity_error:
             print("# PARITY ERROR: " + parity_error, file=sys.stderr, flush=True)
             sys.exit(3)

@@ -716,7 +716,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     // registers -- the interpolation fractions of the crossings are computed HERE, where the samples already are, instead of being
     // gathered again from HBM by the vertex stage (round 4: those gathers pulled 274 MB of 128-byte lines per 512^3 extraction,
     // half of the grid, for 100 MB of vertex records)
-    __shared__ float s_pl[4][2][CX_RJ + 1][CX_PLW];
+    // (dynamic LDS: 41.6 KB per workgroup, asked for at launch only when the extraction hands fractions on -- without it the stream
+    // kernel keeps its 11 KB and leaves the LDS of its CU to the other extraction's emit stages)
+    extern __shared__ __attribute__((aligned(16))) float s_pl_dyn[];
     __shared__ uint32_t s_tot[4][8];
     __shared__ uint8_t s_ntri[256];      // triangles of a voxel by its corner sign mask
 #ifdef CX_S1_OCC_PAD   // experiment: fewer workgroups per CU (what does the stream kernel lose with less occupancy?)
@@ -827,7 +829,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         };
         // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
         // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
-        float (*ring)[CX_RJ + 1][CX_PLW] = s_pl[wave];
+        float (*ring)[CX_RJ + 1][CX_PLW] = reinterpret_cast<float (*)[CX_RJ + 1][CX_PLW]>(s_pl_dyn + (size_t)wave * (2u * (CX_RJ + 1u) * CX_PLW));
         const bool stage_t = P.tq != nullptr;      // wave-uniform: this extraction hands fractions on (else the vertex stage gathers samples)
 #ifdef CX_FORCE_RING      // experiment: what the staging of the planes costs by itself
         const bool stage_ring = true;
@@ -2532,8 +2534,9 @@ cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
 
 void cx_launch_stream(const cx_params& P, const cx_task& T, hipStream_t s) {
     const bool aligned = (P.n2 % 4u == 0u) && ((reinterpret_cast<uintptr_t>(P.grid) & 15u) == 0u);
-    if (aligned) hipLaunchKernelGGL(cx_k_stream<true>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
-    else hipLaunchKernelGGL(cx_k_stream<false>, dim3(T.chunk * 8u), dim3(256), 0, s, P, T);
+    const uint32_t ring = P.tq ? (uint32_t)(4u * 2u * (CX_RJ + 1u) * CX_PLW * sizeof(float)) : 0u;   // the staged sample planes (cx_stream_tile)
+    if (aligned) hipLaunchKernelGGL(cx_k_stream<true>, dim3(T.chunk * 8u), dim3(256), ring, s, P, T);
+    else hipLaunchKernelGGL(cx_k_stream<false>, dim3(T.chunk * 8u), dim3(256), ring, s, P, T);
 }
 
 void cx_launch_stream_levels(const cx_params* host_params, const cx_task& T, uint32_t nlevels, hipStream_t s) {

@@ -19,6 +19,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc/$n
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/$n -- python3 tools/prof_step.py 512 > gpurun_out/pmc/$n.log 2>&1
 done
+# the fabric requests of the L2 by size: what the traffic figure is computed from (tools/traffic.py)
+rm -rf gpurun_out/pmc/ea_rd gpurun_out/pmc/ea_wr
+timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d gpurun_out/pmc/ea_rd -- python3 tools/prof_step.py 512 > gpurun_out/pmc/ea_rd.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d gpurun_out/pmc/ea_wr -- python3 tools/prof_step.py 512 > gpurun_out/pmc/ea_wr.log 2>&1
+bash tools/pmc_sq.sh 1 > gpurun_out/prof/sq_counters.txt 2>&1
 python3 tools/traffic.py gpurun_out/pmc gpurun_out/prof > gpurun_out/prof/traffic.log
 timeout -k 10 300 python3 tools/bench_levels.py 512 > gpurun_out/prof/bench_levels_512.json 2> gpurun_out/prof/levels.err
 # Level 1 of the bench mesh: kernel trace of three post-passes (tools/l1_stats.py prints the per-pass table), and what one rank of an
