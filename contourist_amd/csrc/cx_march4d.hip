@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
                 cx_unravel4(P, clin, cq);
                 const float num = (P.vhi - f0) + P.vlo;
                 const float den = fd - f0;
-                float t = __fdividef(num, den);
+                float t = cx_fraction(num, den);
                 if (fabsf(den) <= 1.001e-8f) {
                     const double dd = (double)fd - (double)f0;
                     t = (fabs(dd) <= 1e-8) ? 0.5f : (float)((P.value - (double)f0) / dd);
@@ -589,10 +589,13 @@ __device__ __forceinline__ void cx_pent_decide(const uint32_t (&S)[16], uint32_t
 #endif
 // LDS of the tetrahedra kernel (per workgroup of 4 waves)
 struct cx_tet_lds {
-    uint32_t vf[4][15][64];        // first vertex of the cells at the 15 owner corners
-    uint16_t em[4][16][64];        // their crossing masks
+    // [cell][corner], the cell slow: in phase 2 a run of ~30 consecutive lanes works on tetrahedra of ONE cell and reads different corners
+    // of it -- with the cell fast ([corner][cell], until round 4) those all fell on bank (cell % 32): SQ_LDS_BANK_CONFLICT was two thirds of
+    // the kernel's LDS cycles (26 of 40 M, a quarter of its time).  Rows of 15 words (odd: the cell lanes' writes spread over all banks too).
+    uint32_t vf[4][64][15];        // first vertex of the cells at the 15 owner corners
+    uint16_t em[4][64][17];        // their crossing masks (rows of 17 halfwords: the cell lanes' writes of one corner spread over the banks)
     uint16_t slot[4][18 * 64 + 64];// per group: cell lane | pentatope in group << 6 | tetrahedron of the entry << 9 (+ a dump row)
-    uint16_t pinfo[4][6][64];      // per group: pattern | permutation id << 5
+    uint16_t pinfo[4][64][6];      // per group: pattern | permutation id << 5
     uint64_t local[32 * 12];
 };
 
@@ -618,7 +621,7 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
     const uint32_t dump = 18u * 64u + lane;      // where the slot words of absent tetrahedra go (no branches, no loops)
 #pragma unroll
     for (int pn = 0; pn < 6; pn++) {
-        L.pinfo[wave][pn][lane] = (uint16_t)(pats[pn] | (perms[pn] << 5));
+        L.pinfo[wave][lane][pn] = (uint16_t)(pats[pn] | (perms[pn] << 5));
         const uint32_t w = lane | ((uint32_t)pn << 6);
         L.slot[wave][nts[pn] ? pos : dump] = (uint16_t)w;
         L.slot[wave][nts[pn] == 3u ? pos + 1u : dump] = (uint16_t)(w | (1u << 9));
@@ -629,8 +632,8 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
     while (unres) {
         const uint32_t pn = __ffs(unres) - 1u;
         unres &= unres - 1u;
-        const uint32_t pi = L.pinfo[wave][pn][lane];
-        L.pinfo[wave][pn][lane] = (uint16_t)((pi & 31u) | (cx_pent_perm_exact(P, q, (uint32_t)G * 6u + pn, pi & 31u) << 5));
+        const uint32_t pi = L.pinfo[wave][lane][pn];
+        L.pinfo[wave][lane][pn] = (uint16_t)((pi & 31u) | (cx_pent_perm_exact(P, q, (uint32_t)G * 6u + pn, pi & 31u) << 5));
     }
     __builtin_amdgcn_wave_barrier();
     // ---- phase 2: one lane per tetrahedron
@@ -642,7 +645,7 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
         const bool ok = j < ttot;
         const uint32_t w = L.slot[wave][ok ? j : 0u];
         const uint32_t cell = w & 63u, pn = (w >> 6) & 7u, k = (w >> 9) & 3u;
-        const uint32_t pi = L.pinfo[wave][pn][cell];
+        const uint32_t pi = L.pinfo[wave][cell][pn];
         // corners of the pentatope (a nibble per local vertex) and its orientation: 6 candidates, compile-time words
         uint32_t pcw = CX_PCW(G * 6 + 0);
         pcw = (pn == 1u) ? CX_PCW(G * 6 + 1) : pcw;
@@ -659,7 +662,7 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
             const uint32_t x = (t20 >> (5u * s_)) & 3u, y = (t20 >> (5u * s_ + 2u)) & 7u;
             const uint32_t c1 = (pcw >> (4u * x)) & 15u, c2 = (pcw >> (4u * y)) & 15u;
             const uint32_t d = c1 ^ c2;
-            const uint32_t vf = L.vf[wave][c1][cell], em = L.em[wave][c1][cell];
+            const uint32_t vf = L.vf[wave][cell][c1], em = L.em[wave][cell][c1];
             tv[s_] = (int32_t)(vf + __popc(em & ((1u << d) - 1u)));
         }
 #ifndef CX4_ABL_STORE
@@ -728,8 +731,8 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
         for (uint32_t c = 0; c < 15; c++) asm volatile("" : "+v"(ew[c]) :: "memory");
 #pragma unroll
         for (uint32_t c = 0; c < 15; c++) {
-            L.vf[wave][c][lane] = (uint32_t)ew[c];
-            L.em[wave][c][lane] = (uint16_t)(ew[c] >> 32);
+            L.vf[wave][lane][c] = (uint32_t)ew[c];
+            L.em[wave][lane][c] = (uint16_t)(ew[c] >> 32);
         }
         // probe codes of the corner hashes (absolute lattice coordinates) for the set-order emulation
         uint32_t S[16];
