@@ -20,6 +20,7 @@ CX_DIAG_CPYTHON310 = 1
 CX_KERNEL_GENERIC = 0x100
 CX_KERNEL_STAGED = 0x200
 CX_KERNEL_FUSED = 0x400
+CX_KERNEL_TILED = 0x800
 
 # every symbol include/contourist_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -594,7 +595,7 @@ class Context(object):
 
     # what cx_timing_read's slots measure, with the algorithmic bytes of each stage (bench.py)
     def level0_path(self):
-        "kernels of the last extraction: 0 generic classify + triangle stage, 1 staged pipeline, 2 stream + scan + fused emit"
+        "kernels of the last extraction: 0 generic classify + triangle stage, 1 staged pipeline, 2 stream + scan + fused emit, 3 stream + scan + tile emit + boundary"
         p = ctypes.c_int()
         self._check(self.lib.cx_level0_path(self.handle, ctypes.byref(p)))
         return p.value
@@ -606,6 +607,9 @@ class Context(object):
         if path == 1:
             return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_list"),
                     ("cells_ms", "cx_k_emit_vertices"), ("emit_ms", "cx_k_emit_triangles_q")]
+        if path == 3:
+            return [("stream_ms", "cx_k_stream"), ("scan_ms", "cx_k_scan_list"),
+                    ("cells_ms", "cx_k_tile_emit"), ("emit_ms", "cx_k_tile_boundary")]
         return [("stream_ms", "cx_k_classify_generic"), ("emit_ms", "cx_k_emit_triangles")]
 
     def vertex_stage_bytes(self, counts):

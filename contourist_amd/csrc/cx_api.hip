@@ -84,6 +84,10 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_release(ctx->rstart, ctx->rstart_cap);
     cx_release(ctx->kstart, ctx->kstart_cap);
     cx_release(ctx->hbytes, ctx->hbytes_cap);
+    cx_release(ctx->fj, ctx->fj_cap);
+    cx_release(ctx->fk, ctx->fk_cap);
+    cx_release(ctx->bnd, ctx->bnd_cap);
+    cx_release(ctx->bndn, ctx->bndn_cap);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -243,7 +247,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     if (!(value == value)) return fail(ctx, CX_ERR_INVALID, "isovalue is NaN");
     // the public flags are the documented ones; the ablation bits (CX_DBG_*) give partial meshes and are only honoured
     // in a process started with CX_DEBUG=1 (tools/)
-    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310 | CX_KERNEL_GENERIC | CX_KERNEL_STAGED | CX_KERNEL_FUSED)) != 0u && !cx_debug_enabled())
+    if ((flags & ~(uint32_t)(CX_DIAG_CPYTHON310 | CX_KERNEL_GENERIC | CX_KERNEL_STAGED | CX_KERNEL_FUSED | CX_KERNEL_TILED)) != 0u && !cx_debug_enabled())
         return fail(ctx, CX_ERR_INVALID, "unknown flag bits in cx_extract3d");
     const int64_t N = ctx->n0 * ctx->n1 * ctx->n2;
     if (!ctx->cells || !ctx->verts || !ctx->tris) {
@@ -263,6 +267,8 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     // fused emit kernel (no per-cell table, no cell records) only on request: measured slower than the staged kernels
     // (DESIGN.md section 4); an extraction that meets the tolerance path is sent through the staged kernels by cx_counts_get
     const bool fused = staged && (flags & CX_KERNEL_FUSED) && !(flags & CX_KERNEL_STAGED);
+    // tile emit (cx_tile3d.h): vertex records and triangles tile by tile, the hand-over between them in LDS
+    const bool tiled = staged && !fused && !(flags & CX_KERNEL_STAGED) && ((flags & CX_KERNEL_TILED) || cx_debug_knob("CX_TILED", 0u));
     if (!staged) {
         // the per-cell table of the generic emit path (one 8-byte entry per sample): only when that path runs
         const int rc = cx_grow(ctx, ctx->celltab, ctx->tables_for, (size_t)N + 64u);
@@ -335,7 +341,16 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         // the triangle stage walks the vertex stage's cell records.  The kernel that walks queue entries instead (no records: 80 MB
         // less HBM traffic per 512^3 extraction) is built and bit-identical, and measured no faster at 512^3 and slower on thin slabs
         // (DESIGN.md section 4): it runs on request (CX_DEBUG=1 CX_K2_ENTRIES=1)
-        P.write_records = (!fused && !cx_debug_knob("CX_K2_ENTRIES", 0u)) ? 1u : 0u;
+        P.write_records = (!fused && !tiled && !cx_debug_knob("CX_K2_ENTRIES", 0u)) ? 1u : 0u;
+        if (tiled) {
+            P.qa = nullptr;       // nobody gathers the queue words: the stream kernel does not store them
+            if ((rc = cx_grow(ctx, ctx->fj, ctx->fj_cap, (size_t)P.n0 * (4u * T.njg) * P.n2 + 64u))) return rc;
+            if ((rc = cx_grow(ctx, ctx->fk, ctx->fk_cap, (size_t)P.n0 * P.n1 * (2u * T.nks) + 64u))) return rc;
+            if ((rc = cx_grow(ctx, ctx->bnd, ctx->bnd_cap, (size_t)T.nblocks * 2u * T.bndcap))) return rc;
+            if ((rc = cx_grow(ctx, ctx->bndn, ctx->bndn_cap, (size_t)T.nblocks * 2u))) return rc;
+            P.fj = ctx->fj; P.fk = ctx->fk; P.bnd = ctx->bnd; P.bndn = ctx->bndn;
+            P.tile_cap = cx_debug_knob("CX_TILE_CAP", cx_tile_cap_default());
+        }
         P.nvw = cx_vertex_stage_waves(P);
         if ((rc = cx_grow(ctx, ctx->rstart, ctx->rstart_cap, (size_t)P.nvw + 1u))) return rc;
         P.rstart = ctx->rstart;
@@ -346,7 +361,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
     }
     ctx->last_task = T;
     ctx->last_flags = flags;
-    ctx->path = staged ? (fused ? 2 : 1) : 0;
+    ctx->path = staged ? (fused ? 2 : (tiled ? 3 : 1)) : 0;
     ctx->records_valid = staged ? (P.write_records != 0u) : true;   // the generic path always writes them
     cx_ctx::evset* ev = nullptr;
     if (ctx->timing) {
@@ -366,6 +381,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (!(flags & CX_DBG_PHASE_A_ONLY)) cx_launch_scan_waves(P, T, ctx->stream);
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
         if (fused) cx_launch_emit_mesh(P, T, ctx->stream);
+        else if (tiled) { if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_tile_emit(P, T, ctx->hash_xy, ctx->stream); }
         else if (!(flags & (CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) cx_launch_emit_vertices(P, T, ctx->stream);
     } else {
         cx_launch_classify_generic(P, ctx->stream);
@@ -373,7 +389,7 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
         if (ev) CX_HIP(ctx, hipEventRecord(ev->e[2], ctx->stream));
     }
     if (ev) CX_HIP(ctx, hipEventRecord(ev->e[3], ctx->stream));
-    if (!fused && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) {
+    if (!fused && !tiled && !(flags & (CX_DBG_NO_EMIT | CX_DBG_PHASE_A_ONLY | CX_DBG_COUNT_ONLY))) {
         if (staged && P.write_records) cx_launch_emit_triangles_q(P, T, ctx->hash_xy, ctx->stream);
         else if (staged) cx_launch_emit_triangles_e(P, T, ctx->hash_xy, ctx->stream);   // (A/B: CX_K2_ENTRIES)
         else cx_launch_emit_triangles(P, ctx->hash_xy, ctx->stream);
@@ -411,6 +427,13 @@ extern "C" int cx_counts_get(cx_ctx* ctx, cx_counts* out) {
         (ctx->last.flat && ctx->counters_host[CX_CNT_BATCHES] > ctx->last.fcap)) {
         ctx->extracted = false;
         return fail(ctx, CX_ERR_CAPACITY, "output buffers too small for this isosurface");
+    }
+    if (ctx->path == 3 && (ctx->counters_host[CX_CNT_NEAR] != 0u || ctx->counters_host[CX_CNT_TILEOVF] != 0u)) {
+        // a wave on the tolerance path, or a tile with more surface cells than a workgroup's LDS words: the tile kernels have
+        // written nothing (or not everything) -- the same extraction again through the staged kernels
+        int rc = enqueue_extract(ctx, ctx->last.value, (ctx->last_flags & ~(uint32_t)CX_KERNEL_TILED) | CX_KERNEL_STAGED);
+        if (rc) return rc;
+        return cx_counts_get(ctx, out);
     }
     if (ctx->path == 2 && ctx->counters_host[CX_CNT_NEAR] != 0u) {
         // a sample within the reference's np.allclose tolerances of the isovalue: its rules may drop vertices, the fused

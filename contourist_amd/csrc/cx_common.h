@@ -96,6 +96,13 @@ struct cx_params {
     // them back in order instead of gathering samples from half of the grid's cache lines.  null: the vertex stage gathers (levels, fused).
     float* tq;                // [nwaves * wcap] one region per streaming wave, filled from the front
     uint32_t tlimit;          // fractions a streaming wave may store (T.wcap); a wave with more hands its cells to the per-cell path
+    // tile emit path (cx_tile3d.h): the words (crossing mask << 32 | first vertex) of the cells on the j- and k-faces of the tiles,
+    // and the voxels that need them (a neighbour cell in the next tile in j or k)
+    uint64_t* fj;             // [n0][4 * njg][n2]: rows j % 8 == 0 (slot 2 (j / 8)) and j % 8 == 7 (slot 2 (j / 8) + 1)
+    uint64_t* fk;             // [n0][n1][2 * nks]: samples k % 256 == 0 (slot 2 ks) and k % 256 == 255 (slot 2 ks + 1)
+    uint4* bnd;               // [2 nblocks][T.bndcap] (per half tile) boundary records {lin, sign|tetskip<<8|ntri<<16|emask<<24, first triangle, first vertex}
+    uint32_t* bndn;           // [2 nblocks] how many
+    uint32_t tile_cap;        // info words a workgroup of the tile kernel holds in LDS (queue entries of its tile + the next chunk's first plane)
 };
 #ifndef CX_SWP
 #define CX_SWP 16u            // plane slots per streaming wave: cell planes per task (ci) + 1, ci <= 15
@@ -133,6 +140,7 @@ struct cx_task {
     uint32_t chunk;        // tasks per XCD (grid = 8 * chunk workgroups)
     uint32_t wcap;         // queue entries per wave (every cell of its task)
     uint32_t bcap;         // batch records per wave
+    uint32_t bndcap;       // boundary records per half tile (tile emit path): the voxels of its last row and last sample column
     cx_fdiv div_nks, div_njg;   // / nks, / njg: a streaming wave's tile from its number (triangle stage)
 };
 
@@ -153,7 +161,8 @@ enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, C
        CX_CNT_NEAR = 5,   // streaming waves that met a sample inside the tolerance screen (their cells take the per-cell path)
        CX_CNT_ROUNDS = 6, // rounds of 64 queued cells over all batches (what the vertex stage divides among its waves)
        CX_CNT_OVERFLOW = 7, // a streaming wave found more cells than its slice of a shared queue pool holds (cx_extract3d_levels)
-       CX_CNT_WORDS = 8 };
+       CX_CNT_TILEOVF = 8,  // tile emit path: a tile holds more active cells than a workgroup's LDS words (the host runs the staged kernels instead)
+       CX_CNT_WORDS = 16 };
 
 // device tables (defined in cx_march3d.hip)
 extern __device__ __constant__ uint8_t cx_d_tet_corners[6][4];
@@ -176,6 +185,8 @@ void cx_launch_emit_triangles(const cx_params& P, const uint64_t* hash_xy, hipSt
 void cx_launch_emit_triangles_q(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_triangles_e(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);
 void cx_launch_emit_mesh(const cx_params& P, const cx_task& T, hipStream_t s);
+void cx_launch_tile_emit(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s);   // cx_k_tile_emit + cx_k_tile_boundary
+uint32_t cx_tile_cap_default();
 void cx_launch_hash_bytes(uint8_t* table, const uint64_t* hash_xy, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t org2, hipStream_t s);
 void cx_launch_expand_verts(const cx_vrec* recs, float4* out, uint32_t n, uint32_t n1, uint32_t n2, hipStream_t s);
 void cx_launch_hash_xy(uint64_t* table, uint32_t n0, uint32_t n1, uint32_t org0, uint32_t org1, hipStream_t s);

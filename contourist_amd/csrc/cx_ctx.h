@@ -49,13 +49,21 @@ struct cx_ctx {
     size_t rstart_cap = 0;
     uint32_t* kstart = nullptr;        // the same for the triangle stage (cx_params::kstart)
     size_t kstart_cap = 0;
+    uint64_t* fj = nullptr;            // tile emit path: face words (cx_params::fj, fk), boundary records and their counts per tile
+    size_t fj_cap = 0;
+    uint64_t* fk = nullptr;
+    size_t fk_cap = 0;
+    uint4* bnd = nullptr;
+    size_t bnd_cap = 0;
+    uint32_t* bndn = nullptr;
+    size_t bndn_cap = 0;
     uint8_t* hbytes = nullptr;         // fused emit: CPython set-order code per lattice point (valid for hash_xy's shape and origin)
     size_t hbytes_cap = 0;
     bool hbytes_valid = false;
     int64_t hbytes_n2 = 0, hbytes_o2 = 0;
     cx_task last_task = {};
     uint32_t last_flags = 0;
-    int path = 0;                      // kernels of the last extraction: 0 generic, 1 staged, 2 fused
+    int path = 0;                      // kernels of the last extraction: 0 generic, 1 staged, 2 fused, 3 tile emit
     bool records_valid = false;        // ctx->cells holds the cell records of the last extraction
     uint64_t* hash_xy = nullptr;       // CPython tuple-hash prefix per (i,j), for CX_DIAG_CPYTHON310
     size_t hash_xy_cap = 0;

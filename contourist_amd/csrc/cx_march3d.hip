@@ -1194,6 +1194,7 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
         const uint32_t fl = s_part[0][6] | s_part[1][6] | s_part[2][6] | s_part[3][6];
         P.counters[CX_CNT_NEAR] = fl & 1u;
         P.counters[CX_CNT_OVERFLOW] = (fl >> 1) & 1u;
+        P.counters[CX_CNT_TILEOVF] = 0u;
     }
 }
 __global__ __launch_bounds__(256) void cx_k_scan_list(const cx_params P, const cx_task T, const uint32_t nw) {
@@ -1429,22 +1430,38 @@ constexpr cx_pats_tab cx_make_pats() {
     return T;
 }
 __device__ constexpr cx_pats_tab CX_PATS = cx_make_pats();
+union cx_tri_u {
+    struct {
+        uint16_t slot[12 * 64];  // one word per triangle
+        uint32_t tfirst[64];     // first triangle index of each cell minus its rank in the wave
+    } a;
+    uint32_t hs[8][64];          // low words of the 8 corner hashes of each cell (dead before the slot words are written)
+};
 struct cx_tri_lds {
+    static constexpr bool packed = false;
     uint2 ve[4][7][CX_VE_ROW];   // per wave: (first vertex, crossing mask) of corner c of each cell (rows padded: bank spread)
-    union {
-        struct {
-            uint16_t slot[12 * 64];  // one word per triangle
-            uint32_t tfirst[64];     // first triangle index of each cell minus its rank in the wave
-        } a;
-        uint32_t hs[8][64];          // low words of the 8 corner hashes of each cell (dead before the slot words are written)
-    } u[4];                      // per wave
+    cx_tri_u u[4];               // per wave
     uint16_t slot22[4][6 * 64];  // per wave: one word per 2-2 tetrahedron: cell lane | tet << 6 | pattern << 9
     uint32_t var[4][64];         // per wave: quad diagonal variants of each cell (bit t)
     uint32_t lut[6 * 16 * 2 * 2];
     uint2 pats[256];
     uint16_t c22[6 * 16];
 };
-__device__ __forceinline__ void cx_tri_lds_init(cx_tri_lds& L) {
+// the same tables with ONE word per (corner, cell): first vertex relative to one of two bases (bits 0-22; bit 31 picks the base) |
+// crossing mask << 23 -- the form the tile kernel keeps per queue entry in LDS (cx_tile3d.h): half the bytes, four workgroups per CU
+struct cx_tri_lds_p {
+    static constexpr bool packed = true;
+    uint32_t ve[4][7][CX_VE_ROW];
+    cx_tri_u u[4];
+    uint16_t slot22[4][6 * 64];
+    uint32_t var[4][64];
+    uint32_t lut[6 * 16 * 2 * 2];
+    uint2 pats[256];
+    uint16_t c22[6 * 16];
+    uint32_t vb[2];              // the two bases
+};
+template <typename LDS>
+__device__ __forceinline__ void cx_tri_lds_init(LDS& L) {
     for (uint32_t x = threadIdx.x; x < 6 * 16 * 2 * 2; x += blockDim.x) L.lut[x] = (&CX_TRI_CD[0][0][0][0])[x];
     for (uint32_t x = threadIdx.x; x < 256u; x += blockDim.x) L.pats[x] = make_uint2(CX_PATS.w[x][0], CX_PATS.w[x][1]);
     for (uint32_t x = threadIdx.x; x < 96u; x += blockDim.x) L.c22[x] = CX_PATS.c22[x];
@@ -1533,12 +1550,18 @@ __device__ __forceinline__ void cx_tri_pin(cx_tri_in& I, uint4& nxt) {
 // predicated tetrahedra per cell lane: a voxel has 1.7 of them on average, so two rounds of 64 lanes replace six unrolled
 // hash comparisons per lane.  The corner hashes (low words) of a round's cells go through LDS (hs), overlaying the slot
 // words, which are written afterwards.
-template <bool NEG_ORIGIN>
-__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
+template <bool NEG_ORIGIN, typename LDS>
+__device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, LDS& L, uint32_t lane, uint32_t wave, const cx_tri_in& I) {
     const uint32_t sm = I.rec.y & 0xFFu, tetskip = (I.rec.y >> 8) & 0x3Fu, ntri = (I.rec.y >> 16) & 0xFFu;
-    L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
+    if constexpr (LDS::packed) {     // rec.w and nb[].x carry the packed words as they are
+        L.ve[wave][0][lane] = I.rec.w;
 #pragma unroll
-    for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u];
+        for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u].x;
+    } else {
+        L.ve[wave][0][lane] = make_uint2(I.rec.w, I.rec.y >> 24);
+#pragma unroll
+        for (uint32_t c = 1; c < 7; c++) L.ve[wave][c][lane] = I.nb[c - 1u];
+    }
     const uint2 pw = L.pats[sm];                                  // x: 6 patterns x 4 bits | 2-2 mask << 24; y: 1-3 mask | wanted neighbours << 8
     const uint32_t em6 = ntri ? (~tetskip & 0x3Fu) : 0u;          // tetrahedra that emit
     const uint32_t m22 = (pw.x >> 24) & em6, m1 = pw.y & em6;
@@ -1653,7 +1676,8 @@ __device__ __forceinline__ uint32_t cx_tri_phase1(const cx_params& P, cx_tri_lds
     return ttot;
 }
 // phase 2, one lane per triangle: stores only
-__device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L, uint32_t lane, uint32_t wave, uint32_t ttot) {
+template <typename LDS>
+__device__ __forceinline__ void cx_tri_phase2(const cx_params& P, LDS& L, uint32_t lane, uint32_t wave, uint32_t ttot) {
     for (uint32_t j0 = 0; j0 < ttot; j0 += 64u) {   // wave-uniform
         const uint32_t j = j0 + lane;
         const bool ok = j < ttot;
@@ -1664,8 +1688,13 @@ __device__ __forceinline__ void cx_tri_phase2(const cx_params& P, cx_tri_lds& L,
 #pragma unroll
         for (uint32_t sidx = 0; sidx < 3; sidx++) {
             const uint32_t cd = (tw >> (6u * sidx)) & 63u;
-            const uint2 pr = L.ve[wave][cd & 7u][cell];
-            vi[sidx] = (int32_t)(pr.x + __popc(pr.y & ((1u << (cd >> 3)) - 1u)));
+            if constexpr (LDS::packed) {
+                const uint32_t wd = L.ve[wave][cd & 7u][cell];
+                vi[sidx] = (int32_t)(L.vb[wd >> 31] + (wd & 0x7FFFFFu) + __popc(((wd >> 23) & 0xFEu) & ((1u << (cd >> 3)) - 1u)));
+            } else {
+                const uint2 pr = L.ve[wave][cd & 7u][cell];
+                vi[sidx] = (int32_t)(pr.x + __popc(pr.y & ((1u << (cd >> 3)) - 1u)));
+            }
         }
         if (ok && !(P.flags & CX_DBG_NO_TRIS)) {
             // 32-bit wrap-around on purpose: tfirst = first - rank may be "negative" when the wave's cells come from
@@ -2497,6 +2526,8 @@ __global__ __launch_bounds__(256, CX_EM_MIN_WAVES) void cx_k_emit_mesh(const cx_
     }
 }
 
+#include "cx_tile3d.h"
+
 // ---- launchers --------------------------------------------------------------------------------------
 bool cx_fast_classify_supported(const cx_params& P) {
     return P.n2 >= 4u && ((reinterpret_cast<uintptr_t>(P.grid) & 3u) == 0u);   // a lane loads 4 samples of one row
@@ -2527,6 +2558,7 @@ cx_task cx_fast_task(uint32_t n0, uint32_t n1, uint32_t n2) {
     T.chunk = (T.nblocks + 7u) / 8u;
     T.wcap = CX_RJ * 256u * ci;
     T.bcap = T.wcap / CX_BATCH_MIN + 1u;
+    T.bndcap = (256u + 2u * CX_RJ) * ci;     // per HALF tile
     T.div_nks = cx_fdiv_make(T.nks);
     T.div_njg = cx_fdiv_make(T.njg);
     return T;

@@ -45,6 +45,11 @@ typedef enum {
                                     cells found through the queues, no table per sample, no cell records); same mesh, same
                                     numbering.  An extraction with samples inside the reference's np.allclose tolerances whose
                                     rules drop vertices is sent through the staged kernels automatically */
+#define CX_KERNEL_TILED 0x800u   /* emit vertices and triangles tile by tile (one workgroup per tile of the streaming pass, the
+                                    neighbour cells' vertex indices kept in LDS; the voxels on a tile's last row / last sample
+                                    column by a small second kernel): same mesh, same numbering, ~0.35 GB less HBM traffic per
+                                    512^3 extraction.  Sent through the staged kernels automatically when a sample sits inside the
+                                    reference's np.allclose tolerances or a tile holds more surface cells than the LDS words */
 
 typedef struct {
     int64_t n_cells;         /* lattice cells with a sign change among their corners */

@@ -16,6 +16,12 @@ ctx.reserve(int(c["n_cells"] * 1.1), int(c["n_vertices"] * 1.1), int(c["n_triang
 modes = [(1 | 0x400, "fused cpython"), (0x400, "fused canonical"), (1 | 0x200, "staged cpython"), (0x200, "staged canonical")]
 if len(sys.argv) > 2 and sys.argv[2] == "quick":
     modes = [(1 | 0x400, "fused"), (0x400, "fused canon"), (1, "staged"), (0, "staged canon")]
+if len(sys.argv) > 2 and sys.argv[2] == "tiled":
+    modes = [(1 | 0x800, "tiled"), (1 | 0x200, "staged"), (0x800, "tiled canon"), (0x200, "staged canon")]
+if len(sys.argv) > 2 and sys.argv[2] == "tiled_ablate":
+    F = 0x800
+    modes = [(F | 1, "tiled"), (F, "tiled canon"), (F | 0x1000000, "canon no_vloads"), (F | 0x400000, "canon no_tris"), (F | 0x80000, "canon no_verts"),
+             (F | 0x200000, "canon no_lookup"), (F | 0x1000000 | 0x80000, "canon no_vloads no_verts"), (F | 0x1000000 | 0x80000 | 0x400000, "canon alu+lds only")]
 if len(sys.argv) > 2 and sys.argv[2] == "staged":
     modes = [(1, "staged"), (0, "staged canon")]
 if len(sys.argv) > 2 and sys.argv[2] == "hash":
