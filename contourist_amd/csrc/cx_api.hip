@@ -88,6 +88,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_release(ctx->fk, ctx->fk_cap);
     cx_release(ctx->bnd, ctx->bnd_cap);
     cx_release(ctx->bndn, ctx->bndn_cap);
+    cx_release(ctx->torder, ctx->torder_cap);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->counters_host) (void)hipHostFree(ctx->counters_host);
     for (auto& ev : ctx->events)
@@ -348,7 +349,8 @@ static int enqueue_extract(cx_ctx* ctx, double value, uint32_t flags) {
             if ((rc = cx_grow(ctx, ctx->fk, ctx->fk_cap, (size_t)P.n0 * P.n1 * (2u * T.nks) + 64u))) return rc;
             if ((rc = cx_grow(ctx, ctx->bnd, ctx->bnd_cap, (size_t)T.nblocks * 2u * T.bndcap))) return rc;
             if ((rc = cx_grow(ctx, ctx->bndn, ctx->bndn_cap, (size_t)T.nblocks * 2u))) return rc;
-            P.fj = ctx->fj; P.fk = ctx->fk; P.bnd = ctx->bnd; P.bndn = ctx->bndn;
+            if ((rc = cx_grow(ctx, ctx->torder, ctx->torder_cap, (size_t)T.nblocks * 6u))) return rc;
+            P.fj = ctx->fj; P.fk = ctx->fk; P.bnd = ctx->bnd; P.bndn = ctx->bndn; P.torder = ctx->torder;
             P.tile_cap = cx_debug_knob("CX_TILE_CAP", cx_tile_cap_default());
         }
         P.nvw = cx_vertex_stage_waves(P);

@@ -102,6 +102,7 @@ struct cx_params {
     uint64_t* fk;             // [n0][n1][2 * nks]: samples k % 256 == 0 (slot 2 ks) and k % 256 == 255 (slot 2 ks + 1)
     uint4* bnd;               // [2 nblocks][T.bndcap] (per half tile) boundary records {lin, sign|tetskip<<8|ntri<<16|emask<<24, first triangle, first vertex}
     uint32_t* bndn;           // [2 nblocks] how many
+    uint32_t* torder;         // [3][2 nblocks] half tiles by class of work (most queue entries first; empty ones in none), filled by the scan kernel
     uint32_t tile_cap;        // info words a workgroup of the tile kernel holds in LDS (queue entries of its tile + the next chunk's first plane)
 };
 #ifndef CX_SWP
@@ -162,6 +163,7 @@ enum { CX_CNT_CELLS = 0, CX_CNT_VERTS = 1, CX_CNT_TRIS = 2, CX_CNT_BORDER = 3, C
        CX_CNT_ROUNDS = 6, // rounds of 64 queued cells over all batches (what the vertex stage divides among its waves)
        CX_CNT_OVERFLOW = 7, // a streaming wave found more cells than its slice of a shared queue pool holds (cx_extract3d_levels)
        CX_CNT_TILEOVF = 8,  // tile emit path: a tile holds more active cells than a workgroup's LDS words (the host runs the staged kernels instead)
+       CX_CNT_TCLS = 9,     // ... 9, 10, 11: half tiles in each class of P.torder (zeroed by the stream kernel, counted by the scan kernel)
        CX_CNT_WORDS = 16 };
 
 // device tables (defined in cx_march3d.hip)

@@ -57,6 +57,8 @@ struct cx_ctx {
     size_t bnd_cap = 0;
     uint32_t* bndn = nullptr;
     size_t bndn_cap = 0;
+    uint32_t* torder = nullptr;
+    size_t torder_cap = 0;
     uint8_t* hbytes = nullptr;         // fused emit: CPython set-order code per lattice point (valid for hash_xy's shape and origin)
     size_t hbytes_cap = 0;
     bool hbytes_valid = false;

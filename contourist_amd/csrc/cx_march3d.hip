@@ -727,6 +727,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
 #endif
     if (b >= T.nblocks) return;
     s_ntri[threadIdx.x] = cx_d_voxel_ntri[threadIdx.x];
+    if (b == 0u && threadIdx.x < 3u && P.torder) P.counters[CX_CNT_TCLS + threadIdx.x] = 0u;   // the scan kernel counts the tile kernel's work classes into these
     __syncthreads();
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1184,6 +1185,35 @@ __device__ __forceinline__ void cx_scan_list_chunk(const cx_params& P, const cx_
             for (uint32_t m = (rb + q - 1u) / q; m * q < rb + nrb; m++) P.rstart[m] = ex[4] + i;
             for (uint32_t m = (rb + qk - 1u) / qk; m * qk < rb + nrb; m++) P.kstart[m] = ex[4] + i;   // the same for the triangle stage's waves
             rb += nrb;
+        }
+    }
+    if (P.torder) {
+        // the tile kernel's order of work (cx_tile3d.h): half tiles (the queues of streaming waves 2m, 2m + 1) by class of queue
+        // entries, most first -- with the tiles in launch order the kernel ended in a tail of its heaviest workgroups (60 of 245 us
+        // at 512^3) -- and the empty ones in no list at all.  One reservation per workgroup and class.
+        __shared__ uint32_t s_cls[3][4], s_clsbase[3];
+        const uint32_t nqp = S.nq + (uint32_t)__shfl_down((int)S.nq, 1);        // even lanes: entries of the half tile
+        const bool isht = !(tid & 1u) && w < nw;
+        const uint32_t cls = !isht ? 4u : (nqp >= (P.tile_cap * 5u >> 3) ? 0u : (nqp >= (P.tile_cap * 5u >> 4) ? 1u : (nqp ? 2u : 3u)));
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; c++) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) rank = cx_mbcnt(m);
+            if (lane == 0) s_cls[c][wave] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (tid < 3u) {
+            const uint32_t n = s_cls[tid][0] + s_cls[tid][1] + s_cls[tid][2] + s_cls[tid][3];
+            s_clsbase[tid] = n ? atomicAdd(&P.counters[CX_CNT_TCLS + tid], n) : 0u;
+        }
+        __syncthreads();
+        if (cls < 3u) {
+            uint32_t at = s_clsbase[cls] + rank;
+            for (uint32_t ww = 0; ww < wave; ww++) at += s_cls[cls][ww];
+            P.torder[(size_t)cls * (nw >> 1) + at] = w >> 1;
+        } else if (cls == 3u) {
+            P.bndn[w >> 1] = 0u;          // nothing crosses this half tile: no boundary voxels
         }
     }
     if (g == nchunks - 1u && tid == 255u) {   // this thread's inclusive totals are the grand totals

@@ -111,15 +111,24 @@ __global__ __launch_bounds__(256, CX_TILE_MIN_WAVES) void cx_k_tile_emit(const c
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];      // queue words [2][ci + 1][64] | info words [tile_cap + 16]
     __shared__ __attribute__((aligned(16))) unsigned char s_u[sizeof(cx_tri_lds_p) > 4u * CX_TILE_PASSA_BYTES ? sizeof(cx_tri_lds_p) : 4u * CX_TILE_PASSA_BYTES];
     __shared__ cx_tile_shared SH;
-    // workgroup -> (tile, half): the XCD-contiguous order of the stream kernel, both halves of a tile next to each other
-    const uint32_t seq = blockIdx.x >> 3;
-    const uint32_t b = (blockIdx.x & 7u) * T.chunk + (seq >> 1), h = seq & 1u;
-    if (b >= T.nblocks) return;
     if (P.counters[CX_CNT_NEAR] != 0u) return;                                            // the host runs the staged kernels instead
+    // workgroup -> half tile: the scan kernel's lists, the class with the most queue entries first (P.torder); half tiles that
+    // nothing crosses are in no list
+    uint32_t ht;
+    {
+        const uint32_t n0 = P.counters[CX_CNT_TCLS], n1 = P.counters[CX_CNT_TCLS + 1u], n2c = P.counters[CX_CNT_TCLS + 2u];
+        uint32_t i = blockIdx.x, cls = 0;
+        if (i >= n0) { i -= n0; cls = 1u; if (i >= n1) { i -= n1; cls = 2u; if (i >= n2c) return; } }
+        ht = P.torder[(size_t)cls * (T.nblocks * 2u) + i];
+    }
+    const uint32_t b = ht >> 1, h = ht & 1u;
     if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap) return;    // host re-runs with more room
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qi = wave >> 1, half = wave & 1u;          // which of the two queues, which half of its rounds
+    // diagnostic (cx_debug_stamps): per wave of this kernel {start, pass A done, end, its queue entries} in 10 ns ticks, behind the stream kernel's stamps
+    unsigned long long* kst = P.stamps ? P.stamps + (size_t)T.nblocks * 16u + ((size_t)(2u * b + h) * 4u + wave) * 4u : nullptr;
+    if (kst && lane == 0) kst[0] = __builtin_amdgcn_s_memrealtime();
     const uint32_t sw = 2u * h + qi;                          // streaming wave inside the tile
     const uint32_t w = b * 4u + sw;
     const cx_tile tile = cx_tile_of(P, T, b, sw);
@@ -164,10 +173,6 @@ __global__ __launch_bounds__(256, CX_TILE_MIN_WAVES) void cx_k_tile_emit(const c
     const uint32_t n2 = SH.cnt[qi][1];
     if (tot_own + tot_next > P.tile_cap) {       // workgroup-uniform
         if (threadIdx.x == 0) P.counters[CX_CNT_TILEOVF] = 1u;
-        return;
-    }
-    if (tot_own == 0u) {                         // nothing crosses this half tile
-        if (threadIdx.x == 0) P.bndn[2u * b + h] = 0u;
         return;
     }
     const uint32_t vb0 = SH.vb[0], vb1 = SH.vb[1];
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256, CX_TILE_MIN_WAVES) void cx_k_tile_emit(const c
         }
     }
     if (lane == 0) SH.bn[wave] = nbnd;
+    if (kst && lane == 0) { kst[1] = __builtin_amdgcn_s_memrealtime(); kst[3] = (first < end) ? end - first : 0u; }
     __syncthreads();                       // pass A of all four waves is complete: LDS words, and the pass-A tables are dead
     cx_tri_lds_p& L = *reinterpret_cast<cx_tri_lds_p*>(s_u);
     cx_tri_lds_init(L);
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(256, CX_TILE_MIN_WAVES) void cx_k_tile_emit(const c
             }
         }
     }
+    if (kst && lane == 0) kst[2] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- the voxels on the high j / k faces of the half tiles: their neighbours' words from the face arrays
@@ -392,8 +399,8 @@ uint32_t cx_tile_cap_default() { return 2048u; }
 static uint32_t cx_tile_lds_bytes(const cx_task& T, uint32_t tile_cap) { return (2u * (T.ci + 1u) * 64u + tile_cap + 16u) * (uint32_t)sizeof(uint32_t); }
 void cx_launch_tile_emit(const cx_params& P, const cx_task& T, const uint64_t* hash_xy, hipStream_t s) {
     const uint32_t lds = cx_tile_lds_bytes(T, P.tile_cap);
-    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_tile_emit<true>, dim3(T.chunk * 16u), dim3(256), lds, s, P, T, hash_xy);
-    else hipLaunchKernelGGL(cx_k_tile_emit<false>, dim3(T.chunk * 16u), dim3(256), lds, s, P, T, hash_xy);
+    if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_tile_emit<true>, dim3(T.nblocks * 2u), dim3(256), lds, s, P, T, hash_xy);
+    else hipLaunchKernelGGL(cx_k_tile_emit<false>, dim3(T.nblocks * 2u), dim3(256), lds, s, P, T, hash_xy);
     if ((int32_t)P.org2 < 0) hipLaunchKernelGGL(cx_k_tile_boundary<true>, dim3(T.nblocks * 2u), dim3(256), 0, s, P, T, hash_xy);
     else hipLaunchKernelGGL(cx_k_tile_boundary<false>, dim3(T.nblocks * 2u), dim3(256), 0, s, P, T, hash_xy);
 }
