@@ -613,14 +613,15 @@ class Context(object):
         return [("stream_ms", "cx_k_classify_generic"), ("emit_ms", "cx_k_emit_triangles")]
 
     def vertex_stage_bytes(self, counts):
-        if self.level0_path() == 2:     # fused emit: 8 B per vertex record + 12 B per triangle written
+        if self.level0_path() in (2, 3):     # fused emit / tile emit: 8 B per vertex record + 12 B per triangle written by ONE kernel
             return 8.0 * counts["n_vertices"] + 12.0 * counts["n_triangles"]
         # what the stage must leave: 8-byte vertex records.  (Its cell records and per-entry words are the pipeline's own
         # intermediates -- traffic, not algorithmic bytes.)
         return 8.0 * counts["n_vertices"]
 
-    @staticmethod
-    def triangle_stage_bytes(counts):
+    def triangle_stage_bytes(self, counts):
+        if self.level0_path() == 3:          # the boundary kernel: the triangles of ~13 % of the voxels (counted with the tile kernel above)
+            return 0.0
         return 12.0 * counts["n_triangles"]
 
     def measure_read_bandwidth(self, device_ptr, nbytes, reps=5):

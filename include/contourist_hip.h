@@ -40,7 +40,7 @@ typedef enum {
 #define CX_DIAG_CPYTHON310 1u  /* quad split reproduces CPython 3.10 set iteration order, i.e. the
                                   reference as it runs today (tetrahedral.py:592-595) */
 #define CX_KERNEL_GENERIC 0x100u /* force the shape-agnostic classify kernel (default: auto) */
-#define CX_KERNEL_STAGED 0x200u  /* emit through the staged kernels (vertex stage + per-cell table + triangle stage): the default */
+#define CX_KERNEL_STAGED 0x200u  /* emit through the staged kernels (vertex stage + words per queue entry + triangle stage): the default */
 #define CX_KERNEL_FUSED 0x400u   /* emit vertices and triangles in ONE kernel over the cell queues (vertex indices of neighbour
                                     cells found through the queues, no table per sample, no cell records); same mesh, same
                                     numbering.  An extraction with samples inside the reference's np.allclose tolerances whose

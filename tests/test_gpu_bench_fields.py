@@ -96,6 +96,12 @@ def test_bench_field_against_oracle_whole_volume_and_properties(size, passes):
         c2 = ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310)
         x2, k2, t2 = ctx.download_level0(c2)
         assert c2 == c and np.array_equal(k2.astype(np.int64), keys) and np.array_equal(t2, tris) and np.array_equal(x2.view(np.uint32), xyz.view(np.uint32))
+        # ---- the tile kernels give the same arrays (same numbering by construction; 512^3: a sheet lying flat in a half tile is beyond
+        # their LDS words and the extraction comes back through the staged kernels, path 1)
+        c3 = ctx.extract3d(0.0, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_TILED)
+        assert ctx.level0_path() == (3 if size == 256 else 1)
+        x3, k3, t3 = ctx.download_level0(c3)
+        assert c3 == c and np.array_equal(k3.astype(np.int64), keys) and np.array_equal(t3, tris) and np.array_equal(x3.view(np.uint32), xyz.view(np.uint32))
     finally:
         ctx.close()
         del A

@@ -172,17 +172,17 @@ for shape, v in (((33, 31, 64), 0.0), ((20, 20, 255), 0.3), ((64, 48, 260), -0.2
         for ax in range(3):
             A = (0.25 * np.roll(A, 1, ax) + 0.5 * A + 0.25 * np.roll(A, -1, ax)).astype(np.float32)
     A = (A / A.std()).astype(np.float32)
-    n += T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310, 1)["n_triangles"]
-    T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CANONICAL, 0)
+    n += T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_STAGED, 1)["n_triangles"]
+    T.check_against_oracle(ctx, A, v, _ffi.CX_DIAG_CANONICAL | _ffi.CX_KERNEL_STAGED, 0)
     assert ctx.level0_path() == 1
 # samples exactly at the isovalue and within the reference's tolerances: batches on the per-cell path
 B = np.round(rng.standard_normal((12, 13, 14)) * 2) / 2
-T.check_against_oracle(ctx, B.astype(np.float32), 0.5, _ffi.CX_DIAG_CPYTHON310, 1)
+T.check_against_oracle(ctx, B.astype(np.float32), 0.5, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_STAGED, 1)
 C = (100.0 + rng.standard_normal((12, 12, 12)) * 1.5e-3).astype(np.float32)
-T.check_against_oracle(ctx, C, 100.0, _ffi.CX_DIAG_CPYTHON310, 1)
+T.check_against_oracle(ctx, C, 100.0, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_STAGED, 1)
 # dense white noise: every wave closes many batches, the triangle stage's waves start inside batches
 D = rng.standard_normal((64, 32, 256)).astype(np.float32)
-T.check_against_oracle(ctx, D, 0.0, _ffi.CX_DIAG_CPYTHON310, 1)
+T.check_against_oracle(ctx, D, 0.0, _ffi.CX_DIAG_CPYTHON310 | _ffi.CX_KERNEL_STAGED, 1)
 ctx.close()
 print("ENTRY_KERNEL_OK", n)
 """
