@@ -20,7 +20,7 @@
 void cx_state4_free(cx_ctx* ctx) {
     cx_state4* S = ctx->s4;
     if (!S) return;
-    cx_release(S->grid_owned, S->grid_owned_bytes); cx_release(S->celltab, S->celltab_for);
+    cx_release(S->grid_owned, S->grid_owned_bytes); cx_release(S->items, S->items_cap); cx_release(S->info, S->info_cap);
     cx_release(S->verts, S->vcap); cx_release(S->vkeys, S->vkeys_cap); cx_release(S->cells, S->ccap); cx_release(S->tets, S->tcap);
     cx_release(S->hash_xyz, S->hash_cap); cx_release(S->signbits, S->signbits_cap); cx_release(S->tet_keep, S->keep_cap);
     cx_release(S->queue, S->qcap); cx_release(S->rounds, S->rounds_cap);
@@ -39,10 +39,6 @@ static int set_dims4(cx_ctx* ctx, cx_state4* S, int64_t n0, int64_t n1, int64_t 
     if (n0 < 2 || n1 < 2 || n2 < 2 || n3 < 2) { ctx->err = "4-D grid needs at least 2 samples per axis"; return CX_ERR_INVALID; }
     const int64_t N = n0 * n1 * n2 * n3;
     if (N > (1LL << 28)) { ctx->err = "more than 2^28 samples in one 4-D grid: partition into slabs"; return CX_ERR_UNSUPPORTED; }
-    {
-        const int rc = cx_grow(ctx, S->celltab, S->celltab_for, (size_t)N + 64u);
-        if (rc) return rc;
-    }
     S->n[0] = n0; S->n[1] = n1; S->n[2] = n2; S->n[3] = n3;
     S->extracted = false;
     S->keep_valid = false;
@@ -85,6 +81,7 @@ static int reserve4(cx_ctx* ctx, cx_state4* S, int64_t nc, int64_t nv, int64_t n
     int rc;
     if ((rc = cx_grow(ctx, S->queue, S->qcap, (size_t)nq))) return rc;
     if ((rc = cx_grow(ctx, S->rounds, S->rounds_cap, (size_t)S->qcap / 64 + 8))) return rc;
+    if ((rc = cx_grow(ctx, S->info, S->info_cap, (size_t)S->qcap + 64u))) return rc;
     if ((rc = cx_grow(ctx, S->cells, S->ccap, (size_t)nc))) return rc;
     if ((rc = cx_grow(ctx, S->verts, S->vcap, (size_t)nv))) return rc;
     if ((rc = cx_grow(ctx, S->vkeys, S->vkeys_cap, (size_t)S->vcap))) return rc;
@@ -128,7 +125,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.tol_value = 1e-8 + 1e-5 * std::fabs(value);
         P.flags = flags;
         for (int d = 0; d < 4; d++) P.org[d] = (uint32_t)S->origin[d];
-        P.celltab = S->celltab; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
+        P.info = S->info; P.verts = S->verts; P.vkeys = S->vkeys; P.cells = S->cells; P.tets = S->tets;
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
         P.queue = S->queue; P.qcap = S->qcap; P.rounds = S->rounds;
         P.counters = ctx->counters + CX_CNT_WORDS;   // the 4-D march's own block (cx_ctx_create)
@@ -153,6 +150,8 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
             const size_t need = (size_t)P.nrows * P.nw3 + 64u;
             if ((rc = cx_grow(ctx, S->signbits, S->signbits_cap, need))) return rc;
             P.signbits = S->signbits;
+            if ((rc = cx_grow(ctx, S->items, S->items_cap, need))) return rc;
+            P.items = S->items;
         }
         CX4_HIP(ctx, hipMemsetAsync(ctx->counters + CX_CNT_WORDS, 0, CX_CNT_WORDS * sizeof(uint32_t), ctx->stream));
         cx_launch_signbits4d(P, ctx->stream);

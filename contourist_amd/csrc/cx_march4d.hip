@@ -157,6 +157,7 @@ __device__ __forceinline__ cx_cell4 cx_classify_cell4(const cx_params4& P, const
 }
 
 #define CX4_QCAP 2048u   // one step of the queue kernel adds at most 64 x 32 cells
+#define CX4_WCAP 128u    // ... and at most 64 bitmap words with an active cell
 
 // ---- sign bitmap: one pass over the samples at streaming speed.  A wave takes 8 consecutive chunks of
 // 64 samples of a row (8 loads in flight); a chunk's 64 comparison results are one ballot = 2 words.
@@ -220,12 +221,15 @@ __global__ __launch_bounds__(256) void cx_k_signbits4_flat(const cx_params4 P, c
 // processed thousands of cells while most others had none -- 0.23 of its 0.28 ms).
 __global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uint32_t items_per_block) {
     __shared__ uint32_t s_queue[4][CX4_QCAP];
+    // the bitmap words that queued cells since the last flush: item index, active cells, position of the first in the wave's stage --
+    // what the tetrahedra kernel finds a neighbour cell's queue entry by (P.items), written once the stage's place in the queue is known
+    __shared__ uint32_t s_wi[4][CX4_WCAP], s_wa[4][CX4_WCAP], s_wp[4][CX4_WCAP];
     __shared__ uint32_t s_tot[4];
     __shared__ uint32_t s_base;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* qq = s_queue[wave];
-    uint32_t qn = 0;
+    uint32_t qn = 0, wn = 0;
     const uint32_t nitems = P.nrows * P.nw3;   // one item = one bitmap word = 32 cells of one row
     uint32_t gbase = blockIdx.x * items_per_block + wave * 64u;
     const uint32_t gend = min(blockIdx.x * items_per_block + items_per_block, nitems);
@@ -273,8 +277,15 @@ __global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uin
             const uint32_t cnt = __popc(act);
             const uint32_t incl = cx_wave_incl_scan4(cnt);
             const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
-            if (qn + tot > CX4_QCAP) break;                   // wave-uniform: flush what is queued, then redo this step
+            const uint64_t wm = __ballot(act != 0u);
+            const uint32_t nwords = (uint32_t)__popcll(wm);
+            if (qn + tot > CX4_QCAP || wn + nwords > CX4_WCAP) break;   // wave-uniform: flush what is queued, then redo this step
             uint32_t pos = qn + incl - cnt;
+            if (act) {
+                const uint32_t r = wn + cx_mbcnt(wm);
+                s_wi[wave][r] = ic; s_wa[wave][r] = act; s_wp[wave][r] = pos;
+            }
+            wn += nwords;
             const uint32_t lin0 = row * P.n3 + lw * 32u;
             while (act) {
                 const uint32_t bit = __ffs(act) - 1u;
@@ -303,10 +314,12 @@ __global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uin
             base = __builtin_amdgcn_readfirstlane(b0);
         }
         __builtin_amdgcn_wave_barrier();
-        if (base + qn <= P.qcap)
+        if (base + qn <= P.qcap) {
             for (uint32_t x = lane; x < qn; x += 64u) P.queue[base + x] = qq[x];
+            for (uint32_t x = lane; x < wn; x += 64u) P.items[s_wi[wave][x]] = make_uint2(base + s_wp[wave][x], s_wa[wave][x]);
+        }
         __builtin_amdgcn_wave_barrier();
-        qn = 0;
+        qn = 0; wn = 0;
         if (final_round) break;
     }
 }
@@ -386,7 +399,7 @@ __global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
         const uint32_t vfirst = vbase + vpre;
         // the round's records and tetrahedra are contiguous: the tetrahedra kernel works round by round
         if (lane == 0) P.rounds[idx >> 6] = make_uint4(cbase, cfits ? ctot : 0u, tbase, ttot);
-        if (vfits && nv) P.celltab[lin] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;
+        if (vfits && have) P.info[idx] = ((uint64_t)R.emask << 32) | (uint64_t)vfirst;     // one word per queue entry: 512 contiguous bytes per wave
         if (cfits && rec) {
             uint4 c4;
             c4.x = lin;
@@ -711,21 +724,39 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
         }
         if (!real_voxel) pskip = 0xFFFFFFu;
         // first-vertex index and crossing mask of the 15 corners that can own an edge of this hyper-voxel
-        const uint32_t st[4] = {P.n1 * P.n2 * P.n3, P.n2 * P.n3, P.n3, 1u};
-        // all (up to) 15 table words are requested before the first one is used: written as one loop -- load, then store to LDS --
-        // the compiler put an `s_waitcnt vmcnt(0)` behind every load, fifteen HBM round trips one after the other per round
-        uint64_t ew[15];
+        // The queue entries of the (up to) 15 owner corners: first the item words of their bitmap words -- corners c and c | 1 share
+        // one unless l + 1 starts the row's next word --, then the entries' words; each batch is requested whole before any of it
+        // is used (written as load-use loops the compiler put an `s_waitcnt vmcnt(0)` behind every load: fifteen round trips per round)
+        const uint32_t row0 = (q[0] * P.n1 + q[1]) * P.n2 + q[2];
+        const uint32_t lw0 = q[3] >> 5, lb0 = q[3] & 31u;
+        const bool cross = (lb0 == 31u);                     // l + 1 lies in the next bitmap word of the row
+        uint32_t wantm = 0;                                  // bit c: corner c (0 = the cell itself .. 14) owns a crossing edge of this hyper-voxel
 #pragma unroll
         for (uint32_t c = 0; c < 15; c++) {
             const uint32_t sc = ((sm >> c) & 1u) ? 0xFFFFu : 0u;
             uint32_t sup = 0;
 #pragma unroll
             for (uint32_t c2 = c + 1; c2 < 16; c2++) sup |= ((c2 & c) == c) ? (1u << c2) : 0u;
+            if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) wantm |= 1u << c;
+        }
+        uint2 it0[8], it1[8];
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++) {                   // g = corner >> 1: the (i, j, k) offsets
+            const uint32_t rowc = row0 + ((g & 4u) ? P.n1 * P.n2 : 0u) + ((g & 2u) ? P.n2 : 0u) + (g & 1u);
+            const bool need = ((wantm >> (2u * g)) & 3u) != 0u;
+            const uint32_t at = need ? rowc * P.nw3 + lw0 : 0u;
+            it0[g] = P.items[at];
+            it1[g] = P.items[at + ((need && cross) ? 1u : 0u)];
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++) asm volatile("" : "+v"(it0[g].x), "+v"(it0[g].y), "+v"(it1[g].x), "+v"(it1[g].y) :: "memory");
+        uint64_t ew[15];
+#pragma unroll
+        for (uint32_t c = 0; c < 15; c++) {
+            const uint2 it = (c & 1u) ? it1[c >> 1] : it0[c >> 1];
+            const uint32_t bit = (c & 1u) ? (cross ? 0u : lb0 + 1u) : lb0;
             ew[c] = 0;
-            if (real_voxel && pskip != 0xFFFFFFu && ((sm ^ sc) & sup) != 0u) {
-                const uint32_t lc = lin + ((c & 8u) ? st[0] : 0u) + ((c & 4u) ? st[1] : 0u) + ((c & 2u) ? st[2] : 0u) + (c & 1u);
-                ew[c] = P.celltab[lc];
-            }
+            if ((wantm >> c) & 1u) ew[c] = P.info[it.x + __popc(it.y & ((1u << bit) - 1u))];
         }
 #pragma unroll
         for (uint32_t c = 0; c < 15; c++) asm volatile("" : "+v"(ew[c]) :: "memory");

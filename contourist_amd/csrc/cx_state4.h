@@ -10,7 +10,12 @@ struct cx_params4 {
     double value, tol_value;
     uint32_t flags;
     uint32_t org[4];
-    uint64_t* celltab;
+    // where the vertices of a lattice cell are, without a table of one entry per sample (rounds 1-3: 8 bytes per sample, 1 GiB on config 4):
+    // the cells of one bitmap word (32 cells of a row) sit next to each other in the queue, so
+    //     queue position of cell (row, l) = items[row * nw3 + l / 32].x + popc(items[...].y & bits below l % 32)
+    // and the cells kernel leaves (crossing mask << 32 | first vertex) per QUEUE ENTRY, densely
+    uint2* items;              // [nrows * nw3] {queue position of the word's first active cell, the word's active cells}; written for words with one
+    uint64_t* info;            // [qcap] per queue entry
     float4* verts;
     uint32_t* vkeys;
     uint4* cells;
@@ -40,8 +45,10 @@ struct cx_state4 {
     float* grid_owned = nullptr;
     size_t grid_owned_bytes = 0;
     int64_t n[4] = {0, 0, 0, 0};
-    uint64_t* celltab = nullptr;
-    size_t celltab_for = 0;
+    uint2* items = nullptr;
+    size_t items_cap = 0;
+    uint64_t* info = nullptr;
+    size_t info_cap = 0;
     float4* verts = nullptr;
     uint32_t* vkeys = nullptr;
     size_t vkeys_cap = 0;
