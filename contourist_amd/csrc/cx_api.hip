@@ -39,7 +39,9 @@ extern "C" int cx_ctx_create(int device_id, cx_ctx** out) {
     ctx->own_stream = ctx->stream;
     // two counter blocks: [0, CX_CNT_WORDS) the 3-D march, [CX_CNT_WORDS, 2 CX_CNT_WORDS) the 4-D march -- a 4-D extraction on the
     // same context must not disturb what a later relaunch of the 3-D vertex stage (cx_ensure_cell_records) reads on the device
-    if (hipMalloc(&ctx->counters, 2 * CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess ||
+    // (+ a second page: the 4-D cells kernel's (tetrahedra | border voxels) word sits 4 KB away from its (cells | vertices) word --
+    // two same-line atomics per workgroup executed one after the other at the memory side, 38 us of that kernel's 63)
+    if (hipMalloc(&ctx->counters, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&ctx->counters_host, 2 * CX_CNT_WORDS * sizeof(uint32_t)) != hipSuccess) {
         cx_ctx_destroy(ctx);
         return CX_ERR_NOMEM;

@@ -129,6 +129,7 @@ extern "C" int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts
         P.vcap = S->vcap; P.ccap = S->ccap; P.tcap = S->tcap;
         P.queue = S->queue; P.qcap = S->qcap; P.rounds = S->rounds;
         P.counters = ctx->counters + CX_CNT_WORDS;   // the 4-D march's own block (cx_ctx_create)
+        P.counters_tb = reinterpret_cast<unsigned long long*>(ctx->counters + 1024);
         P.lut = cx_pent_lut_device();
         if (!P.lut) { ctx->err = "pentatope table symbol not found"; return CX_ERR_HIP; }
         if (flags & CX_DIAG_CPYTHON310) {

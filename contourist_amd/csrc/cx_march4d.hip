@@ -192,17 +192,20 @@ __global__ __launch_bounds__(256) void cx_k_signbits4(const cx_params4 P, const 
 // The same for rows that are a whole number of bitmap words (n3 % 32 == 0) on a 16-byte aligned grid: the bitmap is then the
 // flat array's, bit for sample.  A lane loads FOUR consecutive samples with one 16-byte load, four loads in flight (4 KB per
 // wave); the four comparison bits of 8 neighbouring lanes are joined into a word with three DPP steps.
+#ifndef CX4_SB_UNROLL
+#define CX4_SB_UNROLL 8u     // 16-byte loads a lane has in flight (4: 0.121 ms = 4.4 TB/s on config 4)
+#endif
 __global__ __launch_bounds__(256) void cx_k_signbits4_flat(const cx_params4 P, const uint32_t nquads) {
     const uint32_t lane = cx_lane_id();
     const uint32_t wave0 = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typedef float cx_f4 __attribute__((ext_vector_type(4)));
     const cx_f4* __restrict__ A = reinterpret_cast<const cx_f4*>(P.grid);
-    for (uint32_t q0 = wave0 * 256u; q0 < nquads; q0 += gridDim.x * 1024u) {   // uniform
-        cx_f4 f[4];
+    for (uint32_t q0 = wave0 * (64u * CX4_SB_UNROLL); q0 < nquads; q0 += gridDim.x * (256u * CX4_SB_UNROLL)) {   // uniform
+        cx_f4 f[CX4_SB_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) f[u] = A[min(q0 + u * 64u + lane, nquads - 1u)];
+        for (uint32_t u = 0; u < CX4_SB_UNROLL; u++) f[u] = __builtin_nontemporal_load(A + min(q0 + u * 64u + lane, nquads - 1u));
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
+        for (uint32_t u = 0; u < CX4_SB_UNROLL; u++) {
             uint32_t v = ((f[u].x < P.vcmp) ? 1u : 0u) | ((f[u].y < P.vcmp) ? 2u : 0u) | ((f[u].z < P.vcmp) ? 4u : 0u) | ((f[u].w < P.vcmp) ? 8u : 0u);
             v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true) << 4;    // row_shl:1: lane + 1
             v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, true) << 8;    // row_shl:2
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void cx_k_queue4(const cx_params4 P, const uin
     __shared__ uint32_t s_base;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.counters_tb = 0ULL;     // the cells kernel (next on the stream) counts into it
     uint32_t* qq = s_queue[wave];
     uint32_t qn = 0, wn = 0;
     const uint32_t nitems = P.nrows * P.nw3;   // one item = one bitmap word = 32 cells of one row
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512) void cx_k_cells4(const cx_params4 P) {
             for (uint32_t w = 0; w < CX4_CELLS_WAVES; w++) { v += L.tot[w][0]; t += L.tot[w][1]; c += L.tot[w][2]; bb += L.tot[w][3]; }
             unsigned long long* C64 = reinterpret_cast<unsigned long long*>(P.counters);   // words (cells, verts), (tets, border)
             L.base[0] = (v | c) ? atomicAdd(&C64[0], ((unsigned long long)v << 32) | c) : 0ULL;
-            L.base[1] = (t | bb) ? atomicAdd(&C64[1], ((unsigned long long)bb << 32) | t) : 0ULL;
+            L.base[1] = (t | bb) ? atomicAdd(P.counters_tb, ((unsigned long long)bb << 32) | t) : 0ULL;
         }
         __syncthreads();
         uint32_t vbase = (uint32_t)(L.base[0] >> 32), cbase = (uint32_t)L.base[0], tbase = (uint32_t)L.base[1];
@@ -697,7 +701,11 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
     for (uint32_t x = threadIdx.x; x < 32u * 12u; x += 256u) L.local[x] = P.lut[x];
     __syncthreads();
     const uint32_t nq = P.counters[CX4_CNT_QUEUE];
-    if (P.counters[CX_CNT_TRIS] > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap || P.counters[CX_CNT_CELLS] > P.ccap || nq > P.qcap) return;
+    const unsigned long long tbw = *P.counters_tb;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {       // where the host reads them
+        P.counters[CX_CNT_TRIS] = (uint32_t)tbw; P.counters[CX_CNT_BORDER] = (uint32_t)(tbw >> 32);
+    }
+    if ((uint32_t)tbw > P.tcap || P.counters[CX_CNT_VERTS] > P.vcap || P.counters[CX_CNT_CELLS] > P.ccap || nq > P.qcap) return;
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
@@ -796,8 +804,9 @@ const uint64_t* cx_pent_lut_device() {
 void cx_launch_signbits4d(const cx_params4& P, hipStream_t s) {
     if (P.n3 % 32u == 0u && ((uintptr_t)P.grid & 15u) == 0u && !cx_debug_knob("CX4_SB_ROWS", 0)) {
         const uint32_t nquads = P.nsamples / 4u;
-        uint32_t blocks = (nquads + 1023u) / 1024u;
-        if (blocks > 256u * 8u) blocks = 256u * 8u;
+        uint32_t blocks = (nquads + 256u * CX4_SB_UNROLL - 1u) / (256u * CX4_SB_UNROLL);
+        const uint32_t most = 256u * cx_debug_knob("CX4_SB_WGS", 16u);
+        if (blocks > most) blocks = most;
         hipLaunchKernelGGL(cx_k_signbits4_flat, dim3(blocks), dim3(256), 0, s, P, nquads);
         return;
     }

@@ -22,6 +22,7 @@ struct cx_params4 {
     int32_t* tets;
     uint32_t vcap, ccap, tcap;
     uint32_t* counters;
+    unsigned long long* counters_tb;   // (border voxels << 32) | tetrahedra: reserved by the cells kernel, in a cache line of its own
     const uint64_t* hash_xyz;
     const uint64_t* lut;
     uint32_t* queue;           // linear indices of the cells with a sign change among their corners
