@@ -519,16 +519,20 @@ __device__ uint64_t cx_d_pent_local[32][12] = CX_PENT_LOCAL_INIT;
 // ---- set order from probe codes ---------------------------------------------------------------------------
 // CPython inserts an element with hash h into an 8-slot set at the first free slot of the sequence i0 = h & 7,
 // i_k = (5 i_(k-1) + 1 + (h >> 5k)) & 7 (setobject.c: no linear probes when the table has 8 slots).  The sequence
-// depends on the element only, so it is computed ONCE per corner of the hyper-voxel -- ten slots, three bits each, in one
+// depends on the element only, so it is computed ONCE per corner of the hyper-voxel -- CX4_PROBE_STEPS slots, three bits each, in one
 // word -- and every pentatope that contains the corner (each corner is in 6..24 of them) reads its members' slots off
-// the codes: XOR with the occupied slot replicated into all ten fields, first non-zero field.  (The first version ran the
+// the codes: XOR with the occupied slot replicated into all fields, first non-zero field.  (The first version ran the
 // probing recurrence per pentatope and member: ~240 of the kernel's VALU instructions per pentatope, 60 % of the kernel.)
-#define CX4_REP 0x09249249u      // bit 0 of each of the ten 3-bit fields
+#ifndef CX4_PROBE_STEPS
+#define CX4_PROBE_STEPS 6u       // slots of the probe sequence kept per corner (<= 10).  Six come out of the LOW word of the hash (bits 0-27); a
+#endif                           // set whose members still collide after six probes (~4e-6 of them) takes the exact path (cx_pent_perm_exact)
+constexpr uint32_t cx_rep_fields(uint32_t n) { return n ? ((cx_rep_fields(n - 1u) << 3) | 1u) : 0u; }
+constexpr uint32_t CX4_REP = cx_rep_fields(CX4_PROBE_STEPS);      // bit 0 of each of the 3-bit fields (a constant: a call in an expression is compiled as one)
 __device__ __forceinline__ uint32_t cx_probe_code(uint64_t h) {
     const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 30);
     uint32_t i = lo & 7u, code = i;
 #pragma unroll
-    for (uint32_t k = 1; k < 10; k++) {
+    for (uint32_t k = 1; k < CX4_PROBE_STEPS; k++) {
         const uint32_t p = (k <= 5u) ? (lo >> (5u * k)) : (hi >> (5u * (k - 6u)));
         i = (i * 5u + 1u + p) & 7u;
         code |= i << (3u * k);
@@ -538,7 +542,7 @@ __device__ __forceinline__ uint32_t cx_probe_code(uint64_t h) {
 // fields of x that are non-zero, as their bit 0
 __device__ __forceinline__ uint32_t cx_nz_fields(uint32_t x) { return (x | (x >> 1) | (x >> 2)) & CX4_REP; }
 
-// exact set order of one pentatope from the full hashes (after ten occupied probes: about once in 10^6 sets)
+// exact set order of one pentatope from the full hashes (when the codes ran out)
 __device__ __forceinline__ uint32_t cx_pent_perm_exact(const cx_params4& P, const uint32_t q[4], uint32_t n, uint32_t pat) {
     const bool low_is_two = (__popc(pat) == 2);
     uint64_t h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
@@ -619,7 +623,7 @@ struct cx_tet_lds {
 template <int G>
 __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L, uint32_t wave, uint32_t lane, const uint32_t (&S)[16],
                                               const uint32_t q[4], uint32_t sm, bool real_voxel, uint32_t pskip, bool emulate,
-                                              uint32_t& tnext) {
+                                              uint32_t& tnext, const bool emit) {      // emit == false (wave-uniform): only count the group's tetrahedra
     // ---- phase 1: slot words of the group's tetrahedra
     uint32_t cnt = 0, unres = 0;
     uint32_t pats[6], perms[6], nts[6];
@@ -634,6 +638,7 @@ __device__ __forceinline__ void cx_tets_group(const cx_params4& P, cx_tet_lds& L
     for (int pn = 0; pn < 6; pn++) cnt += nts[pn];
     const uint32_t incl = cx_wave_incl_scan4(cnt);
     const uint32_t ttot = (uint32_t)__shfl((int)incl, 63);
+    if (!emit) { tnext += ttot; return; }
     uint32_t pos = incl - cnt;
     const uint32_t dump = 18u * 64u + lane;      // where the slot words of absent tetrahedra go (no branches, no loops)
 #pragma unroll
@@ -709,9 +714,17 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
     const uint32_t lane = cx_lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool emulate = (P.flags & CX_DIAG_CPYTHON310) != 0u;
-    // one wave per round of the cells kernel (<= 64 records, their tetrahedra one contiguous range), grid-stride
+    // One wave per round of the cells kernel (<= 64 records, their tetrahedra one contiguous range), grid-stride.  The rounds left
+    // over after the last full pass of the grid's waves (config 4: 13.5 k rounds, 4096 waves: 1 240 of them) go as HALVES -- pentatope
+    // groups 0-1 / 2-3 -- to twice as many waves: with whole rounds a third of the waves worked a fourth round-time while the rest
+    // stood idle.  The second half counts the first half's tetrahedra (phase 1 only) to know where its own start.
     const uint32_t nrounds = (nq + 63u) >> 6;
-    for (uint32_t r = blockIdx.x * 4u + wave; r < nrounds; r += gridDim.x * 4u) {
+    const uint32_t nwaves = gridDim.x * 4u, wid = blockIdx.x * 4u + wave;
+    const uint32_t nfull = (nrounds / nwaves) * nwaves;
+    const uint32_t nunits = nfull + 2u * (nrounds - nfull);
+    for (uint32_t u = wid; u < nunits; u += nwaves) {
+        const uint32_t r = (u < nfull) ? u : nfull + ((u - nfull) >> 1);
+        const uint32_t part = (u < nfull) ? 0u : 1u + ((u - nfull) & 1u);      // 0: the whole round, 1: groups 0-1, 2: groups 2-3
         const uint4 rd = P.rounds[r];
         const uint32_t cbase = __builtin_amdgcn_readfirstlane(rd.x), ctot = __builtin_amdgcn_readfirstlane(rd.y);
         uint32_t tnext = __builtin_amdgcn_readfirstlane(rd.z);
@@ -787,10 +800,12 @@ __global__ __launch_bounds__(256, CX4_TETS_WAVES) void cx_k_emit_tets(const cx_p
                 S[c + 1] = cx_probe_code(py_finish4(py_round4(pre, q[3] + 1u + P.org[3])));
             }
         }
-        cx_tets_group<0>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
-        cx_tets_group<1>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
-        cx_tets_group<2>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
-        cx_tets_group<3>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext);
+        cx_tets_group<0>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext, part != 2u);
+        cx_tets_group<1>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext, part != 2u);
+        if (part != 1u) {      // wave-uniform
+            cx_tets_group<2>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext, true);
+            cx_tets_group<3>(P, L, wave, lane, S, q, sm, real_voxel, pskip, emulate, tnext, true);
+        }
     }
 }
 
