@@ -37,6 +37,9 @@ __device__ __constant__ uint8_t cx_d_voxel_ntri[256] = CX_VOXEL_NTRI_INIT;
 #ifndef CX_RJ
 #define CX_RJ 4             // cell rows per wave in the stream kernel (a workgroup covers 4*CX_RJ rows)
 #endif
+#ifndef CX_S1_LAZY
+#define CX_S1_LAZY 1         // stream kernel: queued cells are counted in full rounds of 64 when the stage is flushed or a batch closes (0: one round per plane step)
+#endif
 #ifndef CX_S3_MIN_SHARE
 #define CX_S3_MIN_SHARE 4u   // rounds a vertex-stage wave takes at least (small surfaces: fewer waves rather than waves that only start up)
 #endif
@@ -758,7 +761,41 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
     // cx_extract3d_levels share ONE pool, each with a slice of every wave's region -- a wave that finds more cells than its slice
     // holds stops storing them and raises the overflow flag (chunk slot 7): the host then gives that call full-size regions.
     bool overflow = false;
+    // The counts of the queued cells (vertices, triangles, records, border voxels: what the batch records and the scan need) are only
+    // ever used as sums over a batch, so they need not be taken step by step -- with ~30 cells per step half of the lanes of a
+    // counting round stood idle.  Staged entries are counted in FULL rounds of 64 right before they leave the stage or a batch is
+    // closed (CX_S1_LAZY; the fraction stream P.tq works step by step and keeps the old form).
+    uint32_t qc = 0;                 // wave-uniform: staged entries already counted
+    // all eight corners of every cell of this wave's tile inside the array: the validity mask is 0xFF (wave-uniform)
+    const bool interior = (tile.ib < P.n0) && (j0 + (uint32_t)CX_RJ < P.n1) && (k0 + 256u < P.n2);
+    auto count_pending = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t o0 = qc; o0 < ql; o0 += 64u) {       // wave-uniform
+            const uint32_t o = o0 + lane;
+            const bool have = o < ql;
+            const uint32_t e = have ? q[o] : 0u;
+            uint32_t vm = have ? 0xFFu : 0u;
+            if (!interior) {
+                uint32_t ci, cj, ck;
+                cx_decode_entry(P, G, e, ci, cj, ck);
+                vm = have ? cx_corner_valid(P, ci, cj, ck) : 0u;
+            }
+            const uint32_t sm = cx_entry_signs(e);
+            const uint32_t s0 = (sm & 1u) ? 0xFFu : 0u;
+            const uint32_t nv = __popc(((sm ^ s0) & vm) & 0xFEu);
+            const bool real = (vm == 0xFFu);
+            const uint32_t nt = real ? (uint32_t)s_ntri[sm] : 0u;
+            acc.v += nv;
+            acc.t += nt;
+            acc.c += (nv | nt) ? 1u : 0u;
+            acc.b += real ? 1u : 0u;
+        }
+        qc = ql;
+    };
     auto flush_queue = [&]() {
+#if CX_S1_LAZY
+        if (!P.tq) count_pending();
+#endif
         __builtin_amdgcn_wave_barrier();
         if (qflushed + ql <= P.qlimit) {
             for (uint32_t o = lane; o < ql; o += 64u) gq[qflushed + o] = q[o];
@@ -767,7 +804,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             overflow = true;
         }
         __builtin_amdgcn_wave_barrier();
-        ql = 0;
+        ql = 0; qc = 0;
     };
     auto flush_brec = [&]() {
         __builtin_amdgcn_wave_barrier();
@@ -782,6 +819,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
         nbl = 0;
     };
     auto close_batch = [&]() {
+#if CX_S1_LAZY
+        if (!P.tq) count_pending();
+#endif
         const uint32_t bv = cx_wave_sum(acc.v), bt = cx_wave_sum(acc.t), bc = cx_wave_sum(acc.c);
         if (lane == 0) {
             s_br[wave][nbl][0] = qstart; s_br[wave][nbl][1] = qn - qstart; s_br[wave][nbl][2] = rv;
@@ -928,8 +968,16 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
             const uint32_t act0 = o & ~a & mr;
             if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
+#if CX_S1_LAZY
+                // exclusive prefix of the lanes' cell counts by DPP row shifts (9 instructions; five ballots with their mbcnt pairs: 35)
+                const uint32_t cnt0 = __popc(act0);
+                const uint32_t incl0 = cx_wave_incl_scan(cnt0, lane);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+                const uint32_t pre = incl0 - cnt0;
+#else
                 uint32_t tot;
                 const uint32_t pre = cx_wave_prefix_small<5>(__popc(act0), tot);
+#endif
                 const uint32_t sidx = p - G.pstart;
                 const uint32_t ebase = (lane << 15) | (sidx << 21);
                 // where the lane's cells of this step sit in the wave's queue, and which they are (bit 4r+m): lets the triangle stage
@@ -962,7 +1010,7 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                     // of every crossing the cell owns, written to the wave's stream of fractions in the order the vertex stage numbers
                     // the vertices (cell after cell, direction after direction).
                     __builtin_amdgcn_wave_barrier();
-                    for (uint32_t o0 = 0; o0 < ctot; o0 += 64u) {      // wave-uniform
+                    for (uint32_t o0 = 0; o0 < ((CX_S1_LAZY && !stage_t) ? 0u : ctot); o0 += 64u) {      // wave-uniform
                         const uint32_t o = o0 + lane;
                         const bool have = o < ctot;
                         const uint32_t e = have ? q[ql + o] : 0u;
