@@ -967,6 +967,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
             const uint32_t o = op | (op >> CX_ROWBITS) | oc | (oc >> CX_ROWBITS);
             const uint32_t a = ap & (ap >> CX_ROWBITS) & ac & (ac >> CX_ROWBITS);
             const uint32_t act0 = o & ~a & mr;
+#ifdef CX_S1_ABL
+            if (CX_S1_ABL == 2) { wprev = wcur; p++; return; }
+#endif
             if (__ballot(act0 != 0u) != 0ULL) {    // wave-uniform: some cell of this step has a sign change
 #if CX_S1_LAZY
                 // exclusive prefix of the lanes' cell counts by DPP row shifts (9 instructions; five ballots with their mbcnt pairs: 35)
@@ -984,10 +987,18 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                 // find the queue entry of ANY active cell of the volume without a table per sample.  Straight to global memory, one
                 // coalesced 256-byte store per step that queued cells (round 3 staged all steps' words in 17 KB of LDS and wrote them
                 // out at the end, active or not; measured: the direct store is 3 % FASTER, and the LDS goes to the sample planes)
+#ifdef CX_S1_ABL
+                if (P.qa && CX_S1_ABL != 3) (P.qa + (size_t)w * (CX_SWP * 64u))[sidx * 64u + lane] =
+#else
                 if (P.qa) (P.qa + (size_t)w * (CX_SWP * 64u))[sidx * 64u + lane] =
+#endif
                     ((qn + pre) << 16) | (act0 & 0xFu) | ((act0 >> 2) & 0xF0u) | ((act0 >> 4) & 0xF00u) | ((act0 >> 6) & 0xF000u);
                 // The step's cells go through the entry stage in the order of the lanes; more than the stage holds (CX_SQ; up to 1024
                 // on white noise) go in two halves of the lanes -- the order in the queue is the same either way.
+#ifdef CX_S1_ABL      // timing experiments (tools/variants.sh + tools/stream_ab.py; the queues are garbage): 1 = the cells are counted but not
+                      // written to the stage, 2 = nothing of the active block at all, 3 = everything but the per-step queue word store
+                if (CX_S1_ABL == 1) { qn += tot; wprev = wcur; p++; return; }
+#endif
                 const uint32_t nhalf = (tot > CX_SQ) ? 2u : 1u;            // wave-uniform
                 const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)pre, 32);   // cells of lanes 0..31
                 const float* __restrict__ plo = &ring[sidx & 1u][0][0];          // sample plane p   (the cells' lower corners)

@@ -55,6 +55,8 @@ struct cx_post_state {
     } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
     cxp_dev morder;                                     // morph triangles sorted by the bin of their start time (u32 ids), for cx_morph_eval
+    cxp_dev meflags;                                    // cx_morph_eval's own flag bytes (segments | triangles): all zero between two calls
+    size_t meflags_zero_for = 0;                        // ns + nt the zeroed state was set up for (0: not yet)
     uint32_t mbin_start[1025] = {0};                    // first position in morder of every bin (CXP_ME_BINS + 1 entries)
     double mt_lo = 0.0, mt_hi = 0.0, mt_maxdur = 0.0;   // range of the start times, longest life of a triangle
     bool morder_valid = false;
@@ -78,7 +80,7 @@ void cx_post_free(cx_ctx* ctx) {
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
                       &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd, &S->ever,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->morder};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->morder, &S->meflags};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -2821,20 +2823,66 @@ __global__ void cxp_k_me_visible(const double* ttime, const int32_t* tris, const
     tflag[q] = 1;
     sused[a] = 1; sused[b] = 1; sused[c] = 1;
 }
-__global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, const uint8_t* sused,
-                                                       const uint32_t* soff, uint32_t* snew, double* out) {
+// The per-t surface walks flag arrays as long as ALL morph triangles / segments (25 M / 19 M on config 4) for a surface of 0.3 M: its
+// workgroups cover CXP_ME_BLOCK = 4096 flags (16 per thread, one 16-byte load) -- with 1024 per workgroup the 24 k workgroups of a launch cost
+// 25-30 us although nine in ten left at once, and the scan of their counts another 25.
+#define CXP_ME_BLOCK 4096u
+__device__ __forceinline__ uint32_t cxp_block_excl_t(uint32_t t, uint32_t* s, uint32_t& block_total) {   // exclusive prefix of one number per thread, 256 threads
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    block_total = s[255];
+    return s[threadIdx.x] - t;
+}
+// 16 flags (bytes, 0 / 1) of this thread as a bit mask
+__device__ __forceinline__ uint32_t cxp_flags16(const uint8_t* flags, uint32_t base, uint32_t n) {
+    uint32_t m = 0;
+    if (base + 15u < n) {
+        const uint4 w = *reinterpret_cast<const uint4*>(flags + base);     // base is a multiple of 16, the arrays are 64-byte aligned
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            m |= (((ww[k] & 1u) | ((ww[k] >> 7) & 2u) | ((ww[k] >> 14) & 4u) | ((ww[k] >> 21) & 8u))) << (4u * k);
+    } else {
+        for (uint32_t k = 0; k < 16u && base + k < n; k++) m |= flags[base + k] ? (1u << k) : 0u;
+    }
+    return m;
+}
+// block counts of two flag arrays in one launch: workgroups [0, nba) the first, the rest the second
+__global__ __launch_bounds__(256) void cxp_k_me_count16(const uint8_t* fa, uint32_t na, uint32_t nba, uint32_t* ca, const uint8_t* fb, uint32_t nb, uint32_t* cb) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const bool second = blockIdx.x >= nba;
+    const uint32_t blk = second ? blockIdx.x - nba : blockIdx.x;
+    const uint8_t* flags = second ? fb : fa;
+    const uint32_t n = second ? nb : na;
+    uint32_t c = __popc(cxp_flags16(flags, blk * CXP_ME_BLOCK + threadIdx.x * 16u, n));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
+    __syncthreads();
+    if (threadIdx.x == 0) (second ? cb : ca)[blk] = s_n;
+}
+// (A block whose count is zero -- most of them at any one time -- leaves before it reads a flag: the block offsets are there already.)
+__global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, uint8_t* sused,
+                                                       const uint32_t* soff, const uint32_t* total, uint32_t* snew, double* out) {
     __shared__ uint32_t s[256];
-    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
-    uint32_t v[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) v[k] = (base + k < ns && sused[base + k]) ? 1u : 0u;
+    if (((blockIdx.x + 1u < gridDim.x) ? soff[blockIdx.x + 1u] : *total) == soff[blockIdx.x]) return;
+    const uint32_t base = blockIdx.x * CXP_ME_BLOCK + threadIdx.x * 16u;
+    uint32_t m = cxp_flags16(sused, base, ns);
     uint32_t tot;
-    uint32_t id = soff[blockIdx.x] + cxp_block_excl4(v, s, tot);
-    if (tot == 0u) return;       // (after the barriers inside the scan: uniform)
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        if (!v[k]) continue;
+    uint32_t id = soff[blockIdx.x] + cxp_block_excl_t(__popc(m), s, tot);
+    while (m) {
+        const uint32_t k = __ffs(m) - 1u;
+        m &= m - 1u;
         const uint32_t sg = base + k;
+        sused[sg] = 0;            // (the flags are all zero again when the call ends: no 19 MB + 25 MB of memset per surface)
         snew[sg] = id;
         const double* a = P4 + (size_t)segs[(size_t)sg * 2] * 4;
         const double* b = P4 + (size_t)segs[(size_t)sg * 2 + 1] * 4;
@@ -2845,20 +2893,19 @@ __global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const i
         id++;
     }
 }
-__global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32_t nt, const uint8_t* tflag, const uint32_t* toff, const uint32_t* snew,
-                                                     int32_t* out) {
+__global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32_t nt, uint8_t* tflag, const uint32_t* toff, const uint32_t* total,
+                                                     const uint32_t* snew, int32_t* out) {
     __shared__ uint32_t s[256];
-    const uint32_t base = blockIdx.x * CXP_SCAN_BLOCK + threadIdx.x * 4u;
-    uint32_t v[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) v[k] = (base + k < nt && tflag[base + k]) ? 1u : 0u;
+    if (((blockIdx.x + 1u < gridDim.x) ? toff[blockIdx.x + 1u] : *total) == toff[blockIdx.x]) return;
+    const uint32_t base = blockIdx.x * CXP_ME_BLOCK + threadIdx.x * 16u;
+    uint32_t m = cxp_flags16(tflag, base, nt);
     uint32_t tot;
-    uint32_t id = toff[blockIdx.x] + cxp_block_excl4(v, s, tot);
-    if (tot == 0u) return;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        if (!v[k]) continue;
+    uint32_t id = toff[blockIdx.x] + cxp_block_excl_t(__popc(m), s, tot);
+    while (m) {
+        const uint32_t k = __ffs(m) - 1u;
+        m &= m - 1u;
         const uint32_t q = base + k;
+        tflag[q] = 0;
         const uint32_t a = snew[tris[(size_t)q * 3]], b = snew[tris[(size_t)q * 3 + 1]], c = snew[tris[(size_t)q * 3 + 2]];
         int32_t* o = out + (size_t)id * 3;
         o[0] = (int32_t)a; o[1] = (int32_t)b; o[2] = (int32_t)c;
@@ -2917,15 +2964,21 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     if (out_counts) { out_counts[0] = 0; out_counts[1] = 0; }
     if (!ns || !nt) return CX_OK;
     int rc;
-    const uint32_t nbs = cxp_blocks(ns, CXP_SCAN_BLOCK), nbt = cxp_blocks(nt, CXP_SCAN_BLOCK);
-    if ((rc = cxp_reserve(ctx, S->flags, (size_t)ns + nt + 256))) return rc;                         // one byte per segment / triangle
+    const uint32_t nbs = cxp_blocks(ns, CXP_ME_BLOCK), nbt = cxp_blocks(nt, CXP_ME_BLOCK);
+    {
+        // one byte per segment / triangle, in a buffer nothing else writes: the kernels that consume a flag clear it, so the bytes are
+        // all zero between two calls and only a new set of morph triangles (or a new buffer) is cleared as a whole
+        const void* before = S->meflags.p;
+        if ((rc = cxp_reserve(ctx, S->meflags, (size_t)ns + nt + 256))) return rc;
+        if (S->meflags.p != before) S->meflags_zero_for = 0;
+    }
     if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + 32) * sizeof(uint32_t)))) return rc;            // new ids of the segments in use
     // block counts of the two compactions -- and, on the first call for these morph triangles, the histogram of cxp_me_index, which
     // lives in the same buffer: reserved HERE, for the larger of the two, before any pointer into it is taken (until round 4 the
     // index reserved its own 2 x 1 024 words afterwards; when that was more than nbs + nbt + 16 the buffer moved and soff / toff
     // below pointed into freed memory: a GPU memory fault on small morphs whenever the allocator had unmapped the old block)
     if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)std::max<size_t>(nbs + nbt + 16, 2 * CXP_ME_BINS + 16) * sizeof(uint32_t)))) return rc;
-    uint8_t* sused = (uint8_t*)S->flags.p;
+    uint8_t* sused = (uint8_t*)S->meflags.p;
     uint8_t* tflag = sused + (((size_t)ns + 127u) & ~(size_t)63u);
     uint32_t* snew = (uint32_t*)S->scan.p;
     uint32_t* soff = (uint32_t*)S->blocksums.p;
@@ -2934,13 +2987,15 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
     const double* P4 = (const double*)S->pts.p;
     const int32_t* segs = (const int32_t*)S->msegs.p;
     const int32_t* tris = (const int32_t*)S->mtris.p;
-    CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns, st));
-    CXP_HIP(ctx, hipMemsetAsync(tflag, 0, (size_t)nt, st));
     const double* ttime = (const double*)S->mtime.p + (size_t)(ns + 1) * 2;   // behind the segments' ranges (cx_morph_triangles)
+    // (the flag bytes count as zeroed only while a call has run to its end on the same morph triangles)
+    const size_t clean_for = S->morder_valid ? S->meflags_zero_for : 0;
+    S->meflags_zero_for = 0;
     if (!S->morder_valid && (rc = cxp_me_index(ctx, S, ttime, nt))) return rc;      // first surface of these morph triangles: ~2 ms once
+    // the window of start-time bins in which a triangle that exists at t can start (one bin of slack on either side: the bin of
+    // a start time was computed on the device, these two on the host)
+    uint32_t first = 0, n = 0;
     {
-        // the window of start-time bins in which a triangle that exists at t can start (one bin of slack on either side: the bin of
-        // a start time was computed on the device, these two on the host)
         const double width = (S->mt_hi > S->mt_lo) ? (S->mt_hi - S->mt_lo) / (double)CXP_ME_BINS : 1.0;
         auto bin_of = [&](double x) {
             const double b = (x - S->mt_lo) / width;
@@ -2949,20 +3004,24 @@ extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
         const uint32_t b_hi = std::min(bin_of(t) + 1u, CXP_ME_BINS - 1u);
         const uint32_t b_lo0 = bin_of(t - S->mt_maxdur);
         const uint32_t b_lo = b_lo0 ? b_lo0 - 1u : 0u;
-        const uint32_t first = S->mbin_start[b_lo], n = S->mbin_start[b_hi + 1u] - first;
-        if (n) hipLaunchKernelGGL(cxp_k_me_visible, dim3(cxp_blocks(n)), dim3(256), 0, st, ttime, tris, (const uint32_t*)S->morder.p, first, n, t, tflag, sused);
+        first = S->mbin_start[b_lo]; n = S->mbin_start[b_hi + 1u] - first;
     }
-    hipLaunchKernelGGL(cxp_k_me_count, dim3(nbt), dim3(256), 0, st, (const uint8_t*)tflag, nt, toff);
-    hipLaunchKernelGGL(cxp_k_me_count, dim3(nbs), dim3(256), 0, st, (const uint8_t*)sused, ns, soff);
+    // The surface cannot hold more triangles than the window, nor more points than three per triangle: the outputs are reserved for
+    // that before anything is enqueued, so that the call runs to its end without the host in the middle (until round 4 it waited for
+    // the two totals between the scans and the compactions: ~15 us of idle GPU per surface, 64 times over for config 4's stream)
+    if ((rc = cxp_reserve(ctx, S->pts_out, ((size_t)std::min<uint64_t>(ns, 3ull * n) + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->tri_out, ((size_t)n + 1) * 3 * sizeof(int32_t)))) return rc;
+    if (clean_for != (size_t)ns + nt) CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns + nt + 256, st));
+    if (n) hipLaunchKernelGGL(cxp_k_me_visible, dim3(cxp_blocks(n)), dim3(256), 0, st, ttime, tris, (const uint32_t*)S->morder.p, first, n, t, tflag, sused);
+    hipLaunchKernelGGL(cxp_k_me_count16, dim3(nbs + nbt), dim3(256), 0, st, (const uint8_t*)sused, ns, nbs, soff, (const uint8_t*)tflag, nt, toff);
     hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, soff, nbs, misc + 8, toff, nbt, misc + 9);
+    hipLaunchKernelGGL(cxp_k_me_points, dim3(nbs), dim3(256), 0, st, P4, segs, ns, t, sused, (const uint32_t*)soff, (const uint32_t*)(misc + 8), snew, (double*)S->pts_out.p);
+    hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, tflag, (const uint32_t*)toff, (const uint32_t*)(misc + 9), (const uint32_t*)snew, (int32_t*)S->tri_out.p);
     uint32_t tot[2] = {0, 0};
     CXP_HIP(ctx, hipMemcpyAsync(tot, misc + 8, sizeof(tot), hipMemcpyDeviceToHost, st));
     CXP_HIP(ctx, hipStreamSynchronize(st));
-    if ((rc = cxp_reserve(ctx, S->pts_out, (size_t)(tot[0] + 1) * 3 * sizeof(double)))) return rc;
-    if ((rc = cxp_reserve(ctx, S->tri_out, (size_t)(tot[1] + 1) * 3 * sizeof(int32_t)))) return rc;
-    if (tot[0]) hipLaunchKernelGGL(cxp_k_me_points, dim3(nbs), dim3(256), 0, st, P4, segs, ns, t, (const uint8_t*)sused, (const uint32_t*)soff, snew, (double*)S->pts_out.p);
-    if (tot[1]) hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, (const uint8_t*)tflag, (const uint32_t*)toff, (const uint32_t*)snew, (int32_t*)S->tri_out.p);
     CXP_HIP(ctx, hipGetLastError());
+    S->meflags_zero_for = (size_t)ns + nt;
     S->me_points = tot[0]; S->me_tris = tot[1];
     if (out_counts) { out_counts[0] = tot[0]; out_counts[1] = tot[1]; }
     return CX_OK;
