@@ -469,3 +469,65 @@ def test_device_morph_triangles_through_to_json_into_the_viewer(name, tag):
             assert np.all(d <= bound), float((d - bound).max())
         drawn += len(td) > 0
     assert drawn >= 2
+
+
+def test_per_t_surfaces_on_one_context_across_rebuilt_morphs():
+    """cx_morph_eval keeps its flag bytes zeroed between calls (the compaction kernels clear what they consume; a full clear only for
+    new morph triangles or a new buffer): surfaces at several times, then ANOTHER field's morph triangles on the same context (more
+    segments and triangles, then fewer), then the first field again -- every surface equals the one a fresh context gives, and a
+    repeated time gives the same arrays (B6, misc/morph_triangles.js:117-178)"""
+    from contourist_amd import _ffi
+
+    def field(shape, seed):
+        rng = np.random.RandomState(seed)
+        ax = [np.linspace(0.0, 1.0, n, dtype=np.float32) for n in shape]
+        X, Y, Z, T = np.meshgrid(*ax, indexing="ij")
+        A = np.exp(-(((X - 0.35 - 0.3 * T) ** 2 + (Y - 0.4) ** 2 + (Z - 0.5 + 0.1 * T) ** 2) / (2 * 0.16 ** 2)))
+        A += 0.02 * rng.standard_normal(shape)
+        for axis in range(4):
+            for idx in (0, -1):
+                np.moveaxis(A, axis, 0)[idx] = 0.0
+        return np.ascontiguousarray(A.astype(np.float32))
+
+    def surfaces(ctx, A, fracs):
+        ctx.upload_grid4d(A)
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(100)
+        mt = ctx.morph_triangles()
+        tmin, tmax = float(mt[0][:, 3].min()), float(mt[0][:, 3].max())
+        out = []
+        for fr in fracs:
+            p, t = ctx.morph_eval(tmin + fr * (tmax - tmin))
+            out.append((p.copy(), t.copy()))
+        return out
+
+    def canon(points, tris):
+        out = []
+        for tr in np.asarray(tris):
+            q = [tuple(np.round(points[k], 9).tolist()) for k in tr]
+            r = q.index(min(q))
+            out.append((q[r], q[(r + 1) % 3], q[(r + 2) % 3]))
+        return sorted(out)
+
+    fields = [field((14, 13, 12, 9), 1), field((20, 18, 16, 12), 2), field((9, 10, 11, 6), 3)]
+    fracs = (0.21, 0.48, 0.21, 0.77, 0.48)
+    fresh = []
+    for A in fields:
+        c = _ffi.Context(0)
+        try:
+            fresh.append(surfaces(c, A, fracs))
+        finally:
+            c.close()
+    for S in fresh:
+        assert sum(len(t) for _, t in S) > 0
+        assert np.array_equal(S[0][1], S[2][1]) and np.array_equal(S[0][0], S[2][0])      # the same time twice
+    ctx = _ffi.Context(0)
+    try:
+        for k in (0, 1, 2, 0, 1):
+            got = surfaces(ctx, fields[k], fracs)
+            for (p, t), (pf, tf) in zip(got, fresh[k]):
+                # (the ORDER of the 4-D Level-0 output follows the workgroups' reservations: compare the surfaces as sets of triangles)
+                assert len(t) == len(tf) and len(p) == len(pf)
+                assert canon(p, t) == canon(pf, tf)
+    finally:
+        ctx.close()
