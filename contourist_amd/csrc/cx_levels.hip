@@ -41,9 +41,8 @@ struct cx_level_slot {
     size_t flat_cap = 0;
     uint32_t* qa = nullptr;
     size_t qa_cap = 0;
-    uint32_t* counters = nullptr;
-    uint32_t* chunksum = nullptr;
-    size_t chunksum_cap = 0;
+    uint32_t* counters = nullptr;      // a slice of cx_levels_state::counters_all (not owned)
+    uint32_t* chunksum = nullptr;      // a slice of cx_levels_state::chunk_all (not owned)
     uint32_t* rstart = nullptr;        // vertex stage: first batch of every wave's share of the rounds
     size_t rstart_cap = 0;
     uint32_t* kstart = nullptr;        // triangle stage: the same
@@ -65,6 +64,14 @@ struct cx_levels_state {
     size_t dparams_cap = 0;
     uint32_t* hcounters = nullptr;     // pinned: CX_CNT_WORDS per level
     size_t hcounters_cap = 0;
+    // the levels' counters and chunk totals side by side: ONE memset and ONE copy back per call (a memset and a copy per level were
+    // 16 small stream operations in front of and behind the scans: ~0.1 ms of a 2.3 ms call)
+    uint32_t* counters_all = nullptr;
+    size_t counters_all_cap = 0;
+    uint32_t* chunk_all = nullptr;
+    size_t chunk_all_cap = 0;
+    cx_params* hparams = nullptr;      // pinned staging of the levels' parameters (the upload needs no wait)
+    size_t hparams_cap = 0;
     cx_task T;
     uint32_t flags = 0;
     // the emit stages of two levels run side by side (each kernel alone leaves part of the chip idle): a second stream, and a
@@ -83,7 +90,7 @@ struct cx_levels_state {
 };
 
 static void free_slot(cx_level_slot& S) {
-    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.counters, S.chunksum, S.rstart, S.kstart, S.verts, S.cells, S.tris};
+    void* all[] = {S.queue, S.wsum, S.wbase, S.brec, S.flat, S.qa, S.rstart, S.kstart, S.verts, S.cells, S.tris};
     for (void* p : all)
         if (p) (void)hipFree(p);
     S = cx_level_slot();
@@ -103,6 +110,9 @@ void cx_levels_free(cx_ctx* ctx) {
     for (auto& S : L->slots) free_slot(S);
     cx_release(L->dparams, L->dparams_cap);
     if (L->hcounters) (void)hipHostFree(L->hcounters);
+    if (L->hparams) (void)hipHostFree(L->hparams);
+    cx_release(L->counters_all, L->counters_all_cap);
+    cx_release(L->chunk_all, L->chunk_all_cap);
     for (int k = 0; k < CXL_SIDES; k++) cx_release(L->info_side[k], L->info_side_cap[k]);
     cx_release(L->qpool, L->qpool_cap);
     for (int k = 0; k < CXL_SIDES; k++) {
@@ -203,6 +213,10 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
     } else {
         cx_release(L->qpool, L->qpool_cap);
     }
+    const size_t chunk_words = (((nw + 255u) / 256u) * 8u + 63u) & ~(size_t)63u;      // per level, a multiple of 256 bytes
+    if ((rc = grow(ctx, L->counters_all, L->counters_all_cap, (size_t)nlevels * CX_CNT_WORDS))) return rc;
+    if ((rc = grow(ctx, L->chunk_all, L->chunk_all_cap, (size_t)nlevels * chunk_words))) return rc;
+    CXL_HIP(ctx, hipMemsetAsync(L->chunk_all, 0, (size_t)nlevels * chunk_words * sizeof(uint32_t), ctx->stream));
     for (int l = 0; l < nlevels; l++) {
         cx_level_slot& S = L->slots[l];
         S.value = values[l];
@@ -212,9 +226,8 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         if ((rc = grow(ctx, S.brec, S.brec_cap, nw * T.bcap))) return rc;
         if ((rc = grow(ctx, S.flat, S.flat_cap, nflat))) return rc;
         if ((rc = grow(ctx, S.qa, S.qa_cap, nw * CX_SWP * 64u + 64u))) return rc;
-        if (!S.counters) CXL_HIP(ctx, hipMalloc(&S.counters, CX_CNT_WORDS * sizeof(uint32_t)));
-        if ((rc = grow(ctx, S.chunksum, S.chunksum_cap, ((nw + 255u) / 256u) * 8u))) return rc;
-        CXL_HIP(ctx, hipMemsetAsync(S.chunksum, 0, ((nw + 255u) / 256u) * 8u * sizeof(uint32_t), ctx->stream));
+        S.counters = L->counters_all + (size_t)l * CX_CNT_WORDS;
+        S.chunksum = L->chunk_all + (size_t)l * chunk_words;
         cx_params& P = S.P;
         memset(&P, 0, sizeof(P));
         P.grid = ctx->grid;
@@ -251,8 +264,14 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
         CXL_HIP(ctx, hipHostMalloc(&L->hcounters, (size_t)nlevels * CX_CNT_WORDS * sizeof(uint32_t)));
         L->hcounters_cap = (size_t)nlevels;
     }
+    if (L->hparams_cap < (size_t)nlevels) {
+        if (L->hparams) (void)hipHostFree(L->hparams);
+        L->hparams = nullptr; L->hparams_cap = 0;
+        CXL_HIP(ctx, hipHostMalloc(&L->hparams, (size_t)nlevels * sizeof(cx_params)));
+        L->hparams_cap = (size_t)nlevels;
+    }
     {
-        std::vector<cx_params> hp(nlevels);
+        cx_params* hp = L->hparams;       // pinned: the copy below is asynchronous and nothing has to wait for it (every call ends synchronised)
         for (int l = 0; l < nlevels; l++) {
             cx_level_slot& S = L->slots[l];
             S.P.verts = S.verts; S.P.cells = S.cells; S.P.tris = S.tris;
@@ -260,14 +279,11 @@ extern "C" int cx_extract3d_levels(cx_ctx* ctx, const double* values, int32_t nl
             S.P.info64 = pooled ? ctx->info64 + (size_t)l * sub : ctx->info64;
             hp[l] = S.P;
         }
-        CXL_HIP(ctx, hipMemcpyAsync(L->dparams, hp.data(), (size_t)nlevels * sizeof(cx_params), hipMemcpyHostToDevice, ctx->stream));
-        CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // hp goes out of scope
+        CXL_HIP(ctx, hipMemcpyAsync(L->dparams, hp, (size_t)nlevels * sizeof(cx_params), hipMemcpyHostToDevice, ctx->stream));
         // ONE pass over the samples for all levels, then the scans
-        cx_launch_stream_levels(hp.data(), T, (uint32_t)nlevels, ctx->stream);
+        cx_launch_stream_levels(hp, T, (uint32_t)nlevels, ctx->stream);
         cx_launch_scan_levels(L->dparams, T, (uint32_t)nlevels, ctx->stream);
-        for (int l = 0; l < nlevels; l++)
-            CXL_HIP(ctx, hipMemcpyAsync(L->hcounters + (size_t)l * CX_CNT_WORDS, L->slots[l].counters, CX_CNT_WORDS * sizeof(uint32_t),
-                                        hipMemcpyDeviceToHost, ctx->stream));
+        CXL_HIP(ctx, hipMemcpyAsync(L->hcounters, L->counters_all, (size_t)nlevels * CX_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CXL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         // output buffers of every level, sized by what its surface needs
         for (int l = 0; l < nlevels; l++) {
