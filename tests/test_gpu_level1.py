@@ -279,3 +279,32 @@ def test_level1_device_export_equals_download():
     assert pp and tp and nv == len(gp_h) and nt == len(gt_h)
     view_p, view_t = S.contour_maker.context().level1_torch(copy=False)
     assert view_p.data_ptr() == pp and view_t.data_ptr() == tp and torch.equal(view_p, gp_d)
+
+
+def test_level1_equals_oracle_at_mid_size():
+    """a smooth field of 72 x 80 x 88 samples (the bench field's generator, 260-350 k triangles, several components): the triangles of one
+    edge lie in different 512-triangle blocks of the linking kernel, the global edge table and the component passes are in play --
+    weld / tiny collapse / clean / orient == the oracle's canonical pipeline: same counts after every stage, the same triangles as
+    weld-bucket triples, the same windings (tetrahedral.py:190-215, 353-375, surface_geometry.py:14-140)"""
+    from contourist_amd import _ffi, synthetic
+    from oracle import level0, postpass
+    shape = (72, 80, 88)
+    A = synthetic.smooth_noise_host(shape, 4321, 180)
+    ctx = _ffi.Context(0)
+    try:
+        for v in (0.0, 0.6):
+            ctx.upload_grid(A)
+            c = ctx.extract3d(v, _ffi.CX_DIAG_CPYTHON310)
+            post = ctx.postprocess3d(0)
+            pts, tris = ctx.download_level1(post)
+            O = level0.march3d(A, v, diag_mode=1)
+            assert c["n_triangles"] == len(O["tris"]) and len(O["tris"]) > 20000
+            corner = np.array(shape) - 1
+            ko = level0.edge_keys_from_pairs(O["pairs"], shape)
+            L1 = postpass.level1_from_level0(ko, O["xyz"], O["tris"], corner)
+            assert post["n_after_weld"] == L1["n_after_weld"] and post["n_after_tiny"] == L1["n_after_tiny"], v
+            assert len(tris) == len(L1["triangles"]), v
+            cmp = postpass.compare_level1(L1, pts, tris, corner, reach=0)
+            assert not cmp["missing"] and not cmp["extra"] and not cmp["winding"], (v, cmp)
+    finally:
+        ctx.close()
