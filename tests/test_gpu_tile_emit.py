@@ -136,8 +136,8 @@ def test_slab_origin_and_negative_origin():
         same(t, s)
 
 
-def test_seeded_selection_and_level1_after_tiled_extraction():
-    """cell records are produced on demand for the seeded selection (the tile kernels write none), and Level 1 runs on the tile path's mesh"""
+def test_level1_after_tiled_extraction():
+    """Level 1 (weld / tiny collapse / clean / orient) on the tile path's mesh equals Level 1 on the staged kernels' mesh"""
     from contourist_amd import _ffi
     A = field((40, 44, 48), 12)
     res = []
@@ -153,6 +153,34 @@ def test_seeded_selection_and_level1_after_tiled_extraction():
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     for a, b in zip(res[0][2], res[1][2]):
         assert np.array_equal(a, b)
+
+
+def test_seeded_selection_after_tiled_extraction():
+    """cell records are produced on demand for the seeded selection (the tile kernels write none): the voxel groups the reference's
+    breadth-first search reaches from one crossing edge (tetrahedral.py:396-463), against oracle/seeds.py"""
+    from contourist_amd import _ffi
+    from oracle import level0, seeds
+    G = np.load(os.path.join(GOLDEN_DIR, "blobs27.npz"))
+    A, v = G["A"], float(G["value"])
+    ctx = _ffi.Context(0)
+    try:
+        ctx.upload_grid(A)
+        c = ctx.extract3d(v, 1 | _ffi.CX_KERNEL_TILED)
+        assert ctx.level0_path() == 3
+        xyz, keys, tris = ctx.download_level0(c)
+        keys = keys.astype(np.int64)
+        O = level0.march3d(A, v, diag_mode=1)
+        ko = level0.edge_keys_from_pairs(O["pairs"], A.shape)
+        lin, d = keys >> 3, keys & 7
+        n1n2 = A.shape[1] * A.shape[2]
+        q = np.array([lin[0] // n1n2, (lin[0] // A.shape[2]) % A.shape[1], lin[0] % A.shape[2]])
+        dv = np.array([(d[0] >> 2) & 1, (d[0] >> 1) & 1, d[0] & 1])
+        eps = [[tuple(int(x) for x in q), tuple(int(x) for x in q + dv)]]
+        want, _ = seeds.select(A, v, eps, ko, O["tris"])
+        got = ctx.select_seeded(eps)
+        assert got["triangles_kept"] == int(want.sum()) and 0 < got["triangles_kept"] < len(tris)
+    finally:
+        ctx.close()
 
 
 def test_tiled_and_staged_alternate_on_one_context_and_many_chunks():
