@@ -35,6 +35,22 @@ def _tri_hashes(tk):
     return h
 
 
+def _tet_hashes(tk):
+    """one 64-bit hash per tetrahedron of its UNORDERED key quadruple, sorted (as _tri_hashes)"""
+    tk = np.sort(np.asarray(tk, dtype=np.uint64), axis=1)
+
+    def mix(x):      # splitmix64 finaliser
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    h = mix(tk[:, 0] + np.uint64(0x9E3779B97F4A7C15))
+    h = mix(h ^ (tk[:, 1] * np.uint64(0xD6E8FEB86659FD93)))
+    h = mix(h ^ (tk[:, 2] * np.uint64(0xC2B2AE3D27D4EB4F)))
+    h = mix(h ^ (tk[:, 3] * np.uint64(0x165667B19E3779F9)))
+    h.sort()
+    return h
+
+
 @pytest.mark.parametrize("size,passes", [(256, 700), (512, 1400)])
 def test_bench_field_against_oracle_whole_volume_and_properties(size, passes):
     """the WHOLE mesh of the bench field against oracle/march_oracle.c (round 3 compared the first 32 of 511 voxel planes):
@@ -217,7 +233,8 @@ def test_levels_many_tiles_odd_and_even_counts(nlevels):
 
 def test_config4_field_4d_properties():
     """128^3 x 64 (BASELINE config 4: two moving blobs + noise): ids unique, indices in range, every tetrahedron has four
-    distinct vertices inside one hyper-voxel neighbourhood, counts repeat, and a slab of hyper-voxel planes equals the C oracle"""
+    distinct vertices inside one hyper-voxel neighbourhood, counts repeat, a slab of hyper-voxel planes equals the C oracle -- and so
+    does the WHOLE volume (round 4: 28 M tetrahedra, 4.7 M crossing edges, ~15 s of the oracle)"""
     torch = pytest.importorskip("torch")
     from contourist_amd import _ffi, synthetic
     from oracle import level0_4d
@@ -258,6 +275,20 @@ def test_config4_field_4d_properties():
         assert np.array_equal(a, b)
         c2 = ctx.extract4d(v, _ffi.CX_DIAG_CPYTHON310)
         assert c2 == c
+        # ---- the WHOLE volume against the C oracle (pentatopes.py:223-291 over every hyper-voxel): counts, the set of crossing edges,
+        # the set of tetrahedra (unordered key quadruples, CPython-order 2-3 splits) exactly, every coordinate within 1e-6
+        del O, ko, a, b, sub, qt, q
+        host = np.ascontiguousarray(A.cpu().numpy())
+        O = level0_4d.march4d(host, v, diag_mode=1, vcap=c["n_vertices"] + 4096, tcap=c["n_tetrahedra"] + 4096)   # (grows by itself if the counts differ)
+        ko = level0_4d.edge_keys4(O["pairs"], host.shape)
+        assert c["n_vertices"] == len(ko) and c["n_tetrahedra"] == len(O["tets"]), (c, len(ko), len(O["tets"]))
+        order_d, order_o = np.argsort(k), np.argsort(ko)
+        assert np.array_equal(k[order_d], ko[order_o]), "the crossing edges of the volume differ from the oracle"
+        hd = _tet_hashes(tk)
+        ho = _tet_hashes(ko[O["tets"]])
+        assert np.array_equal(hd, ho), "the tetrahedra of the volume differ from the oracle (%d of %d hashes)" % (int((hd != ho).sum()), len(hd))
+        xd, xo = verts[order_d].astype(np.float64), np.asarray(O["xyzt"])[order_o]
+        assert np.all(np.abs(xd - xo) <= 1e-6 * np.abs(xo) + 1e-6)
     finally:
         ctx.close()
         del A
