@@ -531,3 +531,51 @@ def test_per_t_surfaces_on_one_context_across_rebuilt_morphs():
                 assert canon(p, t) == canon(pf, tf)
     finally:
         ctx.close()
+
+
+def test_post_steps_and_morph_triangles_against_the_oracle_at_mid_size():
+    """26 x 24 x 22 x 12 samples, two moving blobs + noise (277 k tetrahedra, 525 k morph triangles -- the reference's own run would take
+    hours: the oracle's restatement stands in, pinned by the small fixtures above): bin_times / drop_instant / tiny collapse (B3),
+    the slicing into morph triangles (B4: segments with direction, triangles as sets of segments) and the time-compatible windings
+    (B5: every triangle the oracle's flood fill orients agrees) -- pentatopes.py:162-189, 314-368, morph_geometry.py:145-237"""
+    from contourist_amd import pentatopes
+    from oracle import level0_4d, postpass4d
+    shape = (26, 24, 22, 12)
+    ax = [np.linspace(0, 1, n, dtype=np.float32) for n in shape]
+    X, Y, Z, T = np.meshgrid(*ax, indexing="ij")
+    rng = np.random.RandomState(5)
+    A = np.exp(-(((X - 0.35 - 0.3 * T) ** 2 + (Y - 0.45) ** 2 + (Z - 0.5 + 0.1 * T) ** 2) / (2 * 0.17 ** 2))) + \
+        np.exp(-(((X - 0.72 + 0.2 * T) ** 2 + (Y - 0.6) ** 2 + (Z - 0.4) ** 2) / (2 * 0.12 ** 2)))
+    A += 0.01 * rng.standard_normal(shape)
+    for axis in range(4):
+        for idx in (0, -1):
+            np.moveaxis(A, axis, 0)[idx] = 0.0
+    A = np.ascontiguousarray(A.astype(np.float32))
+    v = 0.5
+    corner = np.array(shape) - 1
+    maker = pentatopes.GridContour4D(tuple(corner), A, v)
+    R = maker.find_tetrahedra()
+    MT = maker.collect_morph_triangles()
+    kh = R["keys"].astype(np.int64)
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], shape)
+    W = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    assert R["counts"]["n_after_drop"] == W["n_after_drop"] and R["counts"]["n_after_tiny"] == W["n_after_tiny"] and W["n_after_tiny"] > 100000
+    assert np.array_equal(R["points4d"][np.argsort(kh)], W["xyzt"][np.argsort(ko)])          # float64, bit for bit
+    got = level0_4d.canonical4(kh, R["points4d"], R["tetrahedra"].astype(np.int64))[2]
+    want = level0_4d.canonical4(ko, W["xyzt"], W["tets"])[2]
+    assert np.array_equal(got, want)
+    M = postpass4d.collect_morph_triangles(ko, W["xyzt"], W["tets"])
+    seg_d = np.asarray(MT.segment_point_indices, dtype=np.int64)
+    seg_o = np.asarray(M["segments"], dtype=np.int64)
+    # segments with direction: pairs of edge ids
+    sd = np.stack([kh[seg_d[:, 0]], kh[seg_d[:, 1]]], axis=1)
+    so = np.stack([np.asarray(M["keys"])[seg_o[:, 0]], np.asarray(M["keys"])[seg_o[:, 1]]], axis=1)
+    sd = sd[np.lexsort(sd.T[::-1])]; so = so[np.lexsort(so.T[::-1])]
+    assert np.array_equal(sd, so)
+    assert len(MT.triangle_segment_indices) == len(M["triangles"]) > 300000
+    ot, label, flags = postpass4d.orient_morph_triangles(M)
+    common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, M["keys"], M["segments"], ot)
+    assert common == len(ot) and agree == common, (common, agree, len(ot))
+    bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
+    assert seen_d > 0 and bad_d == 0, (bad_d, seen_d)
