@@ -808,18 +808,17 @@ __global__ void cxp_k_edges_link_cross(uint32_t nt, const uint32_t* others, u64*
 // one visit per block (the slot's taker): edges with one triangle in the block (the partner is in another block, or there is none)
 // and edges with a flagged end point (their visitors in other blocks do the same, so three or more triangles on one edge still
 // meet at the claimant, as in cxp_k_edges_link).  The table's compare-and-swaps (executed at the memory side) and the random
-// 16-byte reads of the link step shrink to a sixth.  others[t*3+e]: CXP_NONE = settled here, CXP_FAR = look the edge up in the
-// second kernel.
+// 16-byte reads of the link step shrink to a sixth.  others[t] (one byte per triangle): bit e set = look edge e up in the second
+// kernel, clear = settled here.
 #ifndef CXP_EB
 #define CXP_EB 512u
 #endif
 #define CXP_EB_PER (CXP_EB / 256u)      // triangles per thread
 #define CXP_EB_SLOTS (4u * CXP_EB)       // > 3 * CXP_EB: an insert always finds a free slot
-#define CXP_FAR 0xFFFFFFFEu
 // (probe_limit / overflow: the global table is first sized for what usually reaches it -- a sixth of the edges -- and a probe
 // sequence that long says it was too small for this mesh: the host repeats the stage with the table of the worst case)
 __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uint32_t nt, const uint8_t* ever, u64* tab, u64 mask, u64 mult,
-                                                         u64* parent, uint32_t* others, uint32_t probe_limit, uint32_t* overflow) {
+                                                         u64* parent, uint8_t* others, uint32_t probe_limit, uint32_t* overflow) {
     __shared__ u64 lkey[CXP_EB_SLOTS];
     __shared__ uint16_t lfirst[CXP_EB_SLOTS];
     __shared__ uint8_t lpair[CXP_EB_SLOTS];
@@ -893,13 +892,14 @@ __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uin
     for (uint32_t i = 0; i < CXP_EB_PER; i++) {
         const uint32_t lt = i * 256u + threadIdx.x, t = b0 + lt;
         if (t >= nt) continue;
+        uint32_t farbits = 0;      // bit e: edge e of this triangle went to the global table (one BYTE per triangle: the second kernel reads
+                                   // nothing else of it -- as three 32-bit words this was 270 MB written and read back at 22.5 M triangles)
 #pragma unroll
         for (int e = 0; e < 3; e++) {
             const uint32_t lo = lo_[i][e], hi = hi_[i][e];
             const bool taker = lfirst[slot_[i][e]] == lt;
-            uint32_t far = CXP_NONE;
             if (taker && (flag_[i][e] != 0u || !lpair[slot_[i][e]])) {
-                far = CXP_FAR;
+                farbits |= 1u << e;
                 const u64 key = ((u64)lo << 32) | (u64)hi;
                 u64 slot = cxp_edge_slot(lo, hi, mask, mult);
                 for (uint32_t probes = 0;; probes++) {
@@ -911,8 +911,8 @@ __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uin
                     slot = (slot + 1) & mask;
                 }
             }
-            others[(size_t)t * 3 + e] = far;
         }
+        others[t] = (uint8_t)farbits;
     }
     // the block's forest into the global parent words (nobody else touches them in this kernel); roots = smallest ids
     for (uint32_t x = threadIdx.x; x < CXP_EB; x += 256u) {
@@ -922,15 +922,15 @@ __global__ __launch_bounds__(256) void cxp_k_edges_block(const int32_t* tri, uin
     }
 }
 // second kernel: the visitors the first one sent to the global table unite with the edge's claimant
-__global__ void cxp_k_edges_link_far(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, const uint32_t* others, u64* parent) {
+__global__ void cxp_k_edges_link_far(const int32_t* tri, uint32_t nt, const u64* tab, u64 mask, u64 mult, const uint8_t* others, u64* parent) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
-    const uint32_t f[3] = {others[(size_t)t * 3], others[(size_t)t * 3 + 1], others[(size_t)t * 3 + 2]};
-    if (f[0] != CXP_FAR && f[1] != CXP_FAR && f[2] != CXP_FAR) return;
+    const uint32_t fb = others[t];
+    if (!fb) return;
     const uint32_t v[3] = {(uint32_t)tri[(size_t)t * 3], (uint32_t)tri[(size_t)t * 3 + 1], (uint32_t)tri[(size_t)t * 3 + 2]};
 #pragma unroll
     for (int e = 0; e < 3; e++) {
-        if (f[e] != CXP_FAR) continue;
+        if (!((fb >> e) & 1u)) continue;
         const uint32_t p = v[e], q = v[(e + 1) % 3];
         const uint32_t lo = min(p, q), hi = max(p, q);
         const u64 key = ((u64)lo << 32) | (u64)hi;
@@ -1315,14 +1315,14 @@ static int cxp_clean_orient(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t
             if (blocks) {
                 CXP_HIP(ctx, hipMemsetAsync(misc + 12, 0, sizeof(uint32_t), st));
                 hipLaunchKernelGGL(cxp_k_edges_block, dim3((nt2 + CXP_EB - 1u) / CXP_EB), dim3(256), 0, st, tri2, nt2, (const uint8_t*)(ever + nv), etab, esz - 1,
-                                   emult, parent, others, esz == esz_full ? 0xFFFFFFFFu : 256u, misc + 12);
+                                   emult, parent, (uint8_t*)others, esz == esz_full ? 0xFFFFFFFFu : 256u, misc + 12);
                 if (esz != esz_full) {
                     uint32_t over = 0;
                     CXP_HIP(ctx, hipMemcpyAsync(&over, misc + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     CXP_HIP(ctx, hipStreamSynchronize(st));
                     if (over) { esz = esz_full; continue; }
                 }
-                hipLaunchKernelGGL(cxp_k_edges_link_far, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, (const uint32_t*)others, parent);
+                hipLaunchKernelGGL(cxp_k_edges_link_far, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult, (const uint8_t*)others, parent);
             } else {
                 hipLaunchKernelGGL(cxp_k_edges_claim, dim3(cxp_blocks(nt2)), dim3(256), 0, st, tri2, nt2, etab, esz - 1, emult);
                 if (coherent && !cx_debug_knob("CX_LINK_ONE_STEP", 0)) {
