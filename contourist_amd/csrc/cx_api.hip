@@ -237,6 +237,11 @@ int cx_ensure_hash_xy(cx_ctx* ctx, uint32_t flags) {
 // the value-dependent fields of one extraction
 void cx_fill_value_params(cx_params& P, double value) {
     P.vcmp = fp32_threshold(value);
+    // The stream kernel takes "f < vcmp" from the SIGN BIT of f - vcmp.  With vcmp == +0.0 a sample of -0.0 gives -0.0 - 0.0 = -0.0:
+    // sign bit set, "below the isovalue" -- where the reference's (and every other kernel's) comparison -0.0 < 0.0 is false; a volume
+    // holding negative zeros (np.round of small negative numbers) then got inconsistent meshes at isovalue 0 (found by tools/fuzz_gpu.py,
+    // round 4: present since round 1).  As -0.0 the threshold compares the same and subtracts right: (+-0.0) - (-0.0) = +0.0.
+    if (P.vcmp == 0.0f) P.vcmp = -0.0f;
     // |f-v| <= 1e-8 + 1e-5*max(|f|,|v|)  =>  |f - vcmp| <= 2.2e-5*|v| + 4e-8  (vcmp within 1 ulp of v)
     P.near_abs = std::nextafterf((float)(2.2e-5 * std::fabs(value) + 4e-8), INFINITY);
     P.vhi = (float)value;

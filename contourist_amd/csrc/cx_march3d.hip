@@ -868,8 +868,9 @@ __device__ __forceinline__ void cx_stream_tile(const cx_params& P, const cx_task
                 R.hv[r] = A[rowofs + (halo_in ? k0 + 256u : 0u)];                    // wave-uniform address
             }
         };
-        // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0; NaN samples
-        // are not supported); the same differences feed the tolerance screen (smallest |f - vcmp| seen)
+        // sign bits of a loaded plane.  f < vcmp  <=>  sign bit of (f - vcmp)  (f == vcmp gives +0 -- also for f = -0.0 at isovalue 0:
+        // the host passes that threshold as -0.0, cx_fill_value_params; NaN samples are not supported); the same differences feed the
+        // tolerance screen (smallest |f - vcmp| seen)
         float (*ring)[CX_RJ + 1][CX_PLW] = reinterpret_cast<float (*)[CX_RJ + 1][CX_PLW]>(s_pl_dyn + (size_t)wave * (2u * (CX_RJ + 1u) * CX_PLW));
         const bool stage_t = P.tq != nullptr;      // wave-uniform: this extraction hands fractions on (else the vertex stage gathers samples)
 #ifdef CX_FORCE_RING      // experiment: what the staging of the planes costs by itself

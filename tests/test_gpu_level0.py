@@ -257,3 +257,23 @@ def test_fraction_stream():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert [ln for ln in r.stdout.splitlines() if ln.startswith("ENTRY_KERNEL_OK")], r.stdout[-2000:]
+
+
+def test_negative_zero_samples_at_isovalue_zero(ctx):
+    """samples of -0.0 (np.round of small negative numbers) at isovalue 0.0: `-0.0 < 0.0` is false in the reference (and in the
+    oracle), so such a sample is NOT below the isovalue -- the stream kernel reads the comparison off the sign bit of f - v and has to
+    get this case right (found by tools/fuzz_gpu.py: inconsistent meshes, indices out of range).  Every kernel path, both diagonal
+    modes; the fields hold 5-12 % zeros of either sign."""
+    from contourist_amd import _ffi
+    rng = np.random.RandomState(2024)
+    for shape in ((5, 10, 17), (23, 14, 4), (12, 23, 5), (33, 20, 70), (40, 27, 300)):
+        A = rng.standard_normal(shape)
+        for _ in range(2):
+            for ax in range(3):
+                A = 0.25 * np.roll(A, 1, ax) + 0.5 * A + 0.25 * np.roll(A, -1, ax)
+        A = (np.round(A / A.std() * 4) / 4).astype(np.float32)
+        assert np.any(np.signbit(A) & (A == 0)) and np.any(~np.signbit(A) & (A == 0))
+        for extra in (0, _ffi.CX_KERNEL_STAGED, _ffi.CX_KERNEL_TILED, _ffi.CX_KERNEL_FUSED, _ffi.CX_KERNEL_GENERIC):
+            check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CPYTHON310 | extra, 1)
+        check_against_oracle(ctx, A, 0.0, _ffi.CX_DIAG_CANONICAL, 0)
+        check_against_oracle(ctx, A, -0.0, _ffi.CX_DIAG_CPYTHON310, 1)
