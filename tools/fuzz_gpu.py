@@ -33,11 +33,32 @@ while time.time() - t0 < budget:
     extra = int(rng.choice([0, _ffi.CX_KERNEL_TILED, _ffi.CX_KERNEL_STAGED, _ffi.CX_KERNEL_FUSED]))
     if shape[2] < 4:
         extra = 0
+    origin = tuple(int(x) for x in rng.randint(0, 700, size=3)) if rng.rand() < 0.3 else ((-1, -1, -1) if rng.rand() < 0.1 else (0, 0, 0))
+    ctx.set_origin(*origin)
     ctx.upload_grid(A)
+    if shape[2] >= 4 and rng.rand() < 0.15:
+        # several isovalues in one call (cx_extract3d_levels): every level against the oracle
+        vals = sorted(set([v] + [float(np.float32(x)) for x in rng.uniform(-1.0, 1.0, size=int(rng.randint(1, 4)))]))
+        cs = ctx.extract3d_levels(vals, diag)
+        for li, lv in enumerate(vals):
+            ctx.select_level(li)
+            xyz, keys, tris = ctx.download_level0(cs[li])
+            O = level0.march3d(A, lv, diag_mode=diag, origin=origin)
+            ko = level0.edge_keys_from_pairs(O["pairs"], shape)
+            co = level0.canonical_level0(ko, O["xyz"], O["tris"])
+            ok = len(keys) == len(ko) and len(tris) == len(O["tris"]) and (len(tris) == 0 or (tris.min() >= 0 and tris.max() < len(keys)))
+            if ok:
+                ch = level0.canonical_level0(keys.astype(np.int64), xyz, tris.astype(np.int64))
+                ok = np.array_equal(co[0], ch[0]) and np.array_equal(co[2], ch[2])
+            ncase += 1; ntri += len(tris); paths["levels"] = paths.get("levels", 0) + 1
+            if not ok:
+                nbad += 1
+                print("MISMATCH (levels) shape", shape, "values", vals, "level", li, "diag", diag, "origin", origin, cs[li], len(ko), len(O["tris"]), flush=True)
+        continue
     c = ctx.extract3d(v, diag | extra)
     p = ctx.level0_path(); paths[p] = paths.get(p, 0) + 1
     xyz, keys, tris = ctx.download_level0(c)
-    O = level0.march3d(A, v, diag_mode=diag)
+    O = level0.march3d(A, v, diag_mode=diag, origin=origin)
     ko = level0.edge_keys_from_pairs(O["pairs"], shape)
     co = level0.canonical_level0(ko, O["xyz"], O["tris"])
     if len(tris) and (tris.min() < 0 or tris.max() >= len(keys)):
@@ -51,7 +72,7 @@ while time.time() - t0 < budget:
     ncase += 1; ntri += len(tris)
     if not ok:
         nbad += 1
-        print("MISMATCH shape", shape, "v", v, "diag", diag, "extra", hex(extra), "path", p, c, len(ko), len(O["tris"]), flush=True)
+        print("MISMATCH shape", shape, "v", v, "diag", diag, "extra", hex(extra), "origin", origin, "path", p, c, len(ko), len(O["tris"]), flush=True)
 ctx.close()
-print("fuzz: %d cases, %d triangles, %d mismatches, kernels by path %s, %.0f s" % (ncase, ntri, nbad, dict(sorted(paths.items())), time.time() - t0))
+print("fuzz: %d cases, %d triangles, %d mismatches, kernels by path %s, %.0f s" % (ncase, ntri, nbad, dict(sorted(paths.items(), key=str)), time.time() - t0))
 sys.exit(1 if nbad else 0)
