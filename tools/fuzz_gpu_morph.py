@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised 4-D post-pass parity on the GPU: bin_times / drop_instant / tiny collapse (B3), morph triangles (B4: segments with
+direction, triangles as sets of segments) and the time-compatible windings (B5) of random small 4-D fields against
+oracle/postpass4d.py.  python tools/fuzz_gpu_morph.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from contourist_amd import pentatopes
+from oracle import level0_4d, postpass4d
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
+t0 = time.time(); ncase = 0; nbad = 0; nmt = 0; npatch = 0; nflip = 0; nbreak = 0; nbad_o = 0
+while time.time() - t0 < budget:
+    shape = tuple(int(x) for x in rng.randint(5, 13, size=4))
+    A = rng.standard_normal(shape)
+    for _ in range(int(rng.randint(1, 5))):
+        for ax in range(4):
+            A = 0.25 * np.roll(A, 1, ax) + 0.5 * A + 0.25 * np.roll(A, -1, ax)
+    A = (A / max(A.std(), 1e-9)).astype(np.float32)
+    if rng.rand() < 0.2:
+        A = (np.round(A * 4) / 4).astype(np.float32)
+    if rng.rand() < 0.6:
+        fill = np.float32(A.min() - 1.0)
+        for ax in range(4):
+            for idx in (0, -1):
+                np.moveaxis(A, ax, 0)[idx] = fill
+    A = np.ascontiguousarray(A)
+    v = float(np.float32(rng.choice([0.0, 0.25, float(np.round(rng.uniform(-0.8, 0.8), 3))])))
+    corner = np.array(shape) - 1
+    maker = pentatopes.GridContour4D(tuple(corner), A, v)
+    R = maker.find_tetrahedra()
+    O = level0_4d.march4d(A, v, diag_mode=1)
+    ncase += 1
+    if len(O["tets"]) == 0:
+        continue
+    ko = level0_4d.edge_keys4(O["pairs"], shape)
+    W = postpass4d.find_tetrahedra_post(ko, O["xyzt"], O["tets"], corner)
+    kh = R["keys"].astype(np.int64)
+    why = None
+    if not (R["counts"]["n_after_drop"] == W["n_after_drop"] and R["counts"]["n_after_tiny"] == W["n_after_tiny"]):
+        why = "counts after drop / tiny"
+    elif not np.array_equal(R["points4d"][np.argsort(kh)], W["xyzt"][np.argsort(ko)]):
+        why = "points"
+    elif not np.array_equal(level0_4d.canonical4(kh, R["points4d"], R["tetrahedra"].astype(np.int64))[2], level0_4d.canonical4(ko, W["xyzt"], W["tets"])[2]):
+        why = "tetrahedra"
+    if why is None and W["n_after_tiny"] > 0:
+        MT = maker.collect_morph_triangles()
+        M = postpass4d.collect_morph_triangles(ko, W["xyzt"], W["tets"])
+        got_seg = set((int(kh[i]), int(kh[j])) for i, j in MT.segment_point_indices)
+        want_seg = set((int(M["keys"][i]), int(M["keys"][j])) for i, j in M["segments"])
+        if got_seg != want_seg:
+            why = "segments"
+        elif len(MT.triangle_segment_indices) != len(M["triangles"]):
+            why = "morph triangle count"
+        elif len(M["triangles"]):
+            ot, label, flags = postpass4d.orient_morph_triangles(M)
+            common, agree = postpass4d.winding_agreement(kh, MT.segment_point_indices, MT.triangle_segment_indices, M["keys"], M["segments"], ot)
+            if common != len(ot):
+                why = "morph triangles (sets)"
+            elif agree != common:
+                # two consistent windings may differ by whole patches bounded by segments with three or more triangles, by time-incompatible
+                # pairs or by the rim (the reference's flood fill decides those by its traversal order): what must NOT happen is a forced
+                # break -- a manifold, time-compatible segment whose two triangles differ in their agreement
+                X = postpass4d.winding_excuses(kh, MT.segment_point_indices, MT.triangle_segment_indices, M["keys"], M["segments"], ot, M["points4d"])
+                npatch += len(X["patches"]); nflip += common - agree
+                if X["forced_breaks"]:
+                    # ... on ONE side: the flood fill itself ends inconsistent where it reaches a triangle along two paths of opposite
+                    # parity (rough fields, non-orientable patches).  Whose error it is shows in each side's own forced pairs.
+                    bad_o, seen_o = postpass4d.forced_pair_violations(M["keys"], M["segments"], ot, M["points4d"])
+                    bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
+                    nbreak += X["forced_breaks"]; nbad_o += bad_o
+                    # (reported, not failed: on rough fields both sides come out with all their forced pairs consistent and still a handful of
+                    # such segments -- morph triangles with the same three segments fall on one key in winding_excuses' matching)
+                    if bad_d:
+                        why = "windings: %d forced breaks (%d of %d agree); inconsistent forced pairs: device %d, oracle %d" % (X["forced_breaks"], agree, common, bad_d, bad_o)
+            if why is None:
+                bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
+                if bad_d:
+                    why = "%d of %d forced pairs run their segment in the same direction" % (bad_d, seen_d)
+            nmt += len(ot)
+    if why:
+        nbad += 1
+        print("MISMATCH", why, "shape", shape, "v", v, R["counts"], flush=True)
+print("fuzz 4-D post-pass: %d cases, %d morph triangles, %d mismatches (%d triangles in %d patches wound the other way than the oracle's traversal; %d segments counted as forced breaks by winding_excuses, inconsistent forced pairs of the oracle's own flood fill: %d), %.0f s"
+      % (ncase, nmt, nbad, nflip, npatch, nbreak, nbad_o, time.time() - t0))
+sys.exit(1 if nbad else 0)
