@@ -54,15 +54,18 @@ struct cx_post_state {
         uint32_t n1 = 0, n4 = 0, ncand = 0;   // own triangles next to the lower neighbour, copies of the upper neighbour's, open components
     } shard;
     cxp_dev mpairs, msegs, mtris, mmid, mtime, mnext;   // morph triangles (4-D)
-    cxp_dev morder;                                     // morph triangles sorted by the bin of their start time (u32 ids), for cx_morph_eval
-    cxp_dev meflags;                                    // cx_morph_eval's own flag bytes (segments | triangles): all zero between two calls
-    size_t meflags_zero_for = 0;                        // ns + nt the zeroed state was set up for (0: not yet)
-    uint32_t mbin_start[1025] = {0};                    // first position in morder of every bin (CXP_ME_BINS + 1 entries)
-    double mt_lo = 0.0, mt_hi = 0.0, mt_maxdur = 0.0;   // range of the start times, longest life of a triangle
-    bool morder_valid = false;
+    // The morph triangles and their segments are kept SORTED by the bin of their start time (cxp_morph_sort_by_start, the last step of
+    // cx_morph_triangles): the triangles that exist at a time t are then a window of ids, and so are their segments.
+    cxp_dev msegs2, mtris2, mtime2;                     // the other halves of the double buffers the sort writes into
+    cxp_dev meflags, metflag, menew, mecnt, medesc, me_pts, me_tri;   // cx_morph_eval_many: segment flag bytes (ALL zero between two calls) / triangle flag bytes / new point ids / block counts of the windows, per-time descriptors, outputs
+    bool meflags_clean = false;                         // the segment flag bytes are all zero (the kernels that consume a flag clear it)
+    uint32_t mbin_t[257] = {0}, mbin_s[257] = {0};      // first triangle / segment of every start-time bin (CXP_SB_BINS + 1 entries)
+    double mt_lo = 0.0, mt_width = 1.0;                 // the bins: bin(x) = (x - mt_lo) / mt_width, clamped
+    double mt_maxdur = 0.0, ms_maxdur = 0.0;            // longest life of a triangle / a segment
+    bool msorted = false;
+    std::vector<int64_t> me_off;                        // last cx_morph_eval_many: per time {first point, points, first triangle, triangles}
     int64_t nv_out = 0, nt_out = 0;
     int64_t ms_out = 0, mt_out = 0;
-    int64_t me_points = 0, me_tris = 0;   // last cx_morph_eval
 };
 
 static int cxp_reserve(cx_ctx* ctx, cxp_dev& d, size_t bytes) {
@@ -80,7 +83,8 @@ void cx_post_free(cx_ctx* ctx) {
     cxp_dev* all[] = {&S->pts, &S->prio, &S->rep, &S->tri, &S->alive, &S->parent, &S->parent2, &S->tkeys, &S->tvals,
                       &S->flags, &S->scan, &S->blocksums, &S->pts_out, &S->tri_out, &S->comp, &S->misc,
                       &S->keys_out, &S->keys_tmp, &S->told, &S->cls, &S->bnd, &S->ever,
-                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->morder, &S->meflags};
+                      &S->mpairs, &S->msegs, &S->mtris, &S->mmid, &S->mtime, &S->mnext, &S->msegs2, &S->mtris2, &S->mtime2,
+                      &S->meflags, &S->metflag, &S->menew, &S->mecnt, &S->medesc, &S->me_pts, &S->me_tri};
     for (cxp_dev* d : all)
         if (d->p) (void)hipFree(d->p);
     delete S;
@@ -1466,7 +1470,7 @@ static int cxp_state(cx_ctx* ctx, cx_post_state** out) {
     if (!ctx->post) ctx->post = new (std::nothrow) cx_post_state();
     if (!ctx->post) return CX_ERR_NOMEM;
     *out = ctx->post;
-    return cxp_reserve(ctx, ctx->post->misc, 64 * sizeof(uint32_t));
+    return cxp_reserve(ctx, ctx->post->misc, 512 * sizeof(uint32_t));      // (words 32..288: bin starts of the start-time sort)
 }
 
 // ---- smooth_interpolations(factor) (tetrahedral.py:329-351): every vertex that is part of a triangle moves by
@@ -2598,6 +2602,7 @@ __global__ void cxp_k_edge_union_compat(uint32_t nt, const uint32_t* next, const
 }
 
 
+static int cxp_morph_sort_by_start(cx_ctx* ctx, cx_post_state* S, uint32_t nseg, uint32_t ntri, const u64* mm_host);
 extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
     if (!ctx) return CX_ERR_INVALID;
     cx_state4* G = ctx->s4;
@@ -2613,7 +2618,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
     u64* mm = (u64*)(misc + 16);
     int rc;
     int64_t counts[8] = {nv, 0, 0, 0, 0, 0, 0, 0};
-    S->ms_out = 0; S->mt_out = 0;
+    S->ms_out = 0; S->mt_out = 0; S->msorted = false;
     if (nv && nt) {
         const u64 init[2] = {~0ULL, 0ULL};
         CXP_HIP(ctx, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -2669,7 +2674,6 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             int32_t* tris = (int32_t*)S->mtris.p;
             hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
             hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, smult, stime, mm, tris, ttime);
-            S->morder_valid = false;     // the index by start time is built by the first cx_morph_eval of these triangles
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
             const u64 esz = cxp_edge_table_size((size_t)ntri * 3);
@@ -2721,6 +2725,12 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
         u64 h[2];
         CXP_HIP(ctx, hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, st));
         CXP_HIP(ctx, hipStreamSynchronize(st));
+        // segments and triangles sorted by the bin of their start time: the surface at a time t is then a window of ids (cx_morph_eval_many)
+        S->me_off.clear();
+        if (S->ms_out && S->mt_out && (rc = cxp_morph_sort_by_start(ctx, S, (uint32_t)S->ms_out, (uint32_t)S->mt_out, h))) {
+            S->ms_out = 0; S->mt_out = 0;
+            return rc;
+        }
         memcpy(&counts[5], &h[0], 8); memcpy(&counts[6], &h[1], 8);   // orderable encodings, decoded by the host side
     }
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
@@ -2738,95 +2748,244 @@ extern "C" int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segm
     return cx_copy_to_host(ctx, 3, d, sp, nb);
 }
 
-// ---- B6: the surface at time t from the morph triangles (misc/morph_triangles.js:26-140; MorphTriangles.triangles_at):
-// a triangle is visible while t lies inside the intervals of all three of its segments; its corners are the
-// points of its segments at t (linear interpolation, low t -> high t).  Points and triangles are compacted in index
-// order (the order numpy.unique / boolean indexing give on the host).
-__device__ __forceinline__ bool cxp_seg_inside(const double* P4, const int32_t* segs, uint32_t s, double t) {
-    const double lo = P4[(size_t)segs[(size_t)s * 2] * 4 + 3], hi = P4[(size_t)segs[(size_t)s * 2 + 1] * 4 + 3];
-    return lo <= t && t <= hi;
-}
-// (a triangle is visible while all three of its segments exist: lo <= t <= hi with the intersection of their ranges, which
-// cxp_k_tri_segments left per triangle -- 16 bytes read in order instead of 12 gathers through segments and points per triangle)
+// ---- stable sort of the morph triangles and their segments by the bin of their start time ----------------------------------------
+// (the last step of cx_morph_triangles).  A morph triangle lives for a layer or two of the time axis, and ids follow the march, whose
+// fastest axis is time: in id order the triangles that exist at one t are spread over ALL ids (nearly every block of 1 024 consecutive
+// triangles exists at every t), and rounds 1-4 walked flag arrays as long as all triangles and all segments for every surface.  Sorted
+// by start-time bin -- CXP_SB_BINS bins over the time range of all points, ids keeping their order inside a bin (stable: the
+// neighbourhood the march gives the ids survives inside a time layer) -- the triangles that exist at t start inside the window of
+// bins [bin(t - longest life) - 1, bin(t) + 1], a contiguous range of ids, and so do the segments they use.  The arrays the caller
+// downloads (cx_morph_download) are the sorted ones: the order of morph triangles carries no meaning in the reference (a Python list
+// filled from a dict, pentatopes.py:314-368), and the host-side MorphTriangles.triangles_at of the mirrored class sees the same order.
 //
-// Ordered compaction without materialised scans: flags are bytes, a workgroup covers CXP_SCAN_BLOCK consecutive elements and counts
-// its flags (first pass), one workgroup turns the block counts into offsets, and the consumer kernels redo the scan INSIDE their
-// block while they write (second pass).  (Until round 3: two full exclusive scans per call -- each three kernels that read and
-// write 4 bytes per element twice -- 15 of the 27 ms of the 64 surfaces of config 4.)
-// An index of the morph triangles by START TIME (once, in cx_morph_triangles): bins of equal width over the range of the start times,
-// the triangle ids of a bin next to each other in `order`.  A triangle lives for a layer or two of the 64, so the triangles that exist at
-// a time t start inside a narrow window of bins -- [bin(t - longest life) - 1, bin(t) + 1] -- and cx_morph_eval tests only those (ids
-// follow the march, whose fastest axis is time: in id order nearly every block of 1 024 triangles exists at every t).
-#define CXP_ME_BINS 1024u
-__device__ __forceinline__ uint32_t cxp_me_bin(double x, double lo, double inv_width) {
+// Counting sort with no atomics: a wave takes CXP_SB_UNIT consecutive elements, counts them per bin in LDS (lanes of one bin add up
+// among themselves: neighbouring triangles start at the same few times) and leaves the non-zero counts in a [bin][unit] matrix; an
+// exclusive scan of that matrix in memory order is the position of every (bin, unit)'s first element; a second walk hands out ranks.
+#define CXP_SB_BINS 256u
+#define CXP_SB_UNIT 1024u
+__device__ __forceinline__ uint32_t cxp_sb_bin(double x, double lo, double inv_width) {
     const double b = (x - lo) * inv_width;
-    return b <= 0.0 ? 0u : (b >= (double)(CXP_ME_BINS - 1u) ? CXP_ME_BINS - 1u : (uint32_t)b);
+    return b <= 0.0 ? 0u : (b >= (double)(CXP_SB_BINS - 1u) ? CXP_SB_BINS - 1u : (uint32_t)b);
 }
-// (neighbouring triangles start at the same few times: the lanes of a wave that share a bin add up among themselves and issue ONE
-// atomic per bin -- one per lane meant 25 M read-modify-writes on some 64 addresses)
-__global__ __launch_bounds__(256) void cxp_k_me_hist(const double* ttime, uint32_t nt, double lo, double inv_width, uint32_t* hist, u64* maxdur) {
-    __shared__ uint32_t h[CXP_ME_BINS];
-    for (uint32_t x = threadIdx.x; x < CXP_ME_BINS; x += 256u) h[x] = 0;
+// range = {start, end} per element (16 bytes, in order)
+__global__ __launch_bounds__(256) void cxp_k_sb_hist(const double* range, uint32_t n, double lo, double inv_width, uint8_t* bins, uint32_t* counts,
+                                                     uint32_t nunits, u64* maxdur) {
+    __shared__ uint32_t h[4][CXP_SB_BINS];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (uint32_t x = lane; x < CXP_SB_BINS; x += 64u) h[w][x] = 0;
     __syncthreads();
+    const uint32_t unit = blockIdx.x * 4u + w;
     double dur = 0.0;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t q0 = (blockIdx.x * 256u + (threadIdx.x & ~63u)); q0 < nt; q0 += gridDim.x * 256u) {      // wave-uniform
-        const uint32_t q = q0 + lane;
-        const bool in = q < nt;
+    for (uint32_t r = 0; r < CXP_SB_UNIT / 64u; r++) {
+        const size_t q = (size_t)unit * CXP_SB_UNIT + r * 64u + lane;
+        const bool in = q < n;
         uint32_t bin = 0;
         if (in) {
-            const double a = ttime[(size_t)q * 2], b = ttime[(size_t)q * 2 + 1];
-            bin = cxp_me_bin(a, lo, inv_width);
-            dur = fmax(dur, b - a);
+            const double2 ab = *reinterpret_cast<const double2*>(range + q * 2);
+            bin = cxp_sb_bin(ab.x, lo, inv_width);
+            dur = fmax(dur, ab.y - ab.x);
+            bins[q] = (uint8_t)bin;
         }
         uint64_t todo = __ballot(in);
-        while (todo) {
+        while (todo) {      // wave-uniform: one round per bin present among the 64
             const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
             const uint32_t bb = (uint32_t)__shfl((int)bin, (int)leader);
             const uint64_t same = __ballot(in && bin == bb) & todo;
-            if (lane == leader) atomicAdd(&h[bb], (uint32_t)__popcll(same));
+            if (lane == leader) h[w][bb] += (uint32_t)__popcll(same);
             todo &= ~same;
         }
     }
+    __syncthreads();
+    if (unit < nunits)
+        for (uint32_t x = lane; x < CXP_SB_BINS; x += 64u)
+            if (h[w][x]) counts[(size_t)x * nunits + unit] = h[w][x];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dur = fmax(dur, __shfl_xor(dur, o));
-    if (lane == 0) cxp_max64(maxdur, cxp_orderable(dur));
-    __syncthreads();
-    for (uint32_t x = threadIdx.x; x < CXP_ME_BINS; x += 256u)
-        if (h[x]) atomicAdd(&hist[x], h[x]);
+    if (lane == 0 && dur > 0.0) cxp_max64(maxdur, cxp_orderable(dur));
 }
-__global__ __launch_bounds__(256) void cxp_k_me_scatter(const double* ttime, uint32_t nt, double lo, double inv_width, uint32_t* cursor, uint32_t* order) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool in = q < nt;
-    const uint32_t bin = in ? cxp_me_bin(ttime[(size_t)q * 2], lo, inv_width) : 0u;
-    uint64_t todo = __ballot(in);
-    while (todo) {      // wave-uniform: one reservation per bin present in the wave (ids keep their order inside the reservation)
-        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-        const uint32_t bb = (uint32_t)__shfl((int)bin, (int)leader);
-        const uint64_t same = __ballot(in && bin == bb) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[bb], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, (int)leader);
-        if (in && bin == bb) order[base + (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL))] = q;
-        todo &= ~same;
+__global__ __launch_bounds__(256) void cxp_k_sb_rank(const uint8_t* bins, uint32_t n, const uint32_t* offs, uint32_t nunits, uint32_t* rank) {
+    __shared__ uint32_t h[4][CXP_SB_BINS];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (uint32_t x = lane; x < CXP_SB_BINS; x += 64u) h[w][x] = 0;
+    __syncthreads();
+    const uint32_t unit = blockIdx.x * 4u + w;
+    uint32_t mine[CXP_SB_UNIT / 64u];
+#pragma unroll
+    for (uint32_t r = 0; r < CXP_SB_UNIT / 64u; r++) {
+        const size_t q = (size_t)unit * CXP_SB_UNIT + r * 64u + lane;
+        mine[r] = q < n ? (uint32_t)bins[q] : 0xFFFFFFFFu;
+    }
+    // which bins the unit holds (their cursors are the only ones loaded: a unit of neighbouring ids holds a few)
+#pragma unroll
+    for (uint32_t r = 0; r < CXP_SB_UNIT / 64u; r++) {
+        const bool in = mine[r] != 0xFFFFFFFFu;
+        uint64_t todo = __ballot(in);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t bb = (uint32_t)__shfl((int)mine[r], (int)leader);
+            const uint64_t same = __ballot(in && mine[r] == bb) & todo;
+            if (lane == leader) h[w][bb] = 1u;
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    if (unit < nunits)
+        for (uint32_t x = lane; x < CXP_SB_BINS; x += 64u)
+            if (h[w][x]) h[w][x] = offs[(size_t)x * nunits + unit];
+    __syncthreads();
+    volatile uint32_t* cur = h[w];
+#pragma unroll
+    for (uint32_t r = 0; r < CXP_SB_UNIT / 64u; r++) {
+        const bool in = mine[r] != 0xFFFFFFFFu;
+        uint64_t todo = __ballot(in);
+        uint32_t my_rank = 0;
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t bb = (uint32_t)__shfl((int)mine[r], (int)leader);
+            const uint64_t same = __ballot(in && mine[r] == bb) & todo;
+            const uint32_t base = cur[bb];
+            if (in && mine[r] == bb) my_rank = base + (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) cur[bb] = base + (uint32_t)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        if (in) rank[(size_t)unit * CXP_SB_UNIT + r * 64u + lane] = my_rank;
     }
 }
-// the triangles of the window that exist at t: their flags (bytes, zeroed before) and the flags of their segments
-__global__ void cxp_k_me_visible(const double* ttime, const int32_t* tris, const uint32_t* order, uint32_t first, uint32_t n, double t, uint8_t* tflag,
-                                 uint8_t* sused) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n) return;
-    const uint32_t q = order[first + x];
-    if (!(ttime[(size_t)q * 2] <= t && t <= ttime[(size_t)q * 2 + 1])) return;
-    const uint32_t a = (uint32_t)tris[(size_t)q * 3], b = (uint32_t)tris[(size_t)q * 3 + 1], c = (uint32_t)tris[(size_t)q * 3 + 2];
-    tflag[q] = 1;
-    sused[a] = 1; sused[b] = 1; sused[c] = 1;
+// first element of every bin (the scanned matrix at unit 0) + the total
+__global__ void cxp_k_sb_starts(const uint32_t* offs, uint32_t nunits, uint32_t n, uint32_t* out) {
+    const uint32_t b = threadIdx.x;
+    if (b < CXP_SB_BINS) out[b] = offs[(size_t)b * nunits];
+    if (b == CXP_SB_BINS) out[b] = n;
 }
-// The per-t surface walks flag arrays as long as ALL morph triangles / segments (25 M / 19 M on config 4) for a surface of 0.3 M: its
-// workgroups cover CXP_ME_BLOCK = 4096 flags (16 per thread, one 16-byte load) -- with 1024 per workgroup the 24 k workgroups of a launch cost
-// 25-30 us although nine in ten left at once, and the scan of their counts another 25.
+__global__ void cxp_k_sb_move_segs(const int32_t* segs, const double* stime, uint32_t ns, const uint32_t* rank, int32_t* segs2, double* stime2) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    const int2 ab = *reinterpret_cast<const int2*>(segs + (size_t)s * 2);
+    const double2 tt = *reinterpret_cast<const double2*>(stime + (size_t)s * 2);
+    const uint32_t r = rank[s];
+    *reinterpret_cast<int2*>(segs2 + (size_t)r * 2) = ab;
+    *reinterpret_cast<double2*>(stime2 + (size_t)r * 2) = tt;
+}
+__global__ void cxp_k_sb_move_tris(const int32_t* tris, const double* ttime, uint32_t nt, const uint32_t* rank_t, const uint32_t* rank_s, int32_t* tris2,
+                                   double* ttime2) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nt) return;
+    const uint32_t a = (uint32_t)tris[(size_t)q * 3], b = (uint32_t)tris[(size_t)q * 3 + 1], c = (uint32_t)tris[(size_t)q * 3 + 2];
+    const double2 tt = *reinterpret_cast<const double2*>(ttime + (size_t)q * 2);
+    const uint32_t r = rank_t[q];
+    const uint32_t na = rank_s[a], nb = rank_s[b], nc = rank_s[c];
+    tris2[(size_t)r * 3] = (int32_t)na; tris2[(size_t)r * 3 + 1] = (int32_t)nb; tris2[(size_t)r * 3 + 2] = (int32_t)nc;
+    *reinterpret_cast<double2*>(ttime2 + (size_t)r * 2) = tt;
+}
+static inline double cxp_host_from_orderable(u64 o) {
+    const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+// ranks of n elements by the bin of range[2 q]; bin starts (CXP_SB_BINS + 1) and the longest range[2 q + 1] - range[2 q] to the host.
+// Scratch: S->mnext (bins), S->flags (count matrix), S->scan (its scan), S->misc + 32.. (starts), S->misc + 20 (longest life).
+static int cxp_sb_ranks(cx_ctx* ctx, cx_post_state* S, const double* range, uint32_t n, double lo, double inv_width, uint32_t* rank,
+                        uint32_t* starts_host, double* maxdur_host) {
+    int rc;
+    hipStream_t st = ctx->stream;
+    const uint32_t nunits = cxp_blocks(n, CXP_SB_UNIT);
+    const size_t cells = (size_t)CXP_SB_BINS * nunits;
+    if (cells >= 0xFFFFFFFFull) { ctx->err = "cx_morph_triangles: too many morph triangles for the start-time sort"; return CX_ERR_INVALID; }
+    if ((rc = cxp_reserve(ctx, S->mnext, (size_t)n + 64))) return rc;
+    if ((rc = cxp_reserve(ctx, S->flags, (cells + 16) * sizeof(uint32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->scan, (cells + 16) * sizeof(uint32_t)))) return rc;
+    uint8_t* bins = (uint8_t*)S->mnext.p;
+    uint32_t* counts = (uint32_t*)S->flags.p;
+    uint32_t* offs = (uint32_t*)S->scan.p;
+    uint32_t* misc = (uint32_t*)S->misc.p;
+    u64* maxdur = (u64*)(misc + 20);
+    CXP_HIP(ctx, hipMemsetAsync(counts, 0, cells * sizeof(uint32_t), st));
+    CXP_HIP(ctx, hipMemsetAsync(maxdur, 0, sizeof(u64), st));
+    const uint32_t nblocks = cxp_blocks(nunits, 4);
+    hipLaunchKernelGGL(cxp_k_sb_hist, dim3(nblocks), dim3(256), 0, st, range, n, lo, inv_width, bins, counts, nunits, maxdur);
+    if ((rc = cxp_scan(ctx, S, counts, offs, (uint32_t)cells, misc + 22))) return rc;
+    hipLaunchKernelGGL(cxp_k_sb_rank, dim3(nblocks), dim3(256), 0, st, (const uint8_t*)bins, n, (const uint32_t*)offs, nunits, rank);
+    hipLaunchKernelGGL(cxp_k_sb_starts, dim3(1), dim3(512), 0, st, (const uint32_t*)offs, nunits, n, misc + 32);
+    u64 md = 0;
+    CXP_HIP(ctx, hipMemcpyAsync(starts_host, misc + 32, (CXP_SB_BINS + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipMemcpyAsync(&md, maxdur, sizeof(md), hipMemcpyDeviceToHost, st));
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    CXP_HIP(ctx, hipGetLastError());
+    *maxdur_host = md ? cxp_host_from_orderable(md) : 0.0;
+    return CX_OK;
+}
+// mm_host = orderable min / max of the time of all points (S->misc + 16, read by the caller)
+static int cxp_morph_sort_by_start(cx_ctx* ctx, cx_post_state* S, uint32_t nseg, uint32_t ntri, const u64* mm_host) {
+    int rc;
+    hipStream_t st = ctx->stream;
+    S->msorted = false;
+    if (!nseg || !ntri) return CX_OK;
+    const double lo = cxp_host_from_orderable(mm_host[0]), hi = cxp_host_from_orderable(mm_host[1]);
+    const double inv_width = (hi > lo) ? (double)CXP_SB_BINS / (hi - lo) : 0.0;
+    if ((rc = cxp_reserve(ctx, S->msegs2, (size_t)(nseg + 1) * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->mtris2, (size_t)(ntri + 1) * 3 * sizeof(int32_t)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->mtime2, ((size_t)(nseg + 1) * 2 + (size_t)(ntri + 1) * 2) * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->parent, ((size_t)nseg + ntri + 64) * sizeof(uint32_t)))) return rc;
+    uint32_t* rank_s = (uint32_t*)S->parent.p;
+    uint32_t* rank_t = rank_s + nseg + 16;
+    const int32_t* segs = (const int32_t*)S->msegs.p;
+    const int32_t* tris = (const int32_t*)S->mtris.p;
+    const double* stime = (const double*)S->mtime.p;
+    const double* ttime = stime + (size_t)(nseg + 1) * 2;
+    double* stime2 = (double*)S->mtime2.p;
+    double* ttime2 = stime2 + (size_t)(nseg + 1) * 2;
+    if ((rc = cxp_sb_ranks(ctx, S, stime, nseg, lo, inv_width, rank_s, S->mbin_s, &S->ms_maxdur))) return rc;
+    if ((rc = cxp_sb_ranks(ctx, S, ttime, ntri, lo, inv_width, rank_t, S->mbin_t, &S->mt_maxdur))) return rc;
+    hipLaunchKernelGGL(cxp_k_sb_move_segs, dim3(cxp_blocks(nseg)), dim3(256), 0, st, segs, stime, nseg, (const uint32_t*)rank_s, (int32_t*)S->msegs2.p, stime2);
+    hipLaunchKernelGGL(cxp_k_sb_move_tris, dim3(cxp_blocks(ntri)), dim3(256), 0, st, tris, ttime, ntri, (const uint32_t*)rank_t, (const uint32_t*)rank_s,
+                       (int32_t*)S->mtris2.p, ttime2);
+    CXP_HIP(ctx, hipStreamSynchronize(st));
+    CXP_HIP(ctx, hipGetLastError());
+    std::swap(S->msegs, S->msegs2);
+    std::swap(S->mtris, S->mtris2);
+    std::swap(S->mtime, S->mtime2);
+    S->mt_lo = lo;
+    S->mt_width = (hi > lo) ? (hi - lo) / (double)CXP_SB_BINS : 1.0;
+    S->msorted = true;
+    return CX_OK;
+}
+
+// ---- B6: the surfaces at times t[0..n) from the morph triangles (misc/morph_triangles.js:26-140; MorphTriangles.triangles_at):
+// a triangle is visible while t lies inside the intervals of all three of its segments (lo <= t <= hi with the intersection of their
+// ranges, which cxp_k_tri_segments left per triangle); its corners are the points of its segments at t (linear interpolation, low t ->
+// high t).  Points and triangles of a surface are compacted in index order (the order numpy.unique / boolean indexing give on the host).
+//
+// ALL the times of a call go through ONE set of launches (config 4's per-t isosurface stream: 64 surfaces).  Time i tests the window of
+// triangle ids [tf, tf + tn) that can exist at t_i and flags inside the window of segment ids [sf, sf + sn) (see the sort above); the
+// windows of all times lie one behind the other in the flag arrays, each padded to whole blocks of CXP_ME_BLOCK flags, and a block finds
+// its time by bisection over the descriptors.  Ordered compaction without materialised scans: flags are bytes, a workgroup counts the
+// flags of its block (first pass), one workgroup per (time, kind) turns the block counts into offsets, and the consumer kernels redo the
+// scan INSIDE their block while they write.  The surfaces lie one behind the other in the two output arrays, tightly.
 #define CXP_ME_BLOCK 4096u
+struct cxp_me_desc {
+    double t;
+    uint32_t tf, tn, sf, sn;   // windows of triangle / segment ids
+    uint32_t tb0, sb0;         // first block of the time's triangle flags / segment flags (blocks of CXP_ME_BLOCK, all times one behind the other)
+};
+__device__ __forceinline__ uint32_t cxp_me_time_of_tblock(const cxp_me_desc* D, uint32_t nd, uint32_t blk) {
+    uint32_t lo = 0, hi = nd;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (D[mid].tb0 <= blk) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t cxp_me_time_of_sblock(const cxp_me_desc* D, uint32_t nd, uint32_t blk) {
+    uint32_t lo = 0, hi = nd;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (D[mid].sb0 <= blk) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 __device__ __forceinline__ uint32_t cxp_block_excl_t(uint32_t t, uint32_t* s, uint32_t& block_total) {   // exclusive prefix of one number per thread, 256 threads
     s[threadIdx.x] = t;
     __syncthreads();
@@ -2837,201 +2996,293 @@ __device__ __forceinline__ uint32_t cxp_block_excl_t(uint32_t t, uint32_t* s, ui
         __syncthreads();
     }
     block_total = s[255];
-    return s[threadIdx.x] - t;
+    const uint32_t r = s[threadIdx.x] - t;
+    __syncthreads();
+    return r;
 }
-// 16 flags (bytes, 0 / 1) of this thread as a bit mask
-__device__ __forceinline__ uint32_t cxp_flags16(const uint8_t* flags, uint32_t base, uint32_t n) {
+// 16 flags (bytes, 0 / 1) as a bit mask; p is 16-byte aligned and the 16 bytes exist (the windows are padded to whole blocks)
+__device__ __forceinline__ uint32_t cxp_flags16(const uint8_t* p) {
+    const uint4 w = *reinterpret_cast<const uint4*>(p);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
     uint32_t m = 0;
-    if (base + 15u < n) {
-        const uint4 w = *reinterpret_cast<const uint4*>(flags + base);     // base is a multiple of 16, the arrays are 64-byte aligned
-        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-            m |= (((ww[k] & 1u) | ((ww[k] >> 7) & 2u) | ((ww[k] >> 14) & 4u) | ((ww[k] >> 21) & 8u))) << (4u * k);
-    } else {
-        for (uint32_t k = 0; k < 16u && base + k < n; k++) m |= flags[base + k] ? (1u << k) : 0u;
-    }
+    for (uint32_t k = 0; k < 4; k++)
+        m |= (((ww[k] & 1u) | ((ww[k] >> 7) & 2u) | ((ww[k] >> 14) & 4u) | ((ww[k] >> 21) & 8u))) << (4u * k);
     return m;
 }
-// block counts of two flag arrays in one launch: workgroups [0, nba) the first, the rest the second
-__global__ __launch_bounds__(256) void cxp_k_me_count16(const uint8_t* fa, uint32_t na, uint32_t nba, uint32_t* ca, const uint8_t* fb, uint32_t nb, uint32_t* cb) {
+// the triangles of every window that exist at the window's time: a flag byte per window position (written for ALL positions of the
+// padded window: nothing to clear) and the flags of their segments (set only; cleared by the kernel that consumes them).
+// 16 workgroups of 256 per block of CXP_ME_BLOCK window positions.  err: a segment outside its window (cannot happen while the sort and
+// the windows agree; checked because the write would land in another time's flags)
+__global__ __launch_bounds__(256) void cxp_k_me_visible(const cxp_me_desc* D, uint32_t nd, const double* ttime, const int32_t* tris, uint8_t* tflag,
+                                                        uint8_t* sused, uint32_t* err) {
+    const uint32_t blk = blockIdx.x >> 4;
+    const uint32_t i = cxp_me_time_of_tblock(D, nd, blk);
+    const cxp_me_desc d = D[i];
+    const uint32_t in_blk = (blockIdx.x & 15u) * 256u + threadIdx.x;
+    const uint32_t x = (blk - d.tb0) * CXP_ME_BLOCK + in_blk;
+    bool vis = false;
+    if (x < d.tn) {
+        const size_t q = (size_t)d.tf + x;
+        const double2 r = *reinterpret_cast<const double2*>(ttime + q * 2);
+        vis = r.x <= d.t && d.t <= r.y;
+        if (vis) {
+            const uint32_t a = (uint32_t)tris[q * 3] - d.sf, b = (uint32_t)tris[q * 3 + 1] - d.sf, c = (uint32_t)tris[q * 3 + 2] - d.sf;
+            if (a < d.sn && b < d.sn && c < d.sn) {
+                uint8_t* su = sused + (size_t)d.sb0 * CXP_ME_BLOCK;
+                su[a] = 1; su[b] = 1; su[c] = 1;
+            } else {
+                vis = false;
+                *err = 1u;
+            }
+        }
+    }
+    tflag[(size_t)blk * CXP_ME_BLOCK + in_blk] = vis ? 1 : 0;
+}
+// block counts: workgroups [0, nsb) the segment flags, the rest the triangle flags
+__global__ __launch_bounds__(256) void cxp_k_me_count16(const uint8_t* sused, uint32_t nsb, const uint8_t* tflag, uint32_t* scnt, uint32_t* tcnt) {
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const bool second = blockIdx.x >= nba;
-    const uint32_t blk = second ? blockIdx.x - nba : blockIdx.x;
-    const uint8_t* flags = second ? fb : fa;
-    const uint32_t n = second ? nb : na;
-    uint32_t c = __popc(cxp_flags16(flags, blk * CXP_ME_BLOCK + threadIdx.x * 16u, n));
+    const bool second = blockIdx.x >= nsb;
+    const uint32_t blk = second ? blockIdx.x - nsb : blockIdx.x;
+    const uint8_t* flags = second ? tflag : sused;
+    uint32_t c = __popc(cxp_flags16(flags + (size_t)blk * CXP_ME_BLOCK + threadIdx.x * 16u));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
     if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
     __syncthreads();
-    if (threadIdx.x == 0) (second ? cb : ca)[blk] = s_n;
+    if (threadIdx.x == 0) (second ? tcnt : scnt)[blk] = s_n;
 }
-// (A block whose count is zero -- most of them at any one time -- leaves before it reads a flag: the block offsets are there already.)
-__global__ __launch_bounds__(256) void cxp_k_me_points(const double* P4, const int32_t* segs, uint32_t ns, double t, uint8_t* sused,
-                                                       const uint32_t* soff, const uint32_t* total, uint32_t* snew, double* out) {
+// one workgroup per (time, kind): its block counts -> exclusive offsets inside the time's surface (in place), the total -> totals[2 i + kind]
+__global__ __launch_bounds__(256) void cxp_k_me_offsets(const cxp_me_desc* D, uint32_t nd, uint32_t* scnt, uint32_t* tcnt, uint32_t* totals) {
     __shared__ uint32_t s[256];
-    if (((blockIdx.x + 1u < gridDim.x) ? soff[blockIdx.x + 1u] : *total) == soff[blockIdx.x]) return;
-    const uint32_t base = blockIdx.x * CXP_ME_BLOCK + threadIdx.x * 16u;
-    uint32_t m = cxp_flags16(sused, base, ns);
+    const uint32_t i = blockIdx.x >> 1, kind = blockIdx.x & 1u;
+    const cxp_me_desc d = D[i];
+    const uint32_t b0 = kind ? d.tb0 : d.sb0;
+    const uint32_t nb = (kind ? d.tn : d.sn) ? ((kind ? d.tn : d.sn) + CXP_ME_BLOCK - 1u) / CXP_ME_BLOCK : 0u;
+    uint32_t* cnt = (kind ? tcnt : scnt) + b0;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 256u) {     // block-uniform
+        const uint32_t k = base + threadIdx.x;
+        const uint32_t v = k < nb ? cnt[k] : 0u;
+        uint32_t tot;
+        const uint32_t e = cxp_block_excl_t(v, s, tot);
+        if (k < nb) cnt[k] = carry + e;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[2u * i + kind] = carry;
+}
+// exclusive prefix of the totals over the times, both kinds (one workgroup; 64-bit: the sums of many surfaces may pass 2^32)
+__global__ __launch_bounds__(256) void cxp_k_me_bases(const uint32_t* totals, uint32_t nd, u64* bases) {
+    __shared__ u64 sp[256], st[256];
+    u64 cp = 0, ct = 0;
+    for (uint32_t base = 0; base < nd; base += 256u) {
+        const uint32_t k = base + threadIdx.x;
+        const u64 vp = k < nd ? totals[2u * k] : 0ull, vt = k < nd ? totals[2u * k + 1u] : 0ull;
+        sp[threadIdx.x] = vp; st[threadIdx.x] = vt;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const u64 xp = (threadIdx.x >= o) ? sp[threadIdx.x - o] : 0ull, xt = (threadIdx.x >= o) ? st[threadIdx.x - o] : 0ull;
+            __syncthreads();
+            sp[threadIdx.x] += xp; st[threadIdx.x] += xt;
+            __syncthreads();
+        }
+        if (k < nd) { bases[2u * k] = cp + sp[threadIdx.x] - vp; bases[2u * k + 1u] = ct + st[threadIdx.x] - vt; }
+        cp += sp[255]; ct += st[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bases[2u * nd] = cp; bases[2u * nd + 1u] = ct; }
+}
+// (A block whose count is zero leaves before it reads a flag.)
+__global__ __launch_bounds__(256) void cxp_k_me_points(const cxp_me_desc* D, uint32_t nd, const double* P4, const int32_t* segs, uint8_t* sused,
+                                                       const uint32_t* soff, const uint32_t* totals, const u64* bases, uint32_t* snew, double* out) {
+    __shared__ uint32_t s[256];
+    const uint32_t blk = blockIdx.x;
+    const uint32_t i = cxp_me_time_of_sblock(D, nd, blk);
+    const cxp_me_desc d = D[i];
+    const uint32_t nb = (d.sn + CXP_ME_BLOCK - 1u) / CXP_ME_BLOCK;
+    const uint32_t rel = blk - d.sb0;
+    if (rel >= nb) return;
+    const uint32_t next = (rel + 1u < nb) ? soff[blk + 1u] : totals[2u * i];
+    if (next == soff[blk]) return;
+    const size_t fbase = (size_t)blk * CXP_ME_BLOCK + threadIdx.x * 16u;
+    uint32_t m = cxp_flags16(sused + fbase);
     uint32_t tot;
-    uint32_t id = soff[blockIdx.x] + cxp_block_excl_t(__popc(m), s, tot);
+    uint32_t id = soff[blk] + cxp_block_excl_t(__popc(m), s, tot);       // inside the surface
+    const u64 gbase = bases[2u * i];
+    const double t = d.t;
+    if (m) *reinterpret_cast<uint4*>(sused + fbase) = make_uint4(0u, 0u, 0u, 0u);      // (the flags are all zero again when the call ends)
     while (m) {
         const uint32_t k = __ffs(m) - 1u;
         m &= m - 1u;
-        const uint32_t sg = base + k;
-        sused[sg] = 0;            // (the flags are all zero again when the call ends: no 19 MB + 25 MB of memset per surface)
-        snew[sg] = id;
-        const double* a = P4 + (size_t)segs[(size_t)sg * 2] * 4;
-        const double* b = P4 + (size_t)segs[(size_t)sg * 2 + 1] * 4;
-        const double lo = a[3], hi = b[3];
+        const size_t sg = (size_t)d.sf + rel * CXP_ME_BLOCK + threadIdx.x * 16u + k;
+        snew[fbase + k] = id;
+        const int2 ab = *reinterpret_cast<const int2*>(segs + sg * 2);
+        const double* a = P4 + (size_t)ab.x * 4;
+        const double* b = P4 + (size_t)ab.y * 4;
+        const double ax = a[0], ay = a[1], az = a[2], lo = a[3], bx = b[0], by = b[1], bz = b[2], hi = b[3];
         const double lam = (hi > lo) ? (t - lo) / (hi - lo) : 0.0;
-        double* o = out + (size_t)id * 3;
-        o[0] = a[0] + lam * (b[0] - a[0]); o[1] = a[1] + lam * (b[1] - a[1]); o[2] = a[2] + lam * (b[2] - a[2]);
+        double* o = out + (size_t)(gbase + id) * 3;
+        o[0] = ax + lam * (bx - ax); o[1] = ay + lam * (by - ay); o[2] = az + lam * (bz - az);
         id++;
     }
 }
-__global__ __launch_bounds__(256) void cxp_k_me_tris(const int32_t* tris, uint32_t nt, uint8_t* tflag, const uint32_t* toff, const uint32_t* total,
-                                                     const uint32_t* snew, int32_t* out) {
+__global__ __launch_bounds__(256) void cxp_k_me_tris(const cxp_me_desc* D, uint32_t nd, const int32_t* tris, const uint8_t* tflag, const uint32_t* toff,
+                                                     const uint32_t* totals, const u64* bases, const uint32_t* snew, int32_t* out) {
     __shared__ uint32_t s[256];
-    if (((blockIdx.x + 1u < gridDim.x) ? toff[blockIdx.x + 1u] : *total) == toff[blockIdx.x]) return;
-    const uint32_t base = blockIdx.x * CXP_ME_BLOCK + threadIdx.x * 16u;
-    uint32_t m = cxp_flags16(tflag, base, nt);
+    const uint32_t blk = blockIdx.x;
+    const uint32_t i = cxp_me_time_of_tblock(D, nd, blk);
+    const cxp_me_desc d = D[i];
+    const uint32_t nb = (d.tn + CXP_ME_BLOCK - 1u) / CXP_ME_BLOCK;
+    const uint32_t rel = blk - d.tb0;
+    if (rel >= nb) return;
+    const uint32_t next = (rel + 1u < nb) ? toff[blk + 1u] : totals[2u * i + 1u];
+    if (next == toff[blk]) return;
+    const size_t fbase = (size_t)blk * CXP_ME_BLOCK + threadIdx.x * 16u;
+    uint32_t m = cxp_flags16(tflag + fbase);
     uint32_t tot;
-    uint32_t id = toff[blockIdx.x] + cxp_block_excl_t(__popc(m), s, tot);
+    uint32_t id = toff[blk] + cxp_block_excl_t(__popc(m), s, tot);
+    const u64 gbase = bases[2u * i + 1u];
+    const uint32_t* sn_ = snew + (size_t)d.sb0 * CXP_ME_BLOCK;
     while (m) {
         const uint32_t k = __ffs(m) - 1u;
         m &= m - 1u;
-        const uint32_t q = base + k;
-        tflag[q] = 0;
-        const uint32_t a = snew[tris[(size_t)q * 3]], b = snew[tris[(size_t)q * 3 + 1]], c = snew[tris[(size_t)q * 3 + 2]];
-        int32_t* o = out + (size_t)id * 3;
+        const size_t q = (size_t)d.tf + rel * CXP_ME_BLOCK + threadIdx.x * 16u + k;
+        const uint32_t a = sn_[(uint32_t)tris[q * 3] - d.sf], b = sn_[(uint32_t)tris[q * 3 + 1] - d.sf], c = sn_[(uint32_t)tris[q * 3 + 2] - d.sf];
+        int32_t* o = out + (size_t)(gbase + id) * 3;
         o[0] = (int32_t)a; o[1] = (int32_t)b; o[2] = (int32_t)c;
         id++;
     }
 }
-static inline double cxp_host_from_orderable(u64 o) {
-    const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
-    double d;
-    memcpy(&d, &b, sizeof(d));
-    return d;
-}
-// the index of the morph triangles by start time (see cxp_k_me_hist): bins over the time range of all points (S->misc + 16: its
-// orderable min / max, left by cx_morph_triangles), a histogram, its scan on the host (1 024 numbers), a scatter
-static int cxp_me_index(cx_ctx* ctx, cx_post_state* S, const double* ttime, uint32_t ntri) {
-    int rc;
-    hipStream_t st = ctx->stream;
-    S->morder_valid = false;
-    if (!ntri) return CX_OK;
-    u64 h[2];
-    CXP_HIP(ctx, hipMemcpyAsync(h, (const u64*)((const uint32_t*)S->misc.p + 16), sizeof(h), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipStreamSynchronize(st));
-    const double lo = cxp_host_from_orderable(h[0]), hi = cxp_host_from_orderable(h[1]);
-    const double inv_width = (hi > lo) ? (double)CXP_ME_BINS / (hi - lo) : 0.0;
-    if ((rc = cxp_reserve(ctx, S->morder, (size_t)(ntri + 16) * sizeof(uint32_t)))) return rc;
-    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)(2 * CXP_ME_BINS + 16) * sizeof(uint32_t)))) return rc;
-    uint32_t* hist = (uint32_t*)S->blocksums.p;
-    uint32_t* cursor = hist + CXP_ME_BINS;
-    u64* maxdur = (u64*)(cursor + CXP_ME_BINS);
-    CXP_HIP(ctx, hipMemsetAsync(hist, 0, (2 * CXP_ME_BINS + 4) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(cxp_k_me_hist, dim3(std::min(cxp_blocks(ntri), 2048u)), dim3(256), 0, st, ttime, ntri, lo, inv_width, hist, maxdur);
-    std::vector<uint32_t> hh(CXP_ME_BINS);
-    u64 md = 0;
-    CXP_HIP(ctx, hipMemcpyAsync(hh.data(), hist, CXP_ME_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipMemcpyAsync(&md, maxdur, sizeof(md), hipMemcpyDeviceToHost, st));
-    CXP_HIP(ctx, hipStreamSynchronize(st));
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < CXP_ME_BINS; b++) { S->mbin_start[b] = run; run += hh[b]; }
-    S->mbin_start[CXP_ME_BINS] = run;
-    if (run != ntri) { ctx->err = "cx_morph_triangles: the start-time histogram does not add up"; return CX_ERR_HIP; }
-    CXP_HIP(ctx, hipMemcpyAsync(cursor, S->mbin_start, CXP_ME_BINS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(cxp_k_me_scatter, dim3(cxp_blocks(ntri)), dim3(256), 0, st, ttime, ntri, lo, inv_width, cursor, (uint32_t*)S->morder.p);
-    CXP_HIP(ctx, hipStreamSynchronize(st));      // (S->mbin_start is read by the copy above)
-    S->mt_lo = lo; S->mt_hi = hi;
-    S->mt_maxdur = md ? cxp_host_from_orderable(md) : 0.0;
-    S->morder_valid = true;
-    return CX_OK;
-}
-extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
-    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+#define CXP_ME_MAX_TIMES 65536
+#define CXP_ME_MAX_BYTES (96ull << 30)
+extern "C" int cx_morph_eval_many(cx_ctx* ctx, const double* times, int32_t n_times, int64_t* out_counts) {
+    if (!ctx || !ctx->post || n_times < 0 || (n_times && !times)) return CX_ERR_INVALID;
+    if (n_times > CXP_ME_MAX_TIMES) { ctx->err = "cx_morph_eval_many: more than 65536 times in one call"; return CX_ERR_INVALID; }
     cx_post_state* S = ctx->post;
     CXP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const uint32_t ns = (uint32_t)S->ms_out, nt = (uint32_t)S->mt_out;
-    S->me_points = 0; S->me_tris = 0;
-    if (out_counts) { out_counts[0] = 0; out_counts[1] = 0; }
-    if (!ns || !nt) return CX_OK;
+    const uint32_t ns = (uint32_t)S->ms_out, nt = (uint32_t)S->mt_out, nd = (uint32_t)n_times;
+    S->me_off.assign((size_t)nd * 4, 0);
+    if (out_counts) memset(out_counts, 0, (size_t)nd * 2 * sizeof(int64_t));
+    if (!nd || !ns || !nt) return CX_OK;
+    if (!S->msorted) { ctx->err = "cx_morph_eval: no sorted morph triangles (cx_morph_triangles first)"; return CX_ERR_STATE; }
+    for (uint32_t i = 0; i < nd; i++)
+        if (!(times[i] == times[i])) { ctx->err = "cx_morph_eval: a time is not a number"; return CX_ERR_INVALID; }
     int rc;
-    const uint32_t nbs = cxp_blocks(ns, CXP_ME_BLOCK), nbt = cxp_blocks(nt, CXP_ME_BLOCK);
-    {
-        // one byte per segment / triangle, in a buffer nothing else writes: the kernels that consume a flag clear it, so the bytes are
-        // all zero between two calls and only a new set of morph triangles (or a new buffer) is cleared as a whole
-        const void* before = S->meflags.p;
-        if ((rc = cxp_reserve(ctx, S->meflags, (size_t)ns + nt + 256))) return rc;
-        if (S->meflags.p != before) S->meflags_zero_for = 0;
+    // the windows: a triangle (segment) that exists at t starts in [t - longest life, t]; one bin of slack on either side (the bin of a
+    // start time was computed on the device, these on the host)
+    auto bin_of = [&](double x) {
+        const double b = (x - S->mt_lo) / S->mt_width;
+        return b <= 0.0 ? 0u : (b >= (double)(CXP_SB_BINS - 1u) ? CXP_SB_BINS - 1u : (uint32_t)b);
+    };
+    std::vector<cxp_me_desc> D(nd + 1);
+    uint64_t tblocks = 0, sblocks = 0, pts_bound = 0, tri_bound = 0;
+    for (uint32_t i = 0; i < nd; i++) {
+        const double t = times[i];
+        const uint32_t b_hi = std::min(bin_of(t) + 1u, CXP_SB_BINS - 1u);
+        const uint32_t bt0 = bin_of(t - S->mt_maxdur), bs0 = bin_of(t - S->ms_maxdur);
+        const uint32_t bt = bt0 ? bt0 - 1u : 0u, bs = bs0 ? bs0 - 1u : 0u;
+        cxp_me_desc& d = D[i];
+        d.t = t;
+        d.tf = S->mbin_t[bt]; d.tn = S->mbin_t[b_hi + 1u] - d.tf;
+        d.sf = S->mbin_s[bs]; d.sn = S->mbin_s[b_hi + 1u] - d.sf;
+        d.tb0 = (uint32_t)tblocks; d.sb0 = (uint32_t)sblocks;
+        tblocks += (d.tn + CXP_ME_BLOCK - 1u) / CXP_ME_BLOCK;
+        sblocks += (d.sn + CXP_ME_BLOCK - 1u) / CXP_ME_BLOCK;
+        pts_bound += std::min<uint64_t>(d.sn, 3ull * d.tn);
+        tri_bound += d.tn;
     }
-    if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ns + 32) * sizeof(uint32_t)))) return rc;            // new ids of the segments in use
-    // block counts of the two compactions -- and, on the first call for these morph triangles, the histogram of cxp_me_index, which
-    // lives in the same buffer: reserved HERE, for the larger of the two, before any pointer into it is taken (until round 4 the
-    // index reserved its own 2 x 1 024 words afterwards; when that was more than nbs + nbt + 16 the buffer moved and soff / toff
-    // below pointed into freed memory: a GPU memory fault on small morphs whenever the allocator had unmapped the old block)
-    if ((rc = cxp_reserve(ctx, S->blocksums, (size_t)std::max<size_t>(nbs + nbt + 16, 2 * CXP_ME_BINS + 16) * sizeof(uint32_t)))) return rc;
+    D[nd].t = 0.0; D[nd].tf = D[nd].tn = D[nd].sf = D[nd].sn = 0; D[nd].tb0 = (uint32_t)tblocks; D[nd].sb0 = (uint32_t)sblocks;
+    // the surfaces cannot hold more triangles than their windows, nor more points than the windows' segments (or three per triangle):
+    // everything is reserved before anything is enqueued, so that the call runs to its end without the host in the middle
+    const uint64_t bytes = (tblocks + sblocks) * (uint64_t)CXP_ME_BLOCK * 5ull + pts_bound * 24ull + tri_bound * 12ull;
+    if (tblocks + sblocks >= (1ull << 20) * 16ull || bytes > CXP_ME_MAX_BYTES) {
+        ctx->err = "cx_morph_eval_many: the windows of these times need more than 96 GB of work space: fewer times per call";
+        return CX_ERR_NOMEM;
+    }
+    if (!tblocks || !sblocks) return CX_OK;       // every window is empty: every surface is
+    const uint32_t ntb = (uint32_t)tblocks, nsb = (uint32_t)sblocks;
+    {
+        const size_t before = S->meflags.bytes;     // (not the address: a freed block often comes back at the same one, larger)
+        if ((rc = cxp_reserve(ctx, S->meflags, (size_t)sblocks * CXP_ME_BLOCK + 256))) return rc;
+        if (S->meflags.bytes != before) S->meflags_clean = false;
+    }
+    if ((rc = cxp_reserve(ctx, S->metflag, (size_t)tblocks * CXP_ME_BLOCK + 256))) return rc;
+    if ((rc = cxp_reserve(ctx, S->menew, (size_t)sblocks * CXP_ME_BLOCK * sizeof(uint32_t) + 256))) return rc;
+    if ((rc = cxp_reserve(ctx, S->mecnt, ((size_t)tblocks + sblocks + 4ull * nd + 64) * sizeof(uint32_t) + (2ull * nd + 8) * sizeof(u64)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->medesc, (size_t)(nd + 1) * sizeof(cxp_me_desc)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->me_pts, (size_t)(pts_bound + 1) * 3 * sizeof(double)))) return rc;
+    if ((rc = cxp_reserve(ctx, S->me_tri, (size_t)(tri_bound + 1) * 3 * sizeof(int32_t)))) return rc;
+    // (the segment flags are a buffer of their own, ALL of it zero between two calls: the next call's windows may be laid out differently)
     uint8_t* sused = (uint8_t*)S->meflags.p;
-    uint8_t* tflag = sused + (((size_t)ns + 127u) & ~(size_t)63u);
-    uint32_t* snew = (uint32_t*)S->scan.p;
-    uint32_t* soff = (uint32_t*)S->blocksums.p;
-    uint32_t* toff = soff + nbs + 8;
-    uint32_t* misc = (uint32_t*)S->misc.p;
+    uint8_t* tflag = (uint8_t*)S->metflag.p;
+    uint32_t* snew = (uint32_t*)S->menew.p;
+    u64* bases = (u64*)S->mecnt.p;                                   // 2 nd + 2 words of 64 bits first (alignment)
+    uint32_t* scnt = (uint32_t*)(bases + 2ull * nd + 8);
+    uint32_t* tcnt = scnt + nsb + 8;
+    uint32_t* totals = tcnt + ntb + 8;
+    uint32_t* err = totals + 2ull * nd;                              // (right behind the totals: one copy back for both)
+    cxp_me_desc* Dd = (cxp_me_desc*)S->medesc.p;
     const double* P4 = (const double*)S->pts.p;
     const int32_t* segs = (const int32_t*)S->msegs.p;
     const int32_t* tris = (const int32_t*)S->mtris.p;
     const double* ttime = (const double*)S->mtime.p + (size_t)(ns + 1) * 2;   // behind the segments' ranges (cx_morph_triangles)
-    // (the flag bytes count as zeroed only while a call has run to its end on the same morph triangles)
-    const size_t clean_for = S->morder_valid ? S->meflags_zero_for : 0;
-    S->meflags_zero_for = 0;
-    if (!S->morder_valid && (rc = cxp_me_index(ctx, S, ttime, nt))) return rc;      // first surface of these morph triangles: ~2 ms once
-    // the window of start-time bins in which a triangle that exists at t can start (one bin of slack on either side: the bin of
-    // a start time was computed on the device, these two on the host)
-    uint32_t first = 0, n = 0;
-    {
-        const double width = (S->mt_hi > S->mt_lo) ? (S->mt_hi - S->mt_lo) / (double)CXP_ME_BINS : 1.0;
-        auto bin_of = [&](double x) {
-            const double b = (x - S->mt_lo) / width;
-            return b <= 0.0 ? 0u : (b >= (double)(CXP_ME_BINS - 1u) ? CXP_ME_BINS - 1u : (uint32_t)b);
-        };
-        const uint32_t b_hi = std::min(bin_of(t) + 1u, CXP_ME_BINS - 1u);
-        const uint32_t b_lo0 = bin_of(t - S->mt_maxdur);
-        const uint32_t b_lo = b_lo0 ? b_lo0 - 1u : 0u;
-        first = S->mbin_start[b_lo]; n = S->mbin_start[b_hi + 1u] - first;
-    }
-    // The surface cannot hold more triangles than the window, nor more points than three per triangle: the outputs are reserved for
-    // that before anything is enqueued, so that the call runs to its end without the host in the middle (until round 4 it waited for
-    // the two totals between the scans and the compactions: ~15 us of idle GPU per surface, 64 times over for config 4's stream)
-    if ((rc = cxp_reserve(ctx, S->pts_out, ((size_t)std::min<uint64_t>(ns, 3ull * n) + 1) * 3 * sizeof(double)))) return rc;
-    if ((rc = cxp_reserve(ctx, S->tri_out, ((size_t)n + 1) * 3 * sizeof(int32_t)))) return rc;
-    if (clean_for != (size_t)ns + nt) CXP_HIP(ctx, hipMemsetAsync(sused, 0, (size_t)ns + nt + 256, st));
-    if (n) hipLaunchKernelGGL(cxp_k_me_visible, dim3(cxp_blocks(n)), dim3(256), 0, st, ttime, tris, (const uint32_t*)S->morder.p, first, n, t, tflag, sused);
-    hipLaunchKernelGGL(cxp_k_me_count16, dim3(nbs + nbt), dim3(256), 0, st, (const uint8_t*)sused, ns, nbs, soff, (const uint8_t*)tflag, nt, toff);
-    hipLaunchKernelGGL(cxp_k_scan_sums2, dim3(2), dim3(1024), 0, st, soff, nbs, misc + 8, toff, nbt, misc + 9);
-    hipLaunchKernelGGL(cxp_k_me_points, dim3(nbs), dim3(256), 0, st, P4, segs, ns, t, sused, (const uint32_t*)soff, (const uint32_t*)(misc + 8), snew, (double*)S->pts_out.p);
-    hipLaunchKernelGGL(cxp_k_me_tris, dim3(nbt), dim3(256), 0, st, tris, nt, tflag, (const uint32_t*)toff, (const uint32_t*)(misc + 9), (const uint32_t*)snew, (int32_t*)S->tri_out.p);
-    uint32_t tot[2] = {0, 0};
-    CXP_HIP(ctx, hipMemcpyAsync(tot, misc + 8, sizeof(tot), hipMemcpyDeviceToHost, st));
+    // (the segment flags count as zeroed only while the last call ran to its end; they may have moved since: a larger call reserves anew)
+    const bool clean = S->meflags_clean;
+    S->meflags_clean = false;
+    if (!clean) CXP_HIP(ctx, hipMemsetAsync(sused, 0, S->meflags.bytes, st));
+    CXP_HIP(ctx, hipMemcpyAsync(Dd, D.data(), (size_t)(nd + 1) * sizeof(cxp_me_desc), hipMemcpyHostToDevice, st));
+    CXP_HIP(ctx, hipMemsetAsync(err, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(cxp_k_me_visible, dim3(ntb * 16u), dim3(256), 0, st, (const cxp_me_desc*)Dd, nd, ttime, tris, tflag, sused, err);
+    hipLaunchKernelGGL(cxp_k_me_count16, dim3(nsb + ntb), dim3(256), 0, st, (const uint8_t*)sused, nsb, (const uint8_t*)tflag, scnt, tcnt);
+    hipLaunchKernelGGL(cxp_k_me_offsets, dim3(2u * nd), dim3(256), 0, st, (const cxp_me_desc*)Dd, nd, scnt, tcnt, totals);
+    hipLaunchKernelGGL(cxp_k_me_bases, dim3(1), dim3(256), 0, st, (const uint32_t*)totals, nd, bases);
+    hipLaunchKernelGGL(cxp_k_me_points, dim3(nsb), dim3(256), 0, st, (const cxp_me_desc*)Dd, nd, P4, segs, sused, (const uint32_t*)scnt, (const uint32_t*)totals,
+                       (const u64*)bases, snew, (double*)S->me_pts.p);
+    hipLaunchKernelGGL(cxp_k_me_tris, dim3(ntb), dim3(256), 0, st, (const cxp_me_desc*)Dd, nd, tris, (const uint8_t*)tflag, (const uint32_t*)tcnt,
+                       (const uint32_t*)totals, (const u64*)bases, (const uint32_t*)snew, (int32_t*)S->me_tri.p);
+    std::vector<uint32_t> tot((size_t)2 * nd + 1);
+    CXP_HIP(ctx, hipMemcpyAsync(tot.data(), totals, ((size_t)2 * nd + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     CXP_HIP(ctx, hipStreamSynchronize(st));
     CXP_HIP(ctx, hipGetLastError());
-    S->meflags_zero_for = (size_t)ns + nt;
-    S->me_points = tot[0]; S->me_tris = tot[1];
-    if (out_counts) { out_counts[0] = tot[0]; out_counts[1] = tot[1]; }
+    if (tot[2 * nd]) { ctx->err = "cx_morph_eval: a visible triangle uses a segment outside its time's window (internal error)"; return CX_ERR_HIP; }
+    S->meflags_clean = true;
+    int64_t p0 = 0, t0 = 0;
+    for (uint32_t i = 0; i < nd; i++) {
+        S->me_off[4 * i] = p0; S->me_off[4 * i + 1] = tot[2 * i]; S->me_off[4 * i + 2] = t0; S->me_off[4 * i + 3] = tot[2 * i + 1];
+        p0 += tot[2 * i]; t0 += tot[2 * i + 1];
+        if (out_counts) { out_counts[2 * i] = tot[2 * i]; out_counts[2 * i + 1] = tot[2 * i + 1]; }
+    }
     return CX_OK;
+}
+extern "C" int cx_morph_eval_many_download(cx_ctx* ctx, int32_t i, double* points_xyz, int32_t* triangles) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    cx_post_state* S = ctx->post;
+    if (i < 0 || (size_t)i * 4 >= S->me_off.size()) { ctx->err = "cx_morph_eval_many_download: no such surface in the last call"; return CX_ERR_INVALID; }
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t* o = &S->me_off[(size_t)i * 4];
+    void* d[2] = {(points_xyz && o[1]) ? (void*)points_xyz : nullptr, (triangles && o[3]) ? (void*)triangles : nullptr};
+    const void* sp[2] = {o[1] ? (const void*)((const double*)S->me_pts.p + (size_t)o[0] * 3) : nullptr,
+                         o[3] ? (const void*)((const int32_t*)S->me_tri.p + (size_t)o[2] * 3) : nullptr};
+    const size_t nb[2] = {(size_t)o[1] * 3 * sizeof(double), (size_t)o[3] * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
+}
+extern "C" int cx_morph_eval_many_device_ptrs(cx_ctx* ctx, int32_t i, void** points_xyz, void** triangles) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    cx_post_state* S = ctx->post;
+    if (i < 0 || (size_t)i * 4 >= S->me_off.size()) { ctx->err = "cx_morph_eval_many_device_ptrs: no such surface in the last call"; return CX_ERR_INVALID; }
+    const int64_t* o = &S->me_off[(size_t)i * 4];
+    if (points_xyz) *points_xyz = o[1] ? (void*)((double*)S->me_pts.p + (size_t)o[0] * 3) : nullptr;
+    if (triangles) *triangles = o[3] ? (void*)((int32_t*)S->me_tri.p + (size_t)o[2] * 3) : nullptr;
+    return CX_OK;
+}
+extern "C" int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts) {
+    return cx_morph_eval_many(ctx, &t, 1, out_counts);
 }
 extern "C" int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles) {
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
-    cx_post_state* S = ctx->post;
-    CXP_HIP(ctx, hipSetDevice(ctx->device));
-    void* d[2] = {(points_xyz && S->me_points) ? (void*)points_xyz : nullptr, (triangles && S->me_tris) ? (void*)triangles : nullptr};
-    const void* sp[2] = {S->pts_out.p, S->tri_out.p};
-    const size_t nb[2] = {(size_t)S->me_points * 3 * sizeof(double), (size_t)S->me_tris * 3 * sizeof(int32_t)};
-    return cx_copy_to_host(ctx, 2, d, sp, nb);
+    if (ctx->post->me_off.empty()) return CX_OK;      // nothing evaluated: nothing to copy
+    return cx_morph_eval_many_download(ctx, 0, points_xyz, triangles);
 }

@@ -199,6 +199,14 @@ class GridContour4D(object):
             self.collect_morph_triangles()
         return self.context().morph_eval(t, download)
 
+    def triangles_at_many(self, times, download=True):
+        """the surfaces at all `times` in one set of launches (cx_morph_eval_many: the per-t isosurface stream the viewer plays
+        frame by frame, misc/morph_triangles.js:117-204) -> list of (points, triangles), each what triangles_at(t) returns;
+        with download=False the (n, 2) array of counts (Context.morph_eval_device_ptrs(i) gives the device addresses)"""
+        if getattr(self, "n_components", None) is None:
+            self.collect_morph_triangles()
+        return self.context().morph_eval_many(times, download)
+
 
 class Delta4DContour(tetrahedral.Delta3DContour):
     "world-coordinate facade (pentatopes.py:42-68)"

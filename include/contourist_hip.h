@@ -321,6 +321,17 @@ int cx_morph_download(cx_ctx* ctx, double* points_xyzt, int32_t* segments, int32
  * Download: points np*3 doubles, triangles nt*3 int32 (indices into those points, original triangle order). */
 int cx_morph_eval(cx_ctx* ctx, double t, int64_t* out_counts);
 int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
+/* The same for n_times times in ONE set of launches -- the per-t isosurface stream the viewer plays frame by frame
+ * (misc/morph_triangles.js:117-204 once per frame; here: all frames of a stream at once).  times: any order, repeats allowed.
+ * out_counts (n_times x 2 x int64): per time [0] points, [1] triangles.  Surface i is exactly what cx_morph_eval(times[i]) returns
+ * (same points, same index triples, same order); the surfaces lie one behind the other in device memory.
+ * _download: surface i of the last call (points np*3 doubles, triangles nt*3 int32, indices local to the surface);
+ * _device_ptrs: where surface i lies on the device (NULL for an empty one) -- valid until the next evaluation on this context.
+ * cx_morph_triangles leaves segments and triangles sorted by their start time, so that the triangles (and segments) that exist at one
+ * time are a window of ids: a call costs what its windows hold, not what the whole morph holds. */
+int cx_morph_eval_many(cx_ctx* ctx, const double* times, int32_t n_times, int64_t* out_counts);
+int cx_morph_eval_many_download(cx_ctx* ctx, int32_t i, double* points_xyz, int32_t* triangles);
+int cx_morph_eval_many_device_ptrs(cx_ctx* ctx, int32_t i, void** points_xyz, void** triangles);
 
 /* ---- 2-D contour lines at several isovalues ------------------------------------------------------
  * Replaces triangulated.Grid2DContour (search_grid :198-212, find_initial_contour_pairs :299-320,

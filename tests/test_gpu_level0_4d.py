@@ -579,3 +579,81 @@ def test_post_steps_and_morph_triangles_against_the_oracle_at_mid_size():
     assert common == len(ot) and agree == common, (common, agree, len(ot))
     bad_d, seen_d = postpass4d.forced_pair_violations(kh, MT.segment_point_indices, MT.triangle_segment_indices, MT.points4d)
     assert seen_d > 0 and bad_d == 0, (bad_d, seen_d)
+
+
+def _blob_field(shape, seed):
+    rng = np.random.RandomState(seed)
+    ax = [np.linspace(0.0, 1.0, n, dtype=np.float32) for n in shape]
+    X, Y, Z, T = np.meshgrid(*ax, indexing="ij")
+    A = np.exp(-(((X - 0.35 - 0.3 * T) ** 2 + (Y - 0.4) ** 2 + (Z - 0.5 + 0.1 * T) ** 2) / (2 * 0.16 ** 2)))
+    A += 0.02 * rng.standard_normal(shape)
+    for axis in range(4):
+        for idx in (0, -1):
+            np.moveaxis(A, axis, 0)[idx] = 0.0
+    return np.ascontiguousarray(A.astype(np.float32))
+
+
+@pytest.mark.parametrize("shape,nbins", [((14, 13, 12, 9), 100), ((22, 20, 18, 40), 100), ((12, 12, 12, 7), 1000)])
+def test_per_t_stream_in_one_call_equals_the_single_surfaces(shape, nbins):
+    """cx_morph_eval_many (config 4's per-t isosurface stream in ONE set of launches): every surface is bit for bit what
+    cx_morph_eval returns for that time and what MorphTriangles.triangles_at computes on the host from the downloaded morph
+    triangles (misc/morph_triangles.js:26-140) -- times unsorted, repeated, on vertex times exactly, outside the range;
+    and the morph triangles / segments come back sorted by the bin of their start time (the windows the evaluation relies on)"""
+    from contourist_amd import _ffi, morph_geometry
+    A = _blob_field(shape, 5)
+    ctx = _ffi.Context(0)
+    try:
+        ctx.upload_grid4d(A)
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(nbins)
+        pts, segs, tris, ncomp = ctx.morph_triangles()
+        assert len(tris) > 1000
+        MT = morph_geometry.MorphTriangles(pts, segs, tris)
+        tmin, tmax = float(pts[:, 3].min()), float(pts[:, 3].max())
+        # sorted by start-time bin (256 bins over [tmin, tmax]); segments point from low t to high t
+        s_lo, s_hi = pts[segs[:, 0], 3], pts[segs[:, 1], 3]
+        assert np.all(s_lo <= s_hi)
+        inv_width = 256.0 / (tmax - tmin)             # (the device's own formula: bins meet vertex times exactly at 1/4, 1/2, 3/4)
+        sbin = np.clip(((s_lo - tmin) * inv_width).astype(np.int64), 0, 255)
+        tbin = np.clip(((s_lo[tris].max(axis=1) - tmin) * inv_width).astype(np.int64), 0, 255)
+        assert np.all(np.diff(sbin) >= 0) and np.all(np.diff(tbin) >= 0)
+        vertex_times = np.unique(pts[:, 3])
+        fr = np.array([0.52, 0.013, 0.97, 0.52, 0.31, 0.0, 1.0, 0.744, 0.25])
+        times = list(tmin + fr * (tmax - tmin)) + [float(vertex_times[len(vertex_times) // 2]), float(vertex_times[1]),
+                                                   tmin - 1.0, tmax + 0.5]
+        many = ctx.morph_eval_many(times)
+        counts = ctx.morph_eval_many(times, download=False)
+        assert len(many) == len(times) and counts.shape == (len(times), 2)
+        nonempty = 0
+        for i, t in enumerate(times):
+            p1, t1 = ctx.morph_eval(t)
+            ph, th = MT.triangles_at(t)
+            pm, tm = many[i]
+            assert counts[i, 0] == len(pm) and counts[i, 1] == len(tm)
+            assert np.array_equal(tm, t1) and np.array_equal(pm, p1)
+            assert np.array_equal(tm, th) and np.allclose(pm, ph, rtol=0, atol=1e-12)
+            if len(tm):
+                assert tm.min() >= 0 and tm.max() < len(pm) and len(np.unique(tm)) == len(pm)
+            nonempty += len(tm) > 0
+        assert nonempty >= 9
+        assert len(many[-1][1]) == 0 and len(many[-2][1]) == 0
+        # the stream again after the single calls, and an empty list of times
+        again = ctx.morph_eval_many(times)
+        for (pa, ta), (pm, tm) in zip(again, many):
+            assert np.array_equal(ta, tm) and np.array_equal(pa, pm)
+        assert ctx.morph_eval_many([]) == []
+        # device addresses of a surface: what the download copies from
+        torch = pytest.importorskip("torch")
+        ctx.morph_eval_many(times, download=False)
+        i = int(np.argmax(counts[:, 1]))
+        dp, dt = ctx.morph_eval_device_ptrs(i)
+        assert dp and dt
+        import ctypes
+        host = np.empty((int(counts[i, 1]), 3), dtype=np.int32)
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(host.ctypes.data, dt, host.nbytes, 2) == 0
+        assert np.array_equal(host, many[i][1])
+        assert ctx.morph_eval_device_ptrs(len(times) - 1) == (0, 0)
+    finally:
+        ctx.close()
