@@ -2245,12 +2245,26 @@ extern "C" int cx_level1_4d_download(cx_ctx* ctx, double* points_xyzt, int32_t* 
 // Canonical numbering: the 4 vertices of a tetrahedron are ordered by edge id (the reference orders them by
 // its dict numbering, which only decides how a 4-segment slice is split).
 // =====================================================================================================
-__global__ void cxp_k_minmax_t(const double* pts, uint32_t nv, u64* mm) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv) return;
-    const u64 o = cxp_orderable(pts[(size_t)v * 4 + 3]);
-    if (__hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > o) atomicMin(&mm[0], o);
-    cxp_max64(&mm[1], o);
+// (grid-stride, reduced per wave before the two read-before-atomic updates: one thread per point with its own pair of updates took
+// 0.28 ms for 4.7 M points -- the first waves all raise the maximum)
+__global__ __launch_bounds__(256) void cxp_k_minmax_t(const double* pts, uint32_t nv, u64* mm) {
+    u64 lo = ~0ULL, hi = 0ULL;
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < nv; v += gridDim.x * 256u) {
+        const u64 o = cxp_orderable(pts[(size_t)v * 4 + 3]);
+        lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 l2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(lo >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)lo, o);
+        const u64 h2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(hi >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (__hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > lo) atomicMin(&mm[0], lo);
+        cxp_max64(&mm[1], hi);
+    }
 }
 __device__ __forceinline__ double cxp_from_orderable(u64 o) {
     const u64 b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
@@ -2468,25 +2482,79 @@ __global__ __launch_bounds__(256) void cxp_k_seg_insert(const u64* pairs, size_t
         }
     }
 }
-__global__ void cxp_k_slot_flags(const u64* tkeys, size_t n, uint32_t* flags) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (tkeys[i] != CXP_EMPTY) ? 1u : 0u;
+// Segment ids = rank of the occupied slot, by ordered compaction without a flag or id word per SLOT (the table has 134 M slots on config 4
+// for 12 M segments: flags + a full scan + ids for every slot were 1.5 GB written and 2 GB read, ~1 ms): a workgroup counts the occupied
+// slots of its 4 096 (cxp_k_occ_count), one workgroup scans the block counts (cxp_k_scan_sums), and cxp_k_seg_write4 redoes the scan inside
+// its block, lists the occupied slots in LDS and writes one record per list entry -- ids[slot] only for occupied slots (what
+// cxp_k_tri_segments looks up), segments / midpoints / time ranges in id order, next to each other.
+#define CXP_OCC_BLOCK 4096u
+__device__ __forceinline__ uint32_t cxp_occ16(const u64* tkeys, size_t base, size_t n) {
+    uint32_t m = 0;
+    if (base + 16u <= n) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(tkeys + base + 2u * k);
+            m |= (w.x != CXP_EMPTY ? 1u : 0u) << (2u * k);
+            m |= (w.y != CXP_EMPTY ? 2u : 0u) << (2u * k);
+        }
+    } else {
+        for (uint32_t k = 0; k < 16u && base + k < n; k++) m |= (tkeys[base + k] != CXP_EMPTY ? 1u : 0u) << k;
+    }
+    return m;
 }
-// segment records: (i,j) pointing from low t to high t (morph_geometry.py:12-18), and the 3-D midpoint
-__global__ void cxp_k_seg_write(const u64* tkeys, const uint32_t* ids, size_t n, const double* pts, int32_t* segs, double* mid, double* stime) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n || tkeys[i] == CXP_EMPTY) return;
-    uint32_t a = (uint32_t)(tkeys[i] >> 32), b = (uint32_t)tkeys[i];
-    // both points whole and the id before the first store (loads behind a store waited for it: they may alias for all the compiler knows)
-    double pa[4], pb[4];
+__global__ __launch_bounds__(256) void cxp_k_occ_count(const u64* tkeys, size_t n, uint32_t* count) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t c = __popc(cxp_occ16(tkeys, (size_t)blockIdx.x * CXP_OCC_BLOCK + threadIdx.x * 16u, n));
 #pragma unroll
-    for (int c = 0; c < 4; c++) { pa[c] = pts[(size_t)a * 4 + c]; pb[c] = pts[(size_t)b * 4 + c]; }
-    const uint32_t s = ids[i];
-    const bool swap = pa[3] > pb[3];
-    segs[(size_t)s * 2] = (int32_t)(swap ? b : a); segs[(size_t)s * 2 + 1] = (int32_t)(swap ? a : b);
-#pragma unroll
-    for (int c = 0; c < 3; c++) mid[(size_t)s * 3 + c] = swap ? 0.5 * (pb[c] + pa[c]) : 0.5 * (pa[c] + pb[c]);
-    stime[(size_t)s * 2] = swap ? pb[3] : pa[3]; stime[(size_t)s * 2 + 1] = swap ? pa[3] : pb[3];
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_n, c);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = s_n;
+}
+__global__ __launch_bounds__(256) void cxp_k_seg_write4(const u64* tkeys, size_t n, const uint32_t* boff, const uint32_t* total, uint32_t nblocks,
+                                                        const double* pts, uint32_t* ids, int32_t* segs, double* mid, double* stime) {
+    __shared__ uint32_t s[256];
+    __shared__ uint16_t list[CXP_OCC_BLOCK];
+    const uint32_t first = boff[blockIdx.x];
+    const uint32_t next = (blockIdx.x + 1u < nblocks) ? boff[blockIdx.x + 1u] : *total;
+    if (next == first) return;
+    const size_t base = (size_t)blockIdx.x * CXP_OCC_BLOCK;
+    uint32_t m = cxp_occ16(tkeys, base + threadIdx.x * 16u, n);
+    // exclusive prefix of the threads' counts (Hillis-Steele over 256), then the positions of the set bits
+    const uint32_t cnt = __popc(m);
+    s[threadIdx.x] = cnt;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t x = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t pos = s[threadIdx.x] - cnt;
+    const uint32_t nl = s[255];
+    while (m) {
+        const uint32_t k = __ffs(m) - 1u;
+        m &= m - 1u;
+        list[pos++] = (uint16_t)(threadIdx.x * 16u + k);
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nl; j += 256u) {
+        const size_t slot = base + list[j];
+        const u64 key = tkeys[slot];
+        const uint32_t a = (uint32_t)(key >> 32), b = (uint32_t)key;
+        const double4 pa = *reinterpret_cast<const double4*>(pts + (size_t)a * 4);
+        const double4 pb = *reinterpret_cast<const double4*>(pts + (size_t)b * 4);
+        const uint32_t sg = first + j;
+        ids[slot] = sg;
+        const bool swap = pa.w > pb.w;
+        segs[(size_t)sg * 2] = (int32_t)(swap ? b : a); segs[(size_t)sg * 2 + 1] = (int32_t)(swap ? a : b);
+        mid[(size_t)sg * 3] = swap ? 0.5 * (pb.x + pa.x) : 0.5 * (pa.x + pb.x);
+        mid[(size_t)sg * 3 + 1] = swap ? 0.5 * (pb.y + pa.y) : 0.5 * (pa.y + pb.y);
+        mid[(size_t)sg * 3 + 2] = swap ? 0.5 * (pb.z + pa.z) : 0.5 * (pa.z + pb.z);
+        stime[(size_t)sg * 2] = swap ? pb.w : pa.w; stime[(size_t)sg * 2 + 1] = swap ? pa.w : pb.w;
+    }
 }
 // triangles as segment-id triples + their time range (morph_geometry.py:69-89)
 __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tkeys, const uint32_t* ids, u64 mask, u64 mult, const double* stime,
@@ -2625,7 +2693,7 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
     if (nv && nt) {
         const u64 init[2] = {~0ULL, 0ULL};
         CXP_HIP(ctx, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(cxp_k_minmax_t, dim3(cxp_blocks(nv)), dim3(256), 0, st, pts, nv, mm);
+        hipLaunchKernelGGL(cxp_k_minmax_t, dim3(std::min(cxp_blocks(nv), 2048u)), dim3(256), 0, st, pts, nv, mm);
         if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
         if ((rc = cxp_reserve(ctx, S->scan, (size_t)(nt + 16) * sizeof(uint32_t)))) return rc;
         uint32_t* cnt = (uint32_t*)S->flags.p;
@@ -2656,16 +2724,17 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             // bound, keeps the load below 0.8 in the worst case and near 0.25 here with half the slots to clear, flag and scan)
             const u64 ssz = cxp_edge_table_size(np);
             if ((rc = cxp_reserve(ctx, S->tkeys, ssz * sizeof(u64)))) return rc;
-            if ((rc = cxp_reserve(ctx, S->flags, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
+            const uint32_t nob = cxp_blocks(ssz, CXP_OCC_BLOCK);
+            if ((rc = cxp_reserve(ctx, S->flags, (size_t)(nob + 16) * sizeof(uint32_t)))) return rc;
             if ((rc = cxp_reserve(ctx, S->scan, (size_t)(ssz + 16) * sizeof(uint32_t)))) return rc;
             u64* skeys = (u64*)S->tkeys.p;
-            uint32_t* sflag = (uint32_t*)S->flags.p;
-            uint32_t* sid = (uint32_t*)S->scan.p;
+            uint32_t* boff = (uint32_t*)S->flags.p;        // occupied slots per block of 4 096, then their exclusive scan
+            uint32_t* sid = (uint32_t*)S->scan.p;          // segment id per slot, written for occupied slots only
             hipLaunchKernelGGL(cxp_k_fill64, dim3(2048), dim3(256), 0, st, skeys, (size_t)ssz, CXP_EMPTY);
             const u64 smult = std::max<u64>(1, ssz / std::max<u64>(1, (u64)nv));
             hipLaunchKernelGGL(cxp_k_seg_insert, dim3(cxp_blocks(np, CXP_SEG_KEYS)), dim3(256), 0, st, pairs, np, skeys, ssz - 1, smult);
-            hipLaunchKernelGGL(cxp_k_slot_flags, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, (size_t)ssz, sflag);
-            if ((rc = cxp_scan(ctx, S, sflag, sid, (uint32_t)ssz, misc + 2))) return rc;
+            hipLaunchKernelGGL(cxp_k_occ_count, dim3(nob), dim3(256), 0, st, (const u64*)skeys, (size_t)ssz, boff);
+            hipLaunchKernelGGL(cxp_k_scan_sums, dim3(1), dim3(1024), 0, st, boff, nob, misc + 2, (unsigned long long*)nullptr);
             uint32_t nseg = 0;
             CXP_HIP(ctx, hipMemcpyAsync(&nseg, misc + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             CXP_HIP(ctx, hipStreamSynchronize(st));
@@ -2678,7 +2747,8 @@ extern "C" int cx_morph_triangles(cx_ctx* ctx, int64_t* out_counts) {
             double* stime = (double*)S->mtime.p;
             double* ttime = stime + (size_t)(nseg + 1) * 2;
             int32_t* tris = (int32_t*)S->mtris.p;
-            hipLaunchKernelGGL(cxp_k_seg_write, dim3(cxp_blocks(ssz)), dim3(256), 0, st, skeys, sid, (size_t)ssz, pts, segs, mid, stime);
+            hipLaunchKernelGGL(cxp_k_seg_write4, dim3(nob), dim3(256), 0, st, (const u64*)skeys, (size_t)ssz, (const uint32_t*)boff, (const uint32_t*)(misc + 2), nob,
+                               pts, sid, segs, mid, stime);
             hipLaunchKernelGGL(cxp_k_tri_segments, dim3(cxp_blocks(ntri)), dim3(256), 0, st, pairs, ntri, skeys, sid, ssz - 1, smult, stime, mm, tris, ttime);
             CXP_HIP(ctx, hipStreamSynchronize(st));   // the segment table is reused below
             // ---- orientation on the segment midpoints, time-compatible neighbours only
