@@ -2292,53 +2292,68 @@ __device__ __forceinline__ uint32_t cxp_morph_slices(const int32_t* tets, uint32
 #define CXP_DSWAP(x, y) if (ts[x] > ts[y]) { const double tmp = ts[x]; ts[x] = ts[y]; ts[y] = tmp; }
     CXP_DSWAP(0, 1) CXP_DSWAP(2, 3) CXP_DSWAP(0, 2) CXP_DSWAP(1, 3) CXP_DSWAP(1, 2)
 #undef CXP_DSWAP
-    const int PI[6] = {0, 0, 0, 1, 1, 2}, PJ[6] = {1, 2, 3, 2, 3, 3};   // scan order (a,b)(a,c)(a,d)(b,c)(b,d)(c,d)
+    // Everything below lives in named scalars, one set per edge, and the crossed edges are picked by select chains from a 6-bit set: with
+    // small arrays indexed by a running count `m` (or by select chains over array elements, which the compiler folds back into an indexed
+    // load) the arrays went to scratch memory -- 160 bytes per lane, 108 registers, 4 waves per SIMD, cxp_k_morph_emit 1.65 ms on config 4.
+    // Same arithmetic, same order of the edges: scan order (a,b)(a,c)(a,d)(b,c)(b,d)(c,d) = edges 0..5.
     uint32_t n = 0;
+    const double wx = tv[1] - tv[0], wy = tv[2] - tv[0], wz = tv[3] - tv[0];
+#define CXP_EDGE(e, I, J)                                                                                                   \
+    const bool cross##e = !(mid + 1e-5 < fmin(tv[I], tv[J]) || mid - 1e-5 > fmax(tv[I], tv[J])); /* morph_geometry.py:218 */ \
+    const u64 sp##e = ((u64)v[I] << 32) | (u64)v[J];                                                                         \
+    const bool zero##e = fabs(tv[I] - tv[J]) <= t_eps;                                           /* pentatopes.py:341-345 */  \
+    const double den##e = tv[J] - tv[I];                                                                                     \
+    const double lam##e = (den##e != 0.0) ? fmin(1.0, fmax(0.0, (mid - tv[I]) / den##e)) : 0.5;                              \
+    const double px##e = ((I) == 1 ? 1.0 : 0.0) + lam##e * (((J) == 1 ? 1.0 : 0.0) - ((I) == 1 ? 1.0 : 0.0));                \
+    const double py##e = ((I) == 2 ? 1.0 : 0.0) + lam##e * (((J) == 2 ? 1.0 : 0.0) - ((I) == 2 ? 1.0 : 0.0));                \
+    const double pz##e = ((I) == 3 ? 1.0 : 0.0) + lam##e * (((J) == 3 ? 1.0 : 0.0) - ((I) == 3 ? 1.0 : 0.0));
+#define CXP_PICK(name, k) ((k) == 5 ? name##5 : (k) == 4 ? name##4 : (k) == 3 ? name##3 : (k) == 2 ? name##2 : (k) == 1 ? name##1 : name##0)
+#pragma unroll
     for (int g = 0; g < 3; g++) {
         if (!((ts[g + 1] - ts[g]) > 1e-4)) continue;               // morph_geometry.py:150
         const double mid = 0.5 * (ts[g + 1] + ts[g]);
-        u64 sp[6];
-        bool zero[6];
-        double px[6], py[6], pz[6];   // the slice points in the tetrahedron's own affine frame: a = 0, b = e1, c = e2, d = e3
-        int m = 0;
-#pragma unroll
-        for (int e = 0; e < 6; e++) {
-            double v1 = tv[PI[e]], v2 = tv[PJ[e]];
-            if (v1 > v2) { const double tmp = v1; v1 = v2; v2 = tmp; }
-            if (mid + 1e-5 < v1 || mid - 1e-5 > v2) continue;      // morph_geometry.py:218
-            sp[m] = ((u64)v[PI[e]] << 32) | (u64)v[PJ[e]];
-            zero[m] = fabs(tv[PI[e]] - tv[PJ[e]]) <= t_eps;        // pentatopes.py:341-345
-            const double den = tv[PJ[e]] - tv[PI[e]];
-            const double lam = (den != 0.0) ? fmin(1.0, fmax(0.0, (mid - tv[PI[e]]) / den)) : 0.5;
-            const double ix = (PI[e] == 1) ? 1.0 : 0.0, iy = (PI[e] == 2) ? 1.0 : 0.0, iz = (PI[e] == 3) ? 1.0 : 0.0;
-            const double jx = (PJ[e] == 1) ? 1.0 : 0.0, jy = (PJ[e] == 2) ? 1.0 : 0.0, jz = (PJ[e] == 3) ? 1.0 : 0.0;
-            px[m] = ix + lam * (jx - ix); py[m] = iy + lam * (jy - iy); pz[m] = iz + lam * (jz - iz);
-            m++;
-        }
+        // the slice points in the tetrahedron's own affine frame: a = 0, b = e1, c = e2, d = e3
+        CXP_EDGE(0, 0, 1) CXP_EDGE(1, 0, 2) CXP_EDGE(2, 0, 3) CXP_EDGE(3, 1, 2) CXP_EDGE(4, 1, 3) CXP_EDGE(5, 2, 3)
+        const uint32_t cm = (cross0 ? 1u : 0u) | (cross1 ? 2u : 0u) | (cross2 ? 4u : 0u) | (cross3 ? 8u : 0u) | (cross4 ? 16u : 0u) | (cross5 ? 32u : 0u);
         // winding: all tetrahedra are oriented alike with respect to the field gradient, so the slice triangle whose
         // normal (inside the tetrahedron) points towards later times is wound alike everywhere -- a rule on the
         // order of the vertex times only, which bin_times and the tiny collapse do not disturb
-        const double wx = tv[1] - tv[0], wy = tv[2] - tv[0], wz = tv[3] - tv[0];
         auto wound = [&](int i0, int i1, int i2) {
-            const double ax = px[i1] - px[i0], ay = py[i1] - py[i0], az = pz[i1] - pz[i0];
-            const double bx = px[i2] - px[i0], by = py[i2] - py[i0], bz = pz[i2] - pz[i0];
+            const double x0 = CXP_PICK(px, i0), y0 = CXP_PICK(py, i0), z0 = CXP_PICK(pz, i0);
+            const double ax = CXP_PICK(px, i1) - x0, ay = CXP_PICK(py, i1) - y0, az = CXP_PICK(pz, i1) - z0;
+            const double bx = CXP_PICK(px, i2) - x0, by = CXP_PICK(py, i2) - y0, bz = CXP_PICK(pz, i2) - z0;
             const double det = (ay * bz - az * by) * wx + (az * bx - ax * bz) * wy + (ax * by - ay * bx) * wz;
-            if (det * tsign >= 0.0) emit(sp[i0], sp[i1], sp[i2]); else emit(sp[i0], sp[i2], sp[i1]);
+            const u64 s0 = CXP_PICK(sp, i0), s1 = CXP_PICK(sp, i1), s2 = CXP_PICK(sp, i2);
+            if (det * tsign >= 0.0) emit(s0, s1, s2); else emit(s0, s2, s1);
         };
+        const int m = __popc(cm);
+        const int e0 = (int)__ffs(cm) - 1;                          // the first crossed edge in scan order
         if (m == 3) {
-            if (!(zero[0] || zero[1] || zero[2])) { wound(0, 1, 2); n++; }
+            const uint32_t c1 = cm & (cm - 1u), c2 = c1 & (c1 - 1u);
+            const int e1 = (int)__ffs(c1) - 1, e2 = (int)__ffs(c2) - 1;
+            if (!(CXP_PICK(zero, e0) || CXP_PICK(zero, e1) || CXP_PICK(zero, e2))) { wound(e0, e1, e2); n++; }
         } else if (m == 4) {                                       // morph_geometry.py:176-186
+            // p2 = the crossed edge without a vertex in common with the first one (the last such one in scan order)
+            const u64 s0 = CXP_PICK(sp, e0);
+            const uint32_t a0 = (uint32_t)(s0 >> 32), a1 = (uint32_t)s0;
             int p2 = -1;
-            for (int e = 1; e < 4; e++) {
-                const uint32_t a0 = (uint32_t)(sp[0] >> 32), a1 = (uint32_t)sp[0], b0 = (uint32_t)(sp[e] >> 32), b1 = (uint32_t)sp[e];
-                if (a0 != b0 && a0 != b1 && a1 != b0 && a1 != b1) p2 = e;
+#define CXP_DISJ(e)                                                                                          \
+            {                                                                                                \
+                const uint32_t b0 = (uint32_t)(sp##e >> 32), b1 = (uint32_t)sp##e;                            \
+                if (cross##e && e != e0 && a0 != b0 && a0 != b1 && a1 != b0 && a1 != b1) p2 = e;             \
             }
-            for (int e = 1; e < 4; e++) {
-                if (e == p2 || p2 < 0) continue;
-                if (!(zero[0] || zero[p2] || zero[e])) { wound(0, p2, e); n++; }
+            CXP_DISJ(0) CXP_DISJ(1) CXP_DISJ(2) CXP_DISJ(3) CXP_DISJ(4) CXP_DISJ(5)
+#undef CXP_DISJ
+            if (p2 >= 0) {
+                const bool z02 = CXP_PICK(zero, e0) || CXP_PICK(zero, p2);
+#define CXP_THIRD(e) if (cross##e && e != e0 && e != p2 && !(z02 || zero##e)) { wound(e0, p2, e); n++; }
+                CXP_THIRD(0) CXP_THIRD(1) CXP_THIRD(2) CXP_THIRD(3) CXP_THIRD(4) CXP_THIRD(5)
+#undef CXP_THIRD
             }
         }
     }
+#undef CXP_EDGE
+#undef CXP_PICK
     return n;
 }
 

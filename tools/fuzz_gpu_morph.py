@@ -9,7 +9,7 @@ from contourist_amd import pentatopes
 from oracle import level0_4d, postpass4d
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
-t0 = time.time(); ncase = 0; nbad = 0; nmt = 0; npatch = 0; nflip = 0; nbreak = 0; nbad_o = 0
+t0 = time.time(); ncase = 0; nbad = 0; nmt = 0; npatch = 0; nflip = 0; nbreak = 0; nbad_o = 0; nsurf = 0; nsurf_tri = 0
 while time.time() - t0 < budget:
     shape = tuple(int(x) for x in rng.randint(5, 13, size=4))
     A = rng.standard_normal(shape)
@@ -78,9 +78,21 @@ while time.time() - t0 < budget:
                 if bad_d:
                     why = "%d of %d forced pairs run their segment in the same direction" % (bad_d, seen_d)
             nmt += len(ot)
+            if why is None:
+                # B6: the per-t stream in one call (cx_morph_eval_many) against the host evaluation of the downloaded morph triangles
+                # (MorphTriangles.triangles_at, the restatement of the viewer) -- random times, vertex times exactly, repeats, the ends
+                tv = np.unique(MT.points4d[:, 3])
+                times = list(rng.uniform(tv[0], tv[-1], size=5)) + [float(x) for x in rng.choice(tv, size=3)] + [float(tv[0]), float(tv[-1])]
+                times += [times[1]]
+                for (pd, td), t in zip(maker.triangles_at_many(times), times):
+                    ph, th = MT.triangles_at(t)
+                    nsurf += 1; nsurf_tri += len(td)
+                    if not (np.array_equal(td, th) and np.allclose(pd, ph, rtol=0, atol=1e-12)):
+                        why = "per-t surface at t = %r: %d / %d triangles, %d / %d points" % (t, len(td), len(th), len(pd), len(ph))
+                        break
     if why:
         nbad += 1
         print("MISMATCH", why, "shape", shape, "v", v, R["counts"], flush=True)
-print("fuzz 4-D post-pass: %d cases, %d morph triangles, %d mismatches (%d triangles in %d patches wound the other way than the oracle's traversal; %d segments counted as forced breaks by winding_excuses, inconsistent forced pairs of the oracle's own flood fill: %d), %.0f s"
-      % (ncase, nmt, nbad, nflip, npatch, nbreak, nbad_o, time.time() - t0))
+print("fuzz 4-D post-pass: %d cases, %d morph triangles, %d mismatches (%d triangles in %d patches wound the other way than the oracle's traversal; %d segments counted as forced breaks by winding_excuses, inconsistent forced pairs of the oracle's own flood fill: %d); %d per-t surfaces (%d triangles) == the host's triangles_at; %.0f s"
+      % (ncase, nmt, nbad, nflip, npatch, nbreak, nbad_o, nsurf, nsurf_tri, time.time() - t0))
 sys.exit(1 if nbad else 0)
