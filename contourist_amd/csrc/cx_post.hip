@@ -1472,6 +1472,9 @@ static int cxp_state(cx_ctx* ctx, cx_post_state** out) {
     if (!ctx->post) ctx->post = new (std::nothrow) cx_post_state();
     if (!ctx->post) return CX_ERR_NOMEM;
     *out = ctx->post;
+    // every post-pass rewrites the points the morph triangles of an earlier cx_morph_triangles index: those are gone (their segments would
+    // point into the new points: cx_morph_eval on them read out of bounds)
+    ctx->post->ms_out = 0; ctx->post->mt_out = 0; ctx->post->msorted = false; ctx->post->me_off.clear();
     return cxp_reserve(ctx, ctx->post->misc, 512 * sizeof(uint32_t));      // (words 32..288: bin starts of the start-time sort)
 }
 

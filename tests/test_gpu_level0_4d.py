@@ -657,3 +657,41 @@ def test_per_t_stream_in_one_call_equals_the_single_surfaces(shape, nbins):
         assert ctx.morph_eval_device_ptrs(len(times) - 1) == (0, 0)
     finally:
         ctx.close()
+
+
+def test_per_t_stream_argument_errors():
+    """cx_morph_eval_many: a NaN among the times, a negative count and a call before any morph triangles are refused with
+    an error code and a message (no launch); the context keeps working afterwards"""
+    from contourist_amd import _ffi
+    ctx = _ffi.Context(0)
+    try:
+        out = np.zeros((4, 2), dtype=np.int64)
+        ts = np.array([0.5, 1.5], dtype=np.float64)
+        # nothing extracted yet: no post state at all
+        assert ctx.lib.cx_morph_eval_many(ctx.handle, ts.ctypes.data, 2, out.ctypes.data) != 0
+        A = _blob_field((12, 11, 10, 8), 9)
+        ctx.upload_grid4d(A)
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(100)
+        # post steps done, morph triangles not yet built: nothing to evaluate, empty surfaces
+        assert ctx.lib.cx_morph_eval_many(ctx.handle, ts.ctypes.data, 2, out.ctypes.data) == 0 and not out.any()
+        pts, segs, tris, _ = ctx.morph_triangles()
+        assert ctx.lib.cx_morph_eval_many(ctx.handle, ts.ctypes.data, -1, out.ctypes.data) != 0
+        bad = np.array([0.5, np.nan], dtype=np.float64)
+        with pytest.raises(_ffi.CxError):
+            ctx.morph_eval_many(bad)
+        assert ctx.lib.cx_morph_eval_many_download(ctx.handle, 7, None, None) != 0
+        t = 0.5 * (pts[:, 3].min() + pts[:, 3].max())
+        p, q = ctx.morph_eval(t)
+        assert len(q) > 0 and q.max() < len(p)
+        # a new post-pass (here: of a smaller field) takes the morph triangles of the old one away: nothing to evaluate until they are rebuilt
+        ctx.upload_grid4d(_blob_field((8, 8, 8, 6), 2))
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(100)
+        p, q = ctx.morph_eval(t)
+        assert len(p) == 0 and len(q) == 0
+        pts2, segs2, tris2, _ = ctx.morph_triangles()
+        p, q = ctx.morph_eval(0.5 * (pts2[:, 3].min() + pts2[:, 3].max()))
+        assert len(q) > 0 and q.max() < len(p)
+    finally:
+        ctx.close()
