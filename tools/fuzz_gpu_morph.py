@@ -10,7 +10,11 @@ from oracle import level0_4d, postpass4d
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 t0 = time.time(); ncase = 0; nbad = 0; nmt = 0; npatch = 0; nflip = 0; nbreak = 0; nbad_o = 0; nsurf = 0; nsurf_tri = 0
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60.0:      # (a GPU box takes a run that says nothing for minutes to be hung)
+        last_note = time.time()
+        print("... %d cases, %d morph triangles, %d mismatches so far, %.0f s" % (ncase, nmt, nbad, time.time() - t0), flush=True)
     shape = tuple(int(x) for x in rng.randint(5, 13, size=4))
     A = rng.standard_normal(shape)
     for _ in range(int(rng.randint(1, 5))):
