@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--strong", action="store_true", help="(default) ONE size^3 volume split into N slabs")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the extra pass on one stream (unoverlapped kernel durations)")
     ap.add_argument("--levels", type=int, default=8, help="BASELINE config 5 after the timed region: this many isovalues (20..90th percentiles) of the same volume in ONE call per rank (0 = skip)")
+    ap.add_argument("--no-config4", action="store_true", help="skip BASELINE config 4 after the timed region (N = 1 only: 128^3 x 64 4-D field, pentatope march, "
+                    "morph triangles, the per-t isosurface stream of 64 times in one call)")
     ap.add_argument("--streams", type=int, default=0, help="extractions in flight: consecutive steps alternate between this many contexts / HIP streams "
                                                            "(0 = auto: 2; 3 from 4 ranks on, where a rank's slab is thin and every step waits for a halo plane)")
     return ap.parse_args()
@@ -265,6 +267,49 @@ def run_levels(args, torch, dist, _ffi, job, stream, device_index, flags, distri
             "note": "BASELINE config 5: every rank marches its slab for ALL isovalues in one cx_extract3d_levels call (one pass over the "
                     "samples for all levels, then vertex + triangle stages per level); synchronous per call (counts come back to size the buffers); "
                     "whole-job figures, max over ranks"}
+
+
+def run_config4(torch, _ffi, synthetic, dev, device_index):
+    """BASELINE config 4 on this GPU (N = 1 only): 128 x 128 x 128 x 64 fp32 4-D field (two moving blobs + noise, seed 1236), the pentatope
+    march (cx_extract4d), find_tetrahedra's post steps, the morph triangles, and the per-t isosurface stream: the surfaces at 64 times
+    from the morph triangles in ONE call (cx_morph_eval_many).  Every figure is a warm call (buffers in place), synchronous."""
+    import numpy as np
+    shape = (128, 128, 128, 64)
+    A = synthetic.moving_blobs_torch(shape, 1236, dev)
+    ctx = _ffi.Context(device_index)
+    try:
+        ctx.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return r, (time.perf_counter() - t0) / reps
+        counts, t_l0 = timed(lambda: ctx.extract4d(0.5, 1), 5)
+        post, t_post = timed(lambda: ctx.postprocess4d(100), 2)
+        out = np.zeros(8, dtype=np.int64)
+        _, t_morph = timed(lambda: ctx._check(ctx.lib.cx_morph_triangles(ctx.handle, out.ctypes.data)), 2)
+        import struct
+
+        def from_orderable(o):
+            o = int(o) & 0xFFFFFFFFFFFFFFFF
+            b = (o & 0x7FFFFFFFFFFFFFFF) if (o >> 63) else (~o & 0xFFFFFFFFFFFFFFFF)
+            return struct.unpack("<d", struct.pack("<Q", b))[0]
+        tmin, tmax = from_orderable(out[5]), from_orderable(out[6])
+        ts = np.linspace(tmin, tmax, shape[3])
+        cm, t_stream = timed(lambda: ctx.morph_eval_many(ts, download=False), 5)
+        n = A.numel()
+        return {"workload": "128x128x128x64 fp32, two moving blobs + noise (seed 1236), v = 0.5", "counts": counts, "post": post,
+                "level0_ms": t_l0 * 1e3, "Mhypervoxels_per_s": n / t_l0 / 1e6, "hbm_frac_input_bytes": 4.0 * n / t_l0 / (HBM_PEAK_GBS * 1e9),
+                "postprocess_ms": t_post * 1e3, "morph_triangles_ms": t_morph * 1e3, "morph_segments": int(out[1]), "morph_triangles": int(out[2]),
+                "per_t_stream": {"times": int(len(ts)), "ms": t_stream * 1e3, "triangles": int(cm[:, 1].sum()), "points": int(cm[:, 0].sum()),
+                                 "Mtriangles_per_s": int(cm[:, 1].sum()) / t_stream / 1e6,
+                                 "note": "cx_morph_eval_many: the surfaces at 64 equally spaced times in one call, meshes left on the device"}}
+    finally:
+        ctx.close()
 
 
 def run_sharded_level1(args, torch, dist, cxdist, job, dev, rank, world, strong, ctx):
@@ -641,6 +686,11 @@ def main():
             out["weak"] = weak_line
         if projection is not None:
             out["slab_projection"] = projection
+        if world == 1 and not args.no_config4:
+            try:
+                out["config4"] = run_config4(torch, _ffi, synthetic, dev, device_index)
+            except Exception as e:      # an extra: the headline stands without it
+                out["config4"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if multi is not None:
             out["multi_level"] = multi
             out["levels"] = len(multi["levels"])
