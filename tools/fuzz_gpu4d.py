@@ -12,7 +12,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 ctx = _ffi.Context(0)
 t0 = time.time(); ncase = 0; nbad = 0; ntet = 0
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60.0:      # (a GPU box takes a run that says nothing for minutes to be hung)
+        last_note = time.time()
+        print("... %.0f s" % (time.time() - t0), flush=True)
     kind = rng.randint(0, 3)
     if kind == 0:
         shape = tuple(int(x) for x in rng.randint(2, 9, size=4))

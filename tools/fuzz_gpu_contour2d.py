@@ -13,7 +13,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 ctx = _ffi.Context(0)
 t0 = time.time(); ncase = 0; nbad = 0; npts = 0
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60.0:      # (a GPU box takes a run that says nothing for minutes to be hung)
+        last_note = time.time()
+        print("... %.0f s" % (time.time() - t0), flush=True)
     shape = (int(rng.randint(2, 60)), int(rng.randint(2, 90)))
     B = rng.standard_normal(shape)
     for _ in range(int(rng.randint(0, 4))):
