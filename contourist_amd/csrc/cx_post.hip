@@ -2609,7 +2609,8 @@ __global__ void cxp_k_tri_segments(const u64* pairs, uint32_t nt, const u64* tke
 // swaps the block's local head in as the edge's new head and hangs the old head behind itself.  One device-scope exchange per (edge,
 // block) instead of one per visit (triangle ids follow the march: most of an edge's triangles sit in one block); the reads and
 // read-modify-writes at the memory side of the fabric are what this stage is bound by.  The order inside a list is of no consequence
-// (cxp_k_edge_union_compat looks at every pair).
+// (cxp_k_edge_union_compat looks at every pair).  Measured and dropped (third session of round 4): key and head of a slot next to each other
+// in ONE table (one line per probe, as the 3-D edge table has it) -- 2.99 -> 3.22 ms on config 4.
 #define CXP_EL 512u
 #define CXP_EL_PER (CXP_EL / 256u)
 #define CXP_EL_SLOTS (4u * CXP_EL)
