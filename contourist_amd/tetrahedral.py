@@ -48,6 +48,12 @@ class GridContour3d(object):
     samples  = dense fp32 array (numpy) or torch tensor on the GPU, shape corner+1.
     """
 
+    # One extraction addresses its samples and edges with 32-bit ids: 2^29 samples at most (include/contourist_hip.h, cx_grid_upload).
+    # A larger volume -- 1024^3 fp32 is 4 GB of the 288 GB of an MI355X -- is marched slab by slab along axis 0 on the same context
+    # (each slab with one plane of its upper neighbour, global edge ids, as the ranks of distributed.level1_slabs do) and
+    # post-processed as ONE mesh.  Lowered by the tests to force the slab path on small volumes.
+    MAX_SAMPLES_PER_EXTRACTION = 1 << 29
+
     def __init__(self, corner, samples, value, segment_endpoints=None, linear_interpolate=True,
                  callback=None, device=None, diagonal="cpython310", context=None, voxel_range=None, function=None, samples64=None):
         self.corner = np.array(corner, dtype=int)
@@ -101,8 +107,73 @@ class GridContour3d(object):
             ctx.upload_grid(s)
         ctx.shadow_grid_f64(self.samples64)
 
+    def _in_slabs(self):
+        "more samples than one extraction addresses: the volume goes through the device slab by slab"
+        return int(np.prod(self.shape, dtype=np.int64)) > int(self.MAX_SAMPLES_PER_EXTRACTION)
+
+    def _slab_planes(self):
+        "planes of axis 0 per slab, so that a slab plus its halo plane stays within one extraction"
+        per_plane = int(self.shape[1]) * int(self.shape[2])
+        planes = int(self.MAX_SAMPLES_PER_EXTRACTION) // per_plane - 1
+        if planes < 2:
+            raise ValueError("a plane of %d x %d samples leaves no room for a slab of two planes and its halo in one extraction "
+                             "(%d samples)" % (self.shape[1], self.shape[2], int(self.MAX_SAMPLES_PER_EXTRACTION)))
+        return planes
+
+    def _post_in_slabs(self, clean=True):
+        """Level 0 slab by slab + Level 1 of the assembled mesh (the single-process form of distributed.level1_slabs: same slabs,
+        same global edge ids, same post-pass on ONE mesh, so components, weld buckets and the max-x rule see the whole surface).
+        Leaves the Level-1 mesh in the context (download_level1 / level1_torch) and returns the post-pass counts."""
+        from . import distributed
+        if (self.end_points is not None and len(self.end_points)) or self.voxel_range is not None or not self.linear_interpolate \
+                or tuple(self.origin) != (0, 0, 0) or self.grid_shift:
+            raise NotImplementedError("a volume of more than %d samples is marched in slabs: exhaustive search, linear interpolation and "
+                                      "an array without a rim only (no end points, no voxel range)" % int(self.MAX_SAMPLES_PER_EXTRACTION))
+        ctx = self.context()
+        s, s64 = self.samples, self.samples64
+        on_device = grid_field._is_torch(s)
+        if on_device:
+            assert s.is_cuda and s.is_contiguous() and str(s.dtype) == "torch.float32", \
+                "device samples must be a contiguous float32 tensor on the GPU"
+        else:
+            s = np.ascontiguousarray(s, dtype=np.float32)
+        n0 = int(self.shape[0])
+        planes = self._slab_planes()
+        parts = []
+        totals = dict(n_cells=0, n_vertices=0, n_triangles=0, n_border_voxels=0)
+        bounds, at = [], 0
+        while at < n0:
+            end = min(n0, at + planes)
+            if n0 - end == 1:          # never leave a last slab of one plane (it would hold no voxel): planes + 1 still fit, it has no halo
+                end = n0
+            bounds.append((at, end))
+            at = end
+        for (i0, i1) in bounds:
+            has_halo = i1 < n0
+            local = s[i0:i1 + (1 if has_halo else 0)]
+            ctx.set_origin(i0, 0, 0)
+            if on_device:
+                ctx.adopt_device_grid(local.data_ptr(), tuple(int(n) for n in local.shape), keepalive=s)
+            else:
+                ctx.upload_grid(local)
+            ctx.shadow_grid_f64(None if s64 is None else s64[i0:i1 + (1 if has_halo else 0)])
+            counts = ctx.extract3d(self.value, self.flags)
+            _xyz32, keys, tris = ctx.download_level0(counts)
+            xyz = ctx.level0_points_f64(counts)            # global coordinates (the origin is added before interpolating)
+            parts.append(distributed.local_to_global(xyz, keys, tris, tuple(local.shape), i0, i1 - i0, has_halo, True))
+            for k in totals:
+                totals[k] += int(counts[k])
+        ctx.set_origin(0, 0, 0)
+        keys, xyz, tris = distributed.assemble(parts)
+        self._slab_counts = dict(totals, n_slabs=len(parts), n_vertices=int(len(keys)), n_triangles=int(len(tris)))
+        ctx.set_reference_corner((0, 0, 0))
+        return ctx.postprocess3d_mesh(xyz, tris, [int(c) for c in self.corner], 0 if clean else 1, self.smooth or 0.0)
+
     def march(self, force=False):
         "Level 0 on the device (idempotent). returns the counts dict."
+        if self._in_slabs():
+            raise NotImplementedError("a volume of more than %d samples has no single Level-0 extraction: get_points_and_triangles() "
+                                      "marches it in slabs" % int(self.MAX_SAMPLES_PER_EXTRACTION))
         if self._counts is None or force:
             self._bind_grid()
             self.context().set_origin(*self.origin)
@@ -120,6 +191,16 @@ class GridContour3d(object):
     # -- reference API -------------------------------------------------------------------------------
     def extract_surface_geometry(self, clean=True):
         "SurfaceGeometry of the welded, cleaned and oriented mesh in grid coordinates (tetrahedral.py:604-621)"
+        if self.flatten:
+            raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
+        if self._in_slabs():
+            if self.smooth:
+                assert self.smooth > 0 and self.smooth <= 1
+            ctx = self.context()
+            if self._post is None:
+                self._post = self._post_in_slabs(clean)
+            pts, tris = ctx.download_level1(self._post)
+            return surface_geometry.SurfaceGeometry._from_device(pts, tris, ctx)
         self.march()
         if self.flatten:
             raise NotImplementedError("flatten=True (lp_tools decimation) is outside the device path")
@@ -147,6 +228,11 @@ class GridContour3d(object):
 
     def _ensure_post(self, clean=True):
         "Level 1 on the device, left there (no download); returns the context"
+        if self._in_slabs():
+            ctx = self.context()
+            if self._post is None:
+                self._post = self._post_in_slabs(clean)
+            return ctx
         self.march()
         ctx = self.context()
         if self._post is None:
@@ -439,7 +525,8 @@ class Delta3DContour(object):
             self.contour_maker.keep_in_range = True
         else:
             self.contour_maker = self.get_contour_maker(None)
-        self.contour_maker.march()
+        if not self.contour_maker._in_slabs():      # (a volume beyond one extraction is marched slab by slab in get_points_and_triangles)
+            self.contour_maker.march()
         self.grid_endpoints = _LazyEndpoints(self.contour_maker, skip, getattr(self, "_grid_shift", 0), self.grid.grid_dimensions)
 
     def _rim_segments(self, shell=2):

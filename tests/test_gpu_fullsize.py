@@ -132,3 +132,84 @@ def test_level1_orientation_at_full_size():
         ctx.close()
         del A
         torch.cuda.empty_cache()
+
+
+def _two_balls(shape, dev=None):
+    "f = min distance to two ball centres minus the radii (fp32), two closed components well inside the volume"
+    import torch
+    ax = [torch.arange(n, dtype=torch.float32, device=dev) for n in shape]
+    X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+    c1 = (0.30 * shape[0], 0.45 * shape[1], 0.50 * shape[2]); r1 = 0.18 * min(shape)
+    c2 = (0.72 * shape[0], 0.55 * shape[1], 0.48 * shape[2]); r2 = 0.13 * min(shape)
+    d1 = torch.sqrt((X - c1[0]) ** 2 + (Y - c1[1]) ** 2 + (Z - c1[2]) ** 2) - r1
+    del X
+    d2 = torch.sqrt((ax[0][:, None, None] - c2[0]) ** 2 + (Y - c2[1]) ** 2 + (Z - c2[2]) ** 2) - r2
+    del Y, Z
+    return torch.minimum(d1, d2).contiguous(), (c1, r1, c2, r2)
+
+
+def _canonical_mesh(points, tris):
+    "vertices in lexicographic order, triangles renumbered, each rotated to start at its smallest index (winding kept), rows sorted"
+    P = np.asarray(points, dtype=np.float64)
+    T = np.asarray(tris, dtype=np.int64)
+    order = np.lexsort((P[:, 2], P[:, 1], P[:, 0]))
+    rank = np.empty(len(P), dtype=np.int64)
+    rank[order] = np.arange(len(P))
+    T = rank[T]
+    r = np.argmin(T, axis=1)
+    rows = np.arange(len(T))
+    T = np.stack([T[rows, r], T[rows, (r + 1) % 3], T[rows, (r + 2) % 3]], axis=1)
+    T = T[np.lexsort((T[:, 2], T[:, 1], T[:, 0]))]
+    return P[order], T
+
+
+def test_volume_in_slabs_equals_the_single_extraction():
+    """A volume with more samples than one extraction addresses goes through the device slab by slab (GridContour3d._post_in_slabs):
+    with the limit lowered, a 70 x 48 x 52 volume in 5 slabs (and in 2, and with a last slab that absorbs a single plane) gives the
+    points and triangles of the single extraction, bit for bit up to the order of the vertices -- host array, device tensor, a smooth noise field and two balls"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import tetrahedral, synthetic
+    fields = [synthetic.smooth_noise_host((70, 48, 52), 77, passes=30) if hasattr(synthetic, "smooth_noise_host") else None]
+    fields = [f for f in fields if f is not None]
+    fields.append(_two_balls((70, 48, 52))[0].numpy())
+    for A in fields:
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        corner = tuple(n - 1 for n in A.shape)
+        ref = tetrahedral.GridContour3d(corner, A, 0.0)
+        p0, t0 = ref.get_points_and_triangles()
+        assert len(t0) > 1000
+        P0, T0 = _canonical_mesh(p0, t0)
+        assert len(np.unique(P0, axis=0)) == len(P0)          # (welded: no two vertices coincide, the canonical order is unique)
+        for limit, on_device in ((48 * 52 * 16, False), (48 * 52 * 36, True), (48 * 52 * 24, False)):
+            S = torch.from_numpy(A).cuda() if on_device else A
+            m = tetrahedral.GridContour3d(corner, S, 0.0)
+            m.MAX_SAMPLES_PER_EXTRACTION = limit
+            assert m._in_slabs()
+            p1, t1 = m.get_points_and_triangles()
+            assert m._slab_counts["n_slabs"] >= 2
+            P1, T1 = _canonical_mesh(p1, t1)          # (the vertex order differs: ascending edge id here, march order there)
+            assert np.array_equal(P1, P0) and np.array_equal(T1, T0)
+            with pytest.raises(NotImplementedError):
+                m.level0()
+
+
+def test_volume_beyond_one_extraction():
+    """1056 x 720 x 720 fp32 = 547 M samples (> 2^29) resident on the GPU, two balls: get_points_and_triangles marches it in slabs;
+    the result is a consistently wound two-component surface on the balls (every point within a quarter voxel of its sphere, no
+    manifold edge run in the same direction by its two triangles; where the weld left no pinched edge: Euler characteristic 2 per component)"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import tetrahedral
+    shape = (1056, 720, 720)
+    assert shape[0] * shape[1] * shape[2] > (1 << 29)
+    A, (c1, r1, c2, r2) = _two_balls(shape, torch.device("cuda", 0))
+    m = tetrahedral.GridContour3d(tuple(n - 1 for n in shape), A, 0.0)
+    assert m._in_slabs()
+    pts, tris = m.get_points_and_triangles()
+    pts, tris = np.asarray(pts), np.asarray(tris)
+    assert m._slab_counts["n_slabs"] >= 2 and m._post["n_components"] == 2
+    d = np.minimum(np.abs(np.linalg.norm(pts - np.array(c1), axis=1) - r1), np.abs(np.linalg.norm(pts - np.array(c2), axis=1) - r2))
+    assert d.max() < 0.25              # linear interpolation on a unit lattice + the weld buckets of this corner (1/9 voxel)
+    manifold, same, other = edge_consistency(tris)
+    assert len(tris) > 2000000 and same == 0 and other <= 1e-3 * manifold
+    if other == 0:
+        assert manifold * 2 == len(tris) * 3 and len(pts) - manifold + len(tris) == 4      # V - E + F = 2 per closed component
