@@ -695,3 +695,45 @@ def test_per_t_stream_argument_errors():
         assert len(q) > 0 and q.max() < len(p)
     finally:
         ctx.close()
+
+
+def test_per_t_stream_at_mid_size_equals_the_host_evaluation():
+    """64 x 64 x 64 x 32 (two moving blobs, ~1.5 M morph triangles): the per-t stream of 40 times in one call -- windows of many blocks,
+    offsets across blocks and across times -- against MorphTriangles.triangles_at on the host for every time, and the single calls"""
+    torch = pytest.importorskip("torch")
+    from contourist_amd import _ffi, morph_geometry
+    dev = torch.device("cuda", 0)
+    shape = (64, 64, 64, 32)
+    ax = [torch.arange(n, device=dev, dtype=torch.float32) / (n - 1) for n in shape]
+    X, Y, Z, T = torch.meshgrid(*ax, indexing="ij")
+    A = torch.exp(-(((X - 0.30 - 0.35 * T) ** 2 + (Y - 0.35 - 0.2 * T) ** 2 + (Z - 0.5) ** 2) / (2 * 0.12 ** 2))) + \
+        torch.exp(-(((X - 0.70 + 0.30 * T) ** 2 + (Y - 0.65 + 0.2 * T) ** 2 + (Z - 0.45 - 0.1 * T) ** 2) / (2 * 0.10 ** 2)))
+    for axis in range(4):
+        for idx in (0, 1, -1, -2):
+            A.select(axis, idx).fill_(0.0)
+    A = A.contiguous()
+    ctx = _ffi.Context(0)
+    try:
+        ctx.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+        ctx.extract4d(0.5, 1)
+        ctx.postprocess4d(100)
+        pts, segs, tris, _ = ctx.morph_triangles()
+        assert len(tris) > 500000
+        MT = morph_geometry.MorphTriangles(pts, segs, tris)
+        tmin, tmax = float(pts[:, 3].min()), float(pts[:, 3].max())
+        rng = np.random.RandomState(3)
+        times = np.concatenate([np.linspace(tmin, tmax, 32), rng.uniform(tmin, tmax, size=6), [tmin + 0.4 * (tmax - tmin)] * 2])
+        rng.shuffle(times)
+        many = ctx.morph_eval_many(times)
+        total = 0
+        for i, t in enumerate(times):
+            ph, th = MT.triangles_at(float(t))
+            pm, tm = many[i]
+            assert np.array_equal(tm, th) and np.allclose(pm, ph, rtol=0, atol=1e-12), (i, t, len(tm), len(th))
+            total += len(tm)
+        assert total > 1000000
+        for i in (0, 7, 21):
+            p1, t1 = ctx.morph_eval(float(times[i]))
+            assert np.array_equal(t1, many[i][1]) and np.array_equal(p1, many[i][0])
+    finally:
+        ctx.close()
