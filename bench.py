@@ -289,6 +289,25 @@ def run_config4(torch, _ffi, synthetic, dev, device_index):
             torch.cuda.synchronize()
             return r, (time.perf_counter() - t0) / reps
         counts, t_l0 = timed(lambda: ctx.extract4d(0.5, 1), 5)
+        # two extractions in flight on two contexts (cx_extract4d_async / cx_counts4d_get), as the 3-D headline has them
+        ctx2 = _ffi.Context(device_index)
+        try:
+            ctx2.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+            ctx2.extract4d(0.5, 1)
+            pair = [ctx, ctx2]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 12
+            for i in range(reps):          # `reps` extractions start and end inside the timed region
+                if i >= 2:
+                    pair[i & 1].counts4d()
+                pair[i & 1].extract4d_async(0.5, 1)
+            last = [c_.counts4d() for c_ in pair]
+            torch.cuda.synchronize()
+            t_l0_two = (time.perf_counter() - t0) / reps
+            assert last[0] == counts and last[1] == counts
+        finally:
+            ctx2.close()
         post, t_post = timed(lambda: ctx.postprocess4d(100), 2)
         out = np.zeros(8, dtype=np.int64)
         _, t_morph = timed(lambda: ctx._check(ctx.lib.cx_morph_triangles(ctx.handle, out.ctypes.data)), 2)
@@ -304,6 +323,7 @@ def run_config4(torch, _ffi, synthetic, dev, device_index):
         n = A.numel()
         return {"workload": "128x128x128x64 fp32, two moving blobs + noise (seed 1236), v = 0.5", "counts": counts, "post": post,
                 "level0_ms": t_l0 * 1e3, "Mhypervoxels_per_s": n / t_l0 / 1e6, "hbm_frac_input_bytes": 4.0 * n / t_l0 / (HBM_PEAK_GBS * 1e9),
+                "level0_two_in_flight_ms": t_l0_two * 1e3, "hbm_frac_input_bytes_two_in_flight": 4.0 * n / t_l0_two / (HBM_PEAK_GBS * 1e9),
                 "postprocess_ms": t_post * 1e3, "morph_triangles_ms": t_morph * 1e3, "morph_segments": int(out[1]), "morph_triangles": int(out[2]),
                 "per_t_stream": {"times": int(len(ts)), "ms": t_stream * 1e3, "triangles": int(cm[:, 1].sum()), "points": int(cm[:, 0].sum()),
                                  "Mtriangles_per_s": int(cm[:, 1].sum()) / t_stream / 1e6,

@@ -28,7 +28,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_device_ptrs", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_rccl_available", "cx_rccl_comm_share", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download", "cx_morph_eval_many", "cx_morph_eval_many_download", "cx_morph_eval_many_device_ptrs",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_extract4d_async", "cx_counts4d_get", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_rccl_available", "cx_rccl_comm_share", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download", "cx_morph_eval_many", "cx_morph_eval_many_download", "cx_morph_eval_many_device_ptrs",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_measure_read_bandwidth", "cx_debug_stamps", "cx_version",
 ]
@@ -132,6 +132,8 @@ def load():
         "cx_grid4d_adopt_device": [vp, vp, i64, i64, i64, i64],
         "cx_set_origin4d": [vp, i64, i64, i64, i64],
         "cx_extract4d": [vp, dbl, u32, ctypes.POINTER(CxCounts)],
+        "cx_extract4d_async": [vp, dbl, u32],
+        "cx_counts4d_get": [vp, ctypes.POINTER(CxCounts)],
         "cx_select_seeded4d": [vp, vp, i64, vp],
         "cx_select_seeded4d_ex": [vp, vp, i64, vp, ctypes.c_uint32, vp],
         "cx_seeded4d_mask_download": [vp, vp],
@@ -455,6 +457,15 @@ class Context(object):
     def extract4d(self, value, flags=CX_DIAG_CPYTHON310):
         c = CxCounts()
         self._check(self.lib.cx_extract4d(self.handle, float(value), int(flags), ctypes.byref(c)))
+        return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
+
+    def extract4d_async(self, value, flags=CX_DIAG_CPYTHON310):
+        "the 4-D march enqueued on this context's stream, not waited for; counts4d() waits and returns what extract4d returns"
+        self._check(self.lib.cx_extract4d_async(self.handle, float(value), int(flags)))
+
+    def counts4d(self):
+        c = CxCounts()
+        self._check(self.lib.cx_counts4d_get(self.handle, ctypes.byref(c)))
         return dict(n_cells=c.n_cells, n_vertices=c.n_vertices, n_tetrahedra=c.n_triangles, n_border_voxels=c.n_border_voxels)
 
     def select_seeded4d(self, endpoints, voxel_range=None, all_in_range=False, parallel=False):

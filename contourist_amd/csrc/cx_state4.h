@@ -68,6 +68,9 @@ struct cx_state4 {
     int64_t origin[4] = {0, 0, 0, 0};
     bool extracted = false;
     bool post_valid = false;
+    bool pending = false;            // a cx_extract4d_async is enqueued, its counters not yet looked at (cx_counts4d_get)
+    double pending_value = 0.0;
+    uint32_t pending_flags = 0;
     double value = 0.0;
     cx_counts counts = {0, 0, 0, 0};
     // seeded selection (cx_select_seeded4d): mask over the Level-0 tetrahedra, valid until the next extraction

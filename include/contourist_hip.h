@@ -280,6 +280,11 @@ int cx_grid4d_upload(cx_ctx* ctx, const float* host, int64_t n0, int64_t n1, int
 int cx_grid4d_adopt_device(cx_ctx* ctx, const void* device_ptr, int64_t n0, int64_t n1, int64_t n2, int64_t n3);
 int cx_set_origin4d(cx_ctx* ctx, int64_t o0, int64_t o1, int64_t o2, int64_t o3);
 int cx_extract4d(cx_ctx* ctx, double value, uint32_t flags, cx_counts* out);
+/* The same march enqueued on the context's stream and not waited for (one volume after the other on two contexts, as
+ * cx_extract3d_async / cx_counts_get for the 3-D path); cx_counts4d_get waits for it, validates the counters and, if a buffer was too
+ * small, grows it and runs the march again synchronously.  CX_ERR_STATE without an extraction in flight. */
+int cx_extract4d_async(cx_ctx* ctx, double value, uint32_t flags);
+int cx_counts4d_get(cx_ctx* ctx, cx_counts* out);
 /* Seeded selection in 4-D, the counterpart of cx_select_seeded3d: GridContour4D(corner, function, value, endpoints)
  * (pentatopes.py:92-100) grows from its end points with the methods it inherits (tetrahedral.py:396-463) over the 80
  * neighbours of pentatopes.py:32-39.  endpoints_ijkl: n x 8 int32 lattice points (i0,j0,k0,l0, i1,j1,k1,l1) whose

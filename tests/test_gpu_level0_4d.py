@@ -737,3 +737,43 @@ def test_per_t_stream_at_mid_size_equals_the_host_evaluation():
             assert np.array_equal(t1, many[i][1]) and np.array_equal(p1, many[i][0])
     finally:
         ctx.close()
+
+
+def test_extract4d_async_equals_the_synchronous_march():
+    """cx_extract4d_async + cx_counts4d_get: two contexts with one extraction in flight each (different isovalues of two fields), the
+    same counts, vertices and tetrahedra as cx_extract4d, three times over; cx_counts4d_get without an extraction in flight is refused"""
+    from contourist_amd import _ffi
+    from oracle import level0_4d
+    fields = [(_blob_field((18, 16, 14, 10), 4), 0.5), (_blob_field((12, 13, 14, 9), 6), 0.42)]
+
+    def canon(ctx, counts, shape):
+        xyzt, keys, tets = ctx.download_level0_4d(counts)
+        return level0_4d.canonical4(keys.astype(np.int64), xyzt, tets.astype(np.int64))
+    want = []
+    for A, v in fields:
+        c = _ffi.Context(0)
+        try:
+            c.upload_grid4d(A)
+            counts = c.extract4d(v, 1)
+            want.append((counts, canon(c, counts, A.shape)))
+        finally:
+            c.close()
+    ctxs = [_ffi.Context(0), _ffi.Context(0)]
+    try:
+        with pytest.raises(_ffi.CxError):
+            ctxs[0].counts4d()
+        for rep in range(3):
+            for c, (A, v) in zip(ctxs, fields):
+                if rep == 0:
+                    c.upload_grid4d(A)
+                c.extract4d_async(v, 1)
+            for c, (A, v), (counts0, canon0) in zip(ctxs, fields, want):
+                counts = c.counts4d()
+                assert counts == counts0
+                got = canon(c, counts, A.shape)
+                assert np.array_equal(got[0], canon0[0]) and np.array_equal(got[2], canon0[2]) and np.array_equal(got[1], canon0[1])
+        with pytest.raises(_ffi.CxError):
+            ctxs[1].counts4d()
+    finally:
+        for c in ctxs:
+            c.close()

@@ -20,6 +20,25 @@ for _ in range(K):
     c = ctx.extract4d(v, 1)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
+# two extractions in flight (two contexts on the same field, cx_extract4d_async / cx_counts4d_get): what the 3-D bench line reports
+ctx2 = _ffi.Context(0)
+ctx2.adopt_device_grid4d(A.data_ptr(), shape, keepalive=A)
+ctx2.extract4d(v, 1)
+pair = [ctx, ctx2]
+K2 = 12
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(K2):              # K2 extractions start and end inside the timed region
+    c_ = pair[i & 1]
+    if i >= 2:
+        c2f = c_.counts4d()
+    c_.extract4d_async(v, 1)
+for c_ in pair:
+    c2f = c_.counts4d()
+torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) / K2
+assert c2f == c
+ctx2.close()
 t0 = time.perf_counter()
 post = ctx.postprocess4d(100)
 torch.cuda.synchronize()
@@ -72,7 +91,7 @@ try:
 except Exception as e:   # the oracle is test infrastructure; the bench line stands without it
     cpu = {"error": str(e)}
 print(json.dumps({"workload": "%dx%dx%dx%d fp32, two moving blobs + noise, v=%g" % (shape + (v,)), "counts": c, "post": post,
-                  "level0_ms": dt * 1e3, "Mhypervoxels_per_s": n / dt / 1e6, "hbm_frac_input_bytes": 4 * n / dt / 8e12,
+                  "level0_ms": dt * 1e3, "level0_two_in_flight_ms": dt2 * 1e3, "hbm_frac_input_bytes_two_in_flight": 4 * n / dt2 / 8e12, "Mhypervoxels_per_s": n / dt / 1e6, "hbm_frac_input_bytes": 4 * n / dt / 8e12,
                   "postprocess_ms": dp * 1e3, "postprocess_first_call_ms": dp_first * 1e3, "morph_triangles_ms": dm * 1e3, "morph_triangles_first_call_with_download_ms": dm_first * 1e3, "morph_triangles": int(len(mt[2])),
                   "per_t_surfaces": {"times": len(ts), "triangles": int(ntris_t), "ms": de * 1e3,
                                      "Mtriangles_per_s": ntris_t / de / 1e6 if de > 0 else 0.0},
