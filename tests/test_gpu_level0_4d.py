@@ -777,3 +777,34 @@ def test_extract4d_async_equals_the_synchronous_march():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_extract4d_grows_its_buffers_sync_and_async():
+    """white noise at its median: nearly every hyper-voxel is active, far more than a fresh context reserves (one cell in eight):
+    cx_extract4d repeats the march with larger buffers, and so does cx_counts4d_get after cx_extract4d_async -- both give the
+    oracle's mesh"""
+    from contourist_amd import _ffi
+    from oracle import level0_4d
+    rng = np.random.RandomState(11)
+    A = np.ascontiguousarray(rng.standard_normal((20, 18, 16, 14)).astype(np.float32))
+    O = level0_4d.march4d(A, 0.0, diag_mode=1)
+    ko = level0_4d.edge_keys4(O["pairs"], A.shape)
+    want = level0_4d.canonical4(ko, O["xyzt"], O["tets"])
+    # beyond the first reservation (cells: a sample in eight + 4096; tetrahedra: 4 per sample + 4096)
+    assert O["nborder_mixed"] > A.size // 8 + 4096 and len(O["tets"]) > 4 * A.size + 4096
+    for use_async in (False, True):
+        ctx = _ffi.Context(0)
+        try:
+            ctx.upload_grid4d(A)
+            if use_async:
+                ctx.extract4d_async(0.0, 1)
+                counts = ctx.counts4d()
+            else:
+                counts = ctx.extract4d(0.0, 1)
+            assert counts["n_tetrahedra"] == len(O["tets"]) and counts["n_vertices"] == len(ko)
+            xyzt, keys, tets = ctx.download_level0_4d(counts)
+            got = level0_4d.canonical4(keys.astype(np.int64), xyzt, tets.astype(np.int64))
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+            assert np.all(np.abs(got[1] - want[1]) <= 1e-6 * np.abs(want[1]) + 1e-6)
+        finally:
+            ctx.close()
