@@ -28,7 +28,7 @@ SYMBOLS = [
     "cx_grid_upload", "cx_grid_adopt_device", "cx_grid_shadow_f64", "cx_set_origin", "cx_reserve",
     "cx_extract3d", "cx_extract3d_async", "cx_counts_get", "cx_extract3d_levels", "cx_levels_select", "cx_level0_path", "cx_level0_download", "cx_level0_device_ptrs", "cx_level0_device_records", "cx_level0_download_records",
     "cx_postprocess3d", "cx_postprocess3d_ex", "cx_level0_points_f64", "cx_postprocess3d_mesh", "cx_select_seeded3d", "cx_select_seeded3d_ex", "cx_seeded_masks_download", "cx_set_reference_corner", "cx_level1_download", "cx_level1_device_ptrs", "cx_level1_download_keys", "cx_postprocess3d_shard_begin", "cx_postprocess3d_shard_boundary", "cx_postprocess3d_shard_candidates", "cx_postprocess3d_shard_finish", "cx_level1_write", "cx_surface_geometry",
-    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_extract4d_async", "cx_counts4d_get", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_rccl_available", "cx_rccl_comm_share", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download", "cx_morph_eval_many", "cx_morph_eval_many_download", "cx_morph_eval_many_device_ptrs",
+    "cx_grid4d_upload", "cx_grid4d_adopt_device", "cx_set_origin4d", "cx_extract4d", "cx_extract4d_async", "cx_counts4d_get", "cx_select_seeded4d", "cx_select_seeded4d_ex", "cx_seeded_mode", "cx_halo_exchange", "cx_rccl_unique_id", "cx_rccl_comm_init", "cx_rccl_comm_destroy", "cx_rccl_available", "cx_rccl_comm_share", "cx_slab_step", "cx_seeded4d_mask_download", "cx_level0_4d_download", "cx_postprocess4d", "cx_postprocess4d_points", "cx_level1_4d_download", "cx_morph_triangles", "cx_morph_download", "cx_morph_eval", "cx_morph_eval_download", "cx_morph_eval_many", "cx_morph_eval_many_download", "cx_morph_eval_many_device_ptrs", "cx_morph_eval_many_download_all",
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_measure_read_bandwidth", "cx_debug_stamps", "cx_version",
 ]
@@ -156,6 +156,7 @@ def load():
         "cx_morph_eval_many": [vp, vp, ctypes.c_int32, vp],
         "cx_morph_eval_many_download": [vp, ctypes.c_int32, vp, vp],
         "cx_morph_eval_many_device_ptrs": [vp, ctypes.c_int32, vp, vp],
+        "cx_morph_eval_many_download_all": [vp, vp, vp],
         "cx_contour2d_extract": [vp, vp, ctypes.c_int, i64, i64, vp, ctypes.c_int32, vp, i64, u32, vp, ctypes.POINTER(CxCounts2D)],
         "cx_contour2d_download": [vp, vp, vp, vp],
         "cx_timing_enable": [vp, ctypes.c_int],
@@ -590,12 +591,15 @@ class Context(object):
         self._check(self.lib.cx_morph_eval_many(self.handle, ts.ctypes.data, len(ts), out.ctypes.data))
         if not download:
             return out
-        res = []
+        # one transfer for all surfaces (cx_morph_eval_many_download_all); the surfaces are views into the two arrays
+        pts_all = np.empty((int(out[:, 0].sum()), 3), dtype=np.float64)
+        tris_all = np.empty((int(out[:, 1].sum()), 3), dtype=np.int32)
+        self._check(self.lib.cx_morph_eval_many_download_all(self.handle, pts_all.ctypes.data, tris_all.ctypes.data))
+        res, p0, t0 = [], 0, 0
         for i in range(len(ts)):
-            pts = np.empty((int(out[i, 0]), 3), dtype=np.float64)
-            tris = np.empty((int(out[i, 1]), 3), dtype=np.int32)
-            self._check(self.lib.cx_morph_eval_many_download(self.handle, i, pts.ctypes.data, tris.ctypes.data))
-            res.append((pts, tris))
+            npi, nti = int(out[i, 0]), int(out[i, 1])
+            res.append((pts_all[p0:p0 + npi], tris_all[t0:t0 + nti]))
+            p0 += npi; t0 += nti
         return res
 
     def morph_eval_device_ptrs(self, i):

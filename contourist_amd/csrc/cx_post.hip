@@ -3393,6 +3393,19 @@ extern "C" int cx_morph_eval_many_download(cx_ctx* ctx, int32_t i, double* point
     const size_t nb[2] = {(size_t)o[1] * 3 * sizeof(double), (size_t)o[3] * 3 * sizeof(int32_t)};
     return cx_copy_to_host(ctx, 2, d, sp, nb);
 }
+// all surfaces of the last call in one transfer: points of surface 0, 1, ... one behind the other (sum of the point counts x 3 doubles),
+// triangles likewise (indices local to their surface) -- one pipelined copy instead of two small ones per surface
+extern "C" int cx_morph_eval_many_download_all(cx_ctx* ctx, double* points_xyz, int32_t* triangles) {
+    if (!ctx || !ctx->post) return CX_ERR_INVALID;
+    cx_post_state* S = ctx->post;
+    CXP_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t np_ = 0, nt_ = 0;
+    for (size_t i = 0; i + 3 < S->me_off.size(); i += 4) { np_ += S->me_off[i + 1]; nt_ += S->me_off[i + 3]; }
+    void* d[2] = {(points_xyz && np_) ? (void*)points_xyz : nullptr, (triangles && nt_) ? (void*)triangles : nullptr};
+    const void* sp[2] = {S->me_pts.p, S->me_tri.p};
+    const size_t nb[2] = {(size_t)np_ * 3 * sizeof(double), (size_t)nt_ * 3 * sizeof(int32_t)};
+    return cx_copy_to_host(ctx, 2, d, sp, nb);
+}
 extern "C" int cx_morph_eval_many_device_ptrs(cx_ctx* ctx, int32_t i, void** points_xyz, void** triangles) {
     if (!ctx || !ctx->post) return CX_ERR_INVALID;
     cx_post_state* S = ctx->post;

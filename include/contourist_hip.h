@@ -337,6 +337,9 @@ int cx_morph_eval_download(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
 int cx_morph_eval_many(cx_ctx* ctx, const double* times, int32_t n_times, int64_t* out_counts);
 int cx_morph_eval_many_download(cx_ctx* ctx, int32_t i, double* points_xyz, int32_t* triangles);
 int cx_morph_eval_many_device_ptrs(cx_ctx* ctx, int32_t i, void** points_xyz, void** triangles);
+/* every surface of the last call in ONE transfer: the points of surface 0, 1, ... one behind the other (sum of the point counts x 3
+ * doubles), the triangles likewise (indices local to their surface) */
+int cx_morph_eval_many_download_all(cx_ctx* ctx, double* points_xyz, int32_t* triangles);
 
 /* ---- 2-D contour lines at several isovalues ------------------------------------------------------
  * Replaces triangulated.Grid2DContour (search_grid :198-212, find_initial_contour_pairs :299-320,

@@ -637,6 +637,13 @@ def test_per_t_stream_in_one_call_equals_the_single_surfaces(shape, nbins):
             nonempty += len(tm) > 0
         assert nonempty >= 9
         assert len(many[-1][1]) == 0 and len(many[-2][1]) == 0
+        # surface by surface (cx_morph_eval_many_download) == the views of the one transfer (cx_morph_eval_many_download_all)
+        ctx.morph_eval_many(times, download=False)
+        for i in (0, 3, len(times) - 3, len(times) - 1):
+            pi = np.empty((int(counts[i, 0]), 3), dtype=np.float64)
+            ti = np.empty((int(counts[i, 1]), 3), dtype=np.int32)
+            ctx._check(ctx.lib.cx_morph_eval_many_download(ctx.handle, i, pi.ctypes.data, ti.ctypes.data))
+            assert np.array_equal(pi, many[i][0]) and np.array_equal(ti, many[i][1])
         # the stream again after the single calls, and an empty list of times
         again = ctx.morph_eval_many(times)
         for (pa, ta), (pm, tm) in zip(again, many):
