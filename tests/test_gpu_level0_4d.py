@@ -691,6 +691,17 @@ def test_per_t_stream_argument_errors():
         t = 0.5 * (pts[:, 3].min() + pts[:, 3].max())
         p, q = ctx.morph_eval(t)
         assert len(q) > 0 and q.max() < len(p)
+        # more times than the pinned staging of descriptors and totals holds (1 151): the pageable path
+        many_t = np.linspace(pts[:, 3].min() - 0.1, pts[:, 3].max() + 0.1, 1500)
+        counts = ctx.morph_eval_many(many_t, download=False)
+        assert counts.shape == (1500, 2) and counts[:, 1].max() > 0 and counts[0, 1] == 0 and counts[-1, 1] == 0
+        for i in (1, 377, 750, 1123, 1498):
+            pi = np.empty((int(counts[i, 0]), 3), dtype=np.float64)
+            ti = np.empty((int(counts[i, 1]), 3), dtype=np.int32)
+            ctx._check(ctx.lib.cx_morph_eval_many_download(ctx.handle, i, pi.ctypes.data, ti.ctypes.data))
+            p1, t1 = ctx.morph_eval(float(many_t[i]))
+            assert np.array_equal(t1, ti) and np.array_equal(p1, pi)
+            ctx.morph_eval_many(many_t, download=False)      # (the single call replaced the stream's surfaces)
         # a new post-pass (here: of a smaller field) takes the morph triangles of the old one away: nothing to evaluate until they are rebuilt
         ctx.upload_grid4d(_blob_field((8, 8, 8, 6), 2))
         ctx.extract4d(0.5, 1)
