@@ -2452,6 +2452,8 @@ __global__ void cxp_k_morph_count(const int32_t* tets, uint32_t nt, const double
     const double t_eps = 1e-7 * (cxp_from_orderable(mm[1]) - cxp_from_orderable(mm[0]));
     counts[t] = cxp_morph_slices(tets, t, pts, prio, t_eps, [](u64, u64, u64) {});
 }
+// (Measured and dropped: the workgroup's triangles put together in LDS and written out as consecutive words -- 0.81 -> 0.83 ms: the kernel is
+// bound by its arithmetic and gathers at 128 registers, not by its stores.)
 __global__ void cxp_k_morph_emit(const int32_t* tets, uint32_t nt, const double* pts, const uint32_t* prio, const u64* mm,
                                  const uint32_t* offsets, u64* pairs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
