@@ -120,6 +120,20 @@ class GridContour3d(object):
                              "(%d samples)" % (self.shape[1], self.shape[2], int(self.MAX_SAMPLES_PER_EXTRACTION)))
         return planes
 
+    @staticmethod
+    def _slab_bounds(n0, planes):
+        """[(i0, i1), ...]: consecutive ranges of planes covering [0, n0), `planes` each (every slab but the last is marched with plane
+        i1 as its halo); a single trailing plane joins the slab before it (alone it would hold no voxel; planes + 1 still fit one
+        extraction, that slab has no halo)"""
+        bounds, at = [], 0
+        while at < n0:
+            end = min(n0, at + planes)
+            if n0 - end == 1:
+                end = n0
+            bounds.append((at, end))
+            at = end
+        return bounds
+
     def _post_in_slabs(self, clean=True):
         """Level 0 slab by slab + Level 1 of the assembled mesh (the single-process form of distributed.level1_slabs: same slabs,
         same global edge ids, same post-pass on ONE mesh, so components, weld buckets and the max-x rule see the whole surface).
@@ -141,13 +155,7 @@ class GridContour3d(object):
         planes = self._slab_planes()
         parts = []
         totals = dict(n_cells=0, n_vertices=0, n_triangles=0, n_border_voxels=0)
-        bounds, at = [], 0
-        while at < n0:
-            end = min(n0, at + planes)
-            if n0 - end == 1:          # never leave a last slab of one plane (it would hold no voxel): planes + 1 still fit, it has no halo
-                end = n0
-            bounds.append((at, end))
-            at = end
+        bounds = self._slab_bounds(n0, planes)
         for (i0, i1) in bounds:
             has_halo = i1 < n0
             local = s[i0:i1 + (1 if has_halo else 0)]

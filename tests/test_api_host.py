@@ -71,3 +71,28 @@ def test_bisect_endpoints_leaves_out_pairs_that_end_outside_the_samples():
         return float(i) - 5.5
     out = tetrahedral.bisect_endpoints(g, 0.0, [((0, 0, 0), (100, 100, 100))], [-1] * 3, [13] * 3)
     assert len(out) == 1 and out[0][0][0] == 5 and out[0][1][0] == 6
+
+
+def test_slab_bounds_of_a_volume_beyond_one_extraction():
+    """GridContour3d._slab_bounds / _slab_planes (host logic of the slab path for volumes of more than 2^29 samples): the slabs cover
+    every plane once, in order; none is a single plane (it would hold no voxel); a slab plus its halo plane fits one extraction"""
+    from contourist_amd import tetrahedral
+    B = tetrahedral.GridContour3d._slab_bounds
+    for n0 in range(2, 60):
+        for planes in range(2, 20):
+            b = B(n0, planes)
+            assert b[0][0] == 0 and b[-1][1] == n0
+            assert all(b[k][1] == b[k + 1][0] for k in range(len(b) - 1))
+            assert all(i1 - i0 >= 2 or n0 < 2 for (i0, i1) in b)
+            # with its halo plane (all but the last) a slab holds at most planes + 1 planes
+            assert all((i1 - i0) + (1 if i1 < n0 else 0) <= planes + 1 for (i0, i1) in b)
+
+    class Fake(object):
+        MAX_SAMPLES_PER_EXTRACTION = 1 << 29
+        shape = (1056, 720, 720)
+    assert tetrahedral.GridContour3d._in_slabs(Fake()) and not tetrahedral.GridContour3d._in_slabs(type("S", (Fake,), {"shape": (512, 512, 512)})())
+    planes = tetrahedral.GridContour3d._slab_planes(Fake())
+    assert (planes + 1) * 720 * 720 <= (1 << 29) < (planes + 2) * 720 * 720
+    small = type("T", (Fake,), {"shape": (4, 30000, 30000)})()
+    with pytest.raises(ValueError):
+        tetrahedral.GridContour3d._slab_planes(small)
