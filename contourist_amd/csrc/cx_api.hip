@@ -75,6 +75,7 @@ extern "C" int cx_ctx_destroy(cx_ctx* ctx) {
     cx_release(ctx->wsum, ctx->wsum_cap);
     cx_release(ctx->wbase, ctx->wbase_cap);
     cx_release(ctx->tri_keep, ctx->keep_cap);
+    for (int k = 0; k < 8; k++) cx_release(ctx->seed_buf[k], ctx->seed_cap[k]);
     cx_release(ctx->brec, ctx->brec_cap);
     cx_release(ctx->flat, ctx->flat_cap);
     cx_release(ctx->hash_xy, ctx->hash_xy_cap);

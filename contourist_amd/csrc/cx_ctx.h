@@ -93,6 +93,10 @@ struct cx_ctx {
     // seeded selection (cx_select_seeded3d): triangle mask followed by vertex mask, valid until the next extraction
     uint8_t* tri_keep = nullptr;
     size_t keep_cap = 0;
+    // scratch of cx_select_seeded3d_ex (bytes), kept between calls: map per sample, union-find, bitmap, flags, seeds, counters, end
+    // points, visited set -- a selection allocated and freed them every time (0.8 of 2.9 ms on the 512^3 bench field)
+    uint8_t* seed_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t seed_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int seed_mode = 0;      // how the last seeded selection (3-D or 4-D) ran its end points: 0 sequential (the reference's shared visited set), 1 one thread per pair
     bool keep_valid = false;
     // Level-1

@@ -59,12 +59,19 @@ __device__ __forceinline__ void cxs_union(uint32_t* parent, uint32_t a, uint32_t
     }
 }
 
-__global__ void cxs_k_map(const uint4* cells, uint32_t ncells, uint32_t* vmap, uint32_t* parent) {
+// abits: one bit per lattice point, set for the surface voxels (cleared by the host before): the union kernel asks it first -- a
+// surface voxel has four or five of its 13 forward neighbours on the surface, and a bit that is clear costs a read of a 17 MB bitmap
+// that stays in the caches instead of a random read of the 537 MB map plus one of the record it names (4.3 ms of the 5.8 ms a selection
+// on the 512^3 bench field took)
+__global__ void cxs_k_map(const uint4* cells, uint32_t ncells, uint32_t* vmap, uint32_t* parent, uint32_t* abits) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= ncells) return;
     parent[r] = r;
     const uint4 c = cells[r];
-    if (cxs_is_voxel_record(c)) vmap[c.x] = r;
+    if (cxs_is_voxel_record(c)) {
+        vmap[c.x] = r;
+        atomicOr(&abits[c.x >> 5], 1u << (c.x & 31u));
+    }
 }
 // record index of the surface voxel at linear index lin, or 0xFFFFFFFF (the map is not cleared: entries validate themselves)
 __device__ __forceinline__ uint32_t cxs_lookup(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t lin) {
@@ -73,24 +80,83 @@ __device__ __forceinline__ uint32_t cxs_lookup(const uint4* cells, uint32_t ncel
     const uint4 c = cells[r];
     return (c.x == lin && cxs_is_voxel_record(c)) ? r : 0xFFFFFFFFu;
 }
-__global__ void cxs_k_union(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs_grid G) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ncells) return;
-    const uint4 c = cells[r];
-    if (!cxs_is_voxel_record(c)) return;
-    const uint32_t plane = G.n1 * G.n2;
-    const uint32_t i = c.x / plane, rem = c.x - i * plane, j = rem / G.n2, k = rem - j * G.n2;
-    if (!cxs_in_range(G, (int)i, (int)j, (int)k)) return;   // only in-range voxels grow (seed voxels outside the box: cxs_k_mark)
-    // the 13 "forward" neighbours (the other 13 are reached from the other side)
+// The unions in two steps (as the Level-1 edge linking of cx_post.hip): records follow the march, so most of a voxel's surface neighbours
+// are records of the same few hundred -- a workgroup unites CXS_UB consecutive records among themselves in an LDS forest and writes the
+// forest into the global parent words with plain stores (cxs_k_union_block); only pairs that straddle two blocks go through the
+// device-scope union-find (cxs_k_union_far).  (One step, every pair through device-scope atomics: 4.2 ms of the 5.8 ms a selection on
+// the 512^3 bench field took -- the look-ups themselves, map and records, were not what it cost: a bitmap in front of them changed nothing.)
+#define CXS_UB 1024u
+__device__ __forceinline__ uint32_t cxs_lfind(uint32_t* lp, uint32_t x) {
+    for (;;) {
+        const uint32_t p = lp[x];
+        if (p == x) return x;
+        const uint32_t g = lp[p];
+        if (g != p) atomicCAS(&lp[x], p, g);   // path halving
+        x = p;
+    }
+}
+// calls f(neighbour's linear index) for the 13 "forward" neighbours of voxel (i, j, k) inside the range whose bit is set (the other
+// 13 are reached from the other side)
+template <typename F>
+__device__ __forceinline__ void cxs_forward_neighbours(const cxs_grid& G, const uint32_t* abits, uint32_t i, uint32_t j, uint32_t k, F f) {
     for (int di = 0; di <= 1; di++)
         for (int dj = -1; dj <= 1; dj++)
             for (int dk = -1; dk <= 1; dk++) {
                 if (di == 0 && (dj < 0 || (dj == 0 && dk <= 0))) continue;
                 const int ni = (int)i + di, nj = (int)j + dj, nk = (int)k + dk;
                 if (!cxs_in_range(G, ni, nj, nk)) continue;   // in_range (:465-469)
-                const uint32_t o = cxs_lookup(cells, ncells, vmap, ((uint32_t)ni * G.n1 + (uint32_t)nj) * G.n2 + (uint32_t)nk);
-                if (o != 0xFFFFFFFFu) cxs_union(parent, r, o);
+                const uint32_t nl = ((uint32_t)ni * G.n1 + (uint32_t)nj) * G.n2 + (uint32_t)nk;
+                if ((abits[nl >> 5] >> (nl & 31u)) & 1u) f(nl);      // (a set bit: cxs_k_map wrote the map entry in this very call)
             }
+}
+__global__ __launch_bounds__(256) void cxs_k_union_block(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs_grid G,
+                                                         const uint32_t* abits) {
+    __shared__ uint32_t lp[CXS_UB];
+    const uint32_t b0 = blockIdx.x * CXS_UB;
+    for (uint32_t x = threadIdx.x; x < CXS_UB; x += 256u) lp[x] = x;
+    __syncthreads();
+    const uint32_t plane = G.n1 * G.n2;
+    for (uint32_t x = threadIdx.x; x < CXS_UB; x += 256u) {
+        const uint32_t r = b0 + x;
+        if (r >= ncells) continue;
+        const uint4 c = cells[r];
+        if (!cxs_is_voxel_record(c)) continue;
+        const uint32_t i = c.x / plane, rem = c.x - i * plane, j = rem / G.n2, k = rem - j * G.n2;
+        if (!cxs_in_range(G, (int)i, (int)j, (int)k)) continue;   // only in-range voxels grow (seed voxels outside the box: cxs_k_mark)
+        cxs_forward_neighbours(G, abits, i, j, k, [&](uint32_t nl) {
+            const uint32_t o = vmap[nl] - b0;
+            if (o >= CXS_UB) return;                              // another block's record: cxs_k_union_far
+            uint32_t a = x, b = o;
+            for (;;) {
+                a = cxs_lfind(lp, a);
+                b = cxs_lfind(lp, b);
+                if (a == b) break;
+                const uint32_t win = min(a, b), lose = max(a, b);
+                if (atomicCAS(&lp[lose], lose, win) == lose) break;
+            }
+        });
+    }
+    __syncthreads();
+    // the block's forest into the global parent words (nobody else touches them in this kernel); roots = smallest ids
+    for (uint32_t x = threadIdx.x; x < CXS_UB; x += 256u) {
+        if (b0 + x >= ncells) continue;
+        const uint32_t root = cxs_lfind(lp, x);
+        if (root != x) parent[b0 + x] = b0 + root;
+    }
+}
+__global__ void cxs_k_union_far(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs_grid G, const uint32_t* abits) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ncells) return;
+    const uint4 c = cells[r];
+    if (!cxs_is_voxel_record(c)) return;
+    const uint32_t plane = G.n1 * G.n2;
+    const uint32_t i = c.x / plane, rem = c.x - i * plane, j = rem / G.n2, k = rem - j * G.n2;
+    if (!cxs_in_range(G, (int)i, (int)j, (int)k)) return;
+    const uint32_t b0 = (r / CXS_UB) * CXS_UB;
+    cxs_forward_neighbours(G, abits, i, j, k, [&](uint32_t nl) {
+        const uint32_t o = vmap[nl];
+        if (o - b0 >= CXS_UB) cxs_union(parent, r, o);            // (pairs inside one block are united already)
+    });
 }
 __global__ void cxs_k_flatten(uint32_t* parent, uint32_t n) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,24 +315,80 @@ __global__ void cxs_k_mark(const uint4* cells, uint32_t ncells, const uint32_t* 
                 if (o != 0xFFFFFFFFu) flag[parent[o]] = 1;
             }
 }
-__global__ void cxs_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* parent, const uint8_t* flag, const uint8_t* seedkeep,
-                           uint8_t* tri_keep, const int32_t* tris, uint8_t* vkeep, uint32_t* out, cxs_grid G, int all_in_range) {
+// Triangles are numbered record after record, so the triangles of a workgroup's 256 records are ONE range of the triangle array: every
+// record's thread decides for its voxel and leaves the decision per triangle in LDS, then the workgroup walks the range with one thread
+// per TRIANGLE -- consecutive flag bytes, consecutive index triples (one thread per record looping over its up to 12 triangles wrote a
+// byte and read a triple of its own per round: 0.76 ms of a selection's 2.0 on the 512^3 bench field).
+#define CXS_KEEP_TRIS (256u * 12u)
+#define CXS_PARTIAL0 32u        // out[32 + 32 p], out[33 + 32 p]: partial sums p = 0 .. CXS_PARTIALS - 1 of (groups kept, triangles kept)
+#define CXS_PARTIALS 128u
+#define CXS_OUT_WORDS (CXS_PARTIAL0 + 32u * CXS_PARTIALS)
+__global__ void cxs_k_keep_sum(uint32_t* out) {
+    uint32_t g = out[CXS_PARTIAL0 + 32u * threadIdx.x], t = out[CXS_PARTIAL0 + 32u * threadIdx.x + 1u];
+    __shared__ uint32_t sg, st;
+    if (threadIdx.x == 0) { sg = 0; st = 0; }
+    __syncthreads();
+    if (g) atomicAdd(&sg, g);
+    if (t) atomicAdd(&st, t);
+    __syncthreads();
+    if (threadIdx.x == 0) { out[2] += sg; out[3] += st; }
+}
+__global__ __launch_bounds__(256) void cxs_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* parent, const uint8_t* flag, const uint8_t* seedkeep,
+                                                  uint8_t* tri_keep, const int32_t* tris, uint8_t* vkeep, uint32_t* out, cxs_grid G, int all_in_range) {
+    __shared__ uint8_t lk[CXS_KEEP_TRIS];
+    __shared__ uint32_t s_first, s_end, s_groups, s_tris;
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ncells) return;
-    const uint4 c = cells[r];
-    const uint32_t ntri = (c.y >> 16) & 0xFFu;
-    if (!ntri) return;
-    const uint32_t plane = G.n1 * G.n2;
-    const bool inr = cxs_in_range(G, (int)(c.x / plane), (int)((c.x % plane) / G.n2), (int)(c.x % G.n2));
-    const bool keep = (inr && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0;
-    if (keep && parent[r] == r) atomicAdd(&out[2], 1u);   // groups kept
-    for (uint32_t t = 0; t < ntri; t++) {
-        tri_keep[c.z + t] = keep ? 1 : 0;
-        if (keep) {
-            for (int s = 0; s < 3; s++) vkeep[tris[(size_t)(c.z + t) * 3 + s]] = 1;
+    if (threadIdx.x == 0) { s_first = 0xFFFFFFFFu; s_end = 0u; s_groups = 0u; s_tris = 0u; }
+    __syncthreads();
+    uint4 c = make_uint4(0, 0, 0, 0);
+    uint32_t ntri = 0;
+    bool keep = false;
+    if (r < ncells) {
+        c = cells[r];
+        ntri = (c.y >> 16) & 0xFFu;
+        if (ntri) {
+            const uint32_t plane = G.n1 * G.n2;
+            const bool inr = cxs_in_range(G, (int)(c.x / plane), (int)((c.x % plane) / G.n2), (int)(c.x % G.n2));
+            keep = (inr && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0;
+            // (counted per workgroup and added to one of 128 partial sums, each in a cache line of its own: one device-scope add per
+            // kept voxel on ONE address -- same-address atomics execute one after the other -- was most of this kernel's 0.75 ms)
+            if (keep && parent[r] == r) atomicAdd(&s_groups, 1u);   // groups kept
+            if (keep) atomicAdd(&s_tris, ntri);
+            atomicMin(&s_first, c.z);
+            atomicMax(&s_end, c.z + ntri);
         }
     }
-    if (keep) atomicAdd(&out[3], ntri);
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_groups | s_tris)) {
+        uint32_t* part = out + CXS_PARTIAL0 + 32u * (blockIdx.x & (CXS_PARTIALS - 1u));
+        if (s_groups) atomicAdd(part, s_groups);
+        if (s_tris) atomicAdd(part + 1, s_tris);
+    }
+    const uint32_t first = s_first, end = s_end;
+    if (first >= end) return;                                      // no record of this workgroup has a triangle
+    const bool fits = end - first <= CXS_KEEP_TRIS;               // (always, for records numbered in order; checked because LDS is finite)
+    if (fits) {
+        for (uint32_t x = threadIdx.x; x < end - first; x += 256u) lk[x] = 2;      // 2 = not a triangle of this workgroup's records
+        __syncthreads();
+        for (uint32_t t = 0; t < ntri; t++) lk[c.z - first + t] = keep ? 1 : 0;
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < end - first; x += 256u) {
+            const uint8_t k = lk[x];
+            if (k == 2) continue;
+            tri_keep[first + x] = k;
+            if (k) {
+                const size_t at = (size_t)(first + x) * 3;
+                const int32_t a = tris[at], b = tris[at + 1], d = tris[at + 2];
+                vkeep[a] = 1; vkeep[b] = 1; vkeep[d] = 1;
+            }
+        }
+    } else {
+        for (uint32_t t = 0; t < ntri; t++) {
+            tri_keep[c.z + t] = keep ? 1 : 0;
+            if (keep)
+                for (int s = 0; s < 3; s++) vkeep[tris[(size_t)(c.z + t) * 3 + s]] = 1;
+        }
+    }
 }
 
 extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, int64_t n, const int32_t* range_lo_hi, uint32_t flags,
@@ -303,7 +425,7 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     uint8_t* vkeep = ctx->tri_keep + nt;
     ctx->keep_valid = false;
     // scratch
-    uint32_t *vmap = nullptr, *parent = nullptr, *seeds = nullptr, *out = nullptr;
+    uint32_t *vmap = nullptr, *parent = nullptr, *seeds = nullptr, *out = nullptr, *abits = nullptr;
     uint8_t* flag = nullptr;
     int32_t* ep = nullptr;
     unsigned long long* visited = nullptr;
@@ -317,22 +439,28 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
     do {
         hipError_t e;
 #define CXS_TRY(call) if ((e = (call)) != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP; break; }
-        CXS_TRY(hipMalloc(&vmap, ((size_t)P.nsamples + 64) * sizeof(uint32_t)));
-        CXS_TRY(hipMalloc(&parent, ((size_t)ncells + 64) * sizeof(uint32_t)));
-        CXS_TRY(hipMalloc(&flag, 2 * ((size_t)ncells + 64)));
-        CXS_TRY(hipMalloc(&seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t)));
-        CXS_TRY(hipMalloc(&out, 16 * sizeof(uint32_t)));
-        CXS_TRY(hipMalloc(&ep, ((size_t)n * 6 + 8) * sizeof(int32_t)));
-        CXS_TRY(hipMalloc(&visited, vsize * sizeof(unsigned long long)));
+        // (scratch kept in the context between calls: cx_grow only ever grows)
+#define CXS_GRAB(slot, ptr, bytes) { if ((rc = cx_grow(ctx, ctx->seed_buf[slot], ctx->seed_cap[slot], (size_t)(bytes)))) break; ptr = reinterpret_cast<decltype(ptr)>(ctx->seed_buf[slot]); }
+        CXS_GRAB(0, vmap, ((size_t)P.nsamples + 64) * sizeof(uint32_t));
+        CXS_GRAB(1, parent, ((size_t)ncells + 64) * sizeof(uint32_t));
+        CXS_GRAB(2, abits, ((size_t)P.nsamples / 32 + 64) * sizeof(uint32_t));
+        CXS_TRY(hipMemsetAsync(abits, 0, ((size_t)P.nsamples / 32 + 64) * sizeof(uint32_t), st));
+        CXS_GRAB(3, flag, 2 * ((size_t)ncells + 64));
+        CXS_GRAB(4, seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t));
+        CXS_GRAB(5, out, CXS_OUT_WORDS * sizeof(uint32_t));
+        CXS_GRAB(6, ep, ((size_t)n * 6 + 8) * sizeof(int32_t));
+        CXS_GRAB(7, visited, vsize * sizeof(unsigned long long));
+#undef CXS_GRAB
         CXS_TRY(hipMemsetAsync(flag, 0, 2 * ((size_t)ncells + 64), st));
-        CXS_TRY(hipMemsetAsync(out, 0, 16 * sizeof(uint32_t), st));
+        CXS_TRY(hipMemsetAsync(out, 0, CXS_OUT_WORDS * sizeof(uint32_t), st));
         CXS_TRY(hipMemsetAsync(visited, 0, vsize * sizeof(unsigned long long), st));
         CXS_TRY(hipMemsetAsync(tri_keep, 0, (size_t)nt + (size_t)nv + 64, st));
         if (n) CXS_TRY(hipMemcpyAsync(ep, endpoints_ijk, (size_t)n * 6 * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (ncells) {
             const uint32_t blocks = (ncells + 255u) / 256u;
-            hipLaunchKernelGGL(cxs_k_map, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent);
-            hipLaunchKernelGGL(cxs_k_union, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, G);
+            hipLaunchKernelGGL(cxs_k_map, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, abits);
+            hipLaunchKernelGGL(cxs_k_union_block, dim3((ncells + CXS_UB - 1u) / CXS_UB), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, G, (const uint32_t*)abits);
+            hipLaunchKernelGGL(cxs_k_union_far, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, G, (const uint32_t*)abits);
             hipLaunchKernelGGL(cxs_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
             if (n <= CXS_SEQUENTIAL_MAX)   // sequential, with the reference's shared visited set
                 hipLaunchKernelGGL(cxs_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
@@ -340,15 +468,13 @@ extern "C" int cx_select_seeded3d_ex(cx_ctx* ctx, const int32_t* endpoints_ijk, 
                 hipLaunchKernelGGL(cxs_k_seeds_parallel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, G, ep, (uint32_t)n, seeds, out);
             hipLaunchKernelGGL(cxs_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, ctx->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
             hipLaunchKernelGGL(cxs_k_keep, dim3(blocks), dim3(256), 0, st, ctx->cells, ncells, parent, flag, flag + ncells + 64, tri_keep, ctx->tris, vkeep, out, G, all_in_range);
+            hipLaunchKernelGGL(cxs_k_keep_sum, dim3(1), dim3(CXS_PARTIALS), 0, st, out);
         }
         CXS_TRY(hipGetLastError());
         CXS_TRY(hipMemcpyAsync(host_out, out, sizeof(host_out), hipMemcpyDeviceToHost, st));
         CXS_TRY(hipStreamSynchronize(st));
 #undef CXS_TRY
     } while (0);
-    void* scratch[] = {vmap, parent, flag, seeds, out, ep, visited};
-    for (void* p : scratch)
-        if (p) (void)hipFree(p);
     if (rc) return rc;
     if (out_counts) {
         out_counts[0] = host_out[0]; out_counts[1] = host_out[2]; out_counts[2] = host_out[3]; out_counts[3] = host_out[1];
