@@ -102,15 +102,23 @@ __device__ __forceinline__ uint32_t cxs4_lookup(const cxs4_grid& G, const uint4*
     const uint4 c = cells[r];
     return (c.x == lin && cxs4_is_voxel_record(G, c)) ? r : CXS4_NONE;
 }
-__global__ void cxs4_k_union(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs4_grid G) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ncells) return;
-    const uint4 c = cells[r];
-    if (!cxs4_is_voxel_record(G, c)) return;
-    int p[4];
-    cxs4_unravel(G, c.x, p);
-    if (!cxs4_in_range(G, p)) return;   // only in-range hyper-voxels grow (seed voxels outside the box: cxs4_k_mark)
-    // the 40 "forward" neighbours (the other 40 are reached from the other side)
+// The unions in two steps, as cx_seed.hip does them for the 3-D march: a workgroup unites CXS4_UB consecutive records among themselves in
+// an LDS forest and writes it into the global parent words with plain stores (cxs4_k_union_block); only pairs that straddle two blocks
+// go through the device-scope union-find (cxs4_k_union_far).  (One step: 2.7 ms for the 0.87 M hyper-voxels of config 4.)
+#define CXS4_UB 1024u
+__device__ __forceinline__ uint32_t cxs4_lfind(uint32_t* lp, uint32_t x) {
+    for (;;) {
+        const uint32_t p = lp[x];
+        if (p == x) return x;
+        const uint32_t g = lp[p];
+        if (g != p) atomicCAS(&lp[x], p, g);   // path halving
+        x = p;
+    }
+}
+// f(record of the neighbour) for the 40 "forward" neighbours of hyper-voxel p that are surface hyper-voxels inside the range (the
+// other 40 are reached from the other side)
+template <typename F>
+__device__ __forceinline__ void cxs4_forward_neighbours(const cxs4_grid& G, const uint4* cells, uint32_t ncells, const uint32_t* vmap, const int p[4], F f) {
     for (int code = 41; code < 81; code++) {   // offsets in lexicographic order, (0,0,0,0) is code 40
         int o[4], x = code;
         o[3] = x % 3 - 1; x /= 3;
@@ -120,8 +128,54 @@ __global__ void cxs4_k_union(const uint4* cells, uint32_t ncells, const uint32_t
         const int q[4] = {p[0] + o[0], p[1] + o[1], p[2] + o[2], p[3] + o[3]};
         if (!cxs4_in_range(G, q)) continue;   // in_range (tetrahedral.py:465-469)
         const uint32_t other = cxs4_lookup(G, cells, ncells, vmap, q);
-        if (other != CXS4_NONE) cxs4_union(parent, r, other);
+        if (other != CXS4_NONE) f(other);
     }
+}
+__global__ __launch_bounds__(256) void cxs4_k_union_block(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs4_grid G) {
+    __shared__ uint32_t lp[CXS4_UB];
+    const uint32_t b0 = blockIdx.x * CXS4_UB;
+    for (uint32_t x = threadIdx.x; x < CXS4_UB; x += 256u) lp[x] = x;
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < CXS4_UB; x += 256u) {
+        const uint32_t r = b0 + x;
+        if (r >= ncells) continue;
+        const uint4 c = cells[r];
+        if (!cxs4_is_voxel_record(G, c)) continue;
+        int p[4];
+        cxs4_unravel(G, c.x, p);
+        if (!cxs4_in_range(G, p)) continue;   // only in-range hyper-voxels grow (seed voxels outside the box: cxs4_k_mark)
+        cxs4_forward_neighbours(G, cells, ncells, vmap, p, [&](uint32_t other) {
+            const uint32_t o = other - b0;
+            if (o >= CXS4_UB) return;                             // another block's record: cxs4_k_union_far
+            uint32_t a = x, b = o;
+            for (;;) {
+                a = cxs4_lfind(lp, a);
+                b = cxs4_lfind(lp, b);
+                if (a == b) break;
+                const uint32_t win = min(a, b), lose = max(a, b);
+                if (atomicCAS(&lp[lose], lose, win) == lose) break;
+            }
+        });
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < CXS4_UB; x += 256u) {
+        if (b0 + x >= ncells) continue;
+        const uint32_t root = cxs4_lfind(lp, x);
+        if (root != x) parent[b0 + x] = b0 + root;      // (nobody else touches these words in this kernel); roots = smallest ids
+    }
+}
+__global__ void cxs4_k_union_far(const uint4* cells, uint32_t ncells, const uint32_t* vmap, uint32_t* parent, cxs4_grid G) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ncells) return;
+    const uint4 c = cells[r];
+    if (!cxs4_is_voxel_record(G, c)) return;
+    int p[4];
+    cxs4_unravel(G, c.x, p);
+    if (!cxs4_in_range(G, p)) return;
+    const uint32_t b0 = (r / CXS4_UB) * CXS4_UB;
+    cxs4_forward_neighbours(G, cells, ncells, vmap, p, [&](uint32_t other) {
+        if (other - b0 >= CXS4_UB) cxs4_union(parent, r, other);  // (pairs inside one block are united already)
+    });
 }
 __global__ void cxs4_k_flatten(uint32_t* parent, uint32_t n) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,21 +337,44 @@ __global__ void cxs4_k_mark(const uint4* cells, uint32_t ncells, const uint32_t*
         if (r2 != CXS4_NONE) flag[parent[r2]] = 1;
     }
 }
+#define CXS4_PARTIAL0 32u       // out[32 + 32 p]: partial sums p = 0 .. CXS4_PARTIALS - 1 of the tetrahedra kept
+#define CXS4_PARTIALS 128u
+#define CXS4_OUT_WORDS (CXS4_PARTIAL0 + 32u * CXS4_PARTIALS)
 // keep[t] = 1 for the tetrahedra of the hyper-voxels in flagged groups; out[2] groups kept, out[3] tetrahedra kept
 __global__ void cxs4_k_keep(const uint4* cells, uint32_t ncells, const uint32_t* vmap, const uint32_t* parent, const uint8_t* flag,
                             const uint8_t* seedkeep, const int32_t* tets, const uint32_t* vkeys, uint32_t nt, uint8_t* keep, uint32_t* out, cxs4_grid G, int all_in_range) {
+    // (the kept tetrahedra are counted per wave, then per workgroup, and added to one of 128 partial sums in cache lines of their own: one
+    // device-scope add per kept tetrahedron on ONE address -- 28 M on config 4, executed one after the other -- took 5.0 of this
+    // selection's 8.1 ms)
+    __shared__ uint32_t s_kept;
+    if (threadIdx.x == 0) s_kept = 0u;
+    __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
-    int b[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
-    for (int k = 0; k < 4; k++) {
-        int p[4];
-        cxs4_unravel(G, vkeys[(uint32_t)tets[(size_t)t * 4 + k]] >> 4, p);
-        for (int a = 0; a < 4; a++) b[a] = min(b[a], p[a]);
+    uint8_t k = 0;
+    if (t < nt) {
+        int b[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+        for (int q = 0; q < 4; q++) {
+            int p[4];
+            cxs4_unravel(G, vkeys[(uint32_t)tets[(size_t)t * 4 + q]] >> 4, p);
+            for (int a = 0; a < 4; a++) b[a] = min(b[a], p[a]);
+        }
+        const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, b);
+        k = (r != CXS4_NONE && ((cxs4_in_range(G, b) && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0)) ? 1 : 0;
+        keep[t] = k;
     }
-    const uint32_t r = cxs4_lookup(G, cells, ncells, vmap, b);
-    const uint8_t k = (r != CXS4_NONE && ((cxs4_in_range(G, b) && (all_in_range || flag[parent[r]] != 0)) || seedkeep[r] != 0)) ? 1 : 0;
-    keep[t] = k;
-    if (k) atomicAdd(&out[3], 1u);
+    const uint32_t nk = (uint32_t)__popcll(__ballot(k != 0));
+    if ((threadIdx.x & 63u) == 0u && nk) atomicAdd(&s_kept, nk);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_kept) atomicAdd(&out[CXS4_PARTIAL0 + 32u * (blockIdx.x & (CXS4_PARTIALS - 1u))], s_kept);
+}
+__global__ void cxs4_k_keep_sum(uint32_t* out) {
+    __shared__ uint32_t s;
+    if (threadIdx.x == 0) s = 0u;
+    __syncthreads();
+    const uint32_t v = out[CXS4_PARTIAL0 + 32u * threadIdx.x];
+    if (v) atomicAdd(&s, v);
+    __syncthreads();
+    if (threadIdx.x == 0) out[3] += s;
 }
 __global__ void cxs4_k_count_groups(const uint32_t* parent, uint32_t ncells, const uint8_t* flag, uint32_t* out) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,22 +421,26 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
     do {
         hipError_t e;
 #define CXS4_TRY(call) if ((e = (call)) != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = (e == hipErrorOutOfMemory) ? CX_ERR_NOMEM : CX_ERR_HIP; break; }
-        CXS4_TRY(hipMalloc(&vmap, (nsamples + 64) * sizeof(uint32_t)));
-        CXS4_TRY(hipMalloc(&parent, ((size_t)ncells + 64) * sizeof(uint32_t)));
-        CXS4_TRY(hipMalloc(&flag, 2 * ((size_t)ncells + 64)));   // flag | seedkeep
-        CXS4_TRY(hipMalloc(&seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t)));
-        CXS4_TRY(hipMalloc(&out, 16 * sizeof(uint32_t)));
-        CXS4_TRY(hipMalloc(&ep, ((size_t)n * 8 + 8) * sizeof(int32_t)));
-        CXS4_TRY(hipMalloc(&visited, vsize * sizeof(unsigned long long)));
+        // (scratch kept in the context between calls, shared with cx_select_seeded3d_ex: cx_grow only ever grows)
+#define CXS4_GRAB(slot, ptr, bytes) { if ((rc = cx_grow(ctx, ctx->seed_buf[slot], ctx->seed_cap[slot], (size_t)(bytes)))) break; ptr = reinterpret_cast<decltype(ptr)>(ctx->seed_buf[slot]); }
+        CXS4_GRAB(0, vmap, (nsamples + 64) * sizeof(uint32_t));
+        CXS4_GRAB(1, parent, ((size_t)ncells + 64) * sizeof(uint32_t));
+        CXS4_GRAB(3, flag, 2 * ((size_t)ncells + 64));   // flag | seedkeep
+        CXS4_GRAB(4, seeds, ((size_t)n * 2 + 64) * sizeof(uint32_t));
+        CXS4_GRAB(5, out, CXS4_OUT_WORDS * sizeof(uint32_t));
+        CXS4_GRAB(6, ep, ((size_t)n * 8 + 8) * sizeof(int32_t));
+        CXS4_GRAB(7, visited, vsize * sizeof(unsigned long long));
+#undef CXS4_GRAB
         CXS4_TRY(hipMemsetAsync(flag, 0, 2 * ((size_t)ncells + 64), st));
-        CXS4_TRY(hipMemsetAsync(out, 0, 16 * sizeof(uint32_t), st));
+        CXS4_TRY(hipMemsetAsync(out, 0, CXS4_OUT_WORDS * sizeof(uint32_t), st));
         CXS4_TRY(hipMemsetAsync(visited, 0, vsize * sizeof(unsigned long long), st));
         CXS4_TRY(hipMemsetAsync(S4->tet_keep, 0, (size_t)nt + 64, st));
         if (n) CXS4_TRY(hipMemcpyAsync(ep, endpoints_ijkl, (size_t)n * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (ncells && nt) {
             const uint32_t blocks = (ncells + 255u) / 256u;
             hipLaunchKernelGGL(cxs4_k_map, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
-            hipLaunchKernelGGL(cxs4_k_union, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
+            hipLaunchKernelGGL(cxs4_k_union_block, dim3((ncells + CXS4_UB - 1u) / CXS4_UB), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
+            hipLaunchKernelGGL(cxs4_k_union_far, dim3(blocks), dim3(256), 0, st, S4->cells, ncells, vmap, parent, G);
             hipLaunchKernelGGL(cxs4_k_flatten, dim3(blocks), dim3(256), 0, st, parent, ncells);
             if (n <= sequential_max)   // sequential, with the reference's shared visited set
                 hipLaunchKernelGGL(cxs4_k_seeds, dim3(1), dim3(64), 0, st, G, ep, (uint32_t)n, visited, vsize - 1ULL, seeds, out);
@@ -368,6 +449,7 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
             hipLaunchKernelGGL(cxs4_k_mark, dim3((uint32_t)((2 * n + 255) / 256) + 1u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, seeds, out, flag, flag + ncells + 64, G);
             hipLaunchKernelGGL(cxs4_k_keep, dim3((nt + 255u) / 256u), dim3(256), 0, st, S4->cells, ncells, vmap, parent, flag, flag + ncells + 64, S4->tets, S4->vkeys, nt,
                                S4->tet_keep, out, G, all_in_range);
+            hipLaunchKernelGGL(cxs4_k_keep_sum, dim3(1), dim3(CXS4_PARTIALS), 0, st, out);
             hipLaunchKernelGGL(cxs4_k_count_groups, dim3(blocks), dim3(256), 0, st, parent, ncells, flag, out);
         }
         CXS4_TRY(hipGetLastError());
@@ -375,9 +457,6 @@ extern "C" int cx_select_seeded4d_ex(cx_ctx* ctx, const int32_t* endpoints_ijkl,
         CXS4_TRY(hipStreamSynchronize(st));
 #undef CXS4_TRY
     } while (0);
-    void* scratch[] = {vmap, parent, flag, seeds, out, ep, visited};
-    for (void* p : scratch)
-        if (p) (void)hipFree(p);
     if (rc) return rc;
     if (out_counts) {
         out_counts[0] = host_out[0]; out_counts[1] = host_out[2]; out_counts[2] = host_out[3]; out_counts[3] = host_out[1];
