@@ -32,6 +32,7 @@ SYMBOLS = [
     "cx_contour2d_extract", "cx_contour2d_download",
     "cx_timing_enable", "cx_timing_read", "cx_measure_read_bandwidth", "cx_debug_stamps", "cx_version",
 ]
+CX_MESH_OF_THE_MARCH = 8      # cx_postprocess3d_mesh flags bit 3: the triangles are ones the march emitted (at most two per edge before merges)
 CX2_ALL_CHAINS = 1
 CX2_NO_DEDUPE = 2
 CX2_SEARCH_SEEDS = 4

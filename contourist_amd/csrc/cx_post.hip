@@ -1595,7 +1595,7 @@ static int cxp_reserve3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt
 // edge_crossings: the vertices are the march's own crossings with their edge ids as priorities (cx_postprocess3d*), not points
 // handed over by a caller (cx_postprocess3d_mesh: refined points, slab meshes with global edge ids as ranks)
 static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, const double corner[3], const uint8_t* vkeep, bool do_clean,
-                     double smooth, bool coherent, int64_t* counts, bool edge_crossings = false, const cxp_shard* shard = nullptr) {
+                     double smooth, bool coherent, int64_t* counts, bool edge_crossings = false, const cxp_shard* shard = nullptr, bool march_mesh = false) {
     int rc;
     hipStream_t st = ctx->stream;
     double* pts = (double*)S->pts.p;
@@ -1607,7 +1607,10 @@ static int cxp_run3d(cx_ctx* ctx, cx_post_state* S, uint32_t nv, uint32_t nt, co
     uint8_t* alive = (uint8_t*)S->alive.p;
     uint32_t* misc = (uint32_t*)S->misc.p;
     uint8_t* ever = nullptr;      // the march's own crossings: which vertices weld or clean-up merge something into
-    if (nv && nt && edge_crossings && coherent) {
+    // (march_mesh: a mesh the march emitted, handed back by the caller -- slabs assembled on the host, refined points --: an edge lies on
+    // at most two triangles until something is merged into one of its ends, which is all the block linking needs; the weld shortcut needs
+    // the crossings' own geometry and stays with edge_crossings)
+    if (nv && nt && (edge_crossings || march_mesh) && coherent) {
         if ((rc = cxp_reserve(ctx, S->ever, 2 * (size_t)nv + 64))) return rc;
         ever = (uint8_t*)S->ever.p;
         CXP_HIP(ctx, hipMemsetAsync(ever, 0, nv, st));
@@ -1881,8 +1884,12 @@ extern "C" int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int6
     int rc = cxp_state(ctx, &S);
     if (rc) return rc;
     const uint32_t nv = (uint32_t)nv64, nt = (uint32_t)nt64;
-    for (int64_t n = 0; n < nt64 * 3; n++)   // a bad index would be a fault on the device
-        if (tris[n] < 0 || tris[n] >= nv64) { ctx->err = "cx_postprocess3d_mesh: triangle index out of range"; return CX_ERR_INVALID; }
+    {   // a bad index would be a fault on the device (smallest and largest index: a loop without an exit, which the compiler vectorises;
+        // with the comparison and its return inside, 67 M iterations took their 10 ms one by one)
+        int32_t lo = 0, hi = -1;
+        for (int64_t n = 0; n < nt64 * 3; n++) { lo = tris[n] < lo ? tris[n] : lo; hi = tris[n] > hi ? tris[n] : hi; }
+        if (lo < 0 || (int64_t)hi >= nv64) { ctx->err = "cx_postprocess3d_mesh: triangle index out of range"; return CX_ERR_INVALID; }
+    }
     hipStream_t st = ctx->stream;
     int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((rc = cxp_reserve3d(ctx, S, nv, nt))) return rc;
@@ -1893,7 +1900,7 @@ extern "C" int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int6
         hipLaunchKernelGGL(cxp_k_iota_prio, dim3(cxp_blocks(nv)), dim3(256), 0, st, (uint32_t*)S->prio.p, nv);
     }
     const double corner[3] = {(double)corner3[0], (double)corner3[1], (double)corner3[2]};
-    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, nullptr, !(flags & 1u), smooth, !(flags & 4u), counts))) return rc;
+    if ((rc = cxp_run3d(ctx, S, nv, nt, corner, nullptr, !(flags & 1u), smooth, !(flags & 4u), counts, false, nullptr, (flags & 8u) != 0u))) return rc;
     ctx->post_valid = true;
     if (out_counts) memcpy(out_counts, counts, sizeof(counts));
     return CX_OK;

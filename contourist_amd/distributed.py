@@ -14,6 +14,11 @@ SURVEY.md section 8e.
 import numpy as np
 
 
+def _ffi_flag_march():
+    from . import _ffi
+    return _ffi.CX_MESH_OF_THE_MARCH
+
+
 def slab_bounds(n0, world, rank):
     "planes [i0, i1) of axis 0 owned by `rank`"
     return (rank * n0) // world, ((rank + 1) * n0) // world
@@ -317,7 +322,7 @@ def level1_slabs(own_planes, value, rank, world, global_shape, device=0, clean=T
     keys, xyz, tris = mesh
     ctx = fn.context
     corner = [int(n) - 1 for n in global_shape]
-    post = ctx.postprocess3d_mesh(xyz, tris, corner, 0 if clean else 1, smooth or 0.0)
+    post = ctx.postprocess3d_mesh(xyz, tris, corner, (0 if clean else 1) | _ffi_flag_march(), smooth or 0.0)
     pts, t1 = ctx.download_level1(post)
     return pts, t1, post
 

@@ -175,7 +175,7 @@ class GridContour3d(object):
         keys, xyz, tris = distributed.assemble(parts)
         self._slab_counts = dict(totals, n_slabs=len(parts), n_vertices=int(len(keys)), n_triangles=int(len(tris)))
         ctx.set_reference_corner((0, 0, 0))
-        return ctx.postprocess3d_mesh(xyz, tris, [int(c) for c in self.corner], 0 if clean else 1, self.smooth or 0.0)
+        return ctx.postprocess3d_mesh(xyz, tris, [int(c) for c in self.corner], (0 if clean else 1) | _ffi.CX_MESH_OF_THE_MARCH, self.smooth or 0.0)
 
     def march(self, force=False):
         "Level 0 on the device (idempotent). returns the counts dict."
@@ -309,7 +309,7 @@ class GridContour3d(object):
             corner = [int(h) - int(l) for l, h in zip(lo, hi)]
         else:
             corner = [int(c) for c in self.corner]
-        return ctx.postprocess3d_mesh(pts, renum[tris], corner, 0 if clean else 1, self.smooth or 0.0)
+        return ctx.postprocess3d_mesh(pts, renum[tris], corner, (0 if clean else 1) | _ffi.CX_MESH_OF_THE_MARCH, self.smooth or 0.0)
 
     def get_points_and_triangles(self, clean=True, device=False):
         """(grid_points (V,3) float64, triangles (T,3) int32 sorted rows)  (tetrahedral.py:528-552).

@@ -212,6 +212,9 @@ int cx_seeded_mode(cx_ctx* ctx, int* mode);
  * priority in the canonical choices) and runs the same weld / tiny collapse / clean / orient on them:
  * corner = voxels per axis of the WHOLE volume, coordinates in its grid coordinates, triangles wound as the march
  * wound them (flags bit 2 set: windings are arbitrary, propagate them like cx_surface_geometry); flags bit 0 as in
+ * (flags bit 3 set: the triangles are ones the march emitted -- slab meshes assembled on the host, a Level-0 mesh with refined points --, i.e.
+ * an edge lies on at most two of them until the post-pass merges something into one of its ends: the components are then linked block by
+ * block in LDS as in cx_postprocess3d instead of through the full edge table; a mesh of any other origin must leave it clear)
  * cx_postprocess3d.  Results through cx_level1_download. */
 int cx_level0_points_f64(cx_ctx* ctx, double* points_xyz);
 int cx_postprocess3d_mesh(cx_ctx* ctx, const double* points_xyz, int64_t nv, const int32_t* tris, int64_t nt, const int64_t* corner3,

@@ -27,7 +27,9 @@ _x, keys, tris = ctx.download_level0(counts)
 order = np.argsort(keys.astype(np.int64), kind="stable")
 rank = np.empty(len(order), dtype=np.int64); rank[order] = np.arange(len(order))
 mp, mt = np.ascontiguousarray(xyz[order]), np.ascontiguousarray(rank[tris].astype(np.int32))     # (prepared outside the timed call)
-pm = timed("cx_postprocess3d_mesh (assembled mesh from the host)", lambda: ctx.postprocess3d_mesh(mp, mt, [n - 1] * 3))
+pm0 = timed("cx_postprocess3d_mesh (a mesh of any origin)", lambda: ctx.postprocess3d_mesh(mp, mt, [n - 1] * 3))
+pm = timed("cx_postprocess3d_mesh (flagged: a mesh of the march)", lambda: ctx.postprocess3d_mesh(mp, mt, [n - 1] * 3, _ffi.CX_MESH_OF_THE_MARCH))
+assert pm == pm0
 post = ctx.postprocess3d()
 pts, t1 = ctx.download_level1(post)
 import ctypes
