@@ -583,18 +583,32 @@ class Context(object):
         self._check(self.lib.cx_morph_eval_download(self.handle, pts.ctypes.data, tris.ctypes.data))
         return pts, tris
 
-    def morph_eval_many(self, times, download=True):
+    def morph_eval_many(self, times, download=True, out=None):
         """the surfaces at all `times` from the last morph_triangles() in one set of launches (cx_morph_eval_many)
         -> list of (points (P,3) float64, triangles (Q,3) int32), one per time, each what morph_eval(t) returns;
-        with download=False the counts array (n,2) int64 (the meshes stay on the device: morph_eval_device_ptrs(i))"""
+        with download=False the counts array (n,2) int64 (the meshes stay on the device: morph_eval_device_ptrs(i)).
+        out = (points (>= sum P, 3) float64, triangles (>= sum Q, 3) int32): arrays to download into (a consumer that plays stream
+        after stream keeps them: fresh arrays cost their page faults, ~20 ms for the 428 MB of config 4's 64 surfaces against 11 ms)"""
+        _out = out
         ts = np.ascontiguousarray(times, dtype=np.float64).reshape(-1)
         out = np.zeros((len(ts), 2), dtype=np.int64)
         self._check(self.lib.cx_morph_eval_many(self.handle, ts.ctypes.data, len(ts), out.ctypes.data))
         if not download:
             return out
         # one transfer for all surfaces (cx_morph_eval_many_download_all); the surfaces are views into the two arrays
-        pts_all = np.empty((int(out[:, 0].sum()), 3), dtype=np.float64)
-        tris_all = np.empty((int(out[:, 1].sum()), 3), dtype=np.int32)
+        counts = out
+        npts, ntri = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+        pts_all = tris_all = None
+        if _out is not None:
+            pts_all, tris_all = _out
+            ok = (pts_all.dtype == np.float64 and tris_all.dtype == np.int32 and pts_all.flags.c_contiguous and tris_all.flags.c_contiguous
+                  and pts_all.ndim == 2 and tris_all.ndim == 2 and pts_all.shape[1] == 3 and tris_all.shape[1] == 3
+                  and len(pts_all) >= npts and len(tris_all) >= ntri)
+            if not ok:
+                raise ValueError("out: C-contiguous (>= %d, 3) float64 and (>= %d, 3) int32 arrays expected" % (npts, ntri))
+        else:
+            pts_all = np.empty((npts, 3), dtype=np.float64)
+            tris_all = np.empty((ntri, 3), dtype=np.int32)
         self._check(self.lib.cx_morph_eval_many_download_all(self.handle, pts_all.ctypes.data, tris_all.ctypes.data))
         res, p0, t0 = [], 0, 0
         for i in range(len(ts)):

@@ -649,6 +649,15 @@ def test_per_t_stream_in_one_call_equals_the_single_surfaces(shape, nbins):
         for (pa, ta), (pm, tm) in zip(again, many):
             assert np.array_equal(ta, tm) and np.array_equal(pa, pm)
         assert ctx.morph_eval_many([]) == []
+        # into arrays of the caller (kept from stream to stream)
+        P = np.full((int(counts[:, 0].sum()) + 5, 3), -1.0)
+        T = np.full((int(counts[:, 1].sum()) + 7, 3), -1, dtype=np.int32)
+        mine = ctx.morph_eval_many(times, out=(P, T))
+        for (pa, ta), (pm, tm) in zip(mine, many):
+            assert np.array_equal(ta, tm) and np.array_equal(pa, pm) and (len(pa) == 0 or np.shares_memory(pa, P))
+        assert np.all(P[-5:] == -1.0) and np.all(T[-7:] == -1)
+        with pytest.raises(ValueError):
+            ctx.morph_eval_many(times, out=(P[:3], T))
         # device addresses of a surface: what the download copies from
         torch = pytest.importorskip("torch")
         ctx.morph_eval_many(times, download=False)

@@ -75,6 +75,15 @@ for _ in range(KM):
 torch.cuda.synchronize()
 dem = (time.perf_counter() - t0) / KM
 assert int(cm[:, 1].sum()) == ntris_t, (int(cm[:, 1].sum()), ntris_t)
+# ... and with all surfaces brought to the host in one transfer (cx_morph_eval_many_download_all)
+_s = ctx.morph_eval_many(ts) if ts else []
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+_s = ctx.morph_eval_many(ts) if ts else []
+torch.cuda.synchronize()
+dem_dl = time.perf_counter() - t0
+dl_bytes = sum(p_.nbytes + t_.nbytes for p_, t_ in _s)
+del _s
 n = A.numel()
 # CPU baseline: the oracle's C restatement (1 thread) on a slab of the same field
 cpu = None
@@ -96,5 +105,6 @@ print(json.dumps({"workload": "%dx%dx%dx%d fp32, two moving blobs + noise, v=%g"
                   "per_t_surfaces": {"times": len(ts), "triangles": int(ntris_t), "ms": de * 1e3,
                                      "Mtriangles_per_s": ntris_t / de / 1e6 if de > 0 else 0.0},
                   "per_t_surfaces_one_call": {"times": len(ts), "triangles": int(cm[:, 1].sum()), "points": int(cm[:, 0].sum()), "ms": dem * 1e3,
-                                              "Mtriangles_per_s": int(cm[:, 1].sum()) / dem / 1e6 if dem > 0 else 0.0},
+                                              "Mtriangles_per_s": int(cm[:, 1].sum()) / dem / 1e6 if dem > 0 else 0.0,
+                                              "ms_with_download": dem_dl * 1e3, "download_MB": dl_bytes / 1e6},
                   "cpu_baseline": cpu}))
